@@ -1,0 +1,25 @@
+# Builds libpmc.so (HIP kernels + C ABI) for gfx950, in-tree.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := parelagmc_amd/csrc
+OBJDIR := build/obj
+SRCS := $(CSRC)/kernels.hip $(CSRC)/sparse.hip $(CSRC)/solver.hip $(CSRC)/sampler.hip $(CSRC)/darcy.hip $(CSRC)/capi.hip
+OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
+HDRS := $(wildcard $(CSRC)/*.hpp) include/pmc.h
+CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+LIB := parelagmc_amd/lib/libpmc.so
+
+all: $(LIB)
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p parelagmc_amd/lib
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -ldl
+
+clean:
+	rm -rf build parelagmc_amd/lib/libpmc.so
+
+.PHONY: all clean

@@ -1,0 +1,194 @@
+/* pmc.h - C ABI of the MI355X-native ParELAGMC hot path (libpmc.so).
+ *
+ * Drop-in boundary for the per-realization work that ParELAGMC performs behind its two
+ * plugin interfaces (all paths relative to /root/reference):
+ *     MLSampler::Sample / Eval               src/MLSampler.hpp:33-52
+ *     PhysicalMLSolver::SolveFwd             src/PhysicalMLSolver.hpp:33-47
+ * as called, and only called, from MLMC_Manager::InitRun (src/MLMC_Manager.cpp:113-173) and
+ * MC_Manager::InitRun (src/MC_Manager.cpp:82-116).
+ *
+ * Conventions
+ *   - plain C types only: opaque handles, pointers + sizes, int32 indices, fp64 values;
+ *   - every function returns PMC_OK (0) or a negative error code; no exception crosses the
+ *     boundary; pmc_last_error() returns a thread-local message for the last failure;
+ *   - operators are passed as host CSR arrays (exactly what ParELAG's SparseMatrix /
+ *     HypreParMatrix diag blocks hold) and are copied/re-laid-out on the device at create
+ *     time; callers keep ownership of everything they pass in;
+ *   - level 0 is the FINEST level (ParELAG convention); P of level i maps level i+1 -> i;
+ *   - vectors may live in host or device memory (`memspace`); batched vectors are
+ *     sample-major: sample b occupies [b*n, (b+1)*n);
+ *   - one handle per GPU; calls on one ctx are serialised by the caller (the reference's
+ *     objects are not re-entrant either: src/DarcySolver.hpp:238).
+ */
+#ifndef PMC_H_
+#define PMC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMC_OK 0
+#define PMC_ERR_INVALID (-1)  /* bad argument (PARELAG_ASSERT / PARELAG_TEST_FOR_EXCEPTION sites) */
+#define PMC_ERR_DEVICE (-2)   /* HIP runtime error, no GPU, out of memory */
+#define PMC_ERR_COMM (-3)     /* RCCL failure */
+#define PMC_ERR_INTERNAL (-4)
+
+enum pmc_memspace { PMC_MEM_HOST = 0, PMC_MEM_DEVICE = 1 };
+enum pmc_projection { PMC_PROJ_NONE = 0, PMC_PROJ_GATHER = 1, PMC_PROJ_L2 = 2 };
+
+typedef struct pmc_ctx pmc_ctx;
+typedef struct pmc_sampler pmc_sampler;
+typedef struct pmc_darcy pmc_darcy;
+
+/* CSR matrix, host pointers, sorted or unsorted column indices. */
+typedef struct pmc_csr {
+    int32_t nrows, ncols;
+    const int32_t* rowptr; /* nrows+1 */
+    const int32_t* colind; /* nnz */
+    const double* vals;    /* nnz */
+} pmc_csr;
+
+/* Linear-solver options.  Defaults restate the reference's "MINRES-BJ-GS" entry
+ * (examples/example_helpers/CreateSamplerParameterList.hpp:54-66): MINRES, 300 iterations,
+ * rel 1e-6, abs 1e-12, block-diagonal preconditioner.  The two diagonal blocks are
+ * GPU-native replacements inside the reference's own configuration space:
+ * a fixed Chebyshev/l1-Jacobi polynomial on M (instead of 3 sequential l1-GS sweeps) and one
+ * V-cycle over the caller's level hierarchy on S = aW + B diag(M)^-1 B^T (instead of
+ * BoomerAMG), both fixed SPD linear operators as MINRES requires. */
+typedef struct pmc_solver_opts {
+    int32_t max_iter;
+    double rel_tol;
+    double abs_tol;
+    int32_t cheb_degree_M;    /* polynomial degree on the M block (default 3) */
+    double cheb_ratio_M;      /* targeted lambda_max/lambda_min of D^-1 M (default 8) */
+    int32_t mg_smooth_degree; /* Chebyshev pre/post smoothing degree per level (default 2) */
+    double mg_smooth_ratio;   /* smoothing interval [lmax/ratio, lmax] (default 4) */
+    int32_t mg_coarse_degree; /* polynomial degree on the coarsest level (default 12) */
+    double mg_coarse_ratio;   /* (default 100) */
+    int32_t check_every;      /* iterations between host convergence polls (default 4) */
+} pmc_solver_opts;
+
+/* Per-realization solver report; the reference returns -1 for iteration counts
+ * (src/PDESampler.hpp:142-145, src/DarcySolver.hpp:104-107) and is silent on non-convergence. */
+typedef struct pmc_stats {
+    int32_t iterations;
+    int32_t converged;
+    double initial_norm; /* preconditioned residual norm before the first iteration */
+    double final_norm;   /* |eta| at exit */
+} pmc_stats;
+
+/* One level of the SPDE sampler hierarchy = the blocks PDESampler::BuildHierarchy assembles
+ * (src/PDESampler.cpp:232-284): A = [M B^T; B -alpha*W]. */
+typedef struct pmc_sampler_level {
+    int32_t n_u, n_s;
+    pmc_csr M;            /* n_u x n_u, SPD, essential rows/cols -> identity (:236-241)     */
+    pmc_csr B;            /* n_s x n_u, = W*D with essential columns zeroed (:243-246)       */
+    const double* w_diag; /* n_s, diag(W) > 0; w_sqrt = sqrt(w_diag) (:248-254)              */
+    pmc_csr P;            /* n_s(level) x n_s(level+1) = ComputeTrueP(sform) (:189-193);
+                             ignored (may be zeroed) on the last level                        */
+} pmc_sampler_level;
+
+/* One level of the Darcy hierarchy = what DarcySolver precomputes (src/DarcySolver.cpp:
+ * 194-227 B/Bt/P, :297-319 obs, :360-384 ess_data, :386-414 rhs) plus the element
+ * decomposition of the mass matrix that ComputeMassOperator(uform,k) re-assembles per sample
+ * (:479):  M(k).vals[p] = sum_{t in c_ptr[p]..c_ptr[p+1]} coef(k[c_elem[t]]) * c_val[t]. */
+typedef struct pmc_darcy_level {
+    int32_t n_u, n_p;
+    pmc_csr M_pattern;       /* n_u x n_u, sparsity of M(k) (vals ignored, may be NULL)       */
+    const int32_t* c_ptr;    /* nnz(M)+1                                                      */
+    const int32_t* c_elem;   /* element (entry of k) of each contribution                      */
+    const double* c_val;     /* unit-coefficient element-matrix value                          */
+    pmc_csr B;               /* n_p x n_u, no boundary elimination (:203-207)                 */
+    const double* rhs;       /* n_u+n_p                                                       */
+    const uint8_t* ess_mask; /* n_u, 1 = essential u-dof (:487-492)                           */
+    const double* ess_data;  /* n_u, essential values (only read where ess_mask)              */
+    const double* obs;       /* n_u+n_p, observation functional (:297-319)                    */
+    pmc_csr P;               /* n_p(level) x n_p(level+1), P0 prolongator; ignored on last    */
+} pmc_darcy_level;
+
+/* ---- library / context ---------------------------------------------------------------- */
+int pmc_version(void);
+const char* pmc_last_error(void);
+void pmc_solver_opts_default(pmc_solver_opts* opts);
+
+int pmc_ctx_create(int device_id, pmc_ctx** out);
+void pmc_ctx_destroy(pmc_ctx* ctx);
+int pmc_ctx_synchronize(pmc_ctx* ctx);
+/* hipStream_t all work of this ctx is enqueued on (for callers that record their own events) */
+void* pmc_ctx_stream(pmc_ctx* ctx);
+/* elapsed device milliseconds between two points on the ctx stream (HIP events) */
+int pmc_timer_start(pmc_ctx* ctx);
+int pmc_timer_stop(pmc_ctx* ctx, double* ms);
+
+/* device memory helpers so non-HIP callers can keep xi / s / k resident in HBM */
+int pmc_malloc(pmc_ctx* ctx, size_t bytes, void** dptr);
+int pmc_free(pmc_ctx* ctx, void* dptr);
+int pmc_memcpy_h2d(pmc_ctx* ctx, void* dst, const void* src, size_t bytes);
+int pmc_memcpy_d2h(pmc_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* ---- NormalDistributionSampler (src/NormalDistributionSampler.cpp:17-37) ---------------- */
+/* Seed the counter-based generator; (nparts, mypart) mirror Split(): sample ids handed to
+ * pmc_*_sample are global, each part simply owns the ids congruent to mypart mod nparts. */
+int pmc_rng_seed(pmc_ctx* ctx, uint64_t seed, int nparts, int mypart);
+/* out[b*n + i] = mean + sqrt(sigma2) * Phi^-1(u),  b < nbatch, realization id first_id+b */
+int pmc_normal_fill(pmc_ctx* ctx, double mean, double sigma2, uint64_t first_sample_id, uint32_t stream,
+                    int nbatch, int n, double* out, int memspace);
+
+/* ---- PDESampler / EmbeddedPDESampler / L2ProjectionPDESampler -------------------------- */
+/* nlevels >= n_mc_levels >= 1: levels [n_mc_levels, nlevels) are never sampled on, they only
+ * deepen the V-cycle of the Schur-complement preconditioner. */
+int pmc_sampler_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_sampler_level* levels,
+                       double alpha, double matern_g, int lognormal, const pmc_solver_opts* opts,
+                       pmc_sampler** out);
+void pmc_sampler_destroy(pmc_sampler* s);
+/* Output map of the embedded variants.  PMC_PROJ_GATHER: s = sbar[gather_idx]
+ * (src/EmbeddedPDESampler.cpp:552-556); PMC_PROJ_L2: s = inv_w_orig .* (Gt sbar)
+ * (src/L2ProjectionPDESampler.cpp:738-750). */
+int pmc_sampler_set_projection(pmc_sampler* s, int level, int kind, const pmc_csr* Gt,
+                               const int32_t* gather_idx, const double* inv_w_orig, int orig_size);
+int pmc_sampler_num_levels(const pmc_sampler* s);
+int pmc_sampler_xi_size(const pmc_sampler* s, int level);     /* size Sample() fills            */
+int pmc_sampler_sample_size(const pmc_sampler* s, int level); /* SampleSize(): size of Eval's s */
+int64_t pmc_sampler_nnz(const pmc_sampler* s, int level);     /* GetNNZ()                       */
+/* Sample(level, xi): xi ~ N(0, 1) of pmc_sampler_xi_size(level) entries per realization */
+int pmc_sampler_sample(pmc_sampler* s, int level, uint64_t first_sample_id, int nbatch, double* xi,
+                       int memspace);
+/* Eval(level, xi, s, embed_s, use_init) (src/PDESampler.cpp:411-535).
+ *   xi_level <= level : level xi was drawn on (the reference infers it from xi.Size(), :419)
+ *   s                 : out, nbatch x sample_size(level); exp() applied if lognormal
+ *   init_s/init_level : in, Gaussian field on a coarser-or-equal level used as the initial
+ *                       guess when use_init != 0 (:498-510); ignored otherwise (may be NULL)
+ *   embed_s_out       : out (may be NULL), Gaussian field on the sampler mesh at `level`
+ *                       (:527); may alias init_s
+ *   stats             : out (may be NULL), nbatch entries */
+int pmc_sampler_eval(pmc_sampler* s, int level, int xi_level, int nbatch, const double* xi, double* s_out,
+                     const double* init_s, int init_level, int use_init, double* embed_s_out, int memspace,
+                     pmc_stats* stats);
+
+/* ---- DarcySolver ------------------------------------------------------------------------ */
+int pmc_darcy_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_darcy_level* levels,
+                     int k_divides, const pmc_solver_opts* opts, pmc_darcy** out);
+void pmc_darcy_destroy(pmc_darcy* d);
+int pmc_darcy_num_dofs(const pmc_darcy* d, int level); /* GetGlobalNumberOfDofs() */
+int64_t pmc_darcy_nnz(const pmc_darcy* d, int level);  /* GetNNZ()                */
+/* SolveFwd(level, k, Q, C) (src/DarcySolver.cpp:416-437).  k: nbatch x n_p(level) in
+ * `memspace`; Q, C: host arrays of nbatch; sol_out (may be NULL): nbatch x (n_u+n_p) in
+ * `memspace` (SolveFwd_RtnPressure, :439-470, reads its p-block). */
+int pmc_darcy_solve_fwd(pmc_darcy* d, int level, int nbatch, const double* k, double* Q, double* C,
+                        double* sol_out, int memspace, pmc_stats* stats);
+
+/* ---- MLMC accumulators across GPUs (new: the reference's manager is serial,
+ *      src/MLMC_Manager.hpp:24) ----------------------------------------------------------- */
+int pmc_comm_unique_id(void* id128);                                        /* 128 bytes    */
+int pmc_comm_init(pmc_ctx* ctx, const void* id128, int nranks, int rank);   /* RCCL over xGMI */
+int pmc_comm_destroy(pmc_ctx* ctx);
+/* in-place SUM all-reduce of a small host buffer (the nlevels x 9 sums table + counts) */
+int pmc_allreduce_sum_f64(pmc_ctx* ctx, double* host_buf, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMC_H_ */

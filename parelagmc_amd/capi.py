@@ -1,0 +1,445 @@
+"""ctypes binding of libpmc.so (include/pmc.h) - the reference-side stub a ParELAGMC maintainer
+would write in C++ is shown in INTEGRATION.md; this is the same binding for the Python test
+harness and launcher.  There is NO CPU fallback: if the library cannot be loaded, or no GPU is
+visible when a context is created, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpmc.so")
+
+PMC_MEM_HOST, PMC_MEM_DEVICE = 0, 1
+PMC_PROJ_NONE, PMC_PROJ_GATHER, PMC_PROJ_L2 = 0, 1, 2
+
+
+class PmcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libpmc error {code}: {msg}")
+        self.code = code
+
+
+class pmc_csr(C.Structure):
+    _fields_ = [("nrows", C.c_int32), ("ncols", C.c_int32), ("rowptr", C.POINTER(C.c_int32)),
+                ("colind", C.POINTER(C.c_int32)), ("vals", C.POINTER(C.c_double))]
+
+
+class pmc_solver_opts(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
+                ("cheb_degree_M", C.c_int32), ("cheb_ratio_M", C.c_double),
+                ("mg_smooth_degree", C.c_int32), ("mg_smooth_ratio", C.c_double),
+                ("mg_coarse_degree", C.c_int32), ("mg_coarse_ratio", C.c_double), ("check_every", C.c_int32)]
+
+
+class pmc_stats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("initial_norm", C.c_double),
+                ("final_norm", C.c_double)]
+
+
+class pmc_sampler_level(C.Structure):
+    _fields_ = [("n_u", C.c_int32), ("n_s", C.c_int32), ("M", pmc_csr), ("B", pmc_csr),
+                ("w_diag", C.POINTER(C.c_double)), ("P", pmc_csr)]
+
+
+class pmc_darcy_level(C.Structure):
+    _fields_ = [("n_u", C.c_int32), ("n_p", C.c_int32), ("M_pattern", pmc_csr), ("c_ptr", C.POINTER(C.c_int32)),
+                ("c_elem", C.POINTER(C.c_int32)), ("c_val", C.POINTER(C.c_double)), ("B", pmc_csr),
+                ("rhs", C.POINTER(C.c_double)), ("ess_mask", C.POINTER(C.c_uint8)),
+                ("ess_data", C.POINTER(C.c_double)), ("obs", C.POINTER(C.c_double)), ("P", pmc_csr)]
+
+
+# every symbol include/pmc.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+_DP = C.c_void_p   # double* that may be a host or a device address
+SYMBOLS = {
+    "pmc_version": (C.c_int, []),
+    "pmc_last_error": (C.c_char_p, []),
+    "pmc_solver_opts_default": (None, [C.POINTER(pmc_solver_opts)]),
+    "pmc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
+    "pmc_ctx_destroy": (None, [_VP]),
+    "pmc_ctx_synchronize": (C.c_int, [_VP]),
+    "pmc_ctx_stream": (_VP, [_VP]),
+    "pmc_timer_start": (C.c_int, [_VP]),
+    "pmc_timer_stop": (C.c_int, [_VP, C.POINTER(C.c_double)]),
+    "pmc_malloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
+    "pmc_free": (C.c_int, [_VP, _VP]),
+    "pmc_memcpy_h2d": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "pmc_memcpy_d2h": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "pmc_rng_seed": (C.c_int, [_VP, C.c_uint64, C.c_int, C.c_int]),
+    "pmc_normal_fill": (C.c_int, [_VP, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_int, C.c_int, _DP, C.c_int]),
+    "pmc_sampler_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_sampler_level), C.c_double, C.c_double,
+                                     C.c_int, C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
+    "pmc_sampler_destroy": (None, [_VP]),
+    "pmc_sampler_set_projection": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_csr), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_double), C.c_int]),
+    "pmc_sampler_num_levels": (C.c_int, [_VP]),
+    "pmc_sampler_xi_size": (C.c_int, [_VP, C.c_int]),
+    "pmc_sampler_sample_size": (C.c_int, [_VP, C.c_int]),
+    "pmc_sampler_nnz": (C.c_int64, [_VP, C.c_int]),
+    "pmc_sampler_sample": (C.c_int, [_VP, C.c_int, C.c_uint64, C.c_int, _DP, C.c_int]),
+    "pmc_sampler_eval": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _DP, _DP, _DP, C.c_int, C.c_int, _DP, C.c_int,
+                                   C.POINTER(pmc_stats)]),
+    "pmc_darcy_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_darcy_level), C.c_int,
+                                   C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
+    "pmc_darcy_destroy": (None, [_VP]),
+    "pmc_darcy_num_dofs": (C.c_int, [_VP, C.c_int]),
+    "pmc_darcy_nnz": (C.c_int64, [_VP, C.c_int]),
+    "pmc_darcy_solve_fwd": (C.c_int, [_VP, C.c_int, C.c_int, _DP, C.POINTER(C.c_double), C.POINTER(C.c_double), _DP,
+                                      C.c_int, C.POINTER(pmc_stats)]),
+    "pmc_comm_unique_id": (C.c_int, [_VP]),
+    "pmc_comm_init": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
+    "pmc_comm_destroy": (C.c_int, [_VP]),
+    "pmc_allreduce_sum_f64": (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int]),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libpmc.so and bind every declared symbol (raises if one is missing)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise PmcError(-2, f"{p} not found - build it with `make` / __graft_entry__.build() (no CPU fallback)")
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PmcError(rc, load_library().pmc_last_error().decode("utf-8", "replace"))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class _Keep:
+    """Holds numpy arrays alive while a C struct points into them."""
+
+    def __init__(self):
+        self.refs = []
+
+    def csr(self, m) -> pmc_csr:
+        if m is None:
+            return pmc_csr(0, 0, None, None, None)
+        m = m.tocsr()
+        rp, ci, v = _i32(m.indptr), _i32(m.indices), _f64(m.data)
+        self.refs += [rp, ci, v]
+        return pmc_csr(m.shape[0], m.shape[1], _ptr(rp, C.c_int32), _ptr(ci, C.c_int32), _ptr(v, C.c_double))
+
+    def f64(self, a):
+        a = _f64(a)
+        self.refs.append(a)
+        return _ptr(a, C.c_double)
+
+    def i32(self, a):
+        a = _i32(a)
+        self.refs.append(a)
+        return _ptr(a, C.c_int32)
+
+    def u8(self, a):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        self.refs.append(a)
+        return _ptr(a, C.c_uint8)
+
+
+def solver_opts(**kw) -> pmc_solver_opts:
+    o = pmc_solver_opts()
+    load_library().pmc_solver_opts_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown solver option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+class DeviceArray:
+    """fp64 array in HBM owned by a Context (pmc_malloc / pmc_free)."""
+
+    def __init__(self, ctx: "Context", n: int):
+        self.ctx, self.n = ctx, int(n)
+        p = _VP()
+        _check(ctx.lib.pmc_malloc(ctx.h, self.n * 8, C.byref(p)))
+        self.ptr = p.value or 0
+
+    def upload(self, a):
+        a = _f64(a).ravel()
+        assert a.size == self.n
+        _check(self.ctx.lib.pmc_memcpy_h2d(self.ctx.h, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.n, np.float64)
+        _check(self.ctx.lib.pmc_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.pmc_free(self.ctx.h, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _addr(x):
+    """(address, memspace) of a numpy array, a DeviceArray or a torch tensor."""
+    if x is None:
+        return None, None
+    if isinstance(x, DeviceArray):
+        return x.ptr, PMC_MEM_DEVICE
+    if isinstance(x, np.ndarray):
+        assert x.dtype == np.float64 and x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data, PMC_MEM_HOST
+    if hasattr(x, "data_ptr"):   # torch tensor: plumbing only (device memory owner)
+        assert str(x.dtype) == "torch.float64" and x.is_contiguous()
+        return x.data_ptr(), (PMC_MEM_DEVICE if x.is_cuda else PMC_MEM_HOST)
+    raise TypeError(type(x))
+
+
+class Context:
+    def __init__(self, device_id: int = 0, seed: int = 0):
+        self.lib = load_library()
+        h = _VP()
+        _check(self.lib.pmc_ctx_create(int(device_id), C.byref(h)))
+        self.h = h
+        self.device_id = device_id
+        self.seed(seed)
+
+    def seed(self, seed: int, nparts: int = 1, mypart: int = 0):
+        _check(self.lib.pmc_rng_seed(self.h, C.c_uint64(seed), nparts, mypart))
+
+    def synchronize(self):
+        _check(self.lib.pmc_ctx_synchronize(self.h))
+
+    def stream(self) -> int:
+        return self.lib.pmc_ctx_stream(self.h) or 0
+
+    def timer_start(self):
+        _check(self.lib.pmc_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_double()
+        _check(self.lib.pmc_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def empty(self, n) -> DeviceArray:
+        return DeviceArray(self, n)
+
+    def array(self, a) -> DeviceArray:
+        a = _f64(a)
+        return DeviceArray(self, a.size).upload(a)
+
+    def normal_fill(self, n, nbatch=1, first_id=0, stream=0, mean=0.0, sigma2=1.0, out=None):
+        """NormalDistributionSampler::operator()(Vector&)."""
+        if out is None:
+            out = np.empty((nbatch, n))
+        p, ms = _addr(out)
+        _check(self.lib.pmc_normal_fill(self.h, mean, sigma2, C.c_uint64(first_id), stream, nbatch, n, p, ms))
+        return out
+
+    # communicator
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(self.lib.pmc_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid: bytes, nranks: int, rank: int):
+        buf = C.create_string_buffer(uid, 128)
+        _check(self.lib.pmc_comm_init(self.h, buf, nranks, rank))
+
+    def allreduce_sum(self, a: np.ndarray) -> np.ndarray:
+        a = _f64(a)
+        _check(self.lib.pmc_allreduce_sum_f64(self.h, _ptr(a, C.c_double), a.size))
+        return a
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pmc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PDESampler:
+    """Device SPDE sampler; mirrors parelagmc::PDESampler / EmbeddedPDESampler /
+    L2ProjectionPDESampler (Sample, Eval, SampleSize, GetNNZ)."""
+
+    def __init__(self, ctx: Context, problem, opts: Optional[pmc_solver_opts] = None, projection: str = "none",
+                 l2_ops=None):
+        self.ctx, self.problem = ctx, problem
+        lib = ctx.lib
+        keep = _Keep()
+        nl = len(problem.levels)
+        arr = (pmc_sampler_level * nl)()
+        for i, L in enumerate(problem.levels):
+            arr[i] = pmc_sampler_level(L.n_u, L.n_s, keep.csr(L.M), keep.csr(L.B), keep.f64(L.w_diag), keep.csr(L.P))
+        h = _VP()
+        o = opts if opts is not None else solver_opts()
+        _check(lib.pmc_sampler_create(ctx.h, nl, problem.n_mc_levels, arr, problem.alpha, problem.matern_g,
+                                      1 if problem.lognormal else 0, C.byref(o), C.byref(h)))
+        self.h = h
+        self.nlevels = problem.n_mc_levels
+        if projection == "gather":
+            for lvl, idx in enumerate(problem.orig_index):
+                k2 = _Keep()
+                _check(lib.pmc_sampler_set_projection(h, lvl, PMC_PROJ_GATHER, None, k2.i32(idx), None, len(idx)))
+        elif projection == "l2":
+            for lvl, (Gt, inv_w) in enumerate(l2_ops):
+                k2 = _Keep()
+                g = k2.csr(Gt)
+                _check(lib.pmc_sampler_set_projection(h, lvl, PMC_PROJ_L2, C.byref(g), None, k2.f64(inv_w), Gt.shape[0]))
+        elif projection != "none":
+            raise ValueError(projection)
+
+    def xi_size(self, level):
+        return self.ctx.lib.pmc_sampler_xi_size(self.h, level)
+
+    def SampleSize(self, level):
+        return self.ctx.lib.pmc_sampler_sample_size(self.h, level)
+
+    def GetNNZ(self, level):
+        return self.ctx.lib.pmc_sampler_nnz(self.h, level)
+
+    def Sample(self, level, first_id=0, nbatch=1, out=None):
+        n = self.xi_size(level)
+        if out is None:
+            out = np.empty((nbatch, n))
+        p, ms = _addr(out)
+        _check(self.ctx.lib.pmc_sampler_sample(self.h, level, C.c_uint64(first_id), nbatch, p, ms))
+        return out
+
+    def Eval(self, level, xi, xi_level=None, init_s=None, init_level=None, use_init=False, s_out=None,
+             embed_out=None, want_embed=False, return_stats=False):
+        """xi: (nbatch, n_xi) numpy (host) or DeviceArray/torch tensor (device, with nbatch=...).
+        Returns s (and embed_s, stats) as numpy arrays for host inputs."""
+        lib = self.ctx.lib
+        if isinstance(xi, np.ndarray):
+            xi = _f64(np.atleast_2d(xi))
+            nbatch = xi.shape[0]
+            if xi_level is None:     # reference behaviour: infer from the length (PDESampler.cpp:419)
+                sizes = [self.xi_size(l) for l in range(self.nlevels)]
+                xi_level = sizes.index(xi.shape[1])
+            if s_out is None:
+                s_out = np.empty((nbatch, self.SampleSize(level)))
+            if want_embed and embed_out is None:
+                embed_out = np.empty((nbatch, self.xi_size(level)))
+            if init_s is not None:
+                init_s = _f64(np.atleast_2d(init_s))
+        else:
+            nbatch = xi.n // self.xi_size(xi_level)
+        stats = (pmc_stats * nbatch)()
+        pxi, ms = _addr(xi)
+        ps, _ = _addr(s_out)
+        pinit, _ = _addr(init_s)
+        pemb, _ = _addr(embed_out)
+        _check(lib.pmc_sampler_eval(self.h, level, xi_level, nbatch, pxi, ps, pinit,
+                                    -1 if init_level is None else init_level, 1 if use_init else 0, pemb, ms, stats))
+        out = [s_out]
+        if want_embed or embed_out is not None:
+            out.append(embed_out)
+        if return_stats:
+            out.append([(s.iterations, s.converged, s.initial_norm, s.final_norm) for s in stats])
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.pmc_sampler_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DarcySolver:
+    """Device mixed Darcy solver; mirrors parelagmc::DarcySolver (SolveFwd, GetNNZ, ...)."""
+
+    def __init__(self, ctx: Context, problem, opts: Optional[pmc_solver_opts] = None):
+        self.ctx, self.problem = ctx, problem
+        keep = _Keep()
+        nl = len(problem.levels)
+        arr = (pmc_darcy_level * nl)()
+        for i, L in enumerate(problem.levels):
+            arr[i] = pmc_darcy_level(L.n_u, L.n_p, keep.csr(L.M_pattern), keep.i32(L.c_ptr), keep.i32(L.c_elem),
+                                     keep.f64(L.c_val), keep.csr(L.B), keep.f64(L.rhs), keep.u8(L.ess_mask),
+                                     keep.f64(L.ess_data), keep.f64(L.obs), keep.csr(L.P))
+        h = _VP()
+        o = opts if opts is not None else solver_opts()
+        _check(ctx.lib.pmc_darcy_create(ctx.h, nl, problem.n_mc_levels, arr, 1 if problem.k_divides else 0,
+                                        C.byref(o), C.byref(h)))
+        self.h = h
+        self.nlevels = problem.n_mc_levels
+
+    def GetGlobalNumberOfDofs(self, level):
+        return self.ctx.lib.pmc_darcy_num_dofs(self.h, level)
+
+    GetNumberOfDofs = GetGlobalNumberOfDofs
+
+    def GetNNZ(self, level):
+        return self.ctx.lib.pmc_darcy_nnz(self.h, level)
+
+    def SolveFwd(self, level, k, nbatch=None, want_solution=False, sol_out=None, return_stats=False):
+        """Returns (Q, C) arrays of length nbatch (plus solution / stats on request)."""
+        lib = self.ctx.lib
+        if isinstance(k, np.ndarray):
+            k = _f64(np.atleast_2d(k))
+            nbatch = k.shape[0]
+            if want_solution and sol_out is None:
+                sol_out = np.empty((nbatch, self.GetGlobalNumberOfDofs(level)))
+        assert nbatch is not None
+        Q = np.empty(nbatch)
+        Cc = np.empty(nbatch)
+        stats = (pmc_stats * nbatch)()
+        pk, ms = _addr(k)
+        psol, _ = _addr(sol_out)
+        _check(lib.pmc_darcy_solve_fwd(self.h, level, nbatch, pk, _ptr(Q, C.c_double), _ptr(Cc, C.c_double), psol, ms,
+                                       stats))
+        out = [Q, Cc]
+        if want_solution or sol_out is not None:
+            out.append(sol_out)
+        if return_stats:
+            out.append([(s.iterations, s.converged, s.initial_norm, s.final_norm) for s in stats])
+        return tuple(out)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.pmc_darcy_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

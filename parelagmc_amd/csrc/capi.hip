@@ -1,0 +1,369 @@
+// extern "C" surface of libpmc.so (see include/pmc.h).  No exception leaves this file.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <mutex>
+
+#include "handles.hpp"
+
+namespace pmc {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& m) { g_last_error = m; }
+
+void Ctx::activate() const { PMC_HIP(hipSetDevice(device)); }
+
+template <class F>
+static int guarded(F&& f) {
+    try {
+        f();
+        return PMC_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return PMC_ERR_INTERNAL;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return PMC_ERR_INTERNAL;
+    } catch (...) {
+        set_last_error("unknown exception");
+        return PMC_ERR_INTERNAL;
+    }
+}
+
+// ---- RCCL, resolved lazily so that single-GPU use never needs the library ---------------------
+struct UniqueId { char internal[128]; };
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) {
+            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    });
+    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy)
+        throw Error(PMC_ERR_COMM, "RCCL (librccl.so) could not be loaded");
+    return r;
+}
+static void rccl_check(int rc, const char* what) {
+    if (rc != 0) {
+        Rccl& r = rccl();
+        throw Error(PMC_ERR_COMM, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error"));
+    }
+}
+
+}  // namespace pmc
+
+using namespace pmc;
+
+extern "C" {
+
+int pmc_version(void) { return 100; }
+const char* pmc_last_error(void) { return g_last_error.c_str(); }
+
+void pmc_solver_opts_default(pmc_solver_opts* o) {
+    if (!o) return;
+    o->max_iter = 300;
+    o->rel_tol = 1e-6;
+    o->abs_tol = 1e-12;
+    o->cheb_degree_M = 3;
+    o->cheb_ratio_M = 8.0;
+    o->mg_smooth_degree = 2;
+    o->mg_smooth_ratio = 4.0;
+    o->mg_coarse_degree = 12;
+    o->mg_coarse_ratio = 100.0;
+    o->check_every = 4;
+}
+
+int pmc_ctx_create(int device_id, pmc_ctx** out) {
+    return guarded([&] {
+        PMC_REQUIRE(out != nullptr, "pmc_ctx_create: out is NULL");
+        *out = nullptr;
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0)
+            throw Error(PMC_ERR_DEVICE, "no HIP device available (libpmc has no CPU fallback)");
+        PMC_REQUIRE(device_id >= 0 && device_id < ndev, "pmc_ctx_create: device id out of range");
+        std::unique_ptr<pmc_ctx> c(new pmc_ctx());
+        c->device = device_id;
+        PMC_HIP(hipSetDevice(device_id));
+        PMC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        PMC_HIP(hipEventCreate(&c->ev0));
+        PMC_HIP(hipEventCreate(&c->ev1));
+        PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_flag), sizeof(int) * 16, hipHostMallocDefault));
+        PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(double) * 4096, hipHostMallocDefault));
+        *out = c.release();
+    });
+}
+
+void pmc_ctx_destroy(pmc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->nccl) {
+        try { rccl().CommDestroy(c->nccl); } catch (...) {}
+        c->nccl = nullptr;
+    }
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
+    if (c->h_scal) (void)hipHostFree(c->h_scal);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pmc_ctx_synchronize(pmc_ctx* c) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr, "ctx is NULL");
+        c->activate();
+        PMC_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+void* pmc_ctx_stream(pmc_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int pmc_timer_start(pmc_ctx* c) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr, "ctx is NULL");
+        c->activate();
+        PMC_HIP(hipEventRecord(c->ev0, c->stream));
+    });
+}
+int pmc_timer_stop(pmc_ctx* c, double* ms) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr && ms != nullptr, "ctx/ms is NULL");
+        c->activate();
+        PMC_HIP(hipEventRecord(c->ev1, c->stream));
+        PMC_HIP(hipEventSynchronize(c->ev1));
+        float f = 0.f;
+        PMC_HIP(hipEventElapsedTime(&f, c->ev0, c->ev1));
+        *ms = (double)f;
+    });
+}
+
+int pmc_malloc(pmc_ctx* c, size_t bytes, void** dptr) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr && dptr != nullptr, "pmc_malloc: NULL argument");
+        c->activate();
+        *dptr = nullptr;
+        if (bytes) PMC_HIP(hipMalloc(dptr, bytes));
+    });
+}
+int pmc_free(pmc_ctx* c, void* dptr) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr, "ctx is NULL");
+        c->activate();
+        if (dptr) PMC_HIP(hipFree(dptr));
+    });
+}
+int pmc_memcpy_h2d(pmc_ctx* c, void* dst, const void* src, size_t bytes) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr, "ctx is NULL");
+        c->activate();
+        if (bytes) {
+            PMC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+            PMC_HIP(hipStreamSynchronize(c->stream));
+        }
+    });
+}
+int pmc_memcpy_d2h(pmc_ctx* c, void* dst, const void* src, size_t bytes) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr, "ctx is NULL");
+        c->activate();
+        if (bytes) {
+            PMC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+            PMC_HIP(hipStreamSynchronize(c->stream));
+        }
+    });
+}
+
+int pmc_rng_seed(pmc_ctx* c, uint64_t seed, int nparts, int mypart) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr, "ctx is NULL");
+        PMC_REQUIRE(nparts >= 1 && mypart >= 0 && mypart < nparts, "pmc_rng_seed: need 0 <= mypart < nparts");
+        c->seed = seed;
+        c->nparts = nparts;
+        c->mypart = mypart;
+    });
+}
+
+int pmc_normal_fill(pmc_ctx* c, double mean, double sigma2, uint64_t first_id, uint32_t stream, int nbatch, int n,
+                    double* out, int memspace) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr && out != nullptr, "pmc_normal_fill: NULL argument");
+        PMC_REQUIRE(n >= 0 && nbatch >= 0 && sigma2 >= 0.0, "pmc_normal_fill: bad size / variance");
+        c->activate();
+        const double sigma = std::sqrt(sigma2);   // NormalDistributionSampler ctor, cpp:17-19
+        if (memspace == PMC_MEM_DEVICE) {
+            k::normal_fill(c->stream, n, nbatch, c->seed, first_id, stream, mean, sigma, out);
+        } else {
+            DevBuf<double> tmp((size_t)n * nbatch);
+            k::normal_fill(c->stream, n, nbatch, c->seed, first_id, stream, mean, sigma, tmp.p);
+            PMC_HIP(hipMemcpyAsync(out, tmp.p, sizeof(double) * n * nbatch, hipMemcpyDeviceToHost, c->stream));
+            PMC_HIP(hipStreamSynchronize(c->stream));
+        }
+    });
+}
+
+// ---- sampler -----------------------------------------------------------------------------------
+int pmc_sampler_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_sampler_level* levels, double alpha,
+                       double matern_g, int lognormal, const pmc_solver_opts* opts, pmc_sampler** out) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr && out != nullptr, "pmc_sampler_create: NULL argument");
+        *out = nullptr;
+        pmc_solver_opts o;
+        pmc_solver_opts_default(&o);
+        if (opts) o = *opts;
+        PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 1 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
+                        o.cheb_ratio_M > 1.0 && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
+                    "solver options out of range");
+        *out = new pmc_sampler(*c, nlevels, n_mc_levels, levels, alpha, matern_g, lognormal != 0, o);
+        for (int l = 0; l < (*out)->impl.nlevels; ++l) (*out)->impl.lv[l].out_size = (*out)->impl.lv[l].n_s;
+    });
+}
+void pmc_sampler_destroy(pmc_sampler* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->impl.ctx.device);
+    (void)hipStreamSynchronize(s->impl.ctx.stream);
+    delete s;
+}
+int pmc_sampler_set_projection(pmc_sampler* s, int level, int kind, const pmc_csr* Gt, const int32_t* idx,
+                               const double* inv_w, int orig_size) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr, "sampler is NULL");
+        s->impl.set_projection(level, kind, Gt, idx, inv_w, orig_size);
+    });
+}
+int pmc_sampler_num_levels(const pmc_sampler* s) { return s ? s->impl.n_mc : PMC_ERR_INVALID; }
+int pmc_sampler_xi_size(const pmc_sampler* s, int level) {
+    if (!s || level < 0 || level >= s->impl.nlevels) return PMC_ERR_INVALID;
+    return s->impl.lv[level].n_s;
+}
+int pmc_sampler_sample_size(const pmc_sampler* s, int level) {
+    if (!s || level < 0 || level >= s->impl.nlevels) return PMC_ERR_INVALID;
+    return s->impl.lv[level].out_size;
+}
+int64_t pmc_sampler_nnz(const pmc_sampler* s, int level) {
+    if (!s || level < 0 || level >= s->impl.nlevels) return PMC_ERR_INVALID;
+    return s->impl.lv[level].nnz;
+}
+int pmc_sampler_sample(pmc_sampler* s, int level, uint64_t first_id, int nbatch, double* xi, int memspace) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr, "sampler is NULL");
+        s->impl.sample(level, first_id, nbatch, xi, memspace);
+    });
+}
+int pmc_sampler_eval(pmc_sampler* s, int level, int xi_level, int nbatch, const double* xi, double* s_out,
+                     const double* init_s, int init_level, int use_init, double* embed_s_out, int memspace,
+                     pmc_stats* stats) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr, "sampler is NULL");
+        s->impl.eval(level, xi_level, nbatch, xi, s_out, init_s, init_level, use_init != 0, embed_s_out, memspace, stats);
+    });
+}
+
+// ---- Darcy ------------------------------------------------------------------------------------
+int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_level* levels, int k_divides,
+                     const pmc_solver_opts* opts, pmc_darcy** out) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr && out != nullptr, "pmc_darcy_create: NULL argument");
+        *out = nullptr;
+        pmc_solver_opts o;
+        pmc_solver_opts_default(&o);
+        if (opts) o = *opts;
+        PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 1 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
+                        o.cheb_ratio_M > 1.0 && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
+                    "solver options out of range");
+        *out = new pmc_darcy(*c, nlevels, n_mc_levels, levels, k_divides != 0, o);
+    });
+}
+void pmc_darcy_destroy(pmc_darcy* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->impl.ctx.device);
+    (void)hipStreamSynchronize(d->impl.ctx.stream);
+    delete d;
+}
+int pmc_darcy_num_dofs(const pmc_darcy* d, int level) {
+    if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
+    return d->impl.lv[level].n_u + d->impl.lv[level].n_p;
+}
+int64_t pmc_darcy_nnz(const pmc_darcy* d, int level) {
+    if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
+    return d->impl.lv[level].nnz;
+}
+int pmc_darcy_solve_fwd(pmc_darcy* d, int level, int nbatch, const double* kf, double* Q, double* C, double* sol_out,
+                        int memspace, pmc_stats* stats) {
+    return guarded([&] {
+        PMC_REQUIRE(d != nullptr, "darcy is NULL");
+        d->impl.solve_fwd(level, nbatch, kf, Q, C, sol_out, memspace, stats);
+    });
+}
+
+// ---- communicator -----------------------------------------------------------------------------
+int pmc_comm_unique_id(void* id128) {
+    return guarded([&] {
+        PMC_REQUIRE(id128 != nullptr, "id buffer is NULL");
+        UniqueId id;
+        rccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+        std::memcpy(id128, &id, sizeof(id));
+    });
+}
+int pmc_comm_init(pmc_ctx* c, const void* id128, int nranks, int rank) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr && id128 != nullptr, "pmc_comm_init: NULL argument");
+        PMC_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "pmc_comm_init: bad rank");
+        c->activate();
+        UniqueId id;
+        std::memcpy(&id, id128, sizeof(id));
+        rccl_check(rccl().CommInitRank(&c->nccl, nranks, id, rank), "ncclCommInitRank");
+        c->nranks = nranks;
+        c->rank = rank;
+    });
+}
+int pmc_comm_destroy(pmc_ctx* c) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr, "ctx is NULL");
+        if (c->nccl) {
+            c->activate();
+            rccl_check(rccl().CommDestroy(c->nccl), "ncclCommDestroy");
+            c->nccl = nullptr;
+        }
+        c->nranks = 1;
+        c->rank = 0;
+    });
+}
+int pmc_allreduce_sum_f64(pmc_ctx* c, double* host_buf, int n) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr && (host_buf != nullptr || n == 0) && n >= 0, "pmc_allreduce_sum_f64: bad argument");
+        if (n == 0 || c->nranks == 1) return;
+        PMC_REQUIRE(c->nccl != nullptr, "pmc_allreduce_sum_f64: communicator not initialised");
+        c->activate();
+        c->comm_buf.ensure((size_t)n);
+        PMC_HIP(hipMemcpyAsync(c->comm_buf.p, host_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        rccl_check(rccl().AllReduce(c->comm_buf.p, c->comm_buf.p, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->nccl,
+                                    c->stream),
+                   "ncclAllReduce");
+        PMC_HIP(hipMemcpyAsync(host_buf, c->comm_buf.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        PMC_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+}  // extern "C"

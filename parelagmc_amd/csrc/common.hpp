@@ -1,0 +1,127 @@
+// Internal C++ declarations shared by the translation units of libpmc.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pmc.h"
+
+namespace pmc {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define PMC_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            throw ::pmc::Error(PMC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_) + \
+                                                   " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+#define PMC_REQUIRE(cond, msg)                                                                 \
+    do {                                                                                       \
+        if (!(cond)) throw ::pmc::Error(PMC_ERR_INVALID, std::string(msg) + " [" #cond "]");   \
+    } while (0)
+
+void set_last_error(const std::string& msg);
+
+// ---- device memory ------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t n_) { alloc(n_); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t n_) {
+        release();
+        n = n_;
+        if (n) PMC_HIP(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+    }
+    void ensure(size_t n_) {
+        if (n_ > n) alloc(n_);
+    }
+    void upload(const T* h, size_t cnt, hipStream_t st) {
+        ensure(cnt);
+        if (cnt) PMC_HIP(hipMemcpyAsync(p, h, cnt * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+    void upload(const std::vector<T>& h, hipStream_t st) { upload(h.data(), h.size(), st); }
+    void zero(hipStream_t st) {
+        if (n) PMC_HIP(hipMemsetAsync(p, 0, n * sizeof(T), st));
+    }
+};
+
+// ---- host CSR helper ----------------------------------------------------------------------
+struct HostCsr {
+    int nrows = 0, ncols = 0;
+    std::vector<int> rowptr, colind;
+    std::vector<double> vals;
+    int64_t nnz() const { return (int64_t)colind.size(); }
+};
+HostCsr csr_from_c(const pmc_csr& c, bool need_vals, const char* what);
+HostCsr csr_transpose(const HostCsr& a);
+void csr_sort_rows(HostCsr& a);
+std::vector<double> csr_diag(const HostCsr& a);
+// vertical/horizontal assembly of the saddle-point operator [M Bt; B D] (D diagonal or absent)
+HostCsr csr_block2x2(const HostCsr& M, const HostCsr& Bt, const HostCsr& B, const double* d11);
+
+// ---- SELL-64 device matrix ---------------------------------------------------------------
+// Rows are grouped in slices of 64 (one wavefront); inside a slice entries are stored
+// column-major: slot(s, j, lane) = slice_off[s] + j*64 + lane, so a wavefront's loads of
+// values / column indices are fully coalesced 512 B / 256 B segments.  Padding slots carry the
+// row's own index with value 0.  `src` (optional) maps a slot to the CSR nonzero it came from.
+struct Sell {
+    int nrows = 0, ncols = 0, nslices = 0;
+    int64_t nnz = 0;       // algorithmic (CSR) nonzeros
+    int64_t nslots = 0;    // stored incl. padding
+    DevBuf<int> slice_off; // nslices+1
+    DevBuf<int> cols;      // nslots
+    DevBuf<double> vals;   // nslots (shared values) - empty for batched-value matrices
+    std::vector<int> h_slice_off, h_cols, h_src;  // host mirrors (h_src: slot -> csr nnz or -1)
+    // algorithmic bytes of one SpMV with this matrix: 12 nnz + 12 nrows + 8 ncols
+    double spmv_bytes() const { return 12.0 * nnz + 12.0 * nrows + 8.0 * ncols; }
+};
+void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st);
+
+// ---- context ------------------------------------------------------------------------------
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t seed = 0;
+    int nparts = 1, mypart = 0;
+    void* nccl = nullptr;          // ncclComm_t
+    int nranks = 1, rank = 0;
+    DevBuf<double> comm_buf;
+    int* h_flag = nullptr;         // pinned host word for convergence polls
+    double* h_scal = nullptr;      // pinned host scratch (>= 4096 doubles)
+    void activate() const;
+};
+
+static constexpr int kMaxBatch = 16;
+inline bool valid_batch(int nb) { return nb == 1 || nb == 2 || nb == 4 || nb == 8 || nb == 16; }
+
+}  // namespace pmc
+
+struct pmc_ctx : pmc::Ctx {};

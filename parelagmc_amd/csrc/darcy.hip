@@ -1,0 +1,385 @@
+// Mixed Darcy forward solve on the device: DarcySolver::SolveFwd (reference:
+// src/DarcySolver.cpp:416-437 -> assemble :472-520 -> solve :562-649).  The reference re-assembles
+// M(k) and REBUILDS the whole solver (incl. AMG setup) for every realization (:568-601,
+// src/DarcySolver.hpp:34); here all symbolic work is done once at create time and a realization
+// only refreshes values on fixed patterns (K12-K14 of SURVEY.md 2.3).
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <numeric>
+
+#include "handles.hpp"
+
+namespace pmc {
+
+namespace {
+
+struct Triple { int r, c, idx; double w; };
+
+// pattern + contribution lists from a bag of (row, col, idx, w) tuples; `extra` pattern entries
+// (row, col) are added with empty lists.  Output CSR has sorted columns; lists are in CSR order.
+struct Symbolic {
+    HostCsr pat;                // vals unused (zeros)
+    std::vector<int> ptr, idx;  // ptr: nnz+1
+    std::vector<double> w;
+};
+
+Symbolic build_symbolic(int n, std::vector<Triple>& t) {
+    std::sort(t.begin(), t.end(), [](const Triple& a, const Triple& b) {
+        if (a.r != b.r) return a.r < b.r;
+        if (a.c != b.c) return a.c < b.c;
+        return a.idx < b.idx;
+    });
+    Symbolic s;
+    s.pat.nrows = s.pat.ncols = n;
+    s.pat.rowptr.assign(n + 1, 0);
+    s.ptr.push_back(0);
+    size_t i = 0;
+    while (i < t.size()) {
+        size_t j = i;
+        while (j < t.size() && t[j].r == t[i].r && t[j].c == t[i].c) {
+            if (t[j].idx >= 0) { s.idx.push_back(t[j].idx); s.w.push_back(t[j].w); }
+            ++j;
+        }
+        s.pat.colind.push_back(t[i].c);
+        s.pat.rowptr[t[i].r + 1]++;
+        s.ptr.push_back((int)s.idx.size());
+        i = j;
+    }
+    std::partial_sum(s.pat.rowptr.begin(), s.pat.rowptr.end(), s.pat.rowptr.begin());
+    s.pat.vals.assign(s.pat.colind.size(), 0.0);
+    return s;
+}
+
+// re-order CSR-nnz-indexed lists into SELL slot order
+void lists_to_slots(const Sell& S, const Symbolic& sym, std::vector<int>& ptr, std::vector<int>& idx,
+                    std::vector<double>& w) {
+    ptr.assign(S.nslots + 1, 0);
+    idx.clear();
+    w.clear();
+    idx.reserve(sym.idx.size());
+    w.reserve(sym.w.size());
+    for (int64_t s = 0; s < S.nslots; ++s) {
+        const int p = S.h_src[s];
+        if (p >= 0)
+            for (int t = sym.ptr[p]; t < sym.ptr[p + 1]; ++t) { idx.push_back(sym.idx[t]); w.push_back(sym.w[t]); }
+        ptr[s + 1] = (int)idx.size();
+    }
+}
+
+std::vector<int> nnz_to_slot(const Sell& S, int64_t nnz) {
+    std::vector<int> m(nnz, -1);
+    for (int64_t s = 0; s < S.nslots; ++s)
+        if (S.h_src[s] >= 0) m[S.h_src[s]] = (int)s;
+    return m;
+}
+
+HostCsr drop_columns(const HostCsr& B, const unsigned char* mask) {
+    HostCsr o;
+    o.nrows = B.nrows;
+    o.ncols = B.ncols;
+    o.rowptr.assign(B.nrows + 1, 0);
+    for (int i = 0; i < B.nrows; ++i) {
+        for (int p = B.rowptr[i]; p < B.rowptr[i + 1]; ++p)
+            if (!mask[B.colind[p]]) { o.colind.push_back(B.colind[p]); o.vals.push_back(B.vals[p]); }
+        o.rowptr[i + 1] = (int)o.colind.size();
+    }
+    return o;
+}
+
+}  // namespace
+
+Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kdiv, const pmc_solver_opts& o)
+    : ctx(c), nlevels(nlevels_), n_mc(n_mc_), k_divides(kdiv), opts(o) {
+    PMC_REQUIRE(nlevels >= 1 && n_mc >= 1 && n_mc <= nlevels, "darcy: need 1 <= n_mc_levels <= nlevels");
+    PMC_REQUIRE(in != nullptr, "darcy: levels is NULL");
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    lv.resize(nlevels);
+    mg.L.resize(nlevels);
+    mg.smooth_degree = o.mg_smooth_degree;
+    mg.smooth_ratio = o.mg_smooth_ratio;
+    mg.coarse_degree = o.mg_coarse_degree;
+    mg.coarse_ratio = o.mg_coarse_ratio;
+
+    std::vector<Symbolic> schur(nlevels);          // own (rediscretised) Schur lists per level
+    std::vector<HostCsr> Pl(nlevels);
+    for (int l = 0; l < nlevels; ++l) {
+        const pmc_darcy_level& L = in[l];
+        DarcyLevel& d = lv[l];
+        PMC_REQUIRE(L.n_u > 0 && L.n_p > 0, "darcy level: empty block");
+        PMC_REQUIRE(L.c_ptr && L.c_elem && L.c_val && L.rhs && L.ess_mask && L.ess_data && L.obs,
+                    "darcy level: NULL array");
+        d.n_u = L.n_u;
+        d.n_p = L.n_p;
+        HostCsr Mp = csr_from_c(L.M_pattern, false, "darcy M_pattern");
+        PMC_REQUIRE(Mp.nrows == L.n_u && Mp.ncols == L.n_u, "darcy M_pattern: wrong shape");
+        const int64_t nnzM = Mp.nnz();
+        PMC_REQUIRE(L.c_ptr[0] == 0, "darcy c_ptr[0] != 0");
+        for (int64_t p = 0; p < nnzM; ++p) PMC_REQUIRE(L.c_ptr[p + 1] >= L.c_ptr[p], "darcy c_ptr not monotone");
+        const int ncontrib = L.c_ptr[nnzM];
+        for (int t = 0; t < ncontrib; ++t) PMC_REQUIRE(L.c_elem[t] >= 0 && L.c_elem[t] < L.n_p, "darcy c_elem out of range");
+        bool has_diag_all = true;
+        for (int i = 0; i < Mp.nrows && has_diag_all; ++i) {
+            bool f = false;
+            for (int p = Mp.rowptr[i]; p < Mp.rowptr[i + 1]; ++p) f |= (Mp.colind[p] == i);
+            has_diag_all = f;
+        }
+        PMC_REQUIRE(has_diag_all, "darcy M_pattern must store the diagonal");
+        sell_build(d.M, Mp, false, true, st);
+        d.slot_src.upload(d.M.h_src, st);
+        d.c_ptr.upload(L.c_ptr, nnzM + 1, st);
+        d.c_elem.upload(L.c_elem, ncontrib, st);
+        d.c_val.upload(L.c_val, ncontrib, st);
+        d.ess.upload(L.ess_mask, L.n_u, st);
+        d.ess_data.upload(L.ess_data, L.n_u, st);
+        d.rhs_u0.upload(L.rhs, L.n_u, st);
+        d.obs.upload(L.obs, L.n_u + L.n_p, st);
+
+        HostCsr Bfull = csr_from_c(L.B, true, "darcy B");
+        PMC_REQUIRE(Bfull.nrows == L.n_p && Bfull.ncols == L.n_u, "darcy B: wrong shape");
+        csr_sort_rows(Bfull);
+        // p-block of rhs_bc: rhs_p - B[:,ess] ess_data  (EliminateRowCol, DarcySolver.cpp:498)
+        std::vector<double> rp(L.n_p);
+        for (int e = 0; e < L.n_p; ++e) {
+            double s = L.rhs[L.n_u + e];
+            for (int p = Bfull.rowptr[e]; p < Bfull.rowptr[e + 1]; ++p)
+                if (L.ess_mask[Bfull.colind[p]]) s -= Bfull.vals[p] * L.ess_data[Bfull.colind[p]];
+            rp[e] = s;
+        }
+        d.rhs_p.upload(rp, st);
+        HostCsr B = drop_columns(Bfull, L.ess_mask);
+        HostCsr Bt = csr_transpose(B);
+        sell_build(d.B, B, true, false, st);
+        sell_build(d.Bt, Bt, true, false, st);
+        d.nnz = nnzM + 2 * B.nnz();
+
+        // symbolic S = B diag(M)^-1 B^T
+        std::vector<Triple> tr;
+        tr.reserve((size_t)B.nnz() * 3);
+        for (int e = 0; e < B.nrows; ++e) {
+            tr.push_back({e, e, -1, 0.0});
+            for (int p = B.rowptr[e]; p < B.rowptr[e + 1]; ++p) {
+                const int f = B.colind[p];
+                for (int q = Bt.rowptr[f]; q < Bt.rowptr[f + 1]; ++q)
+                    tr.push_back({e, Bt.colind[q], f, B.vals[p] * Bt.vals[q]});
+            }
+        }
+        schur[l] = build_symbolic(L.n_p, tr);
+        if (l + 1 < nlevels) {
+            Pl[l] = csr_from_c(L.P, true, "darcy P");
+            PMC_REQUIRE(Pl[l].nrows == L.n_p && Pl[l].ncols == in[l + 1].n_p, "darcy P: wrong shape");
+        }
+        PMC_HIP(hipStreamSynchronize(st));
+    }
+
+    // Level patterns: S_l pattern = own pattern U Galerkin image of level l-1's pattern.
+    std::vector<HostCsr> pattern(nlevels);
+    pattern[0] = schur[0].pat;
+    std::vector<Symbolic> galerkin(nlevels);   // galerkin[l+1]: lists over CSR nnz of pattern[l]
+    for (int l = 0; l + 1 < nlevels; ++l) {
+        const HostCsr& S = pattern[l];
+        const HostCsr& P = Pl[l];
+        std::vector<Triple> tr;
+        for (int e = 0; e < S.nrows; ++e)
+            for (int p = S.rowptr[e]; p < S.rowptr[e + 1]; ++p) {
+                const int e2 = S.colind[p];
+                for (int a = P.rowptr[e]; a < P.rowptr[e + 1]; ++a)
+                    for (int b = P.rowptr[e2]; b < P.rowptr[e2 + 1]; ++b)
+                        tr.push_back({P.colind[a], P.colind[b], p, 0.5 * P.vals[a] * P.vals[b]});
+            }
+        const HostCsr& own = schur[l + 1].pat;
+        for (int e = 0; e < own.nrows; ++e)
+            for (int p = own.rowptr[e]; p < own.rowptr[e + 1]; ++p) tr.push_back({e, own.colind[p], -1, 0.0});
+        galerkin[l + 1] = build_symbolic(own.nrows, tr);
+        pattern[l + 1] = galerkin[l + 1].pat;
+    }
+
+    for (int l = 0; l < nlevels; ++l) {
+        DarcyLevel& d = lv[l];
+        MgLevel& m = mg.L[l];
+        m.n = d.n_p;
+        m.bv = true;
+        m.lmax = 2.0 * 1.0001;   // weakly diagonally dominant M-matrix: spec(D^-1 S) in (0, 2]
+        sell_build(m.S, pattern[l], false, true, st);
+        m.vals_bv.alloc((size_t)m.S.nslots * kMaxBatch);
+        m.dinv.alloc((size_t)m.n * kMaxBatch);
+        // own Schur lists mapped onto the (possibly larger) level pattern
+        {
+            // map own CSR nnz -> level-pattern CSR nnz by (row, col) search
+            const HostCsr& own = schur[l].pat;
+            const HostCsr& pat = pattern[l];
+            Symbolic onpat;
+            onpat.ptr.assign(pat.nnz() + 1, 0);
+            std::vector<int> own_of(pat.nnz(), -1);
+            for (int e = 0; e < own.nrows; ++e)
+                for (int p = own.rowptr[e]; p < own.rowptr[e + 1]; ++p) {
+                    auto b = pat.colind.begin() + pat.rowptr[e], en = pat.colind.begin() + pat.rowptr[e + 1];
+                    auto it = std::lower_bound(b, en, own.colind[p]);
+                    PMC_REQUIRE(it != en && *it == own.colind[p], "darcy: Schur pattern mismatch");
+                    own_of[it - pat.colind.begin()] = p;
+                }
+            for (int64_t q = 0; q < pat.nnz(); ++q) {
+                const int p = own_of[q];
+                if (p >= 0)
+                    for (int t = schur[l].ptr[p]; t < schur[l].ptr[p + 1]; ++t) {
+                        onpat.idx.push_back(schur[l].idx[t]);
+                        onpat.w.push_back(schur[l].w[t]);
+                    }
+                onpat.ptr[q + 1] = (int)onpat.idx.size();
+            }
+            std::vector<int> ptr, idx;
+            std::vector<double> w;
+            lists_to_slots(m.S, onpat, ptr, idx, w);
+            d.s_ptr.upload(ptr, st);
+            d.s_idx.upload(idx, st);
+            d.s_w.upload(w, st);
+        }
+        // diagonal slots
+        {
+            std::vector<int> ds(m.n, -1);
+            const HostCsr& pat = pattern[l];
+            std::vector<int> n2s = nnz_to_slot(m.S, pat.nnz());
+            for (int e = 0; e < pat.nrows; ++e)
+                for (int p = pat.rowptr[e]; p < pat.rowptr[e + 1]; ++p)
+                    if (pat.colind[p] == e) ds[e] = n2s[p];
+            for (int v : ds) PMC_REQUIRE(v >= 0, "darcy: Schur pattern lacks a diagonal entry");
+            d.s_diag_slot.upload(ds, st);
+        }
+        if (l + 1 < nlevels) {
+            HostCsr Pt = csr_transpose(Pl[l]);
+            sell_build(m.P, Pl[l], true, false, st);
+            sell_build(m.Pt, Pt, true, false, st);
+        }
+        PMC_HIP(hipStreamSynchronize(st));
+    }
+    // Galerkin lists: indices are CSR nnz of the finer pattern -> convert to the finer level's SELL slots
+    for (int l = 0; l + 1 < nlevels; ++l) {
+        std::vector<int> n2s = nnz_to_slot(mg.L[l].S, pattern[l].nnz());
+        Symbolic g = galerkin[l + 1];
+        for (int& v : g.idx) v = n2s[v];
+        std::vector<int> ptr, idx;
+        std::vector<double> w;
+        lists_to_slots(mg.L[l + 1].S, g, ptr, idx, w);
+        lv[l + 1].g_ptr.upload(ptr, st);
+        lv[l + 1].g_idx.upload(idx, st);
+        lv[l + 1].g_w.upload(w, st);
+        PMC_HIP(hipStreamSynchronize(st));
+    }
+    for (int l = 0; l < nlevels; ++l) {   // host mirrors no longer needed
+        mg.L[l].S.h_src.clear(); mg.L[l].S.h_src.shrink_to_fit();
+        mg.L[l].S.h_cols.clear(); mg.L[l].S.h_cols.shrink_to_fit();
+        lv[l].M.h_src.clear(); lv[l].M.h_src.shrink_to_fit();
+        lv[l].M.h_cols.clear(); lv[l].M.h_cols.shrink_to_fit();
+    }
+}
+
+void Darcy::ensure(int level, int nb) {
+    DarcyLevel& d = lv[level];
+    const size_t n = (size_t)d.n_u + d.n_p;
+    d.coef.ensure((size_t)d.n_p * nb);
+    d.mvals.ensure((size_t)d.M.nslots * nb);
+    d.diagM.ensure((size_t)d.n_u * nb);
+    d.l1invM.ensure((size_t)d.n_u * nb);
+    d.rhs_bc.ensure(n * nb);
+    sol.ensure(n * nb);
+    cx.ensure((size_t)d.n_u * nb);
+    cd.ensure((size_t)d.n_u * nb);
+    stage_k.ensure((size_t)d.n_p * nb);
+    stage_sol.ensure(n * nb);
+    qpartial.ensure((size_t)dot_blocks((int)n) * kMaxBatch);
+    qout.ensure(kMaxBatch);
+}
+
+void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats) {
+    hipStream_t st = ctx.stream;
+    DarcyLevel& d = lv[level];
+    const int n_u = d.n_u, n_p = d.n_p, n = n_u + n_p;
+    ensure(level, nb);
+    // K12/K13: M(k), elimination, rhs_bc
+    k::darcy_coef(st, nb, n_p, k_d, k_divides, d.coef.p);
+    SellView Mpat = view(d.M);
+    k::darcy_assemble(st, nb, Mpat, d.slot_src.p, d.c_ptr.p, d.c_elem.p, d.c_val.p, d.coef.p, d.ess.p, d.ess_data.p,
+                      d.rhs_u0.p, d.mvals.p, d.diagM.p, d.l1invM.p, d.rhs_bc.p);
+    k::broadcast(st, nb, n_p, d.rhs_p.p, d.rhs_bc.p + (size_t)n_u * nb);
+    // K14: Schur complement values on the level hierarchy
+    {
+        MgLevel& m = mg.L[level];
+        k::refresh(st, nb, m.S.nslots, d.s_ptr.p, d.s_idx.p, d.s_w.p, d.diagM.p, true, m.vals_bv.p);
+        k::diag_inv(st, nb, m.n, d.s_diag_slot.p, m.vals_bv.p, m.dinv.p);
+        for (int l = level; l + 1 < nlevels; ++l) {
+            MgLevel& f = mg.L[l];
+            MgLevel& c = mg.L[l + 1];
+            DarcyLevel& dc = lv[l + 1];
+            k::refresh(st, nb, c.S.nslots, dc.g_ptr.p, dc.g_idx.p, dc.g_w.p, f.vals_bv.p, false, c.vals_bv.p);
+            k::diag_inv(st, nb, c.n, dc.s_diag_slot.p, c.vals_bv.p, c.dinv.p);
+        }
+    }
+    // operator [M(k) Bt; B 0] and block-diagonal preconditioner
+    const SellView Mv = view_bv(d.M, d.mvals.p);
+    const SellView Bv = view(d.B), Btv = view(d.Bt);
+    LinOp A;
+    A.n = n;
+    A.apply = [=](hipStream_t s, int nb_, const double* x, double* y, double* partial) {
+        k::spmm(s, nb_, Mv, x, y, false, nullptr, nullptr);
+        k::spmm(s, nb_, Btv, x + (size_t)n_u * nb_, y, true, nullptr, nullptr);
+        k::spmm(s, nb_, Bv, x, y + (size_t)n_u * nb_, false, nullptr, nullptr);
+        if (partial) k::dot(s, nb_, n, x, y, partial);
+    };
+    ChebParams cpM{opts.cheb_degree_M, 1.0, opts.cheb_ratio_M};
+    const double* l1 = d.l1invM.p;
+    double* cxp = cx.p;
+    double* cdp = cd.p;
+    Multigrid* mgp = &mg;
+    PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z) {
+        const int flips = cheb_flips(cpM.degree, true);
+        double* start = (flips % 2 == 0) ? z : cxp;
+        double* other = (flips % 2 == 0) ? cxp : z;
+        double* res = cheb_apply(s, nb_, Mv, l1, true, cpM, r, start, other, cdp, true);
+        if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
+        mgp->vcycle(s, nb_, level, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_);
+    };
+    MinresResult res = minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol.p, true, opts, work);
+    if (stats)
+        for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
+    // K15: Q = <obs, sol>
+    k::wdot(st, nb, n, d.obs.p, sol.p, qpartial.p);
+    k::reduce_final(st, nb, dot_blocks(n), qpartial.p, qout.p);
+    PMC_HIP(hipMemcpyAsync(ctx.h_scal, qout.p, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+    if (sol_d) k::deinterleave(st, nb, n, sol.p, nullptr, nullptr, false, sol_d);
+    PMC_HIP(hipStreamSynchronize(st));
+    for (int kcol = 0; kcol < nb; ++kcol) Q_host[kcol] = ctx.h_scal[kcol];
+}
+
+void Darcy::solve_fwd(int level, int nbatch, const double* kf, double* Q, double* C, double* sol_out, int memspace,
+                      pmc_stats* stats) {
+    PMC_REQUIRE(level >= 0 && level < n_mc, "SolveFwd: level out of range");
+    PMC_REQUIRE(nbatch >= 1 && kf != nullptr && Q != nullptr, "SolveFwd: bad arguments");
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    DarcyLevel& d = lv[level];
+    const size_t n = (size_t)d.n_u + d.n_p;
+    int done = 0;
+    while (done < nbatch) {
+        int nb = 16;
+        while (nb > nbatch - done) nb >>= 1;
+        const double* k_d = kf + (size_t)done * d.n_p;
+        double* sol_d = sol_out ? sol_out + (size_t)done * n : nullptr;
+        if (memspace == PMC_MEM_HOST) {
+            ensure(level, nb);
+            PMC_HIP(hipMemcpyAsync(stage_k.p, k_d, sizeof(double) * d.n_p * nb, hipMemcpyHostToDevice, st));
+            solve_chunk(level, nb, stage_k.p, Q + done, sol_d ? stage_sol.p : nullptr, stats ? stats + done : nullptr);
+            if (sol_d) {
+                PMC_HIP(hipMemcpyAsync(sol_d, stage_sol.p, sizeof(double) * n * nb, hipMemcpyDeviceToHost, st));
+                PMC_HIP(hipStreamSynchronize(st));
+            }
+        } else {
+            solve_chunk(level, nb, k_d, Q + done, sol_d, stats ? stats + done : nullptr);
+        }
+        if (C)
+            for (int b = 0; b < nb; ++b) C[done + b] = (double)n;   // global true dofs (DarcySolver.cpp:429)
+        done += nb;
+    }
+}
+
+}  // namespace pmc

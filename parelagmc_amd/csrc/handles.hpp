@@ -1,0 +1,89 @@
+// Device-side objects behind the opaque C handles.
+#pragma once
+#include "solver.hpp"
+
+namespace pmc {
+
+HostCsr schur_host(const HostCsr& B, const HostCsr& Bt, const std::vector<double>& dM, const double* diag_add);
+
+struct SamplerLevel {
+    int n_u = 0, n_s = 0;
+    int64_t nnz = 0;
+    Sell A;                 // [M Bt; B -aW]
+    Sell M;
+    DevBuf<double> dinvM;   // 1 / l1 row sums of M
+    DevBuf<double> w_sqrt;
+    int proj = PMC_PROJ_NONE;
+    int out_size = 0;
+    Sell Gt;
+    DevBuf<int> gather;
+    DevBuf<double> inv_w;
+};
+
+struct Sampler {
+    Ctx& ctx;
+    int nlevels, n_mc;
+    double alpha, g;
+    bool lognormal;
+    pmc_solver_opts opts;
+    std::vector<SamplerLevel> lv;
+    Multigrid mg;
+    MinresWork work;
+    DevBuf<double> rhs, sol, tA, tB, cx, cd, stage_in, stage_out, stage_emb;
+
+    Sampler(Ctx& c, int nlevels, int n_mc, const pmc_sampler_level* in, double alpha, double g, bool lognormal,
+            const pmc_solver_opts& o);
+    void set_projection(int level, int kind, const pmc_csr* Gt, const int32_t* idx, const double* inv_w, int orig_size);
+    void sample(int level, uint64_t first_id, int nbatch, double* xi, int memspace);
+    void eval(int level, int xi_level, int nbatch, const double* xi, double* s_out, const double* init_s, int init_level,
+              bool use_init, double* emb_out, int memspace, pmc_stats* stats);
+
+  private:
+    void ensure(int level, int nb);
+    void eval_chunk(int level, int xi_level, int nb, const double* xi_d, double* s_d, const double* init_d,
+                    int init_level, bool use_init, double* emb_d, pmc_stats* stats);
+};
+
+struct DarcyLevel {
+    int n_u = 0, n_p = 0, n_coef = 0;
+    int64_t nnz = 0;
+    Sell M;                          // pattern only; values are per-realization
+    DevBuf<int> slot_src, c_ptr, c_elem;
+    DevBuf<double> c_val;
+    Sell B, Bt;                      // shared +-1 values (essential columns/rows removed)
+    DevBuf<unsigned char> ess;
+    DevBuf<double> ess_data, rhs_u0, rhs_p, obs;
+    // Schur complement refresh: S(k) = B diag(M(k))^-1 B^T on the fixed pattern of mg.L[level].S
+    DevBuf<int> s_ptr, s_idx;        // per SELL slot of S: faces contributing
+    DevBuf<double> s_w;
+    DevBuf<int> s_diag_slot;         // per row: SELL slot of the diagonal entry
+    // Galerkin coarse operator refresh: S_{l+1} = 1/2 P^T S_l P (lists of fine SELL slots per coarse slot)
+    DevBuf<int> g_ptr, g_idx;
+    DevBuf<double> g_w;
+    // per-realization values
+    DevBuf<double> coef, mvals, diagM, l1invM, rhs_bc;
+};
+
+struct Darcy {
+    Ctx& ctx;
+    int nlevels, n_mc;
+    bool k_divides;
+    pmc_solver_opts opts;
+    std::vector<DarcyLevel> lv;
+    Multigrid mg;                    // batched values
+    MinresWork work;
+    DevBuf<double> sol, cx, cd, stage_k, stage_sol, qpartial, qout;
+
+    Darcy(Ctx& c, int nlevels, int n_mc, const pmc_darcy_level* in, bool k_divides, const pmc_solver_opts& o);
+    void solve_fwd(int level, int nbatch, const double* k, double* Q, double* C, double* sol_out, int memspace,
+                   pmc_stats* stats);
+
+  private:
+    void ensure(int level, int nb);
+    void solve_chunk(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats);
+};
+
+}  // namespace pmc
+
+struct pmc_sampler { pmc::Sampler impl; template <class... A> explicit pmc_sampler(A&&... a) : impl(std::forward<A>(a)...) {} };
+struct pmc_darcy { pmc::Darcy impl; template <class... A> explicit pmc_darcy(A&&... a) : impl(std::forward<A>(a)...) {} };

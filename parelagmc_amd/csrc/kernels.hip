@@ -1,0 +1,858 @@
+// CDNA4 (gfx950) kernels of the ParELAGMC hot path.  fp64 values, int32 indices, HBM-bound:
+// no MFMA (<= 0.17 flop/byte), 64-wide wavefronts, SELL-64 operators so that every matrix load
+// of a wavefront is one contiguous 512 B (values) / 256 B (columns) segment.
+//
+// Kernel <-> reference operation:
+//   sell_spmm / sell_residual / sell_cheb_step : K5 block saddle-point SpMV, K7 smoother on M,
+//        K8 V-cycle smoothing/residual/transfer, K3/K4 restriction/prolongation, K11 projection
+//   minres_* / lincomb3 / dot                  : K6 MINRES vector operations
+//   normal_fill                                : K1 NormalDistributionSampler
+//   rhs_interleave / finish_field              : K2 white-noise RHS, K9 exp, K10 gather
+//   darcy_*                                    : K12-K15 per-sample M(k), BC elimination, Schur refresh, QoI
+#include "kernels.hpp"
+
+namespace pmc {
+
+static constexpr int kBlock = 256;
+static constexpr int kWave = 64;
+
+int dot_blocks(int nrows) { return (nrows + kBlock - 1) / kBlock; }
+
+template <int NB>
+struct Vec;  // helper to move NB contiguous doubles with the widest loads
+template <>
+struct Vec<1> { using T = double; };
+
+template <int NB>
+__device__ __forceinline__ void load_row(const double* __restrict__ p, double (&v)[NB]) {
+    if constexpr (NB == 1) {
+        v[0] = p[0];
+    } else {
+        const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+        for (int i = 0; i < NB / 2; ++i) {
+            double2 t = q[i];
+            v[2 * i] = t.x;
+            v[2 * i + 1] = t.y;
+        }
+    }
+}
+template <int NB>
+__device__ __forceinline__ void store_row(double* __restrict__ p, const double (&v)[NB]) {
+    if constexpr (NB == 1) {
+        p[0] = v[0];
+    } else {
+        double2* q = reinterpret_cast<double2*>(p);
+#pragma unroll
+        for (int i = 0; i < NB / 2; ++i) q[i] = make_double2(v[2 * i], v[2 * i + 1]);
+    }
+}
+
+// Block-wide sum of NB per-thread values -> partial[blockIdx.x*NB + k].  Deterministic:
+// fixed shuffle tree inside a wavefront, fixed order across the 4 wavefronts.
+template <int NB>
+__device__ __forceinline__ void block_reduce_store(double (&p)[NB], double* __restrict__ partial) {
+    __shared__ double lds[kBlock / kWave][NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        double v = p[k];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+        p[k] = v;
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) lds[wave][k] = p[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) s += lds[w][threadIdx.x];
+        partial[(size_t)blockIdx.x * NB + threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SELL-64 sparse matrix times interleaved multi-vector.  One lane per row, NB accumulators.
+// MODE 0: y = Ax   1: y += Ax   2: y = r - Ax   3: Chebyshev step (d = a d + b dinv (r - Ax); xo = x + d)
+template <int NB, bool BV>
+__device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_off, const int* __restrict__ cols,
+                                                 const double* __restrict__ vals, const double* __restrict__ x,
+                                                 int slice, int lane, double (&acc)[NB]) {
+    const int off = slice_off[slice];
+    const int width = (slice_off[slice + 1] - off) >> 6;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc[k] = 0.0;
+    int slot = off + lane;
+#pragma unroll 4
+    for (int j = 0; j < width; ++j, slot += kWave) {
+        const int c = cols[slot];
+        double xv[NB];
+        load_row<NB>(x + (size_t)c * NB, xv);
+        if constexpr (BV) {
+            double av[NB];
+            load_row<NB>(vals + (size_t)slot * NB, av);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) acc[k] = fma(av[k], xv[k], acc[k]);
+        } else {
+            const double a = vals[slot];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) acc[k] = fma(a, xv[k], acc[k]);
+        }
+    }
+}
+
+template <int NB, bool BV, int MODE, bool DOT>
+__global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+                                                           const int* __restrict__ cols,
+                                                           const double* __restrict__ vals,
+                                                           const double* __restrict__ x, double* __restrict__ y,
+                                                           const double* __restrict__ r,
+                                                           const double* __restrict__ dot_with,
+                                                           double* __restrict__ partial) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    const int slice = row >> 6, lane = row & 63;
+    double acc[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc[k] = 0.0;
+    if (slice < nslices) sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
+    const bool live = row < nrows;
+    if (live) {
+        double* yr = y + (size_t)row * NB;
+        if constexpr (MODE == 1) {
+            double old[NB];
+            load_row<NB>(yr, old);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) acc[k] += old[k];
+        } else if constexpr (MODE == 2) {
+            double rv[NB];
+            load_row<NB>(r + (size_t)row * NB, rv);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) acc[k] = rv[k] - acc[k];
+        }
+        store_row<NB>(yr, acc);
+    }
+    if constexpr (DOT) {
+        double p[NB];
+        if (live) {
+            double w[NB];
+            load_row<NB>(dot_with + (size_t)row * NB, w);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) p[k] = w[k] * acc[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) p[k] = 0.0;
+        }
+        block_reduce_store<NB>(p, partial);
+    }
+}
+
+template <int NB, bool BV>
+__global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+                                                           const int* __restrict__ cols,
+                                                           const double* __restrict__ vals,
+                                                           const double* __restrict__ dinv,
+                                                           const double* __restrict__ r,
+                                                           const double* __restrict__ xin, double* __restrict__ d,
+                                                           double* __restrict__ xout, double a, double b) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    const int slice = row >> 6, lane = row & 63;
+    if (slice >= nslices) return;
+    double acc[NB];
+    sell_row_product<NB, BV>(slice_off, cols, vals, xin, slice, lane, acc);
+    if (row >= nrows) return;
+    double rv[NB], dv[NB], xv[NB], di[NB];
+    load_row<NB>(r + (size_t)row * NB, rv);
+    load_row<NB>(xin + (size_t)row * NB, xv);
+    if (a != 0.0) {
+        load_row<NB>(d + (size_t)row * NB, dv);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) dv[k] = 0.0;
+    }
+    if constexpr (BV) {
+        load_row<NB>(dinv + (size_t)row * NB, di);
+    } else {
+        const double s = dinv[row];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) di[k] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        dv[k] = a * dv[k] + b * di[k] * (rv[k] - acc[k]);
+        xv[k] += dv[k];
+    }
+    store_row<NB>(d + (size_t)row * NB, dv);
+    store_row<NB>(xout + (size_t)row * NB, xv);
+}
+
+template <int NB, bool BV>
+__global__ __launch_bounds__(kBlock) void cheb_first_kernel(int n, const double* __restrict__ dinv,
+                                                            const double* __restrict__ r, double* __restrict__ d,
+                                                            double* __restrict__ x, double b) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    double rv[NB], di[NB];
+    load_row<NB>(r + (size_t)row * NB, rv);
+    if constexpr (BV) {
+        load_row<NB>(dinv + (size_t)row * NB, di);
+    } else {
+        const double s = dinv[row];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) di[k] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) rv[k] = b * di[k] * rv[k];
+    store_row<NB>(d + (size_t)row * NB, rv);
+    store_row<NB>(x + (size_t)row * NB, rv);
+}
+
+template <int NB>
+__global__ __launch_bounds__(kBlock) void dot_kernel(int n, const double* __restrict__ a, const double* __restrict__ b,
+                                                     double* __restrict__ partial) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    double p[NB];
+    if (row < n) {
+        double av[NB], bv[NB];
+        load_row<NB>(a + (size_t)row * NB, av);
+        load_row<NB>(b + (size_t)row * NB, bv);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) p[k] = av[k] * bv[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) p[k] = 0.0;
+    }
+    block_reduce_store<NB>(p, partial);
+}
+
+template <int NB>
+__global__ __launch_bounds__(kBlock) void lincomb3_kernel(int n, const double* __restrict__ c0,
+                                                          const double* __restrict__ a, const double* __restrict__ c1,
+                                                          const double* __restrict__ b, const double* __restrict__ c2,
+                                                          double* __restrict__ y) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    double av[NB], bv[NB], yv[NB];
+    load_row<NB>(a + (size_t)row * NB, av);
+    load_row<NB>(b + (size_t)row * NB, bv);
+    load_row<NB>(y + (size_t)row * NB, yv);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) yv[k] = c0[k] * av[k] + c1[k] * bv[k] + c2[k] * yv[k];
+    store_row<NB>(y + (size_t)row * NB, yv);
+}
+
+template <int NB>
+__global__ __launch_bounds__(kBlock) void minres_wx_kernel(int n, const double* __restrict__ c0,
+                                                           const double* __restrict__ u, const double* __restrict__ c1,
+                                                           double* __restrict__ w0, const double* __restrict__ c2,
+                                                           const double* __restrict__ w1, const double* __restrict__ c3,
+                                                           double* __restrict__ x) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    double uv[NB], w0v[NB], w1v[NB], xv[NB];
+    load_row<NB>(u + (size_t)row * NB, uv);
+    load_row<NB>(w0 + (size_t)row * NB, w0v);
+    load_row<NB>(w1 + (size_t)row * NB, w1v);
+    load_row<NB>(x + (size_t)row * NB, xv);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        w0v[k] = c0[k] * uv[k] + c1[k] * w0v[k] + c2[k] * w1v[k];
+        xv[k] += c3[k] * w0v[k];
+    }
+    store_row<NB>(w0 + (size_t)row * NB, w0v);
+    store_row<NB>(x + (size_t)row * NB, xv);
+}
+
+__global__ void fill_kernel(size_t n, double* __restrict__ x, double v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) x[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// MINRES scalar recurrences.  One block; column k handled by the threads of wavefront (k % 4)
+// in turn.  Restates the preconditioned MINRES of Paige & Saunders in the form MFEM's
+// MINRESSolver uses (normalised Lanczos vectors); the vectors are kept UNnormalised here and
+// the 1/beta factors are folded into the update coefficients.
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ partial, int nblocks, int nb, int k) {
+    // all 256 threads participate, fixed order
+    __shared__ double lds[kBlock / kWave];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) s += partial[(size_t)b * nb + k];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
+    __syncthreads();
+    if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = s;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) t += lds[w];
+    return t;
+}
+
+__global__ __launch_bounds__(kBlock) void minres_init_kernel(k::MinresState* st, const double* __restrict__ partial,
+                                                             int nblocks, int nb, double rel_tol, double abs_tol) {
+    for (int k = 0; k < nb; ++k) {
+        const double d = reduce_partials(partial, nblocks, nb, k);
+        if (threadIdx.x == 0) {
+            const double beta = d > 0.0 ? sqrt(d) : 0.0;
+            st->beta[k] = beta;
+            st->beta_old[k] = 1.0;
+            st->eta[k] = beta;
+            st->eta0[k] = beta;
+            st->gamma0[k] = st->gamma1[k] = 1.0;
+            st->sigma0[k] = st->sigma1[k] = 0.0;
+            st->goal[k] = fmax(rel_tol * beta, abs_tol);
+            st->iters[k] = 0;
+            st->flag[k] = (d < 0.0 || d != d) ? -1 : 0;   // preconditioner not SPD / NaN
+            st->active[k] = (beta > st->goal[k] && st->flag[k] == 0) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int na = 0;
+        for (int k = 0; k < nb; ++k) na += st->active[k];
+        st->n_active = na;
+        st->it = 0;
+    }
+}
+
+// after q = A u1 and d1 = <u1, q>
+__global__ __launch_bounds__(kBlock) void minres_scal1_kernel(k::MinresState* st, const double* __restrict__ partial,
+                                                              int nblocks, int nb) {
+    for (int k = 0; k < nb; ++k) {
+        const double d1 = reduce_partials(partial, nblocks, nb, k);
+        if (threadIdx.x == 0) {
+            if (st->active[k]) {
+                const double beta = st->beta[k];
+                const double ib = 1.0 / beta;
+                const double alpha = d1 * ib * ib;
+                st->alpha[k] = alpha;
+                st->cV[0][k] = ib;                       // q / beta
+                st->cV[1][k] = -alpha * ib;              // - alpha v1
+                st->cV[2][k] = -beta / st->beta_old[k];  // - beta v0
+                st->delta[k] = st->gamma1[k] * alpha - st->gamma0[k] * st->sigma1[k] * beta;
+                st->rho3[k] = st->sigma0[k] * beta;
+                st->rho2[k] = st->sigma1[k] * alpha + st->gamma0[k] * st->gamma1[k] * beta;
+            } else {
+                st->cV[0][k] = st->cV[1][k] = st->cV[2][k] = 0.0;
+            }
+        }
+    }
+}
+
+// after z_new = prec(v_new) and d2 = <v_new, z_new>
+__global__ __launch_bounds__(kBlock) void minres_scal2_kernel(k::MinresState* st, const double* __restrict__ partial,
+                                                              int nblocks, int nb) {
+    for (int k = 0; k < nb; ++k) {
+        const double d2 = reduce_partials(partial, nblocks, nb, k);
+        if (threadIdx.x == 0) {
+            if (st->active[k]) {
+                if (d2 < 0.0 || d2 != d2) st->flag[k] = -1;
+                const double beta_new = d2 > 0.0 ? sqrt(d2) : 0.0;
+                const double delta = st->delta[k];
+                const double rho1 = hypot(delta, beta_new);
+                const double ir = rho1 > 0.0 ? 1.0 / rho1 : 0.0;
+                st->cW[0][k] = ir / st->beta[k];
+                st->cW[1][k] = -st->rho3[k] * ir;
+                st->cW[2][k] = -st->rho2[k] * ir;
+                st->gamma0[k] = st->gamma1[k];
+                st->gamma1[k] = delta * ir;
+                st->cW[3][k] = st->gamma1[k] * st->eta[k];
+                st->sigma0[k] = st->sigma1[k];
+                st->sigma1[k] = beta_new * ir;
+                st->eta[k] = -st->sigma1[k] * st->eta[k];
+                st->beta_old[k] = st->beta[k];
+                st->beta[k] = beta_new;
+                st->iters[k] = st->it + 1;
+                if (fabs(st->eta[k]) <= st->goal[k] || beta_new == 0.0 || st->flag[k] != 0) st->active[k] = 0;
+            } else {
+                st->cW[0][k] = st->cW[1][k] = st->cW[2][k] = st->cW[3][k] = 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int na = 0;
+        for (int k = 0; k < nb; ++k) na += st->active[k];
+        st->n_active = na;
+        st->it += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 + AS241 inverse normal CDF (bit-level twin: oracle/rng_oracle.py)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    c[0] = hi1 ^ c[1] ^ k0;
+    c[1] = lo1;
+    c[2] = hi0 ^ c[3] ^ k1;
+    c[3] = lo0;
+}
+
+__device__ __forceinline__ double u01_open(uint32_t hi, uint32_t lo) {
+    const uint64_t m = ((uint64_t)(hi >> 5) << 26) + (uint64_t)(lo >> 6);
+    return ((double)m + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+#pragma clang fp contract(off)
+__device__ double inv_normal_cdf(double p) {
+    const double q = p - 0.5;
+    if (fabs(q) <= 0.425) {
+        const double r = 0.180625 - q * q;
+        const double num = (((((((2.5090809287301226727e+3 * r + 3.3430575583588128105e+4) * r +
+                                 6.7265770927008700853e+4) * r + 4.5921953931549871457e+4) * r +
+                               1.3731693765509461125e+4) * r + 1.9715909503065514427e+3) * r +
+                             1.3314166789178437745e+2) * r + 3.3871328727963666080e0);
+        const double den = (((((((5.2264952788528545610e+3 * r + 2.8729085735721942674e+4) * r +
+                                 3.9307895800092710610e+4) * r + 2.1213794301586595867e+4) * r +
+                               5.3941960214247511077e+3) * r + 6.8718700749205790830e+2) * r +
+                             4.2313330701600911252e+1) * r + 1.0);
+        return q * num / den;
+    }
+    double r = q < 0.0 ? p : 1.0 - p;
+    r = sqrt(-log(r));
+    double val;
+    if (r <= 5.0) {
+        r -= 1.6;
+        const double num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r +
+                                 2.41780725177450611770e-1) * r + 1.27045825245236838258e0) * r +
+                               3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r +
+                             4.63033784615654529590e0) * r + 1.42343711074968357734e0);
+        const double den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r +
+                                 1.51986665636164571966e-2) * r + 1.48103976427480074590e-1) * r +
+                               6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r +
+                             2.05319162663775882187e0) * r + 1.0);
+        val = num / den;
+    } else {
+        r -= 5.0;
+        const double num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r +
+                                 1.24266094738807843860e-3) * r + 2.65321895265761230930e-2) * r +
+                               2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r +
+                             5.46378491116411436990e0) * r + 6.65790464350110377720e0);
+        const double den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r +
+                                 1.84631831751005468180e-5) * r + 7.86869131145613259100e-4) * r +
+                               1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r +
+                             5.99832206555887937690e-1) * r + 1.0);
+        val = num / den;
+    }
+    return q < 0.0 ? -val : val;
+}
+#pragma clang fp contract(fast)
+
+// out[b*n + i], sample-major.  One thread per (pair of elements, realization).
+__global__ __launch_bounds__(kBlock) void normal_fill_kernel(int n, int nbatch, uint64_t seed, uint64_t first_id,
+                                                             uint32_t stream, double mean, double sigma,
+                                                             double* __restrict__ out) {
+    const int npair = (n + 1) >> 1;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const int b = blockIdx.y;
+    if (j >= npair || b >= nbatch) return;
+    const uint64_t sid = first_id + (uint64_t)b;
+    uint32_t c[4] = {(uint32_t)j, (uint32_t)sid, (uint32_t)(sid >> 32), stream};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    double* o = out + (size_t)b * n + 2 * (size_t)j;
+    o[0] = mean + sigma * inv_normal_cdf(u01_open(c[0], c[1]));
+    if (2 * j + 1 < n) o[1] = mean + sigma * inv_normal_cdf(u01_open(c[2], c[3]));
+}
+
+// ------------------------------------------------------------------------------------------
+// layout changes fused with the sampler's pointwise maps
+// out[i*NB + k] = scale * in[k*n + i] * (w ? w[i] : 1)        (K2: rhs_s = -g W^{1/2} xi)
+template <int NB>
+__global__ __launch_bounds__(kBlock) void interleave_kernel(int n, const double* __restrict__ in,
+                                                            const double* __restrict__ w, double scale,
+                                                            double* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double f = w ? scale * w[i] : scale;
+    double v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) v[k] = f * in[(size_t)k * n + i];
+    store_row<NB>(out + (size_t)i * NB, v);
+}
+
+// out[k*m + i] = post( rowscale[i] * in[idx ? idx[i] : i][k] ),  post = exp if do_exp   (K9, K10)
+template <int NB>
+__global__ __launch_bounds__(kBlock) void deinterleave_kernel(int m, const double* __restrict__ in,
+                                                              const int* __restrict__ idx,
+                                                              const double* __restrict__ rowscale, int do_exp,
+                                                              double* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const int src = idx ? idx[i] : i;
+    double v[NB];
+    load_row<NB>(in + (size_t)src * NB, v);
+    const double f = rowscale ? rowscale[i] : 1.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        double t = f * v[k];
+        if (do_exp) t = exp(t);
+        out[(size_t)k * m + i] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Darcy per-sample numeric refresh (K12-K14), batched values: arrays are [slot][NB].
+// coef[e*NB+k] = 1/k or k.
+template <int NB>
+__global__ __launch_bounds__(kBlock) void darcy_coef_kernel(int n, const double* __restrict__ kfield, int k_divides,
+                                                            double* __restrict__ coef) {
+    // kfield sample-major [NB][n] -> interleaved coefficient
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const double t = kfield[(size_t)k * n + i];
+        v[k] = k_divides ? 1.0 / t : t;
+    }
+    store_row<NB>(coef + (size_t)i * NB, v);
+}
+
+// One lane per row of the SELL-stored M: raw values from element contributions, essential
+// row/col elimination (DarcySolver.cpp:487-498), rhs fix-up, diagonal and l1 row sums.
+template <int NB>
+__global__ __launch_bounds__(kBlock) void darcy_assemble_kernel(
+    int nrows, int nslices, const int* __restrict__ slice_off, const int* __restrict__ cols,
+    const int* __restrict__ slot_src, const int* __restrict__ c_ptr, const int* __restrict__ c_elem,
+    const double* __restrict__ c_val, const double* __restrict__ coef, const unsigned char* __restrict__ ess,
+    const double* __restrict__ ess_data, const double* __restrict__ rhs0, double* __restrict__ mvals,
+    double* __restrict__ diag, double* __restrict__ l1inv, double* __restrict__ rhs_bc) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    const int slice = row >> 6, lane = row & 63;
+    if (slice >= nslices) return;
+    const int off = slice_off[slice];
+    const int width = (slice_off[slice + 1] - off) >> 6;
+    const bool live = row < nrows;
+    const bool row_ess = live && ess[row];
+    double dg[NB], l1[NB], fix[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) dg[k] = l1[k] = fix[k] = 0.0;
+    int slot = off + lane;
+    for (int j = 0; j < width; ++j, slot += kWave) {
+        const int p = slot_src[slot];
+        double v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) v[k] = 0.0;
+        const int c = cols[slot];
+        if (p >= 0) {
+            for (int t = c_ptr[p]; t < c_ptr[p + 1]; ++t) {
+                const double cv = c_val[t];
+                double ce[NB];
+                load_row<NB>(coef + (size_t)c_elem[t] * NB, ce);
+#pragma unroll
+                for (int k = 0; k < NB; ++k) v[k] = fma(ce[k], cv, v[k]);
+            }
+            const bool col_ess = ess[c];
+            if (row_ess || col_ess) {
+                if (col_ess && !row_ess) {
+                    const double dval = ess_data[c];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) fix[k] = fma(v[k], dval, fix[k]);
+                }
+                const double e = (c == row) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) v[k] = e;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                l1[k] += fabs(v[k]);
+                if (c == row) dg[k] = v[k];
+            }
+        }
+        store_row<NB>(mvals + (size_t)slot * NB, v);
+    }
+    if (!live) return;
+    double rb[NB];
+    const double r0 = row_ess ? ess_data[row] : rhs0[row];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        rb[k] = row_ess ? r0 : r0 - fix[k];
+        l1[k] = 1.0 / l1[k];
+    }
+    store_row<NB>(diag + (size_t)row * NB, dg);
+    store_row<NB>(l1inv + (size_t)row * NB, l1);
+    store_row<NB>(rhs_bc + (size_t)row * NB, rb);
+}
+
+// Generic numeric refresh of a derived matrix on a fixed pattern:
+//   out[slot][k] = sum_{t in ptr[slot]..ptr[slot+1]} w[t] * f(src[idx[t]][k]),  f = 1/x if recip else x
+// used for S = B diag(M)^-1 B^T (recip, src = diag(M)) and for coarse S_c = 1/2 P^T S P.
+// Also produces 1/diag of the derived matrix when dinv != nullptr (is_diag[slot] marks diagonal slots).
+template <int NB>
+__global__ __launch_bounds__(kBlock) void refresh_kernel(int64_t nslots, const int* __restrict__ ptr,
+                                                         const int* __restrict__ idx, const double* __restrict__ w,
+                                                         const double* __restrict__ src, int recip,
+                                                         double* __restrict__ out) {
+    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= nslots) return;
+    double acc[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc[k] = 0.0;
+    for (int t = ptr[slot]; t < ptr[slot + 1]; ++t) {
+        double s[NB];
+        load_row<NB>(src + (size_t)idx[t] * NB, s);
+        const double wt = w[t];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc[k] = fma(wt, recip ? 1.0 / s[k] : s[k], acc[k]);
+    }
+    store_row<NB>(out + (size_t)slot * NB, acc);
+}
+
+// dinv[row][k] = 1 / vals[diag_slot[row]][k]
+template <int NB>
+__global__ __launch_bounds__(kBlock) void diag_inv_kernel(int n, const int* __restrict__ diag_slot,
+                                                          const double* __restrict__ vals, double* __restrict__ dinv) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    double v[NB];
+    load_row<NB>(vals + (size_t)diag_slot[row] * NB, v);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) v[k] = 1.0 / v[k];
+    store_row<NB>(dinv + (size_t)row * NB, v);
+}
+
+// partial sums of <w, x[:,k]> with a shared (non-batched) weight vector w   (K15 QoI)
+template <int NB>
+__global__ __launch_bounds__(kBlock) void wdot_kernel(int n, const double* __restrict__ w, const double* __restrict__ x,
+                                                      double* __restrict__ partial) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    double p[NB];
+    if (row < n) {
+        double xv[NB];
+        load_row<NB>(x + (size_t)row * NB, xv);
+        const double ww = w[row];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) p[k] = ww * xv[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) p[k] = 0.0;
+    }
+    block_reduce_store<NB>(p, partial);
+}
+
+// out[k] = sum_b partial[b*nb+k]   (single block)
+__global__ __launch_bounds__(kBlock) void reduce_final_kernel(const double* __restrict__ partial, int nblocks, int nb,
+                                                              double* __restrict__ out) {
+    for (int k = 0; k < nb; ++k) {
+        const double s = reduce_partials(partial, nblocks, nb, k);
+        if (threadIdx.x == 0) out[k] = s;
+    }
+}
+
+// out[i*NB+k] = a[i] (broadcast a shared vector into an interleaved batch)
+template <int NB>
+__global__ __launch_bounds__(kBlock) void broadcast_kernel(int n, const double* __restrict__ a, double* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double v[NB];
+    const double t = a[i];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) v[k] = t;
+    store_row<NB>(out + (size_t)i * NB, v);
+}
+
+// ==========================================================================================
+// launchers
+#define PMC_DISPATCH_NB(nb, ...)                                          \
+    switch (nb) {                                                         \
+        case 1: { constexpr int NB = 1; __VA_ARGS__; } break;             \
+        case 2: { constexpr int NB = 2; __VA_ARGS__; } break;             \
+        case 4: { constexpr int NB = 4; __VA_ARGS__; } break;             \
+        case 8: { constexpr int NB = 8; __VA_ARGS__; } break;             \
+        case 16: { constexpr int NB = 16; __VA_ARGS__; } break;           \
+        default: throw Error(PMC_ERR_INTERNAL, "unsupported batch width"); \
+    }
+
+static inline dim3 grid_rows(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+static inline void check_launch() { PMC_HIP(hipGetLastError()); }
+
+namespace k {
+
+void spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate, double* dot_partial,
+          const double* dot_with) {
+    if (A.nrows == 0) return;
+    const dim3 g = grid_rows(A.nslices * kWave);
+    PMC_DISPATCH_NB(nb, {
+        if (A.bv) {
+            if (dot_partial)
+                sell_spmm_kernel<NB, true, 0, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+            else if (accumulate)
+                sell_spmm_kernel<NB, true, 1, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+            else
+                sell_spmm_kernel<NB, true, 0, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+        } else {
+            if (dot_partial)
+                sell_spmm_kernel<NB, false, 0, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+            else if (accumulate)
+                sell_spmm_kernel<NB, false, 1, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+            else
+                sell_spmm_kernel<NB, false, 0, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+        }
+    });
+    check_launch();
+}
+
+void residual(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out) {
+    if (A.nrows == 0) return;
+    const dim3 g = grid_rows(A.nslices * kWave);
+    PMC_DISPATCH_NB(nb, {
+        if (A.bv)
+            sell_spmm_kernel<NB, true, 2, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, out, r, nullptr, nullptr);
+        else
+            sell_spmm_kernel<NB, false, 2, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, out, r, nullptr, nullptr);
+    });
+    check_launch();
+}
+
+void cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
+               const double* xin, double* d, double* xout, double a, double b) {
+    if (A.nrows == 0) return;
+    if (A.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "cheb_step: value/diagonal batching mismatch");
+    const dim3 g = grid_rows(A.nslices * kWave);
+    PMC_DISPATCH_NB(nb, {
+        if (A.bv)
+            sell_cheb_kernel<NB, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b);
+        else
+            sell_cheb_kernel<NB, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b);
+    });
+    check_launch();
+}
+
+void cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d, double* x,
+                double b) {
+    if (n == 0) return;
+    PMC_DISPATCH_NB(nb, {
+        if (dinv_bv)
+            cheb_first_kernel<NB, true><<<grid_rows(n), kBlock, 0, st>>>(n, dinv, r, d, x, b);
+        else
+            cheb_first_kernel<NB, false><<<grid_rows(n), kBlock, 0, st>>>(n, dinv, r, d, x, b);
+    });
+    check_launch();
+}
+
+void dot(hipStream_t st, int nb, int n, const double* a, const double* b, double* partial) {
+    PMC_DISPATCH_NB(nb, { dot_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, a, b, partial); });
+    check_launch();
+}
+
+void wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial) {
+    PMC_DISPATCH_NB(nb, { wdot_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, w, x, partial); });
+    check_launch();
+}
+
+void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, double* out) {
+    reduce_final_kernel<<<1, kBlock, 0, st>>>(partial, nblocks, nb, out);
+    check_launch();
+}
+
+void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b,
+              const double* c2, double* y) {
+    PMC_DISPATCH_NB(nb, { lincomb3_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, c0, a, c1, b, c2, y); });
+    check_launch();
+}
+
+void minres_wx(hipStream_t st, int nb, int n, const double* c0, const double* u, const double* c1, double* w0,
+               const double* c2, const double* w1, const double* c3, double* x) {
+    PMC_DISPATCH_NB(nb, { minres_wx_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, c0, u, c1, w0, c2, w1, c3, x); });
+    check_launch();
+}
+
+void fill(hipStream_t st, size_t n, double* x, double v) {
+    if (n == 0) return;
+    if (v == 0.0) {
+        PMC_HIP(hipMemsetAsync(x, 0, n * sizeof(double), st));
+        return;
+    }
+    const unsigned g = (unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, 2048);
+    fill_kernel<<<g, kBlock, 0, st>>>(n, x, v);
+    check_launch();
+}
+
+void copy(hipStream_t st, size_t n, const double* src, double* dst) {
+    if (n && src != dst) PMC_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+}
+
+void minres_init(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks, double rel_tol,
+                 double abs_tol) {
+    minres_init_kernel<<<1, kBlock, 0, st>>>(s, partial, nblocks, nb, rel_tol, abs_tol);
+    check_launch();
+}
+void minres_scal1(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks) {
+    minres_scal1_kernel<<<1, kBlock, 0, st>>>(s, partial, nblocks, nb);
+    check_launch();
+}
+void minres_scal2(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks) {
+    minres_scal2_kernel<<<1, kBlock, 0, st>>>(s, partial, nblocks, nb);
+    check_launch();
+}
+
+void normal_fill(hipStream_t st, int n, int nbatch, uint64_t seed, uint64_t first_id, uint32_t stream, double mean,
+                 double sigma, double* out) {
+    if (n == 0 || nbatch == 0) return;
+    const int npair = (n + 1) / 2;
+    dim3 g((unsigned)((npair + kBlock - 1) / kBlock), (unsigned)nbatch);
+    normal_fill_kernel<<<g, kBlock, 0, st>>>(n, nbatch, seed, first_id, stream, mean, sigma, out);
+    check_launch();
+}
+
+void interleave(hipStream_t st, int nb, int n, const double* in, const double* w, double scale, double* out) {
+    PMC_DISPATCH_NB(nb, { interleave_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, in, w, scale, out); });
+    check_launch();
+}
+
+void deinterleave(hipStream_t st, int nb, int m, const double* in, const int* idx, const double* rowscale, bool do_exp,
+                  double* out) {
+    if (m == 0) return;
+    PMC_DISPATCH_NB(nb, { deinterleave_kernel<NB><<<grid_rows(m), kBlock, 0, st>>>(m, in, idx, rowscale, do_exp ? 1 : 0, out); });
+    check_launch();
+}
+
+void broadcast(hipStream_t st, int nb, int n, const double* a, double* out) {
+    PMC_DISPATCH_NB(nb, { broadcast_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, a, out); });
+    check_launch();
+}
+
+void darcy_coef(hipStream_t st, int nb, int n, const double* kfield, bool k_divides, double* coef) {
+    PMC_DISPATCH_NB(nb, { darcy_coef_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, kfield, k_divides ? 1 : 0, coef); });
+    check_launch();
+}
+
+void darcy_assemble(hipStream_t st, int nb, const SellView& Mp, const int* slot_src, const int* c_ptr, const int* c_elem,
+                    const double* c_val, const double* coef, const unsigned char* ess, const double* ess_data,
+                    const double* rhs0, double* mvals, double* diag, double* l1inv, double* rhs_bc) {
+    const dim3 g = grid_rows(Mp.nslices * kWave);
+    PMC_DISPATCH_NB(nb, {
+        darcy_assemble_kernel<NB><<<g, kBlock, 0, st>>>(Mp.nrows, Mp.nslices, Mp.slice_off, Mp.cols, slot_src, c_ptr, c_elem,
+                                                       c_val, coef, ess, ess_data, rhs0, mvals, diag, l1inv, rhs_bc);
+    });
+    check_launch();
+}
+
+void refresh(hipStream_t st, int nb, int64_t nslots, const int* ptr, const int* idx, const double* w, const double* src,
+             bool recip, double* out) {
+    if (nslots == 0) return;
+    const dim3 g((unsigned)((nslots + kBlock - 1) / kBlock));
+    PMC_DISPATCH_NB(nb, { refresh_kernel<NB><<<g, kBlock, 0, st>>>(nslots, ptr, idx, w, src, recip ? 1 : 0, out); });
+    check_launch();
+}
+
+void diag_inv(hipStream_t st, int nb, int n, const int* diag_slot, const double* vals, double* dinv) {
+    PMC_DISPATCH_NB(nb, { diag_inv_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, diag_slot, vals, dinv); });
+    check_launch();
+}
+
+}  // namespace k
+}  // namespace pmc

@@ -1,0 +1,83 @@
+// Launchers of the CDNA4 kernels (kernels.hip).  All vectors are "interleaved" batches:
+// row i, column (realization) k of a batch of NB lives at v[i*NB + k], NB in {1,2,4,8,16}.
+#pragma once
+#include "common.hpp"
+
+namespace pmc {
+
+// Device view of a SELL-64 matrix.  vals == shared values (nslots) or, when bv, per-realization
+// values (nslots*NB, interleaved like vectors).
+struct SellView {
+    int nrows = 0, nslices = 0;
+    const int* slice_off = nullptr;
+    const int* cols = nullptr;
+    const double* vals = nullptr;
+    bool bv = false;
+};
+inline SellView view(const Sell& S) { return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, S.vals.p, false}; }
+inline SellView view_bv(const Sell& S, const double* vals) {
+    return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, vals, true};
+}
+
+// number of per-block partial sums a (fused) dot over n rows writes per column
+int dot_blocks(int nrows);
+
+namespace k {
+
+// Device-resident MINRES scalars, one entry per batch column.
+struct MinresState {
+    double beta[kMaxBatch], beta_old[kMaxBatch], eta[kMaxBatch], eta0[kMaxBatch];
+    double gamma0[kMaxBatch], gamma1[kMaxBatch], sigma0[kMaxBatch], sigma1[kMaxBatch];
+    double goal[kMaxBatch], alpha[kMaxBatch], delta[kMaxBatch], rho2[kMaxBatch], rho3[kMaxBatch];
+    double cV[3][kMaxBatch];  // v_new = cV0*q + cV1*v1 + cV2*v0
+    double cW[4][kMaxBatch];  // w_new = cW0*u1 + cW1*w0 + cW2*w1 ; x += cW3*w_new
+    int active[kMaxBatch], iters[kMaxBatch], flag[kMaxBatch];
+    int n_active, it;
+};
+
+// y = A x (accumulate=false) or y += A x.  If dot_partial != nullptr (accumulate must be false) also
+// writes per-block partial sums of <dot_with, A x>: dot_blocks(A.nslices*64)*nb doubles.
+void spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate,
+          double* dot_partial, const double* dot_with);
+// out = r - A x
+void residual(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out);
+// Chebyshev / Jacobi step:  d = a*d + b*dinv.*(r - A xin);  xout = xin + d   (xin != xout)
+void cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
+               const double* xin, double* d, double* xout, double a, double b);
+// first step from a zero guess: d = b*dinv.*r; x = d
+void cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d,
+                double* x, double b);
+void dot(hipStream_t st, int nb, int n, const double* a, const double* b, double* partial);
+void wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial);
+void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, double* out);
+void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b,
+              const double* c2, double* y);
+void minres_wx(hipStream_t st, int nb, int n, const double* c0, const double* u, const double* c1, double* w0,
+               const double* c2, const double* w1, const double* c3, double* x);
+void fill(hipStream_t st, size_t n, double* x, double v);
+void copy(hipStream_t st, size_t n, const double* src, double* dst);
+
+void minres_init(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks, double rel_tol,
+                 double abs_tol);
+void minres_scal1(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks);
+void minres_scal2(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks);
+
+void normal_fill(hipStream_t st, int n, int nbatch, uint64_t seed, uint64_t first_id, uint32_t stream, double mean,
+                 double sigma, double* out);
+// out[i*nb+k] = scale * in[k*n+i] * (w ? w[i] : 1)
+void interleave(hipStream_t st, int nb, int n, const double* in, const double* w, double scale, double* out);
+// out[k*m+i] = post(rowscale[i] * in[(idx?idx[i]:i)*nb + k])
+void deinterleave(hipStream_t st, int nb, int m, const double* in, const int* idx, const double* rowscale, bool do_exp,
+                  double* out);
+void broadcast(hipStream_t st, int nb, int n, const double* a, double* out);
+
+void darcy_coef(hipStream_t st, int nb, int n, const double* kfield, bool k_divides, double* coef);
+void darcy_assemble(hipStream_t st, int nb, const SellView& Mp, const int* slot_src, const int* c_ptr, const int* c_elem,
+                    const double* c_val, const double* coef, const unsigned char* ess, const double* ess_data,
+                    const double* rhs0, double* mvals, double* diag, double* l1inv, double* rhs_bc);
+void refresh(hipStream_t st, int nb, int64_t nslots, const int* ptr, const int* idx, const double* w, const double* src,
+             bool recip, double* out);
+void diag_inv(hipStream_t st, int nb, int n, const int* diag_slot, const double* vals, double* dinv);
+
+}  // namespace k
+}  // namespace pmc

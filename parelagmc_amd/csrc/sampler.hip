@@ -1,0 +1,292 @@
+// SPDE Matérn sampler on the device: PDESampler / EmbeddedPDESampler / L2ProjectionPDESampler
+// ::Sample and ::Eval (reference: src/PDESampler.cpp:336-535, src/EmbeddedPDESampler.cpp:438-563,
+// src/L2ProjectionPDESampler.cpp:621-757).
+#include <algorithm>
+#include <cmath>
+
+#include "handles.hpp"
+
+namespace pmc {
+
+// S = diag_add + B diag(dM)^-1 B^T as host CSR (setup).  B has its essential columns removed.
+HostCsr schur_host(const HostCsr& B, const HostCsr& Bt, const std::vector<double>& dM, const double* diag_add) {
+    HostCsr S;
+    S.nrows = S.ncols = B.nrows;
+    S.rowptr.assign(B.nrows + 1, 0);
+    std::vector<int> marker(B.nrows, -1);
+    std::vector<std::pair<int, double>> row;
+    for (int e = 0; e < B.nrows; ++e) {
+        row.clear();
+        auto add = [&](int c, double v) {
+            if (marker[c] < 0) { marker[c] = (int)row.size(); row.emplace_back(c, v); }
+            else row[marker[c]].second += v;
+        };
+        add(e, diag_add ? diag_add[e] : 0.0);
+        for (int p = B.rowptr[e]; p < B.rowptr[e + 1]; ++p) {
+            const int f = B.colind[p];
+            const double w = B.vals[p] / dM[f];
+            for (int q = Bt.rowptr[f]; q < Bt.rowptr[f + 1]; ++q) add(Bt.colind[q], w * Bt.vals[q]);
+        }
+        std::sort(row.begin(), row.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        for (auto& cv : row) { S.colind.push_back(cv.first); S.vals.push_back(cv.second); marker[cv.first] = -1; }
+        S.rowptr[e + 1] = (int)S.colind.size();
+    }
+    return S;
+}
+
+static std::vector<double> l1_inverse(const HostCsr& M) {
+    std::vector<double> d(M.nrows);
+    for (int i = 0; i < M.nrows; ++i) {
+        double s = 0.0;
+        for (int p = M.rowptr[i]; p < M.rowptr[i + 1]; ++p) s += std::fabs(M.vals[p]);
+        PMC_REQUIRE(s > 0.0, "mass matrix has an empty row");
+        d[i] = 1.0 / s;
+    }
+    return d;
+}
+
+Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, double alpha_, double g_, bool logn,
+                 const pmc_solver_opts& o)
+    : ctx(c), nlevels(nlevels_), n_mc(n_mc_), alpha(alpha_), g(g_), lognormal(logn), opts(o) {
+    PMC_REQUIRE(nlevels >= 1 && n_mc >= 1 && n_mc <= nlevels, "sampler: need 1 <= n_mc_levels <= nlevels");
+    PMC_REQUIRE(in != nullptr, "sampler: levels is NULL");
+    PMC_REQUIRE(alpha > 0.0, "sampler: alpha must be positive");
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    lv.resize(nlevels);
+    mg.L.resize(nlevels);
+    mg.smooth_degree = o.mg_smooth_degree;
+    mg.smooth_ratio = o.mg_smooth_ratio;
+    mg.coarse_degree = o.mg_coarse_degree;
+    mg.coarse_ratio = o.mg_coarse_ratio;
+    for (int l = 0; l < nlevels; ++l) {
+        const pmc_sampler_level& L = in[l];
+        SamplerLevel& d = lv[l];
+        PMC_REQUIRE(L.n_u > 0 && L.n_s > 0, "sampler level: empty block");
+        d.n_u = L.n_u;
+        d.n_s = L.n_s;
+        HostCsr M = csr_from_c(L.M, true, "sampler M");
+        HostCsr B = csr_from_c(L.B, true, "sampler B");
+        PMC_REQUIRE(M.nrows == L.n_u && M.ncols == L.n_u, "sampler M: wrong shape");
+        PMC_REQUIRE(B.nrows == L.n_s && B.ncols == L.n_u, "sampler B: wrong shape");
+        PMC_REQUIRE(L.w_diag != nullptr, "sampler w_diag is NULL");
+        csr_sort_rows(M);
+        csr_sort_rows(B);
+        HostCsr Bt = csr_transpose(B);
+        std::vector<double> maw(L.n_s), wsq(L.n_s), aw(L.n_s);
+        for (int i = 0; i < L.n_s; ++i) {
+            PMC_REQUIRE(L.w_diag[i] > 0.0, "sampler w_diag must be positive");
+            maw[i] = -alpha * L.w_diag[i];
+            aw[i] = alpha * L.w_diag[i];
+            wsq[i] = std::sqrt(L.w_diag[i]);
+        }
+        HostCsr A = csr_block2x2(M, Bt, B, maw.data());
+        d.nnz = A.nnz();
+        sell_build(d.A, A, true, false, st);
+        sell_build(d.M, M, true, false, st);
+        std::vector<double> dM = csr_diag(M);
+        for (double v : dM) PMC_REQUIRE(v > 0.0, "sampler M must have a positive diagonal");
+        d.dinvM.upload(l1_inverse(M), st);
+        d.w_sqrt.upload(wsq, st);
+        // Schur complement level
+        HostCsr S = schur_host(B, Bt, dM, aw.data());
+        MgLevel& m = mg.L[l];
+        m.n = L.n_s;
+        m.bv = false;
+        sell_build(m.S, S, true, false, st);
+        std::vector<double> dS = csr_diag(S);
+        m.lmax = gershgorin_scaled(S, dS) * 1.0001;
+        for (double& v : dS) v = 1.0 / v;
+        m.dinv.upload(dS, st);
+        if (l + 1 < nlevels) {
+            HostCsr P = csr_from_c(L.P, true, "sampler P");
+            PMC_REQUIRE(P.nrows == L.n_s && P.ncols == in[l + 1].n_s, "sampler P: wrong shape");
+            HostCsr Pt = csr_transpose(P);
+            sell_build(m.P, P, true, false, st);
+            sell_build(m.Pt, Pt, true, false, st);
+        }
+        PMC_HIP(hipStreamSynchronize(st));
+    }
+}
+
+void Sampler::set_projection(int level, int kind, const pmc_csr* Gt, const int32_t* idx, const double* inv_w,
+                             int orig_size) {
+    PMC_REQUIRE(level >= 0 && level < n_mc, "set_projection: level out of range");
+    SamplerLevel& d = lv[level];
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    if (kind == PMC_PROJ_NONE) {
+        d.proj = PMC_PROJ_NONE;
+        d.out_size = d.n_s;
+    } else if (kind == PMC_PROJ_GATHER) {
+        PMC_REQUIRE(idx != nullptr && orig_size > 0 && orig_size <= d.n_s, "set_projection: bad gather arguments");
+        for (int i = 0; i < orig_size; ++i) PMC_REQUIRE(idx[i] >= 0 && idx[i] < d.n_s, "set_projection: gather index out of range");
+        d.gather.upload(idx, orig_size, st);
+        d.proj = kind;
+        d.out_size = orig_size;
+    } else if (kind == PMC_PROJ_L2) {
+        PMC_REQUIRE(Gt != nullptr && inv_w != nullptr, "set_projection: Gt / inv_w is NULL");
+        HostCsr G = csr_from_c(*Gt, true, "Gt");
+        PMC_REQUIRE(G.ncols == d.n_s && G.nrows == orig_size && orig_size > 0, "set_projection: Gt has the wrong shape");
+        sell_build(d.Gt, G, true, false, st);
+        d.inv_w.upload(inv_w, orig_size, st);
+        d.proj = kind;
+        d.out_size = orig_size;
+    } else {
+        throw Error(PMC_ERR_INVALID, "set_projection: unknown kind");
+    }
+    PMC_HIP(hipStreamSynchronize(st));
+}
+
+void Sampler::ensure(int level, int nb) {
+    size_t nmax = 0, smax = 0;
+    for (int l = 0; l <= level; ++l) {
+        nmax = std::max(nmax, (size_t)lv[l].n_u + lv[l].n_s);
+        smax = std::max(smax, (size_t)lv[l].n_s);
+    }
+    for (int l = level; l < nlevels; ++l) smax = std::max(smax, (size_t)lv[l].n_s);
+    rhs.ensure(nmax * nb);
+    sol.ensure(nmax * nb);
+    tA.ensure(smax * nb);
+    tB.ensure(smax * nb);
+    cx.ensure((size_t)lv[level].n_u * nb);
+    cd.ensure((size_t)lv[level].n_u * nb);
+    stage_in.ensure(smax * nb);
+    stage_out.ensure(smax * nb);
+    stage_emb.ensure(smax * nb);
+}
+
+void Sampler::sample(int level, uint64_t first_id, int nbatch, double* xi, int memspace) {
+    PMC_REQUIRE(level >= 0 && level < n_mc, "Sample: level out of range");
+    PMC_REQUIRE(nbatch >= 1 && xi != nullptr, "Sample: bad arguments");
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    const int n = lv[level].n_s;
+    if (memspace == PMC_MEM_DEVICE) {
+        k::normal_fill(st, n, nbatch, ctx.seed, first_id, (uint32_t)level, 0.0, 1.0, xi);
+    } else {
+        DevBuf<double> tmp((size_t)n * nbatch);
+        k::normal_fill(st, n, nbatch, ctx.seed, first_id, (uint32_t)level, 0.0, 1.0, tmp.p);
+        PMC_HIP(hipMemcpyAsync(xi, tmp.p, sizeof(double) * n * nbatch, hipMemcpyDeviceToHost, st));
+        PMC_HIP(hipStreamSynchronize(st));
+    }
+}
+
+void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, double* s_d, const double* init_d,
+                         int init_level, bool use_init, double* emb_d, pmc_stats* stats) {
+    hipStream_t st = ctx.stream;
+    SamplerLevel& d = lv[level];
+    const int n_u = d.n_u, n_s = d.n_s, n = n_u + n_s;
+    ensure(level, nb);
+    // rhs_s = -g W^{1/2} xi on xi_level, restricted with Ps^T (PDESampler.cpp:423-438); rhs_u = 0 (:441-442)
+    k::fill(st, (size_t)n_u * nb, rhs.p, 0.0);
+    double* rhs_s = rhs.p + (size_t)n_u * nb;
+    if (xi_level == level) {
+        k::interleave(st, nb, n_s, xi_d, lv[xi_level].w_sqrt.p, -g, rhs_s);
+    } else {
+        double* cur = tA.p;
+        double* nxt = tB.p;
+        k::interleave(st, nb, lv[xi_level].n_s, xi_d, lv[xi_level].w_sqrt.p, -g, cur);
+        for (int l = xi_level; l < level; ++l) {
+            double* dst = (l + 1 == level) ? rhs_s : nxt;
+            k::spmm(st, nb, view(mg.L[l].Pt), cur, dst, false, nullptr, nullptr);
+            std::swap(cur, nxt);
+        }
+    }
+    // initial guess (:498-515)
+    bool zero_guess = true;
+    if (use_init) {
+        double* sol_s = sol.p + (size_t)n_u * nb;
+        k::fill(st, (size_t)n_u * nb, sol.p, 0.0);
+        if (init_level == level) {
+            k::interleave(st, nb, n_s, init_d, nullptr, 1.0, sol_s);
+        } else {
+            double* cur = tA.p;
+            double* nxt = tB.p;
+            k::interleave(st, nb, lv[init_level].n_s, init_d, nullptr, 1.0, cur);
+            for (int l = init_level; l > level; --l) {
+                double* dst = (l - 1 == level) ? sol_s : nxt;
+                k::spmm(st, nb, view(mg.L[l - 1].P), cur, dst, false, nullptr, nullptr);
+                std::swap(cur, nxt);
+            }
+        }
+        zero_guess = false;
+    }
+    LinOp A;
+    A.n = n;
+    const SellView Av = view(d.A);
+    A.apply = [Av](hipStream_t s, int nb_, const double* x, double* y, double* partial) {
+        k::spmm(s, nb_, Av, x, y, false, partial, x);
+    };
+    const SellView Mv = view(d.M);
+    const double* dinvM = d.dinvM.p;
+    ChebParams cpM{opts.cheb_degree_M, 1.0, opts.cheb_ratio_M};
+    double* cxp = cx.p;
+    double* cdp = cd.p;
+    Multigrid* mgp = &mg;
+    PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z) {
+        const int flips = cheb_flips(cpM.degree, true);
+        double* start = (flips % 2 == 0) ? z : cxp;
+        double* other = (flips % 2 == 0) ? cxp : z;
+        double* res = cheb_apply(s, nb_, Mv, dinvM, false, cpM, r, start, other, cdp, true);
+        if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
+        mgp->vcycle(s, nb_, level, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_);
+    };
+    MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work);
+    if (stats)
+        for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
+    // outputs (:526-533 and the embedded variants' maps)
+    const double* sol_s = sol.p + (size_t)n_u * nb;
+    if (d.proj == PMC_PROJ_NONE) {
+        k::deinterleave(st, nb, n_s, sol_s, nullptr, nullptr, lognormal, s_d);
+    } else if (d.proj == PMC_PROJ_GATHER) {
+        k::deinterleave(st, nb, d.out_size, sol_s, d.gather.p, nullptr, lognormal, s_d);
+    } else {
+        k::spmm(st, nb, view(d.Gt), sol_s, tA.p, false, nullptr, nullptr);
+        k::deinterleave(st, nb, d.out_size, tA.p, nullptr, d.inv_w.p, lognormal, s_d);
+    }
+    if (emb_d) k::deinterleave(st, nb, n_s, sol_s, nullptr, nullptr, false, emb_d);
+}
+
+void Sampler::eval(int level, int xi_level, int nbatch, const double* xi, double* s_out, const double* init_s,
+                   int init_level, bool use_init, double* emb_out, int memspace, pmc_stats* stats) {
+    PMC_REQUIRE(level >= 0 && level < n_mc, "Eval: level out of range");
+    PMC_REQUIRE(xi_level >= 0 && xi_level <= level, "Eval: xi_level must satisfy 0 <= xi_level <= level");
+    PMC_REQUIRE(nbatch >= 1 && xi != nullptr && s_out != nullptr, "Eval: bad arguments");
+    if (use_init) {
+        PMC_REQUIRE(init_s != nullptr, "Eval: use_init without init_s");
+        PMC_REQUIRE(init_level >= level && init_level < nlevels, "Eval: init_level must be coarser than or equal to level");
+    }
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    const int n_xi = lv[xi_level].n_s, n_out = lv[level].out_size, n_s = lv[level].n_s;
+    const int n_init = use_init ? lv[init_level].n_s : 0;
+    int done = 0;
+    while (done < nbatch) {
+        int nb = 16;
+        while (nb > nbatch - done) nb >>= 1;
+        const double* xi_d = xi + (size_t)done * n_xi;
+        const double* init_d = use_init ? init_s + (size_t)done * n_init : nullptr;
+        double* s_d = s_out + (size_t)done * n_out;
+        double* emb_d = emb_out ? emb_out + (size_t)done * n_s : nullptr;
+        if (memspace == PMC_MEM_HOST) {
+            ensure(level, nb);
+            PMC_HIP(hipMemcpyAsync(stage_in.p, xi_d, sizeof(double) * n_xi * nb, hipMemcpyHostToDevice, st));
+            const double* init_dev = nullptr;
+            if (use_init) {
+                PMC_HIP(hipMemcpyAsync(stage_emb.p, init_d, sizeof(double) * n_init * nb, hipMemcpyHostToDevice, st));
+                init_dev = stage_emb.p;
+            }
+            eval_chunk(level, xi_level, nb, stage_in.p, stage_out.p, init_dev, init_level, use_init,
+                       emb_d ? stage_emb.p : nullptr, stats ? stats + done : nullptr);
+            PMC_HIP(hipMemcpyAsync(s_d, stage_out.p, sizeof(double) * n_out * nb, hipMemcpyDeviceToHost, st));
+            if (emb_d) PMC_HIP(hipMemcpyAsync(emb_d, stage_emb.p, sizeof(double) * n_s * nb, hipMemcpyDeviceToHost, st));
+            PMC_HIP(hipStreamSynchronize(st));
+        } else {
+            eval_chunk(level, xi_level, nb, xi_d, s_d, init_d, init_level, use_init, emb_d, stats ? stats + done : nullptr);
+        }
+        done += nb;
+    }
+}
+
+}  // namespace pmc

@@ -1,0 +1,188 @@
+// Host orchestration: Chebyshev smoother, level V-cycle, batched preconditioned MINRES.
+#include "solver.hpp"
+
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+
+namespace pmc {
+
+double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
+                   const double* r, double* xa, double* xb, double* d, bool zero_guess) {
+    if (cp.degree < 1) throw Error(PMC_ERR_INVALID, "Chebyshev degree must be >= 1");
+    const double lmax = cp.lmax, lmin = cp.lmax / cp.ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+    const double sigma = theta / delta;
+    double rho_old = 1.0 / sigma;
+    double* cur = xa;
+    double* oth = xb;
+    int step = 0;
+    if (zero_guess) {
+        k::cheb_first(st, nb, A.nrows, dinv, dinv_bv, r, d, cur, 1.0 / theta);
+        step = 1;
+    } else {
+        k::cheb_step(st, nb, A, dinv, dinv_bv, r, cur, d, oth, 0.0, 1.0 / theta);
+        std::swap(cur, oth);
+        step = 1;
+    }
+    for (; step < cp.degree; ++step) {
+        const double rho = 1.0 / (2.0 * sigma - rho_old);
+        k::cheb_step(st, nb, A, dinv, dinv_bv, r, cur, d, oth, rho * rho_old, 2.0 * rho / delta);
+        std::swap(cur, oth);
+        rho_old = rho;
+    }
+    return cur;
+}
+
+void MgLevel::ensure(int nb) {
+    const size_t need = (size_t)n * nb;
+    r.ensure(need);
+    xa.ensure(need);
+    xb.ensure(need);
+    d.ensure(need);
+    res.ensure(need);
+}
+
+double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target) {
+    MgLevel& lv = L[l];
+    lv.ensure(nb);
+    const SellView A = lv.sview();
+    const bool last = (l == (int)L.size() - 1);
+    const int flips = last ? cheb_flips(coarse_degree, true)
+                           : cheb_flips(smooth_degree, true) + cheb_flips(smooth_degree, false);
+    double* start = lv.xa.p;
+    double* other = lv.xb.p;
+    if (target) {
+        if (flips % 2 == 0) start = target; else other = target;
+    }
+    if (last) {
+        ChebParams cp{coarse_degree, lv.lmax, coarse_ratio};
+        return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true);
+    }
+    ChebParams cp{smooth_degree, lv.lmax, smooth_ratio};
+    double* x = cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true);
+    double* oth = (x == start) ? other : start;
+    k::residual(st, nb, A, r, x, lv.res.p);
+    MgLevel& lc = L[l + 1];
+    lc.ensure(nb);
+    k::spmm(st, nb, view(lv.Pt), lv.res.p, lc.r.p, false, nullptr, nullptr);
+    double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr);
+    k::spmm(st, nb, view(lv.P), xc, x, true, nullptr, nullptr);
+    return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, x, oth, lv.d.p, false);
+}
+
+void Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout) {
+    double* res = cycle(st, nb, l0, l0, r, xout);
+    if (res != xout) throw Error(PMC_ERR_INTERNAL, "V-cycle result landed in the wrong buffer");
+}
+
+void MinresWork::ensure(int n, int nb) {
+    const size_t need = (size_t)n * nb;
+    v0.ensure(need); v1.ensure(need); u0.ensure(need); u1.ensure(need);
+    w0.ensure(need); w1.ensure(need); q.ensure(need);
+    partial.ensure((size_t)dot_blocks(n) * kMaxBatch);
+    if (!state.p) state.alloc(1);
+}
+
+// y = a*x + b*y with host scalars, via lincomb on a tiny device constant block would need a copy;
+// keep it simple with a dedicated kernel.
+__global__ void axpby_kernel(size_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = a * x[i] + b * y[i];
+}
+static void axpby(hipStream_t st, size_t n, double a, const double* x, double b, double* y) {
+    if (!n) return;
+    const unsigned g = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    axpby_kernel<<<g, 256, 0, st>>>(n, a, x, b, y);
+    PMC_HIP(hipGetLastError());
+}
+
+MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, const double* b, double* x,
+                          bool zero_guess, const pmc_solver_opts& o, MinresWork& w) {
+    hipStream_t st = ctx.stream;
+    const int n = A.n;
+    const size_t len = (size_t)n * nb;
+    const int nblocks = dot_blocks(n);
+    w.ensure(n, nb);
+    k::MinresState* S = w.state.p;
+    double* v0 = w.v0.p; double* v1 = w.v1.p; double* u0 = w.u0.p; double* u1 = w.u1.p;
+    double* w0 = w.w0.p; double* w1 = w.w1.p; double* q = w.q.p;
+
+    // v1 = b - A x0
+    if (zero_guess) {
+        k::fill(st, len, x, 0.0);
+        k::copy(st, len, b, v1);
+    } else {
+        A.apply(st, nb, x, v1, nullptr);
+        axpby(st, len, 1.0, b, -1.0, v1);
+    }
+    prec(st, nb, v1, u1);
+    k::dot(st, nb, n, v1, u1, w.partial.p);
+    k::minres_init(st, nb, S, w.partial.p, nblocks, o.rel_tol, o.abs_tol);
+    k::fill(st, len, v0, 0.0);
+    k::fill(st, len, w0, 0.0);
+    k::fill(st, len, w1, 0.0);
+
+    auto coef = [&](size_t off) { return reinterpret_cast<const double*>(reinterpret_cast<const char*>(S) + off); };
+    const double* cV0 = coef(offsetof(k::MinresState, cV));
+    const double* cV1 = cV0 + kMaxBatch;
+    const double* cV2 = cV1 + kMaxBatch;
+    const double* cW0 = coef(offsetof(k::MinresState, cW));
+    const double* cW1 = cW0 + kMaxBatch;
+    const double* cW2 = cW1 + kMaxBatch;
+    const double* cW3 = cW2 + kMaxBatch;
+    const int* d_nactive = reinterpret_cast<const int*>(reinterpret_cast<const char*>(S) + offsetof(k::MinresState, n_active));
+
+    auto poll = [&]() {
+        PMC_HIP(hipMemcpyAsync(ctx.h_flag, d_nactive, sizeof(int), hipMemcpyDeviceToHost, st));
+        PMC_HIP(hipStreamSynchronize(st));
+        return *ctx.h_flag;
+    };
+
+    MinresResult out;
+    const int every = o.check_every > 0 ? o.check_every : 1;
+    int it = 0;
+    int n_active = poll();
+    while (n_active > 0 && it < o.max_iter) {
+        ++it;
+        A.apply(st, nb, u1, q, w.partial.p);
+        k::minres_scal1(st, nb, S, w.partial.p, nblocks);
+        k::lincomb3(st, nb, n, cV0, q, cV1, v1, cV2, v0);
+        prec(st, nb, v0, u0);
+        k::dot(st, nb, n, v0, u0, w.partial.p);
+        k::minres_scal2(st, nb, S, w.partial.p, nblocks);
+        k::minres_wx(st, nb, n, cW0, u1, cW1, w0, cW2, w1, cW3, x);
+        std::swap(u0, u1);
+        std::swap(v0, v1);
+        std::swap(w0, w1);
+        if (it % every == 0 || it == o.max_iter) n_active = poll();
+    }
+    out.iterations = it;
+    static_assert(sizeof(k::MinresState) <= 4096 * sizeof(double), "pinned scratch too small");
+    PMC_HIP(hipMemcpyAsync(ctx.h_scal, S, sizeof(k::MinresState), hipMemcpyDeviceToHost, st));
+    PMC_HIP(hipStreamSynchronize(st));
+    k::MinresState hs;
+    std::memcpy(&hs, ctx.h_scal, sizeof(hs));
+    for (int kcol = 0; kcol < nb; ++kcol) {
+        pmc_stats& s = out.col[kcol];
+        s.iterations = hs.iters[kcol];
+        s.initial_norm = hs.eta0[kcol];
+        s.final_norm = std::fabs(hs.eta[kcol]);
+        s.converged = (hs.flag[kcol] == 0 && hs.active[kcol] == 0 && s.final_norm <= hs.goal[kcol]) ? 1 : 0;
+        if (hs.flag[kcol] != 0) s.converged = -1;   // indefinite preconditioner / NaN
+    }
+    return out;
+}
+
+double gershgorin_scaled(const HostCsr& A, const std::vector<double>& diag) {
+    double lmax = 0.0;
+    for (int i = 0; i < A.nrows; ++i) {
+        double s = 0.0;
+        for (int p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) s += std::fabs(A.vals[p]);
+        lmax = std::max(lmax, s / diag[i]);
+    }
+    return lmax;
+}
+
+}  // namespace pmc
