@@ -23,3 +23,11 @@ clean:
 	rm -rf build parelagmc_amd/lib/libpmc.so
 
 .PHONY: all clean
+
+# host-side managers (plain C++, links against libpmc.so next to it)
+HOSTLIB := parelagmc_amd/lib/libpmc_host.so
+HOSTSRC := parelagmc_amd/host/host.cpp
+$(HOSTLIB): $(HOSTSRC) parelagmc_amd/host/parelagmc.hpp include/pmc.h include/pmc_host.h $(LIB)
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -o $@ $(HOSTSRC) -Lparelagmc_amd/lib -lpmc -Wl,-rpath,'$$ORIGIN'
+
+all: $(HOSTLIB)

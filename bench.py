@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MC samples/sec of the SPDE Matérn sampler (BASELINE.json config 2:
+PDESampler on cube_tet refined 5x -> 595 968 DoF, single Monte Carlo level) on N MI355X.
+
+A step = Sample + Eval of one batch of `--batch` realizations, white noise drawn on the device so
+all inputs are resident in HBM when the timed region starts.  Contract: W untimed warm-up steps,
+then exactly K steps bracketed by barrier + torch.cuda.synchronize(); MAX over ranks; rank 0
+prints ONE JSON line.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every
+rank owns a full replica of the operators and its own realizations (weak scaling, no data-path
+collective); the only exchange is the SUM all-reduce of the MLMC-style accumulators.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def build_problem(nref, extra_coarse=True):
+    from parelagmc_amd.fe import build_hierarchy, build_sampler_problem, mesh_from_json
+    mesh = mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet.json"))
+    h = build_hierarchy(mesh, nref)
+    # one Monte Carlo level (config 2); the coarser refinement levels only deepen the V-cycle
+    return build_sampler_problem(h, corlen=0.1, lognormal=False, n_mc_levels=1)
+
+
+def host_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota and by
+    PMC_CPU_CORES; a 1-GPU box grants a 16-core share of the host, so that is the default cap."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:   # noqa: BLE001
+        pass
+    return max(1, min(n, int(os.environ.get("PMC_CPU_CORES", "16"))))
+
+
+def cpu_baseline(problem, seed, nsamples_per_core=2):
+    """Reference algorithm restated in C (oracle/c/pmc_ref.c), farmed over the host cores: a bounded
+    sample of the same workload."""
+    from oracle.cport import CPort
+    from oracle.rng_oracle import normal_fill
+    cores = host_cores()
+    cp = CPort(problem)
+    ns = nsamples_per_core * cores
+    n = problem.levels[0].n_s
+    xi = np.stack([normal_fill(n, seed, i, 0) for i in range(ns)])
+    rhs = cp.rhs(0, 0, xi)
+    cp.solve(0, rhs[:cores], nthreads=cores)          # warm-up (page in, thread pool)
+    t0 = time.perf_counter()
+    _, iters = cp.solve(0, rhs, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": ns / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{ns} realizations ({nsamples_per_core} per core), MINRES(300,1e-6)+BJ[symGS x3 | V-cycle], "
+                      f"mean {float(np.mean(np.abs(iters))):.1f} iterations, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--refine", type=int, default=5, help="uniform refinements of cube_tet (5 -> 595 968 DoF)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=20261003)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from parelagmc_amd import capi
+
+    problem = build_problem(args.refine)
+    L = problem.levels[0]
+    ctx = capi.Context(local_rank if world > 1 else 0, seed=args.seed)
+    ctx.seed(args.seed, nparts=world, mypart=rank)
+    smp = capi.PDESampler(ctx, problem)
+    nb, n = args.batch, L.n_s
+    xi_d, s_d = ctx.empty(nb * n), ctx.empty(nb * n)
+
+    def step(i):
+        # realization ids: block-cyclic over ranks, never repeated
+        first = (i * world + rank) * nb
+        smp.Sample(0, first_id=first, nbatch=nb, out=xi_d)
+        return smp.Eval(0, xi_d, xi_level=0, s_out=s_d, return_stats=True)[1]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    iters = []
+    for i in range(args.steps):
+        st = step(args.warmup + i)
+        iters += [t[0] for t in st]
+    barrier()
+    dt = time.perf_counter() - t0
+    # the one exchange of a sample farm: SUM all-reduce of the accumulators (here: field statistics)
+    acc = np.array([float(np.sum(iters)), float(len(iters)), dt])
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        a = torch.from_numpy(acc).cuda()
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        acc = a.cpu().numpy()
+    total_samples = args.steps * nb * world
+    value = total_samples / dt
+
+    out = None
+    if rank == 0:
+        # dominant kernel: the block saddle-point SpMM (K5), timed with HIP events on the ctx stream
+        x = ctx.array(np.random.default_rng(0).standard_normal(nb * (L.n_u + L.n_s)))
+        _, k_ms, k_bytes = smp.Mult(0, x, repeat=50)
+        x1 = ctx.array(np.random.default_rng(0).standard_normal(L.n_u + L.n_s))
+        _, k1_ms, k1_bytes = smp.Mult(0, x1, repeat=50)
+        peak = 8000.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                key = f"r{args.refine}_nb{nb}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:   # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "MC samples/sec (SPDE field) at stated DoF; SpMV HBM GB/s vs roofline",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"PDESampler cube_tet r={args.refine}, {L.n_u + L.n_s} DoF "
+                                   f"(n_s={L.n_s}, n_u={L.n_u}, nnz(A)={L.nnz}), 1 MC level, corlen 0.1, "
+                                   f"MINRES 300/1e-6/1e-12, batch {nb} realizations per step",
+                       "mean_minres_iterations": acc[0] / max(acc[1], 1.0), "batch": nb,
+                       "parallelism": f"sample-farm x{world}"},
+            "roofline": {"bound": "hbm", "kernel": f"sell_spmm_kernel<{nb},false,0,false> (block operator K5)",
+                         "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": peak, "unit": "GB/s",
+                         "frac": k_bytes / (k_ms * 1e-3) / 1e9 / peak, "traffic": traffic,
+                         "bytes_per_launch": k_bytes, "avg_kernel_ms": k_ms,
+                         "spmv_nb1": {"achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "bytes_per_launch": k1_bytes,
+                                      "avg_kernel_ms": k1_ms, "frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / peak}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(problem, args.seed)
+    smp.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

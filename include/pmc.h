@@ -168,6 +168,14 @@ int pmc_sampler_eval(pmc_sampler* s, int level, int xi_level, int nbatch, const 
                      const double* init_s, int init_level, int use_init, double* embed_s_out, int memspace,
                      pmc_stats* stats);
 
+/* y = A x with A = [M B^T; B -alpha W] of `level` (src/PDESampler.cpp:279-284; the oper->Mult inside the
+ * Krylov loop, kernel K5) for nbatch in {1,2,4,8,16} vectors of n_u+n_s entries each.  The SpMM kernel is
+ * launched `repeat` >= 1 times between two HIP events on the ctx stream; avg_ms (may be NULL) receives the
+ * mean kernel duration, bytes (may be NULL) the algorithmic bytes of ONE launch:
+ * 12 nnz + 4 nrows + nbatch * 8 * (nrows + ncols). */
+int pmc_sampler_apply_operator(pmc_sampler* s, int level, int nbatch, const double* x, double* y, int memspace,
+                               int repeat, double* avg_ms, double* bytes);
+
 /* ---- DarcySolver ------------------------------------------------------------------------ */
 int pmc_darcy_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_darcy_level* levels,
                      int k_divides, const pmc_solver_opts* opts, pmc_darcy** out);

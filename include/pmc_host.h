@@ -1,0 +1,93 @@
+/* pmc_host.h - C ABI of libpmc_host.so: the host-side Monte Carlo managers.
+ *
+ * Restates, in C++ behind a C surface, the two outer loops that drive the hot path in the
+ * reference (paths relative to /root/reference):
+ *     MLMC_Manager::Run / InitRun / computeNSamplesMSE   src/MLMC_Manager.cpp:103-214,300-401
+ *     MC_Manager::Run / InitRun / computeNSamplesMSE     src/MC_Manager.cpp:82-146,194-239
+ * They call ONLY the MLSampler / PhysicalMLSolver plugin surface (src/MLSampler.hpp:33-52,
+ * src/PhysicalMLSolver.hpp:33-47), here either the device objects of pmc.h or user callbacks
+ * (any other sampler/solver, and CPU-side tests of the managers).
+ *
+ * New relative to the reference ("serial multi-level MC manager", src/MLMC_Manager.hpp:24):
+ * realizations of one InitRun round are sharded over ranks (one rank per GPU) in blocks of
+ * `batch` consecutive sample ids and the nlevels x 9 sums table is SUM-all-reduced once per
+ * round before computeNSamplesMSE.
+ */
+#ifndef PMC_HOST_H_
+#define PMC_HOST_H_
+
+#include "pmc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMC_MLMC_NVAR 9 /* Y2,Y,ABSY,Q2,Q,ABSQ,C,Y3,Y4 - enum order of src/MLMC_Manager.hpp:65 */
+
+typedef struct pmc_mlmc pmc_mlmc;
+
+/* in-place SUM all-reduce of a host buffer over the sample-farm ranks */
+typedef int (*pmc_reduce_fn)(double* buf, int n, void* user);
+
+/* plugin callbacks (host pointers, batched sample-major like pmc.h) */
+typedef int (*pmc_cb_sample)(void* user, int level, uint64_t first_id, int nbatch, double* xi);
+typedef int (*pmc_cb_eval)(void* user, int level, int xi_level, int nbatch, const double* xi, double* s,
+                           const double* init_s, int init_level, int use_init, double* embed_s_out);
+typedef int (*pmc_cb_solve)(void* user, int level, int nbatch, const double* k, double* Q, double* C);
+
+typedef struct pmc_plugin_callbacks {
+    void* user;
+    pmc_cb_sample sample;
+    pmc_cb_eval eval;
+    pmc_cb_solve solve_fwd;
+    const int32_t* xi_size;     /* nlevels: size Sample() fills      */
+    const int32_t* sample_size; /* nlevels: size of Eval's s         */
+    const int32_t* ndofs;       /* nlevels: GetGlobalNumberOfDofs()  */
+} pmc_plugin_callbacks;
+
+/* "Problem parameters" read by the managers (src/MLMC_Manager.cpp:30-36) */
+typedef struct pmc_mlmc_params {
+    double eps2;              /* "Mean square error", default 0.001; < 0 = automatic        */
+    double ratio;             /* "MSE splitting ratio", default 0.5                         */
+    int32_t init_nsamples;    /* "Number of samples", default 10                            */
+    const int32_t* array_nsamples; /* "Array number of samples" (nlevels) or NULL           */
+    int32_t wall_time;        /* public member wallTime (src/MLMC_Manager.hpp:61), default 1 */
+    int32_t batch;            /* realizations per plugin call (1,2,4,8,16), default 16      */
+    int32_t max_rounds;       /* safety bound on the adaptive loop, default 1000            */
+    const char* log_file;     /* "Output filename for MC managers" or NULL                  */
+} pmc_mlmc_params;
+void pmc_mlmc_params_default(pmc_mlmc_params* p);
+
+typedef struct pmc_mlmc_result {
+    int32_t nlevels;
+    double estimate, eps2, actual_mse, estimator_variance, bias2, alpha, alpha_abs, beta, gamma;
+    /* arrays of nlevels, owned by the manager, valid until the next call */
+    const double *eY, *eABSY, *eQ, *eABSQ, *eC, *varY, *varQ, *consistency, *kurtosis, *VC, *cost;
+    const double* sums;            /* nlevels x PMC_MLMC_NVAR, row-major */
+    const int64_t* nsamples;       /* per level, global                   */
+    const int64_t* nsamples_missing;
+    const double* level_seconds;   /* wall time spent per level on this rank */
+} pmc_mlmc_result;
+
+/* manager over the device sampler + solver of pmc.h (device-resident vectors, no PCIe traffic) */
+int pmc_mlmc_create(pmc_ctx* ctx, pmc_sampler* sampler, pmc_darcy* solver, int nlevels,
+                    const pmc_mlmc_params* params, pmc_mlmc** out);
+/* manager over arbitrary plugins */
+int pmc_mlmc_create_callbacks(int nlevels, const pmc_plugin_callbacks* cb, const pmc_mlmc_params* params,
+                              pmc_mlmc** out);
+void pmc_mlmc_destroy(pmc_mlmc* m);
+/* sample-farm layout; reduce == NULL with nranks > 1 uses pmc_allreduce_sum_f64 (RCCL) of the ctx */
+int pmc_mlmc_set_farm(pmc_mlmc* m, int nranks, int rank, pmc_reduce_fn reduce, void* user);
+int pmc_mlmc_run(pmc_mlmc* m);                               /* MLMC_Manager::Run      */
+int pmc_mlmc_reset(pmc_mlmc* m);                             /* zero sums and counters */
+int pmc_mlmc_init_run(pmc_mlmc* m, const int32_t* nsamples); /* MLMC_Manager::InitRun  */
+int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* out);
+const char* pmc_host_last_error(void);
+
+/* expWRegression (src/Utilities.cpp:257-283), exported for the host-logic tests */
+double pmc_exp_w_regression(const double* y, const double* x, int n, int skip_n_last);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMC_HOST_H_ */

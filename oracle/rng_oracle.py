@@ -40,11 +40,12 @@ def philox4x32_10(ctr, key):
 
 
 def u01_open(hi, lo):
-    """53-bit uniform in the open interval (0,1) from two 32-bit words."""
+    """52-bit uniform in the OPEN interval (0,1) from two 32-bit words: (m + 1/2) / 2^52 is
+    exactly representable for every 52-bit m, so neither 0 nor 1 can occur."""
     hi = np.asarray(hi, dtype=np.uint64)
     lo = np.asarray(lo, dtype=np.uint64)
-    m = (hi >> np.uint64(5)) * np.uint64(1 << 26) + (lo >> np.uint64(6))     # 27 + 26 = 53 bits
-    return (m.astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+    m = (hi >> np.uint64(6)) * np.uint64(1 << 26) + (lo >> np.uint64(6))     # 26 + 26 = 52 bits
+    return (m.astype(np.float64) + 0.5) * (1.0 / 4503599627370496.0)
 
 
 _A = [3.3871328727963666080e0, 1.3314166789178437745e+2, 1.9715909503065514427e+3, 1.3731693765509461125e+4,

@@ -84,6 +84,8 @@ SYMBOLS = {
     "pmc_sampler_sample": (C.c_int, [_VP, C.c_int, C.c_uint64, C.c_int, _DP, C.c_int]),
     "pmc_sampler_eval": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _DP, _DP, _DP, C.c_int, C.c_int, _DP, C.c_int,
                                    C.POINTER(pmc_stats)]),
+    "pmc_sampler_apply_operator": (C.c_int, [_VP, C.c_int, C.c_int, _DP, _DP, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double)]),
     "pmc_darcy_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_darcy_level), C.c_int,
                                    C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
     "pmc_darcy_destroy": (None, [_VP]),
@@ -183,6 +185,7 @@ class DeviceArray:
         p = _VP()
         _check(ctx.lib.pmc_malloc(ctx.h, self.n * 8, C.byref(p)))
         self.ptr = p.value or 0
+        ctx._adopt(self)
 
     def upload(self, a):
         a = _f64(a).ravel()
@@ -196,9 +199,9 @@ class DeviceArray:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.ctx.h:
             self.ctx.lib.pmc_free(self.ctx.h, self.ptr)
-            self.ptr = 0
+        self.ptr = 0
 
     def __del__(self):
         try:
@@ -229,7 +232,12 @@ class Context:
         _check(self.lib.pmc_ctx_create(int(device_id), C.byref(h)))
         self.h = h
         self.device_id = device_id
+        self._children = []     # weakrefs to handles that must die before the context does
         self.seed(seed)
+
+    def _adopt(self, obj):
+        import weakref
+        self._children.append(weakref.ref(obj))
 
     def seed(self, seed: int, nparts: int = 1, mypart: int = 0):
         _check(self.lib.pmc_rng_seed(self.h, C.c_uint64(seed), nparts, mypart))
@@ -280,6 +288,11 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for ref in self._children:      # samplers / solvers / device arrays hold a reference to this ctx
+                obj = ref()
+                if obj is not None:
+                    (obj.close if hasattr(obj, "close") else obj.free)()
+            self._children = []
             self.lib.pmc_ctx_destroy(self.h)
             self.h = None
 
@@ -308,6 +321,7 @@ class PDESampler:
         _check(lib.pmc_sampler_create(ctx.h, nl, problem.n_mc_levels, arr, problem.alpha, problem.matern_g,
                                       1 if problem.lognormal else 0, C.byref(o), C.byref(h)))
         self.h = h
+        ctx._adopt(self)
         self.nlevels = problem.n_mc_levels
         if projection == "gather":
             for lvl, idx in enumerate(problem.orig_index):
@@ -371,6 +385,24 @@ class PDESampler:
             out.append([(s.iterations, s.converged, s.initial_norm, s.final_norm) for s in stats])
         return out[0] if len(out) == 1 else tuple(out)
 
+    def Mult(self, level, x, repeat=1):
+        """y = [M Bt; B -aW] x (the block operator's Mult).  x: (nbatch, n_u+n_s) numpy or a
+        DeviceArray (then pass nbatch via x.n).  Returns (y, avg_kernel_ms, algorithmic_bytes)."""
+        L = self.problem.levels[level]
+        n = L.n_u + L.n_s
+        if isinstance(x, np.ndarray):
+            x = _f64(np.atleast_2d(x))
+            nb = x.shape[0]
+            y = np.empty_like(x)
+        else:
+            nb = x.n // n
+            y = self.ctx.empty(x.n)
+        px, ms = _addr(x)
+        py, _ = _addr(y)
+        t, b = C.c_double(), C.c_double()
+        _check(self.ctx.lib.pmc_sampler_apply_operator(self.h, level, nb, px, py, ms, repeat, C.byref(t), C.byref(b)))
+        return y, t.value, b.value
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.pmc_sampler_destroy(self.h)
@@ -400,6 +432,7 @@ class DarcySolver:
         _check(ctx.lib.pmc_darcy_create(ctx.h, nl, problem.n_mc_levels, arr, 1 if problem.k_divides else 0,
                                         C.byref(o), C.byref(h)))
         self.h = h
+        ctx._adopt(self)
         self.nlevels = problem.n_mc_levels
 
     def GetGlobalNumberOfDofs(self, level):

@@ -280,6 +280,14 @@ int pmc_sampler_eval(pmc_sampler* s, int level, int xi_level, int nbatch, const 
     });
 }
 
+int pmc_sampler_apply_operator(pmc_sampler* s, int level, int nbatch, const double* x, double* y, int memspace,
+                               int repeat, double* avg_ms, double* bytes) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr, "sampler is NULL");
+        s->impl.apply_operator(level, nbatch, x, y, memspace, repeat, avg_ms, bytes);
+    });
+}
+
 // ---- Darcy ------------------------------------------------------------------------------------
 int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_level* levels, int k_divides,
                      const pmc_solver_opts* opts, pmc_darcy** out) {

@@ -287,7 +287,7 @@ void Darcy::ensure(int level, int nb) {
     cd.ensure((size_t)d.n_u * nb);
     stage_k.ensure((size_t)d.n_p * nb);
     stage_sol.ensure(n * nb);
-    qpartial.ensure((size_t)dot_blocks((int)n) * kMaxBatch);
+    qpartial.ensure((size_t)dot_capacity((int)n) * kMaxBatch);
     qout.ensure(kMaxBatch);
 }
 
@@ -324,7 +324,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
         k::spmm(s, nb_, Mv, x, y, false, nullptr, nullptr);
         k::spmm(s, nb_, Btv, x + (size_t)n_u * nb_, y, true, nullptr, nullptr);
         k::spmm(s, nb_, Bv, x, y + (size_t)n_u * nb_, false, nullptr, nullptr);
-        if (partial) k::dot(s, nb_, n, x, y, partial);
+        return partial ? k::dot(s, nb_, n, x, y, partial) : 0;
     };
     ChebParams cpM{opts.cheb_degree_M, 1.0, opts.cheb_ratio_M};
     const double* l1 = d.l1invM.p;
@@ -343,8 +343,8 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     if (stats)
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
     // K15: Q = <obs, sol>
-    k::wdot(st, nb, n, d.obs.p, sol.p, qpartial.p);
-    k::reduce_final(st, nb, dot_blocks(n), qpartial.p, qout.p);
+    const int qblocks = k::wdot(st, nb, n, d.obs.p, sol.p, qpartial.p);
+    k::reduce_final(st, nb, qblocks, qpartial.p, qout.p);
     PMC_HIP(hipMemcpyAsync(ctx.h_scal, qout.p, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
     if (sol_d) k::deinterleave(st, nb, n, sol.p, nullptr, nullptr, false, sol_d);
     PMC_HIP(hipStreamSynchronize(st));

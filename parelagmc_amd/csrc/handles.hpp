@@ -37,6 +37,8 @@ struct Sampler {
     void sample(int level, uint64_t first_id, int nbatch, double* xi, int memspace);
     void eval(int level, int xi_level, int nbatch, const double* xi, double* s_out, const double* init_s, int init_level,
               bool use_init, double* emb_out, int memspace, pmc_stats* stats);
+    void apply_operator(int level, int nb, const double* x, double* y, int memspace, int repeat, double* avg_ms,
+                        double* bytes);
 
   private:
     void ensure(int level, int nb);

@@ -16,12 +16,35 @@ namespace pmc {
 static constexpr int kBlock = 256;
 static constexpr int kWave = 64;
 
-int dot_blocks(int nrows) { return (nrows + kBlock - 1) / kBlock; }
+int dot_capacity(int nrows) {
+    // upper bound on the partial blocks any (fused) dot over nrows rows writes, for every batch width
+    return (nrows + 63) / 64 / (kBlock / kWave) + (int)(((size_t)nrows * kMaxBatch / 2 + kBlock - 1) / kBlock) + 2;
+}
 
+// Batch layout helper.  A row of NB interleaved values is handled by T lanes, C = 2 doubles (one 16 B
+// access) each, so a group of T lanes touches NB*8 contiguous bytes and a wavefront G = 64/T rows.
 template <int NB>
-struct Vec;  // helper to move NB contiguous doubles with the widest loads
-template <>
-struct Vec<1> { using T = double; };
+struct Lay {
+    static constexpr int C = NB >= 2 ? 2 : 1;
+    static constexpr int T = NB / C;
+    static constexpr int G = kWave / T;
+};
+
+template <int C>
+__device__ __forceinline__ void load_c(const double* __restrict__ p, double (&v)[C]) {
+    if constexpr (C == 1) {
+        v[0] = p[0];
+    } else {
+        const double2 t = *reinterpret_cast<const double2*>(p);
+        v[0] = t.x;
+        v[1] = t.y;
+    }
+}
+template <int C>
+__device__ __forceinline__ void store_c(double* __restrict__ p, const double (&v)[C]) {
+    if constexpr (C == 1) p[0] = v[0];
+    else *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]);
+}
 
 template <int NB>
 __device__ __forceinline__ void load_row(const double* __restrict__ p, double (&v)[NB]) {
@@ -48,22 +71,24 @@ __device__ __forceinline__ void store_row(double* __restrict__ p, const double (
     }
 }
 
-// Block-wide sum of NB per-thread values -> partial[blockIdx.x*NB + k].  Deterministic:
-// fixed shuffle tree inside a wavefront, fixed order across the 4 wavefronts.
+// Column-wise block reduction.  Every lane holds partial sums p[0..C) for columns (lane % T)*C + c.
+// Deterministic: fixed xor tree over the lanes that share a column, fixed order over the 4 wavefronts.
+// Writes partial[blockIdx.x*NB + k].
 template <int NB>
-__device__ __forceinline__ void block_reduce_store(double (&p)[NB], double* __restrict__ partial) {
+__device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], double* __restrict__ partial) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T;
     __shared__ double lds[kBlock / kWave][NB];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        double v = p[k];
+    for (int c = 0; c < C; ++c) {
+        double v = p[c];
 #pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-        p[k] = v;
+        for (int off = kWave / 2; off >= T; off >>= 1) v += __shfl_xor(v, off, kWave);
+        p[c] = v;
     }
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (lane == 0) {
+    if (lane < T) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) lds[wave][k] = p[k];
+        for (int c = 0; c < C; ++c) lds[wave][lane * C + c] = p[c];
     }
     __syncthreads();
     if (threadIdx.x < NB) {
@@ -75,35 +100,50 @@ __device__ __forceinline__ void block_reduce_store(double (&p)[NB], double* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// SELL-64 sparse matrix times interleaved multi-vector.  One lane per row, NB accumulators.
-// MODE 0: y = Ax   1: y += Ax   2: y = r - Ax   3: Chebyshev step (d = a d + b dinv (r - Ax); xo = x + d)
+// SELL-64 sparse matrix times interleaved multi-vector.  One wavefront per 64-row slice.  Every lane
+// loads the value / column of "its" row for slice column j (one fully coalesced 512 B + 256 B access
+// per wavefront), then the wavefront sweeps the slice in T steps of G rows: lane (g, t) takes row
+// rs*G+g and the 16 B column pair t, fetching that row's value / column index with a cross-lane
+// shuffle, so each x gather and each y store is one contiguous NB*8-byte segment per row.
 template <int NB, bool BV>
 __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_off, const int* __restrict__ cols,
                                                  const double* __restrict__ vals, const double* __restrict__ x,
-                                                 int slice, int lane, double (&acc)[NB]) {
+                                                 int slice, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int off = slice_off[slice];
     const int width = (slice_off[slice + 1] - off) >> 6;
+    const int g = lane / T, t = lane % T;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) acc[k] = 0.0;
+    for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
     int slot = off + lane;
-#pragma unroll 4
+#pragma unroll 2
     for (int j = 0; j < width; ++j, slot += kWave) {
-        const int c = cols[slot];
-        double xv[NB];
-        load_row<NB>(x + (size_t)c * NB, xv);
-        if constexpr (BV) {
-            double av[NB];
-            load_row<NB>(vals + (size_t)slot * NB, av);
+        const int cj = cols[slot];
+        double vj = 0.0;
+        if constexpr (!BV) vj = vals[slot];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) acc[k] = fma(av[k], xv[k], acc[k]);
-        } else {
-            const double a = vals[slot];
+        for (int rs = 0; rs < T; ++rs) {
+            const int src = rs * G + g;
+            const int cc = (T == 1) ? cj : __shfl(cj, src, kWave);
+            double xv[C];
+            load_c<C>(x + (size_t)cc * NB + t * C, xv);
+            if constexpr (BV) {
+                double av[C];
+                load_c<C>(vals + (size_t)(slot - lane + src) * NB + t * C, av);
 #pragma unroll
-            for (int k = 0; k < NB; ++k) acc[k] = fma(a, xv[k], acc[k]);
+                for (int c = 0; c < C; ++c) acc[rs][c] = fma(av[c], xv[c], acc[rs][c]);
+            } else {
+                const double a = (T == 1) ? vj : __shfl(vj, src, kWave);
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[rs][c] = fma(a, xv[c], acc[rs][c]);
+            }
         }
     }
 }
 
+// MODE 0: y = Ax   1: y += Ax   2: y = r - Ax ; DOT: partial sums of <dot_with, result>
 template <int NB, bool BV, int MODE, bool DOT>
 __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ cols,
@@ -112,43 +152,46 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                                                            const double* __restrict__ r,
                                                            const double* __restrict__ dot_with,
                                                            double* __restrict__ partial) {
-    const int row = blockIdx.x * kBlock + threadIdx.x;
-    const int slice = row >> 6, lane = row & 63;
-    double acc[NB];
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int slice = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = lane / T, t = lane % T;
+    double acc[T][C];
+    double p[C];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) acc[k] = 0.0;
-    if (slice < nslices) sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
-    const bool live = row < nrows;
-    if (live) {
-        double* yr = y + (size_t)row * NB;
-        if constexpr (MODE == 1) {
-            double old[NB];
-            load_row<NB>(yr, old);
+    for (int c = 0; c < C; ++c) p[c] = 0.0;
+    if (slice < nslices) {
+        sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
 #pragma unroll
-            for (int k = 0; k < NB; ++k) acc[k] += old[k];
-        } else if constexpr (MODE == 2) {
-            double rv[NB];
-            load_row<NB>(r + (size_t)row * NB, rv);
+        for (int rs = 0; rs < T; ++rs) {
+            const int row = slice * kWave + rs * G + g;
+            if (row < nrows) {
+                const size_t at = (size_t)row * NB + t * C;
+                if constexpr (MODE == 1) {
+                    double old[C];
+                    load_c<C>(y + at, old);
 #pragma unroll
-            for (int k = 0; k < NB; ++k) acc[k] = rv[k] - acc[k];
+                    for (int c = 0; c < C; ++c) acc[rs][c] += old[c];
+                } else if constexpr (MODE == 2) {
+                    double rv[C];
+                    load_c<C>(r + at, rv);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[rs][c] = rv[c] - acc[rs][c];
+                }
+                store_c<C>(y + at, acc[rs]);
+                if constexpr (DOT) {
+                    double w[C];
+                    load_c<C>(dot_with + at, w);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) p[c] = fma(w[c], acc[rs][c], p[c]);
+                }
+            }
         }
-        store_row<NB>(yr, acc);
     }
-    if constexpr (DOT) {
-        double p[NB];
-        if (live) {
-            double w[NB];
-            load_row<NB>(dot_with + (size_t)row * NB, w);
-#pragma unroll
-            for (int k = 0; k < NB; ++k) p[k] = w[k] * acc[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < NB; ++k) p[k] = 0.0;
-        }
-        block_reduce_store<NB>(p, partial);
-    }
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
 }
 
+// Chebyshev / Jacobi step: d = a d + b dinv (r - A xin); xout = xin + d
 template <int NB, bool BV>
 __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ cols,
@@ -157,112 +200,148 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
                                                            const double* __restrict__ r,
                                                            const double* __restrict__ xin, double* __restrict__ d,
                                                            double* __restrict__ xout, double a, double b) {
-    const int row = blockIdx.x * kBlock + threadIdx.x;
-    const int slice = row >> 6, lane = row & 63;
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int slice = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     if (slice >= nslices) return;
-    double acc[NB];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = lane / T, t = lane % T;
+    double acc[T][C];
     sell_row_product<NB, BV>(slice_off, cols, vals, xin, slice, lane, acc);
-    if (row >= nrows) return;
-    double rv[NB], dv[NB], xv[NB], di[NB];
-    load_row<NB>(r + (size_t)row * NB, rv);
-    load_row<NB>(xin + (size_t)row * NB, xv);
-    if (a != 0.0) {
-        load_row<NB>(d + (size_t)row * NB, dv);
-    } else {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) dv[k] = 0.0;
-    }
-    if constexpr (BV) {
-        load_row<NB>(dinv + (size_t)row * NB, di);
-    } else {
-        const double s = dinv[row];
+    for (int rs = 0; rs < T; ++rs) {
+        const int row = slice * kWave + rs * G + g;
+        if (row >= nrows) continue;
+        const size_t at = (size_t)row * NB + t * C;
+        double rv[C], dv[C], xv[C], di[C];
+        load_c<C>(r + at, rv);
+        load_c<C>(xin + at, xv);
+        if (a != 0.0) {
+            load_c<C>(d + at, dv);
+        } else {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) di[k] = s;
-    }
+            for (int c = 0; c < C; ++c) dv[c] = 0.0;
+        }
+        if constexpr (BV) {
+            load_c<C>(dinv + at, di);
+        } else {
+            const double s = dinv[row];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        dv[k] = a * dv[k] + b * di[k] * (rv[k] - acc[k]);
-        xv[k] += dv[k];
+            for (int c = 0; c < C; ++c) di[c] = s;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            dv[c] = a * dv[c] + b * di[c] * (rv[c] - acc[rs][c]);
+            xv[c] += dv[c];
+        }
+        store_c<C>(d + at, dv);
+        store_c<C>(xout + at, xv);
     }
-    store_row<NB>(d + (size_t)row * NB, dv);
-    store_row<NB>(xout + (size_t)row * NB, xv);
 }
 
+// ---- flat element-wise kernels: thread i owns the C doubles at flat index i*C, i.e. row (i*C)/NB and
+// columns ((i*C) % NB) + c; consecutive lanes touch consecutive 16 B -> fully coalesced.
 template <int NB, bool BV>
-__global__ __launch_bounds__(kBlock) void cheb_first_kernel(int n, const double* __restrict__ dinv,
+__global__ __launch_bounds__(kBlock) void cheb_first_kernel(size_t nflat, const double* __restrict__ dinv,
                                                             const double* __restrict__ r, double* __restrict__ d,
                                                             double* __restrict__ x, double b) {
-    const int row = blockIdx.x * kBlock + threadIdx.x;
-    if (row >= n) return;
-    double rv[NB], di[NB];
-    load_row<NB>(r + (size_t)row * NB, rv);
+    constexpr int C = Lay<NB>::C;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nflat) return;
+    const size_t e = i * C;
+    double rv[C], di[C];
+    load_c<C>(r + e, rv);
     if constexpr (BV) {
-        load_row<NB>(dinv + (size_t)row * NB, di);
+        load_c<C>(dinv + e, di);
     } else {
-        const double s = dinv[row];
+        const double s = dinv[e / NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) di[k] = s;
+        for (int c = 0; c < C; ++c) di[c] = s;
     }
 #pragma unroll
-    for (int k = 0; k < NB; ++k) rv[k] = b * di[k] * rv[k];
-    store_row<NB>(d + (size_t)row * NB, rv);
-    store_row<NB>(x + (size_t)row * NB, rv);
+    for (int c = 0; c < C; ++c) rv[c] = b * di[c] * rv[c];
+    store_c<C>(d + e, rv);
+    store_c<C>(x + e, rv);
 }
 
 template <int NB>
-__global__ __launch_bounds__(kBlock) void dot_kernel(int n, const double* __restrict__ a, const double* __restrict__ b,
-                                                     double* __restrict__ partial) {
-    const int row = blockIdx.x * kBlock + threadIdx.x;
-    double p[NB];
-    if (row < n) {
-        double av[NB], bv[NB];
-        load_row<NB>(a + (size_t)row * NB, av);
-        load_row<NB>(b + (size_t)row * NB, bv);
+__global__ __launch_bounds__(kBlock) void dot_kernel(size_t nflat, const double* __restrict__ a,
+                                                     const double* __restrict__ b, double* __restrict__ partial) {
+    constexpr int C = Lay<NB>::C;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    double p[C];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) p[k] = av[k] * bv[k];
-    } else {
+    for (int c = 0; c < C; ++c) p[c] = 0.0;
+    if (i < nflat) {
+        double av[C], bv[C];
+        load_c<C>(a + i * C, av);
+        load_c<C>(b + i * C, bv);
 #pragma unroll
-        for (int k = 0; k < NB; ++k) p[k] = 0.0;
+        for (int c = 0; c < C; ++c) p[c] = av[c] * bv[c];
     }
-    block_reduce_store<NB>(p, partial);
+    reduce_cols_store<NB>(p, partial);
 }
 
 template <int NB>
-__global__ __launch_bounds__(kBlock) void lincomb3_kernel(int n, const double* __restrict__ c0,
+__global__ __launch_bounds__(kBlock) void lincomb3_kernel(size_t nflat, const double* __restrict__ c0,
                                                           const double* __restrict__ a, const double* __restrict__ c1,
                                                           const double* __restrict__ b, const double* __restrict__ c2,
                                                           double* __restrict__ y) {
-    const int row = blockIdx.x * kBlock + threadIdx.x;
-    if (row >= n) return;
-    double av[NB], bv[NB], yv[NB];
-    load_row<NB>(a + (size_t)row * NB, av);
-    load_row<NB>(b + (size_t)row * NB, bv);
-    load_row<NB>(y + (size_t)row * NB, yv);
+    constexpr int C = Lay<NB>::C;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nflat) return;
+    const size_t e = i * C;
+    const int k0 = (int)(e % NB);
+    double av[C], bv[C], yv[C];
+    load_c<C>(a + e, av);
+    load_c<C>(b + e, bv);
+    load_c<C>(y + e, yv);
 #pragma unroll
-    for (int k = 0; k < NB; ++k) yv[k] = c0[k] * av[k] + c1[k] * bv[k] + c2[k] * yv[k];
-    store_row<NB>(y + (size_t)row * NB, yv);
+    for (int c = 0; c < C; ++c) yv[c] = c0[k0 + c] * av[c] + c1[k0 + c] * bv[c] + c2[k0 + c] * yv[c];
+    store_c<C>(y + e, yv);
 }
 
 template <int NB>
-__global__ __launch_bounds__(kBlock) void minres_wx_kernel(int n, const double* __restrict__ c0,
+__global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const double* __restrict__ c0,
                                                            const double* __restrict__ u, const double* __restrict__ c1,
                                                            double* __restrict__ w0, const double* __restrict__ c2,
                                                            const double* __restrict__ w1, const double* __restrict__ c3,
                                                            double* __restrict__ x) {
-    const int row = blockIdx.x * kBlock + threadIdx.x;
-    if (row >= n) return;
-    double uv[NB], w0v[NB], w1v[NB], xv[NB];
-    load_row<NB>(u + (size_t)row * NB, uv);
-    load_row<NB>(w0 + (size_t)row * NB, w0v);
-    load_row<NB>(w1 + (size_t)row * NB, w1v);
-    load_row<NB>(x + (size_t)row * NB, xv);
+    constexpr int C = Lay<NB>::C;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nflat) return;
+    const size_t e = i * C;
+    const int k0 = (int)(e % NB);
+    double uv[C], w0v[C], w1v[C], xv[C];
+    load_c<C>(u + e, uv);
+    load_c<C>(w0 + e, w0v);
+    load_c<C>(w1 + e, w1v);
+    load_c<C>(x + e, xv);
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        w0v[k] = c0[k] * uv[k] + c1[k] * w0v[k] + c2[k] * w1v[k];
-        xv[k] += c3[k] * w0v[k];
+    for (int c = 0; c < C; ++c) {
+        w0v[c] = c0[k0 + c] * uv[c] + c1[k0 + c] * w0v[c] + c2[k0 + c] * w1v[c];
+        xv[c] += c3[k0 + c] * w0v[c];
     }
-    store_row<NB>(w0 + (size_t)row * NB, w0v);
-    store_row<NB>(x + (size_t)row * NB, xv);
+    store_c<C>(w0 + e, w0v);
+    store_c<C>(x + e, xv);
+}
+
+// partial sums of <w, x[:,k]> with a shared (non-batched) weight vector w   (K15 QoI)
+template <int NB>
+__global__ __launch_bounds__(kBlock) void wdot_kernel(size_t nflat, const double* __restrict__ w,
+                                                      const double* __restrict__ x, double* __restrict__ partial) {
+    constexpr int C = Lay<NB>::C;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    double p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = 0.0;
+    if (i < nflat) {
+        double xv[C];
+        load_c<C>(x + i * C, xv);
+        const double ww = w[(i * C) / NB];
+#pragma unroll
+        for (int c = 0; c < C; ++c) p[c] = ww * xv[c];
+    }
+    reduce_cols_store<NB>(p, partial);
 }
 
 __global__ void fill_kernel(size_t n, double* __restrict__ x, double v) {
@@ -396,8 +475,9 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
 }
 
 __device__ __forceinline__ double u01_open(uint32_t hi, uint32_t lo) {
-    const uint64_t m = ((uint64_t)(hi >> 5) << 26) + (uint64_t)(lo >> 6);
-    return ((double)m + 0.5) * (1.0 / 9007199254740992.0);
+    // 52 bits: (m + 1/2) / 2^52 is exact, strictly inside (0,1)
+    const uint64_t m = ((uint64_t)(hi >> 6) << 26) + (uint64_t)(lo >> 6);
+    return ((double)m + 0.5) * (1.0 / 4503599627370496.0);
 }
 
 #pragma clang fp contract(off)
@@ -624,25 +704,6 @@ __global__ __launch_bounds__(kBlock) void diag_inv_kernel(int n, const int* __re
     store_row<NB>(dinv + (size_t)row * NB, v);
 }
 
-// partial sums of <w, x[:,k]> with a shared (non-batched) weight vector w   (K15 QoI)
-template <int NB>
-__global__ __launch_bounds__(kBlock) void wdot_kernel(int n, const double* __restrict__ w, const double* __restrict__ x,
-                                                      double* __restrict__ partial) {
-    const int row = blockIdx.x * kBlock + threadIdx.x;
-    double p[NB];
-    if (row < n) {
-        double xv[NB];
-        load_row<NB>(x + (size_t)row * NB, xv);
-        const double ww = w[row];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) p[k] = ww * xv[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) p[k] = 0.0;
-    }
-    block_reduce_store<NB>(p, partial);
-}
-
 // out[k] = sum_b partial[b*nb+k]   (single block)
 __global__ __launch_bounds__(kBlock) void reduce_final_kernel(const double* __restrict__ partial, int nblocks, int nb,
                                                               double* __restrict__ out) {
@@ -677,14 +738,17 @@ __global__ __launch_bounds__(kBlock) void broadcast_kernel(int n, const double* 
     }
 
 static inline dim3 grid_rows(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+static inline dim3 grid_slices(int nslices) { return dim3((unsigned)((nslices + kBlock / kWave - 1) / (kBlock / kWave))); }
+static inline size_t flat_count(int n, int nb) { return (size_t)n * nb / (nb >= 2 ? 2 : 1); }
+static inline dim3 grid_flat(int n, int nb) { return dim3((unsigned)((flat_count(n, nb) + kBlock - 1) / kBlock)); }
 static inline void check_launch() { PMC_HIP(hipGetLastError()); }
 
 namespace k {
 
-void spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate, double* dot_partial,
-          const double* dot_with) {
-    if (A.nrows == 0) return;
-    const dim3 g = grid_rows(A.nslices * kWave);
+int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate, double* dot_partial,
+         const double* dot_with) {
+    if (A.nrows == 0) return 0;
+    const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
         if (A.bv) {
             if (dot_partial)
@@ -703,11 +767,12 @@ void spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y,
         }
     });
     check_launch();
+    return (int)g.x;
 }
 
 void residual(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out) {
     if (A.nrows == 0) return;
-    const dim3 g = grid_rows(A.nslices * kWave);
+    const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
         if (A.bv)
             sell_spmm_kernel<NB, true, 2, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, out, r, nullptr, nullptr);
@@ -721,7 +786,7 @@ void cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bo
                const double* xin, double* d, double* xout, double a, double b) {
     if (A.nrows == 0) return;
     if (A.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "cheb_step: value/diagonal batching mismatch");
-    const dim3 g = grid_rows(A.nslices * kWave);
+    const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
         if (A.bv)
             sell_cheb_kernel<NB, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b);
@@ -734,23 +799,28 @@ void cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bo
 void cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d, double* x,
                 double b) {
     if (n == 0) return;
+    const size_t nf = flat_count(n, nb);
     PMC_DISPATCH_NB(nb, {
         if (dinv_bv)
-            cheb_first_kernel<NB, true><<<grid_rows(n), kBlock, 0, st>>>(n, dinv, r, d, x, b);
+            cheb_first_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(nf, dinv, r, d, x, b);
         else
-            cheb_first_kernel<NB, false><<<grid_rows(n), kBlock, 0, st>>>(n, dinv, r, d, x, b);
+            cheb_first_kernel<NB, false><<<grid_flat(n, nb), kBlock, 0, st>>>(nf, dinv, r, d, x, b);
     });
     check_launch();
 }
 
-void dot(hipStream_t st, int nb, int n, const double* a, const double* b, double* partial) {
-    PMC_DISPATCH_NB(nb, { dot_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, a, b, partial); });
+int dot(hipStream_t st, int nb, int n, const double* a, const double* b, double* partial) {
+    const dim3 g = grid_flat(n, nb);
+    PMC_DISPATCH_NB(nb, { dot_kernel<NB><<<g, kBlock, 0, st>>>(flat_count(n, nb), a, b, partial); });
     check_launch();
+    return (int)g.x;
 }
 
-void wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial) {
-    PMC_DISPATCH_NB(nb, { wdot_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, w, x, partial); });
+int wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial) {
+    const dim3 g = grid_flat(n, nb);
+    PMC_DISPATCH_NB(nb, { wdot_kernel<NB><<<g, kBlock, 0, st>>>(flat_count(n, nb), w, x, partial); });
     check_launch();
+    return (int)g.x;
 }
 
 void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, double* out) {
@@ -760,13 +830,13 @@ void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, do
 
 void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b,
               const double* c2, double* y) {
-    PMC_DISPATCH_NB(nb, { lincomb3_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, c0, a, c1, b, c2, y); });
+    PMC_DISPATCH_NB(nb, { lincomb3_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y); });
     check_launch();
 }
 
 void minres_wx(hipStream_t st, int nb, int n, const double* c0, const double* u, const double* c1, double* w0,
                const double* c2, const double* w1, const double* c3, double* x) {
-    PMC_DISPATCH_NB(nb, { minres_wx_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, c0, u, c1, w0, c2, w1, c3, x); });
+    PMC_DISPATCH_NB(nb, { minres_wx_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x); });
     check_launch();
 }
 

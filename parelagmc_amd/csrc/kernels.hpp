@@ -19,8 +19,8 @@ inline SellView view_bv(const Sell& S, const double* vals) {
     return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, vals, true};
 }
 
-// number of per-block partial sums a (fused) dot over n rows writes per column
-int dot_blocks(int nrows);
+// capacity (in blocks) of a partial-sum buffer for (fused) dots over nrows rows: allocate dot_capacity*kMaxBatch doubles
+int dot_capacity(int nrows);
 
 namespace k {
 
@@ -36,8 +36,8 @@ struct MinresState {
 };
 
 // y = A x (accumulate=false) or y += A x.  If dot_partial != nullptr (accumulate must be false) also
-// writes per-block partial sums of <dot_with, A x>: dot_blocks(A.nslices*64)*nb doubles.
-void spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate,
+// writes per-block partial sums of <dot_with, A x>; returns the number of partial blocks written.
+int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate,
           double* dot_partial, const double* dot_with);
 // out = r - A x
 void residual(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out);
@@ -47,8 +47,9 @@ void cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bo
 // first step from a zero guess: d = b*dinv.*r; x = d
 void cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d,
                 double* x, double b);
-void dot(hipStream_t st, int nb, int n, const double* a, const double* b, double* partial);
-void wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial);
+// both return the number of partial blocks written
+int dot(hipStream_t st, int nb, int n, const double* a, const double* b, double* partial);
+int wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial);
 void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, double* out);
 void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b,
               const double* c2, double* y);

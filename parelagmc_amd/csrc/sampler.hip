@@ -216,7 +216,7 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     A.n = n;
     const SellView Av = view(d.A);
     A.apply = [Av](hipStream_t s, int nb_, const double* x, double* y, double* partial) {
-        k::spmm(s, nb_, Av, x, y, false, partial, x);
+        return k::spmm(s, nb_, Av, x, y, false, partial, x);
     };
     const SellView Mv = view(d.M);
     const double* dinvM = d.dinvM.p;
@@ -246,6 +246,40 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
         k::deinterleave(st, nb, d.out_size, tA.p, nullptr, d.inv_w.p, lognormal, s_d);
     }
     if (emb_d) k::deinterleave(st, nb, n_s, sol_s, nullptr, nullptr, false, emb_d);
+}
+
+void Sampler::apply_operator(int level, int nb, const double* x, double* y, int memspace, int repeat, double* avg_ms,
+                             double* bytes) {
+    PMC_REQUIRE(level >= 0 && level < nlevels, "apply_operator: level out of range");
+    PMC_REQUIRE(valid_batch(nb) && x != nullptr && y != nullptr && repeat >= 1, "apply_operator: bad arguments");
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    SamplerLevel& d = lv[level];
+    const size_t n = (size_t)d.n_u + d.n_s;
+    DevBuf<double> xi(n * nb), yi(n * nb), stage;
+    const double* xd = x;
+    double* yd = y;
+    if (memspace == PMC_MEM_HOST) {
+        stage.alloc(n * nb);
+        PMC_HIP(hipMemcpyAsync(stage.p, x, sizeof(double) * n * nb, hipMemcpyHostToDevice, st));
+        xd = stage.p;
+        yd = stage.p;
+    }
+    k::interleave(st, nb, (int)n, xd, nullptr, 1.0, xi.p);
+    const SellView Av = view(d.A);
+    k::spmm(st, nb, Av, xi.p, yi.p, false, nullptr, nullptr);   // untimed first touch
+    PMC_HIP(hipEventRecord(ctx.ev0, st));
+    for (int r = 0; r < repeat; ++r) k::spmm(st, nb, Av, xi.p, yi.p, false, nullptr, nullptr);
+    PMC_HIP(hipEventRecord(ctx.ev1, st));
+    k::deinterleave(st, nb, (int)n, yi.p, nullptr, nullptr, false, yd);
+    if (memspace == PMC_MEM_HOST) PMC_HIP(hipMemcpyAsync(y, stage.p, sizeof(double) * n * nb, hipMemcpyDeviceToHost, st));
+    PMC_HIP(hipStreamSynchronize(st));
+    if (avg_ms) {
+        float ms = 0.f;
+        PMC_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+        *avg_ms = (double)ms / repeat;
+    }
+    if (bytes) *bytes = 12.0 * d.A.nnz + 4.0 * d.A.nrows + (double)nb * 8.0 * ((double)d.A.nrows + d.A.ncols);
 }
 
 void Sampler::eval(int level, int xi_level, int nbatch, const double* xi, double* s_out, const double* init_s,

@@ -80,7 +80,7 @@ void MinresWork::ensure(int n, int nb) {
     const size_t need = (size_t)n * nb;
     v0.ensure(need); v1.ensure(need); u0.ensure(need); u1.ensure(need);
     w0.ensure(need); w1.ensure(need); q.ensure(need);
-    partial.ensure((size_t)dot_blocks(n) * kMaxBatch);
+    partial.ensure((size_t)dot_capacity(n) * kMaxBatch);
     if (!state.p) state.alloc(1);
 }
 
@@ -103,7 +103,6 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     hipStream_t st = ctx.stream;
     const int n = A.n;
     const size_t len = (size_t)n * nb;
-    const int nblocks = dot_blocks(n);
     w.ensure(n, nb);
     k::MinresState* S = w.state.p;
     double* v0 = w.v0.p; double* v1 = w.v1.p; double* u0 = w.u0.p; double* u1 = w.u1.p;
@@ -118,7 +117,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         axpby(st, len, 1.0, b, -1.0, v1);
     }
     prec(st, nb, v1, u1);
-    k::dot(st, nb, n, v1, u1, w.partial.p);
+    int nblocks = k::dot(st, nb, n, v1, u1, w.partial.p);
     k::minres_init(st, nb, S, w.partial.p, nblocks, o.rel_tol, o.abs_tol);
     k::fill(st, len, v0, 0.0);
     k::fill(st, len, w0, 0.0);
@@ -146,11 +145,11 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     int n_active = poll();
     while (n_active > 0 && it < o.max_iter) {
         ++it;
-        A.apply(st, nb, u1, q, w.partial.p);
+        nblocks = A.apply(st, nb, u1, q, w.partial.p);
         k::minres_scal1(st, nb, S, w.partial.p, nblocks);
         k::lincomb3(st, nb, n, cV0, q, cV1, v1, cV2, v0);
         prec(st, nb, v0, u0);
-        k::dot(st, nb, n, v0, u0, w.partial.p);
+        nblocks = k::dot(st, nb, n, v0, u0, w.partial.p);
         k::minres_scal2(st, nb, S, w.partial.p, nblocks);
         k::minres_wx(st, nb, n, cW0, u1, cW1, w0, cW2, w1, cW3, x);
         std::swap(u0, u1);

@@ -52,8 +52,9 @@ struct Multigrid {
 // Abstract pieces MINRES needs.
 struct LinOp {
     int n = 0;
-    // y = A x ; when dot_partial != nullptr also the per-block partials of <x, A x> (dot_blocks(n)*nb)
-    std::function<void(hipStream_t, int nb, const double* x, double* y, double* dot_partial)> apply;
+    // y = A x ; when dot_partial != nullptr also per-block partials of <x, A x>; returns the number of
+    // partial blocks written (0 when dot_partial == nullptr)
+    std::function<int(hipStream_t, int nb, const double* x, double* y, double* dot_partial)> apply;
 };
 using PrecFn = std::function<void(hipStream_t, int nb, const double* r, double* z)>;
 

@@ -2,7 +2,8 @@
 
 Host-only numpy/scipy code that produces the CSR operators the C-ABI consumes; it stands in
 for the MFEM/ParELAG setup calls of the reference drivers and is outside every timed region."""
-from .mesh import Mesh, box_mesh, build_faces, kuhn_cube_tet, read_mfem_mesh, refine_uniform  # noqa: F401
+from .mesh import (Mesh, box_mesh, build_faces, kuhn_cube_tet, mesh_from_json, read_mfem_mesh,  # noqa: F401
+                   refine_uniform)
 from .problems import (DarcyLevel, DarcyProblem, Hierarchy, SamplerLevel, SamplerProblem,  # noqa: F401
                        build_darcy_problem, build_hierarchy, build_sampler_problem,
                        l2_projection_ops, matern_coefficient)

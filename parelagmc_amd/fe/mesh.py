@@ -442,3 +442,19 @@ def element_volumes(m: Mesh) -> np.ndarray:
 
 def element_centroids(m: Mesh) -> np.ndarray:
     return m.verts[m.elems].mean(axis=1)
+
+
+def mesh_from_json(path) -> Mesh:
+    """Load a mesh stored as JSON arrays (tests/golden/meshes/*.json, written by
+    tests/golden/make_golden.py from the reference's mesh data files)."""
+    import json
+    with open(path, "r") as f:
+        d = json.load(f)
+    et = d["etype"]
+    nvf = _FACE_NV[et]
+    m = Mesh(et, np.asarray(d["verts"], np.float64), np.asarray(d["elems"], np.int64),
+             np.asarray(d["elem_attr"], np.int32), np.asarray(d["bdr"], np.int64).reshape(-1, nvf),
+             np.asarray(d["bdr_attr"], np.int32))
+    if et in ("tri", "tet"):
+        _orient_simplices(m)
+    return m

@@ -1,0 +1,563 @@
+// libpmc_host.so: plugin wrappers + Monte Carlo managers (see parelagmc.hpp / include/pmc_host.h).
+#include "parelagmc.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <sstream>
+
+namespace parelagmc {
+
+namespace {
+void check(int rc, const char* what) {
+    if (rc != PMC_OK) throw std::runtime_error(std::string(what) + ": " + pmc_last_error());
+}
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+// ---- Vector -----------------------------------------------------------------------------------
+Vector::~Vector() {
+    if (!data_) return;
+    if (memspace_ == PMC_MEM_DEVICE) pmc_free(ctx_, data_);
+    else delete[] data_;
+}
+void Vector::SetSize(int size, int nbatch) {
+    if (size < 0 || nbatch < 1) throw std::invalid_argument("Vector::SetSize: bad size");
+    const size_t need = (size_t)size * nbatch;
+    if (need > cap_) {
+        if (data_) {
+            if (memspace_ == PMC_MEM_DEVICE) pmc_free(ctx_, data_);
+            else delete[] data_;
+            data_ = nullptr;
+        }
+        if (memspace_ == PMC_MEM_DEVICE) {
+            void* p = nullptr;
+            check(pmc_malloc(ctx_, need * sizeof(double), &p), "Vector::SetSize");
+            data_ = static_cast<double*>(p);
+        } else {
+            data_ = new double[need];
+        }
+        cap_ = need;
+    }
+    size_ = size;
+    nbatch_ = nbatch;
+}
+
+void Vector::Swap(Vector& o) {
+    if (ctx_ != o.ctx_ || memspace_ != o.memspace_) throw std::invalid_argument("Vector::Swap: incompatible vectors");
+    std::swap(data_, o.data_);
+    std::swap(cap_, o.cap_);
+    std::swap(size_, o.size_);
+    std::swap(nbatch_, o.nbatch_);
+}
+
+// ---- NormalDistributionSampler ---------------------------------------------------------------
+void NormalDistributionSampler::Split(int nparts, int mypart) {
+    nparts_ = nparts;
+    mypart_ = mypart;
+    check(pmc_rng_seed(ctx_, seed_, nparts, mypart), "NormalDistributionSampler::Split");
+}
+void NormalDistributionSampler::operator()(Vector& v, uint64_t first_id, uint32_t stream) {
+    check(pmc_normal_fill(ctx_, mu_, sigma2_, first_id, stream, v.Batch(), v.Size(), v.GetData(), v.MemSpace()),
+          "NormalDistributionSampler");
+}
+
+// ---- PDESampler -------------------------------------------------------------------------------
+int PDESampler::level_of_xi(int size) const {
+    const int nl = pmc_sampler_num_levels(h_);
+    for (int l = 0; l < nl; ++l)
+        if (pmc_sampler_xi_size(h_, l) == size) return l;
+    throw std::runtime_error("PDESampler: vector length matches no level");   // level_size.Find() == -1
+}
+int PDESampler::level_of_field(int size) const { return level_of_xi(size); }
+void PDESampler::Sample(const int level, Vector& xi, uint64_t first_id, int nbatch) {
+    const int n = pmc_sampler_xi_size(h_, level);
+    if (n < 0) throw std::out_of_range("PDESampler::Sample: level");
+    xi.SetSize(n, nbatch);
+    check(pmc_sampler_sample(h_, level, first_id, nbatch, xi.GetData(), xi.MemSpace()), "PDESampler::Sample");
+}
+void PDESampler::Eval(const int level, const Vector& xi, Vector& s) {
+    const int xi_level = level_of_xi(xi.Size());
+    if (xi_level > level) throw std::runtime_error("PDESampler::Eval: xi_level <= level violated");
+    s.SetSize(SampleSize(level), xi.Batch());
+    std::vector<pmc_stats> st(xi.Batch());
+    check(pmc_sampler_eval(h_, level, xi_level, xi.Batch(), xi.GetData(), s.GetData(), nullptr, -1, 0, nullptr,
+                           xi.MemSpace(), st.data()),
+          "PDESampler::Eval");
+    last_iters_ = st[0].iterations;
+}
+void PDESampler::Eval(const int level, const Vector& xi, Vector& s, Vector& u, bool use_init) {
+    const int xi_level = level_of_xi(xi.Size());
+    if (xi_level > level) throw std::runtime_error("PDESampler::Eval: xi_level <= level violated");
+    int init_level = -1;
+    if (use_init) {
+        if (u.Batch() != xi.Batch()) throw std::runtime_error("PDESampler::Eval: init batch mismatch");
+        init_level = level_of_field(u.Size());
+    }
+    s.SetSize(SampleSize(level), xi.Batch());
+    const int n_field = pmc_sampler_xi_size(h_, level);
+    std::vector<pmc_stats> st(xi.Batch());
+    if (use_init && (size_t)n_field * xi.Batch() > (size_t)u.Size() * u.Batch()) {
+        // u must grow (coarse -> fine): evaluate into a fresh buffer, then swap it in
+        Vector tmp(ctx_, u.MemSpace());
+        tmp.SetSize(n_field, xi.Batch());
+        check(pmc_sampler_eval(h_, level, xi_level, xi.Batch(), xi.GetData(), s.GetData(), u.GetData(), init_level, 1,
+                               tmp.GetData(), xi.MemSpace(), st.data()),
+              "PDESampler::Eval");
+        u.Swap(tmp);
+    } else {
+        const double* init = use_init ? u.GetData() : nullptr;
+        u.SetSize(n_field, xi.Batch());   // capacity suffices: pointer unchanged
+        check(pmc_sampler_eval(h_, level, xi_level, xi.Batch(), xi.GetData(), s.GetData(), init, init_level,
+                               use_init ? 1 : 0, u.GetData(), xi.MemSpace(), st.data()),
+              "PDESampler::Eval");
+    }
+    last_iters_ = st[0].iterations;
+}
+int PDESampler::SampleSize(int level) const { return pmc_sampler_sample_size(h_, level); }
+size_t PDESampler::GetNNZ(int level) const { return (size_t)pmc_sampler_nnz(h_, level); }
+
+// ---- DarcySolver ------------------------------------------------------------------------------
+void DarcySolver::SolveFwd(int ilevel, Vector& k, double* Q, double* C) {
+    check(pmc_darcy_solve_fwd(h_, ilevel, k.Batch(), k.GetData(), Q, C, nullptr, k.MemSpace(), nullptr),
+          "DarcySolver::SolveFwd");
+}
+int DarcySolver::GetNumberOfDofs(int l) const { return pmc_darcy_num_dofs(h_, l); }
+int DarcySolver::GetGlobalNumberOfDofs(int l) const { return pmc_darcy_num_dofs(h_, l); }
+int DarcySolver::GetNNZ(int l) const { return (int)pmc_darcy_nnz(h_, l); }
+
+// ---- callback plugins ---------------------------------------------------------------------------
+CallbackSampler::CallbackSampler(int nlevels, const pmc_plugin_callbacks& cb) : cb_(cb) {
+    if (!cb.sample || !cb.eval || !cb.xi_size || !cb.sample_size) throw std::invalid_argument("sampler callbacks missing");
+    xsize_.assign(cb.xi_size, cb.xi_size + nlevels);
+    ssize_.assign(cb.sample_size, cb.sample_size + nlevels);
+}
+void CallbackSampler::Sample(const int level, Vector& xi, uint64_t first_id, int nbatch) {
+    xi.SetSize(xsize_.at(level), nbatch);
+    if (cb_.sample(cb_.user, level, first_id, nbatch, xi.GetData()) != 0) throw std::runtime_error("sample callback failed");
+}
+void CallbackSampler::Eval(const int level, const Vector& xi, Vector& s) {
+    const int xl = (int)(std::find(xsize_.begin(), xsize_.end(), xi.Size()) - xsize_.begin());
+    if (xl >= (int)xsize_.size() || xl > level) throw std::runtime_error("Eval: xi_level <= level violated");
+    s.SetSize(ssize_.at(level), xi.Batch());
+    if (cb_.eval(cb_.user, level, xl, xi.Batch(), xi.GetData(), s.GetData(), nullptr, -1, 0, nullptr) != 0)
+        throw std::runtime_error("eval callback failed");
+}
+void CallbackSampler::Eval(const int level, const Vector& xi, Vector& s, Vector& u, bool use_init) {
+    const int xl = (int)(std::find(xsize_.begin(), xsize_.end(), xi.Size()) - xsize_.begin());
+    if (xl >= (int)xsize_.size() || xl > level) throw std::runtime_error("Eval: xi_level <= level violated");
+    int il = -1;
+    std::vector<double> init;
+    if (use_init) {
+        il = (int)(std::find(xsize_.begin(), xsize_.end(), u.Size()) - xsize_.begin());
+        if (il >= (int)xsize_.size()) throw std::runtime_error("Eval: init size matches no level");
+        init.assign(u.GetData(), u.GetData() + (size_t)u.Size() * u.Batch());
+    }
+    s.SetSize(ssize_.at(level), xi.Batch());
+    u.SetSize(xsize_.at(level), xi.Batch());
+    if (cb_.eval(cb_.user, level, xl, xi.Batch(), xi.GetData(), s.GetData(), use_init ? init.data() : nullptr, il,
+                 use_init ? 1 : 0, u.GetData()) != 0)
+        throw std::runtime_error("eval callback failed");
+}
+CallbackSolver::CallbackSolver(int nlevels, const pmc_plugin_callbacks& cb) : cb_(cb) {
+    if (!cb.solve_fwd || !cb.ndofs) throw std::invalid_argument("solver callbacks missing");
+    ndofs_.assign(cb.ndofs, cb.ndofs + nlevels);
+}
+void CallbackSolver::SolveFwd(int ilevel, Vector& k, double* Q, double* C) {
+    if (cb_.solve_fwd(cb_.user, ilevel, k.Batch(), k.GetData(), Q, C) != 0) throw std::runtime_error("solve callback failed");
+}
+
+// ---- statistics -------------------------------------------------------------------------------
+// y = x^out : weighted least-squares slope of log-ratios (src/Utilities.cpp:257-283)
+double expWRegression(const std::vector<double>& y, const std::vector<double>& x, int skip_n_last) {
+    const int n = (int)y.size() - 1 - skip_n_last;
+    if (n < 1) return 0.0;
+    double num = 0.0, den = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double logdy = std::log(std::fabs(y[i] / y[i + 1]));
+        const double logdx = std::log(x[i] / x[i + 1]);
+        const double w = std::pow(.5, i);
+        num += w * logdy * logdx;
+        den += w * logdx * logdx;
+    }
+    return num / den;
+}
+
+MLMC_Manager::MLMC_Manager(pmc_ctx* ctx, int memspace, int nlevels_, PhysicalMLSolver& pSolver_, MLSampler& sampler_,
+                           const pmc_mlmc_params& p)
+    : wallTime(p.wall_time != 0),
+      nlevels(nlevels_),
+      eps2(p.eps2),
+      ratio(p.ratio),
+      ml_estimator_variance(std::numeric_limits<double>::infinity()),
+      expected_discretization_error2(std::numeric_limits<double>::infinity()),
+      actualMSE(std::numeric_limits<double>::infinity()),
+      ctx_(ctx),
+      memspace_(memspace),
+      pSolver(pSolver_),
+      sampler(sampler_),
+      auto_eps2(p.eps2 < 0 ? 1 : 0),
+      batch_(p.batch),
+      max_rounds_(p.max_rounds),
+      xi(ctx, memspace),
+      sparam(ctx, memspace),
+      init_s(ctx, memspace) {
+    if (nlevels < 1) throw std::invalid_argument("MLMC_Manager: nlevels < 1");
+    if (batch_ < 1 || batch_ > 16) throw std::invalid_argument("MLMC_Manager: batch must be in 1..16");
+    if (!(ratio > 0.0 && ratio < 1.0)) throw std::invalid_argument("MLMC_Manager: ratio must be in (0,1)");
+    if (p.array_nsamples) v_init_nsamples.assign(p.array_nsamples, p.array_nsamples + nlevels);
+    else v_init_nsamples.assign(nlevels, p.init_nsamples);
+    M.resize(nlevels);
+    for (int i = 0; i < nlevels; ++i) M[i] = pSolver.GetGlobalNumberOfDofs(i);
+    if (p.log_file && p.log_file[0]) logger.open(p.log_file);
+    Reset();
+}
+
+void MLMC_Manager::SetFarm(int nranks, int rank, std::function<void(double*, int)> reduce) {
+    if (nranks < 1 || rank < 0 || rank >= nranks) throw std::invalid_argument("SetFarm: bad rank");
+    if (nranks > 1 && !reduce) throw std::invalid_argument("SetFarm: reduction missing");
+    nranks_ = nranks;
+    rank_ = rank;
+    reduce_ = std::move(reduce);
+}
+
+void MLMC_Manager::Reset() {
+    auto z = [&](std::vector<double>& v) { v.assign(nlevels, 0.0); };
+    sums.assign((size_t)nlevels * NVAR, 0.0);
+    z(eY); z(eABSY); z(eQ); z(eABSQ); z(eC); z(varY); z(varQ); z(consistency); z(kurtosis); z(VC); z(cost); z(level_seconds);
+    level_nsamples.assign(nlevels, 0);
+    level_nsamples_missing.assign(nlevels, 0);
+    ml_estimator_variance = expected_discretization_error2 = actualMSE = std::numeric_limits<double>::infinity();
+}
+
+// One level of InitRun (src/MLMC_Manager.cpp:113-136 coarsest, :144-173 level pairs), for this
+// rank's share of the `nsamples` new realizations, `batch_` at a time.
+void MLMC_Manager::run_level(int ilevel, int nsamples) {
+    const uint64_t base = (uint64_t)level_nsamples[ilevel];
+    double* psum = pending_.data() + (size_t)ilevel * NVAR;
+    std::vector<double> q(batch_), c(batch_), qc(batch_), cc(batch_);
+    const int nblocks = (nsamples + batch_ - 1) / batch_;
+    const double t0 = now_s();
+    for (int blk = rank_; blk < nblocks; blk += nranks_) {
+        const int first = blk * batch_;
+        const int m = std::min(batch_, nsamples - first);
+        sampler.Sample(ilevel, xi, base + (uint64_t)first, m);
+        if (ilevel == nlevels - 1) {
+            sampler.Eval(ilevel, xi, sparam);
+            pSolver.SolveFwd(ilevel, sparam, q.data(), c.data());
+            for (int b = 0; b < m; ++b) qc[b] = 0.0;
+        } else {
+            sampler.Eval(ilevel + 1, xi, sparam, init_s, false);
+            pSolver.SolveFwd(ilevel + 1, sparam, qc.data(), cc.data());
+            sampler.Eval(ilevel, xi, sparam, init_s, true);
+            pSolver.SolveFwd(ilevel, sparam, q.data(), c.data());
+        }
+        for (int b = 0; b < m; ++b) {
+            const double y = (ilevel == nlevels - 1) ? q[b] : q[b] - qc[b];
+            const double cost_b = (ilevel == nlevels - 1) ? c[b] : c[b] + cc[b];
+            psum[Y3] += y * y * y;
+            psum[Y4] += y * y * y * y;
+            psum[Y2] += y * y;
+            psum[Y] += y;
+            psum[ABSY] += std::fabs(y);
+            psum[Q2] += q[b] * q[b];
+            psum[Q] += q[b];
+            psum[ABSQ] += std::fabs(q[b]);
+            psum[C] += cost_b;
+            if (logger.is_open())
+                logger << std::setw(14) << ilevel << std::setw(14) << y << std::setw(14) << q[b] << std::setw(14)
+                       << qc[b] << std::setw(14) << cost_b << "\n";
+        }
+    }
+    pending_[(size_t)nlevels * NVAR + ilevel] += now_s() - t0;
+}
+
+void MLMC_Manager::InitRun(std::vector<int>& level_nsamples_init) {
+    if ((int)level_nsamples_init.size() != nlevels) throw std::invalid_argument("InitRun: wrong number of levels");
+    if (logger.is_open() && *std::max_element(level_nsamples.begin(), level_nsamples.end()) == 0)
+        logger << "%" << std::setw(13) << "level " << std::setw(14) << "Y(xi) " << std::setw(14) << "Q(xi)"
+               << std::setw(14) << "Q_c(xi)" << std::setw(14) << "c \n";
+    pending_.assign((size_t)nlevels * (NVAR + 1), 0.0);
+    // coarsest level first, then the level pairs from coarse to fine (:110-173)
+    for (int ilevel = nlevels - 1; ilevel >= 0; --ilevel) {
+        const int ns = level_nsamples_init[ilevel];
+        if (ns < 0) throw std::invalid_argument("InitRun: negative sample count");
+        if (ns > 0) run_level(ilevel, ns);
+    }
+    if (nranks_ > 1) reduce_(pending_.data(), (int)pending_.size());
+    for (size_t i = 0; i < (size_t)nlevels * NVAR; ++i) sums[i] += pending_[i];
+    for (int l = 0; l < nlevels; ++l) {
+        level_seconds[l] += pending_[(size_t)nlevels * NVAR + l];
+        level_nsamples[l] += level_nsamples_init[l];
+    }
+    if (logger.is_open()) logger << std::flush;
+    computeNSamplesMSE();
+}
+
+void MLMC_Manager::Run() {
+    Reset();
+    InitRun(v_init_nsamples);
+    std::vector<int> grain(nlevels, 0);
+    int rounds = 0;
+    while (ml_estimator_variance > ratio * eps2) {
+        if (++rounds > max_rounds_) throw std::runtime_error("MLMC_Manager::Run: round limit reached");
+        for (int i = 0; i < nlevels; ++i) {
+            const int64_t miss = level_nsamples_missing[i];
+            grain[i] = (int)std::min<int64_t>(miss, (int64_t)v_init_nsamples[i] + grain[i] + miss / 10);
+        }
+        InitRun(grain);
+    }
+}
+
+void MLMC_Manager::computeNSamplesMSE() {
+    for (int l = 0; l < nlevels; ++l) {
+        const double n = (double)level_nsamples[l];
+        eY[l] = S(l, Y) / n;
+        eABSY[l] = S(l, ABSY) / n;
+        eQ[l] = S(l, Q) / n;
+        eABSQ[l] = S(l, ABSQ) / n;
+        eC[l] = S(l, C) / n;
+        varY[l] = S(l, Y2) / n;
+        varQ[l] = S(l, Q2) / n;
+        kurtosis[l] = S(l, Y4) / n;
+    }
+    for (int l = 0; l < nlevels; ++l) {
+        const double n = (double)level_nsamples[l];
+        kurtosis[l] /= varY[l] * varY[l];
+        varY[l] -= eY[l] * eY[l];
+        varY[l] *= n / (n - 1.0);
+        varQ[l] -= eQ[l] * eQ[l];
+        varQ[l] *= n / (n - 1.0);
+    }
+    for (int l = 0; l < nlevels - 1; ++l)
+        consistency[l] = std::abs(eQ[l] - eQ[l + 1] + eY[l]) /
+                         (3 * (std::sqrt(varQ[l]) + std::sqrt(varQ[l + 1]) + std::sqrt(varY[l])));
+    alpha = expWRegression(eY, M, 1);
+    alphaABS = expWRegression(eABSY, M, 1);
+    beta = expWRegression(varY, M, 1);
+    if (nlevels == 1) {
+        expected_discretization_error2 = 0.;
+    } else {
+        const double m = M[0] / M[1];
+        if (nlevels > 3)
+            expected_discretization_error2 = std::max(std::pow(m, 2. * alphaABS) * eABSY[1] * eABSY[1], eABSY[0] * eABSY[0]) /
+                                             (std::pow(std::pow(m, -2. * alphaABS) - 1., 2));
+        else if (nlevels == 3)
+            expected_discretization_error2 = (eABSY[0] * eABSY[0]) / (std::pow(std::pow(m, -alphaABS) - 1., 2));
+        else
+            expected_discretization_error2 = (eABSY[0] * eABSY[0]);
+    }
+    if (auto_eps2) eps2 = expected_discretization_error2 / (1. - ratio);
+    ml_estimator_variance = 0.;
+    for (int l = 0; l < nlevels; ++l) ml_estimator_variance += varY[l] / (double)level_nsamples[l];
+    actualMSE = expected_discretization_error2 + ml_estimator_variance;
+    if (wallTime)
+        for (int l = 0; l < nlevels; ++l) cost[l] = level_seconds[l] / (double)level_nsamples[l];
+    else
+        cost = eC;
+    gamma = expWRegression(cost, M, 0);
+    double prop = 0.;
+    for (int i = 0; i < nlevels; ++i) prop += std::sqrt(varY[i] * cost[i]);
+    prop /= ratio * eps2;
+    for (int i = 0; i < nlevels; ++i) {
+        double missings = prop * std::sqrt(varY[i] / cost[i]);
+        missings -= (double)level_nsamples[i];
+        const double cm = std::ceil(missings);
+        level_nsamples_missing[i] = (cm > 0.0 && std::isfinite(cm)) ? (int64_t)std::min(cm, 2.0e9) : 0;
+        VC[i] = varY[i] * cost[i];
+    }
+}
+
+void MLMC_Manager::ShowMe(std::ostream& os) const {
+    auto row = [&](const char* name, const std::vector<double>& v) {
+        os << std::setw(42) << std::left << name;
+        for (double x : v) os << x << " ";
+        os << "\n";
+    };
+    os.precision(8);
+    os << std::string(79, '=') << "\nMLMC Manager Errors: \n" << std::string(79, '-') << "\n"
+       << std::setw(42) << std::left << "Estimate";
+    double est = 0;
+    for (double x : eY) est += x;
+    os << est << "\n"
+       << std::setw(42) << "Target MSE" << eps2 << "\n"
+       << std::setw(42) << "Actual MSE" << actualMSE << "\n"
+       << std::setw(42) << "ML Estimator Variance" << ml_estimator_variance << "\n"
+       << std::setw(42) << "Estimator Bias" << expected_discretization_error2 << "\n"
+       << std::setw(42) << "Alpha" << alpha << "\n"
+       << std::setw(42) << "AlphaAbs" << alphaABS << "\n"
+       << std::setw(42) << "Beta" << beta << "\n"
+       << std::setw(42) << "Gamma" << gamma << "\n\n";
+    row("DOFS in Forward Problem", M);
+    row("C_l ", eC);
+    os << std::setw(42) << std::left << "NumSamples ";
+    for (auto x : level_nsamples) os << x << " ";
+    os << "\n";
+    row("E[Y_l] ", eY);
+    row("E[|Y_l|] ", eABSY);
+    row("Var[Y_l] ", varY);
+    row("E[Q_l] ", eQ);
+    row("E[|Q_l|] ", eABSQ);
+    row("Var[Q_l] ", varQ);
+    row("V[Y_l]*C_l ", VC);
+    row("Consistency ", consistency);
+    row("Kurtosis", kurtosis);
+    os << std::string(79, '=') << std::endl;
+}
+
+}  // namespace parelagmc
+
+// =================================================================================================
+// C surface
+using namespace parelagmc;
+
+struct pmc_mlmc {
+    std::unique_ptr<MLSampler> sampler;
+    std::unique_ptr<PhysicalMLSolver> solver;
+    std::unique_ptr<MLMC_Manager> mgr;
+    pmc_ctx* ctx = nullptr;
+    std::vector<int64_t> ns, miss;
+};
+
+static thread_local std::string g_host_err;
+
+template <class F>
+static int hguard(F&& f) {
+    try {
+        f();
+        return PMC_OK;
+    } catch (const std::invalid_argument& e) {
+        g_host_err = e.what();
+        return PMC_ERR_INVALID;
+    } catch (const std::exception& e) {
+        g_host_err = e.what();
+        return PMC_ERR_INTERNAL;
+    } catch (...) {
+        g_host_err = "unknown exception";
+        return PMC_ERR_INTERNAL;
+    }
+}
+
+extern "C" {
+
+const char* pmc_host_last_error(void) { return g_host_err.c_str(); }
+
+void pmc_mlmc_params_default(pmc_mlmc_params* p) {
+    if (!p) return;
+    p->eps2 = 0.001;
+    p->ratio = 0.5;
+    p->init_nsamples = 10;
+    p->array_nsamples = nullptr;
+    p->wall_time = 1;
+    p->batch = 16;
+    p->max_rounds = 1000;
+    p->log_file = nullptr;
+}
+
+int pmc_mlmc_create(pmc_ctx* ctx, pmc_sampler* sampler, pmc_darcy* solver, int nlevels, const pmc_mlmc_params* params,
+                    pmc_mlmc** out) {
+    return hguard([&] {
+        if (!ctx || !sampler || !solver || !out) throw std::invalid_argument("pmc_mlmc_create: NULL argument");
+        pmc_mlmc_params p;
+        pmc_mlmc_params_default(&p);
+        if (params) p = *params;
+        std::unique_ptr<pmc_mlmc> m(new pmc_mlmc());
+        m->ctx = ctx;
+        m->sampler.reset(new PDESampler(ctx, sampler));
+        m->solver.reset(new DarcySolver(ctx, solver));
+        m->mgr.reset(new MLMC_Manager(ctx, PMC_MEM_DEVICE, nlevels, *m->solver, *m->sampler, p));
+        *out = m.release();
+    });
+}
+
+int pmc_mlmc_create_callbacks(int nlevels, const pmc_plugin_callbacks* cb, const pmc_mlmc_params* params, pmc_mlmc** out) {
+    return hguard([&] {
+        if (!cb || !out) throw std::invalid_argument("pmc_mlmc_create_callbacks: NULL argument");
+        pmc_mlmc_params p;
+        pmc_mlmc_params_default(&p);
+        if (params) p = *params;
+        std::unique_ptr<pmc_mlmc> m(new pmc_mlmc());
+        m->sampler.reset(new CallbackSampler(nlevels, *cb));
+        m->solver.reset(new CallbackSolver(nlevels, *cb));
+        m->mgr.reset(new MLMC_Manager(nullptr, PMC_MEM_HOST, nlevels, *m->solver, *m->sampler, p));
+        *out = m.release();
+    });
+}
+
+void pmc_mlmc_destroy(pmc_mlmc* m) { delete m; }
+
+int pmc_mlmc_set_farm(pmc_mlmc* m, int nranks, int rank, pmc_reduce_fn reduce, void* user) {
+    return hguard([&] {
+        if (!m) throw std::invalid_argument("manager is NULL");
+        std::function<void(double*, int)> fn;
+        if (reduce) {
+            fn = [reduce, user](double* b, int n) {
+                if (reduce(b, n, user) != 0) throw std::runtime_error("reduce callback failed");
+            };
+        } else if (nranks > 1) {
+            pmc_ctx* ctx = m->ctx;
+            if (!ctx) throw std::invalid_argument("pmc_mlmc_set_farm: no reduction and no device context");
+            fn = [ctx](double* b, int n) {
+                if (pmc_allreduce_sum_f64(ctx, b, n) != PMC_OK) throw std::runtime_error(pmc_last_error());
+            };
+        }
+        m->mgr->SetFarm(nranks, rank, fn);
+    });
+}
+
+int pmc_mlmc_run(pmc_mlmc* m) {
+    return hguard([&] {
+        if (!m) throw std::invalid_argument("manager is NULL");
+        m->mgr->Run();
+    });
+}
+int pmc_mlmc_reset(pmc_mlmc* m) {
+    return hguard([&] {
+        if (!m) throw std::invalid_argument("manager is NULL");
+        m->mgr->Reset();
+    });
+}
+int pmc_mlmc_init_run(pmc_mlmc* m, const int32_t* nsamples) {
+    return hguard([&] {
+        if (!m || !nsamples) throw std::invalid_argument("pmc_mlmc_init_run: NULL argument");
+        std::vector<int> v(nsamples, nsamples + m->mgr->nlevels);
+        m->mgr->InitRun(v);
+    });
+}
+int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* r) {
+    return hguard([&] {
+        if (!m || !r) throw std::invalid_argument("pmc_mlmc_result_get: NULL argument");
+        MLMC_Manager& g = *m->mgr;
+        r->nlevels = g.nlevels;
+        double est = 0;
+        for (double x : g.eY) est += x;
+        r->estimate = est;
+        r->eps2 = g.eps2;
+        r->actual_mse = g.actualMSE;
+        r->estimator_variance = g.ml_estimator_variance;
+        r->bias2 = g.expected_discretization_error2;
+        r->alpha = g.alpha;
+        r->alpha_abs = g.alphaABS;
+        r->beta = g.beta;
+        r->gamma = g.gamma;
+        r->eY = g.eY.data(); r->eABSY = g.eABSY.data(); r->eQ = g.eQ.data(); r->eABSQ = g.eABSQ.data();
+        r->eC = g.eC.data(); r->varY = g.varY.data(); r->varQ = g.varQ.data(); r->consistency = g.consistency.data();
+        r->kurtosis = g.kurtosis.data(); r->VC = g.VC.data(); r->cost = g.cost.data();
+        r->sums = g.sums.data();
+        r->nsamples = g.level_nsamples.data();
+        r->nsamples_missing = g.level_nsamples_missing.data();
+        r->level_seconds = g.level_seconds.data();
+    });
+}
+
+double pmc_exp_w_regression(const double* y, const double* x, int n, int skip_n_last) {
+    return expWRegression(std::vector<double>(y, y + n), std::vector<double>(x, x + n), skip_n_last);
+}
+
+}  // extern "C"

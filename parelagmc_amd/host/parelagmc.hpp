@@ -1,0 +1,208 @@
+// Host-side C++ mirror of ParELAGMC's plugin surface and Monte Carlo managers.
+//
+// Same class and method names, argument meaning and error behaviour (exceptions) as the
+// reference (paths relative to /root/reference):
+//   MLSampler                 src/MLSampler.hpp:33-52
+//   PhysicalMLSolver          src/PhysicalMLSolver.hpp:33-62
+//   NormalDistributionSampler src/NormalDistributionSampler.hpp:27-64
+//   PDESampler                src/PDESampler.hpp (Sample/Eval/SampleSize/GetNNZ)
+//   DarcySolver               src/DarcySolver.hpp (SolveFwd/GetNumberOfDofs/GetNNZ)
+//   MLMC_Manager              src/MLMC_Manager.hpp:24-181
+//   MC_Manager                src/MC_Manager.hpp
+// mfem::Vector is replaced by parelagmc::Vector, a (pointer, size, memory space) view that can
+// live in HBM, so a whole realization (xi -> s -> Q) never crosses PCIe.  The numerical work is
+// delegated to libpmc.so through include/pmc.h; nothing here touches a GPU API directly.
+#pragma once
+
+#include <cstdint>
+#include <fstream>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pmc.h"
+#include "../../include/pmc_host.h"
+
+namespace parelagmc {
+
+// A batch of `nbatch` vectors of `size` doubles each, sample-major, in host or device memory.
+class Vector {
+  public:
+    Vector() = default;
+    Vector(pmc_ctx* ctx, int memspace) : ctx_(ctx), memspace_(memspace) {}
+    Vector(const Vector&) = delete;
+    Vector& operator=(const Vector&) = delete;
+    ~Vector();
+    void SetSize(int size, int nbatch = 1);   // reallocates when the capacity is too small
+    void Swap(Vector& o);                     // exchange storage (same context and memory space)
+    int Size() const { return size_; }
+    int Batch() const { return nbatch_; }
+    int MemSpace() const { return memspace_; }
+    double* GetData() { return data_; }
+    const double* GetData() const { return data_; }
+
+  private:
+    pmc_ctx* ctx_ = nullptr;
+    int memspace_ = PMC_MEM_HOST;
+    double* data_ = nullptr;
+    size_t cap_ = 0;
+    int size_ = 0, nbatch_ = 1;
+};
+
+class MLSampler {
+  public:
+    virtual ~MLSampler() = default;
+    /// Fill xi with nbatch realizations of white noise for `level`; ids first_id .. first_id+nbatch-1
+    virtual void Sample(const int level, Vector& xi, uint64_t first_id = 0, int nbatch = 1) = 0;
+    /// Evaluate random field at level with random sample xi
+    virtual void Eval(const int level, const Vector& xi, Vector& s) = 0;
+    /// ... storing the Gaussian field in u and optionally warm-starting from it (use_init)
+    virtual void Eval(const int level, const Vector& xi, Vector& s, Vector& u, bool use_init) = 0;
+    virtual int SampleSize(int level) const = 0;
+    virtual size_t GetNNZ(int level) const = 0;
+};
+
+class PhysicalMLSolver {
+  public:
+    virtual ~PhysicalMLSolver() = default;
+    /// Solve and update quantity of interest Q, cost C (arrays of k.Batch() entries)
+    virtual void SolveFwd(int ilevel, Vector& k_over_k_ref, double* Q, double* C) = 0;
+    virtual int GetNumberOfDofs(int ilevel) const = 0;
+    virtual int GetGlobalNumberOfDofs(int ilevel) const = 0;
+    virtual int GetNNZ(int ilevel) const = 0;
+};
+
+/// Uncorrelated N(mu, sigma2) variates (counter-based generator on the device).
+class NormalDistributionSampler {
+  public:
+    NormalDistributionSampler(pmc_ctx* ctx, double mu, double sigma2) : ctx_(ctx), mu_(mu), sigma2_(sigma2) {}
+    NormalDistributionSampler(NormalDistributionSampler const&) = delete;
+    NormalDistributionSampler& operator=(NormalDistributionSampler const&) = delete;
+    /// Provides statistically independent random numbers to each part
+    void Split(int nparts, int mypart);
+    void Seed(uint64_t seed) { seed_ = seed; Split(nparts_, mypart_); }
+    /// Fill v (all batch entries) with realizations first_id...
+    void operator()(Vector& v, uint64_t first_id = 0, uint32_t stream = 0);
+
+  private:
+    pmc_ctx* ctx_;
+    double mu_, sigma2_;
+    uint64_t seed_ = 0;
+    int nparts_ = 1, mypart_ = 0;
+};
+
+/// Device SPDE sampler (plain, matching-embedded or L2-projected: decided by the handle's projection).
+class PDESampler : public MLSampler {
+  public:
+    PDESampler(pmc_ctx* ctx, pmc_sampler* handle) : ctx_(ctx), h_(handle) {}
+    void Sample(const int level, Vector& xi, uint64_t first_id = 0, int nbatch = 1) override;
+    void Eval(const int level, const Vector& xi, Vector& s) override;
+    void Eval(const int level, const Vector& xi, Vector& s, Vector& u, bool use_init) override;
+    int SampleSize(int level) const override;
+    size_t GetNNZ(int level) const override;
+    int GetNumIters() const { return last_iters_; }   // the reference returns -1 (PDESampler.hpp:142-145)
+
+  private:
+    int level_of_xi(int size) const;
+    int level_of_field(int size) const;
+    pmc_ctx* ctx_;
+    pmc_sampler* h_;
+    int last_iters_ = -1;
+};
+
+class DarcySolver : public PhysicalMLSolver {
+  public:
+    DarcySolver(pmc_ctx* ctx, pmc_darcy* handle) : ctx_(ctx), h_(handle) {}
+    void SolveFwd(int ilevel, Vector& k_over_k_ref, double* Q, double* C) override;
+    int GetNumberOfDofs(int ilevel) const override;
+    int GetGlobalNumberOfDofs(int ilevel) const override;
+    int GetNNZ(int ilevel) const override;
+
+  private:
+    pmc_ctx* ctx_;
+    pmc_darcy* h_;
+};
+
+/// Plugins backed by C callbacks (host memory).
+class CallbackSampler : public MLSampler {
+  public:
+    CallbackSampler(int nlevels, const pmc_plugin_callbacks& cb);
+    void Sample(const int level, Vector& xi, uint64_t first_id = 0, int nbatch = 1) override;
+    void Eval(const int level, const Vector& xi, Vector& s) override;
+    void Eval(const int level, const Vector& xi, Vector& s, Vector& u, bool use_init) override;
+    int SampleSize(int level) const override { return ssize_.at(level); }
+    size_t GetNNZ(int) const override { return 0; }
+
+  private:
+    pmc_plugin_callbacks cb_;
+    std::vector<int> xsize_, ssize_;
+};
+class CallbackSolver : public PhysicalMLSolver {
+  public:
+    CallbackSolver(int nlevels, const pmc_plugin_callbacks& cb);
+    void SolveFwd(int ilevel, Vector& k, double* Q, double* C) override;
+    int GetNumberOfDofs(int l) const override { return ndofs_.at(l); }
+    int GetGlobalNumberOfDofs(int l) const override { return ndofs_.at(l); }
+    int GetNNZ(int) const override { return 0; }
+
+  private:
+    pmc_plugin_callbacks cb_;
+    std::vector<int> ndofs_;
+};
+
+double expWRegression(const std::vector<double>& y, const std::vector<double>& x, int skip_n_last);
+
+/// Multi-level Monte Carlo manager: the reference's serial loop, sharded over a sample farm.
+class MLMC_Manager {
+  public:
+    enum { Y2 = 0, Y = 1, ABSY = 2, Q2 = 3, Q = 4, ABSQ = 5, C = 6, Y3 = 7, Y4 = 8, NVAR = 9 };
+
+    MLMC_Manager(pmc_ctx* ctx, int memspace, int nlevels, PhysicalMLSolver& pSolver, MLSampler& sampler,
+                 const pmc_mlmc_params& params);
+    void SetFarm(int nranks, int rank, std::function<void(double*, int)> reduce);
+    /// Run ML simulation by sampling v_init_nsamples then the missing samples until the estimator variance target is met
+    void Run();
+    /// Run ML simulation using level_nsamples_init[i] samples on level i
+    void InitRun(std::vector<int>& level_nsamples_init);
+    void Reset();
+    void ShowMe(std::ostream& os) const;
+
+    bool wallTime;   // public switch, src/MLMC_Manager.hpp:61
+
+    // results (read by pmc_mlmc_result_get)
+    int nlevels;
+    double eps2, ratio;
+    double ml_estimator_variance, expected_discretization_error2, actualMSE;
+    double alpha = 0, alphaABS = 0, beta = 0, gamma = 0;
+    std::vector<double> sums, eY, eABSY, eQ, eABSQ, eC, varY, varQ, consistency, kurtosis, M, VC, cost, level_seconds;
+    std::vector<int64_t> level_nsamples, level_nsamples_missing;
+
+  private:
+    void computeNSamplesMSE();
+    void run_level(int ilevel, int nsamples);
+    double& S(int l, int v) { return sums[(size_t)l * NVAR + v]; }
+
+    pmc_ctx* ctx_;
+    int memspace_;
+    PhysicalMLSolver& pSolver;
+    MLSampler& sampler;
+    int auto_eps2;
+    std::vector<int> v_init_nsamples;
+    int batch_, max_rounds_;
+    int nranks_ = 1, rank_ = 0;
+    std::function<void(double*, int)> reduce_;
+    std::vector<double> pending_;          // this round's local contributions (sums + counts + seconds)
+    Vector xi, sparam, init_s;
+    std::ofstream logger;
+};
+
+/// Single-level Monte Carlo manager (src/MC_Manager.hpp): the nlevels == 1 case of the above.
+class MC_Manager : public MLMC_Manager {
+  public:
+    MC_Manager(pmc_ctx* ctx, int memspace, PhysicalMLSolver& pSolver, MLSampler& sampler, const pmc_mlmc_params& params)
+        : MLMC_Manager(ctx, memspace, 1, pSolver, sampler, params) {}
+};
+
+}  // namespace parelagmc

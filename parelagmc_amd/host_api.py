@@ -1,0 +1,229 @@
+"""ctypes binding of libpmc_host.so (include/pmc_host.h): the MLMC / MC managers."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpmc_host.so")
+
+NVAR = 9
+Y2, Y, ABSY, Q2, Q, ABSQ, CC, Y3, Y4 = range(9)
+
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+CB_SAMPLE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double))
+CB_EVAL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                      C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_double))
+CB_SOLVE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                       C.POINTER(C.c_double))
+
+
+class pmc_plugin_callbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("sample", CB_SAMPLE), ("eval", CB_EVAL), ("solve_fwd", CB_SOLVE),
+                ("xi_size", C.POINTER(C.c_int32)), ("sample_size", C.POINTER(C.c_int32)),
+                ("ndofs", C.POINTER(C.c_int32))]
+
+
+class pmc_mlmc_params(C.Structure):
+    _fields_ = [("eps2", C.c_double), ("ratio", C.c_double), ("init_nsamples", C.c_int32),
+                ("array_nsamples", C.POINTER(C.c_int32)), ("wall_time", C.c_int32), ("batch", C.c_int32),
+                ("max_rounds", C.c_int32), ("log_file", C.c_char_p)]
+
+
+_DPTR = C.POINTER(C.c_double)
+_LPTR = C.POINTER(C.c_int64)
+
+
+class pmc_mlmc_result(C.Structure):
+    _fields_ = [("nlevels", C.c_int32)] + [(n, C.c_double) for n in
+                ("estimate", "eps2", "actual_mse", "estimator_variance", "bias2", "alpha", "alpha_abs", "beta", "gamma")] + \
+               [(n, _DPTR) for n in ("eY", "eABSY", "eQ", "eABSQ", "eC", "varY", "varQ", "consistency", "kurtosis", "VC",
+                                     "cost")] + \
+               [("sums", _DPTR), ("nsamples", _LPTR), ("nsamples_missing", _LPTR), ("level_seconds", _DPTR)]
+
+
+_VP = C.c_void_p
+HOST_SYMBOLS = {
+    "pmc_mlmc_params_default": (None, [C.POINTER(pmc_mlmc_params)]),
+    "pmc_mlmc_create": (C.c_int, [_VP, _VP, _VP, C.c_int, C.POINTER(pmc_mlmc_params), C.POINTER(_VP)]),
+    "pmc_mlmc_create_callbacks": (C.c_int, [C.c_int, C.POINTER(pmc_plugin_callbacks), C.POINTER(pmc_mlmc_params),
+                                            C.POINTER(_VP)]),
+    "pmc_mlmc_destroy": (None, [_VP]),
+    "pmc_mlmc_set_farm": (C.c_int, [_VP, C.c_int, C.c_int, REDUCE_FN, _VP]),
+    "pmc_mlmc_run": (C.c_int, [_VP]),
+    "pmc_mlmc_reset": (C.c_int, [_VP]),
+    "pmc_mlmc_init_run": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
+    "pmc_mlmc_result_get": (C.c_int, [_VP, C.POINTER(pmc_mlmc_result)]),
+    "pmc_host_last_error": (C.c_char_p, []),
+    "pmc_exp_w_regression": (C.c_double, [_DPTR, _DPTR, C.c_int, C.c_int]),
+}
+
+_hlib = None
+
+
+def load_host_library():
+    global _hlib
+    if _hlib is not None:
+        return _hlib
+    capi.load_library()    # libpmc.so first (rpath also finds it)
+    if not os.path.exists(HOST_LIB_PATH):
+        raise capi.PmcError(-2, f"{HOST_LIB_PATH} not found - build it with `make`")
+    lib = C.CDLL(HOST_LIB_PATH)
+    for name, (res, args) in HOST_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _hlib = lib
+    return lib
+
+
+def _hcheck(rc):
+    if rc != 0:
+        raise capi.PmcError(rc, load_host_library().pmc_host_last_error().decode("utf-8", "replace"))
+
+
+def exp_w_regression(y, x, skip_n_last):
+    y = np.ascontiguousarray(y, np.float64)
+    x = np.ascontiguousarray(x, np.float64)
+    return load_host_library().pmc_exp_w_regression(y.ctypes.data_as(_DPTR), x.ctypes.data_as(_DPTR), len(y), skip_n_last)
+
+
+class MLMCManager:
+    """parelagmc::MLMC_Manager (Run / InitRun / results); MC_Manager is the nlevels == 1 case.
+
+    Either over device handles (sampler=capi.PDESampler, solver=capi.DarcySolver) or over Python
+    plugin callbacks (`callbacks=dict(sample=, eval=, solve=, xi_size=, sample_size=, ndofs=)`)."""
+
+    def __init__(self, nlevels, sampler=None, solver=None, callbacks=None, eps2=0.001, ratio=0.5, init_nsamples=10,
+                 array_nsamples: Optional[Sequence[int]] = None, wall_time=True, batch=16, max_rounds=1000,
+                 log_file: Optional[str] = None):
+        self.lib = load_host_library()
+        self.nlevels = nlevels
+        p = pmc_mlmc_params()
+        self.lib.pmc_mlmc_params_default(C.byref(p))
+        p.eps2, p.ratio, p.init_nsamples = eps2, ratio, init_nsamples
+        p.wall_time, p.batch, p.max_rounds = (1 if wall_time else 0), batch, max_rounds
+        self._keep = []
+        if array_nsamples is not None:
+            a = np.ascontiguousarray(array_nsamples, np.int32)
+            assert len(a) == nlevels
+            self._keep.append(a)
+            p.array_nsamples = a.ctypes.data_as(C.POINTER(C.c_int32))
+        if log_file:
+            p.log_file = log_file.encode()
+        h = _VP()
+        if callbacks is not None:
+            cb = pmc_plugin_callbacks()
+            xs = np.ascontiguousarray(callbacks["xi_size"], np.int32)
+            ss = np.ascontiguousarray(callbacks["sample_size"], np.int32)
+            nd = np.ascontiguousarray(callbacks["ndofs"], np.int32)
+            self._keep += [xs, ss, nd]
+            f_sample, f_eval, f_solve = callbacks["sample"], callbacks["eval"], callbacks["solve"]
+
+            def _sample(user, level, first_id, nbatch, xi):
+                try:
+                    out = np.ctypeslib.as_array(xi, shape=(nbatch, int(xs[level])))
+                    out[...] = f_sample(level, int(first_id), nbatch)
+                    return 0
+                except Exception:   # noqa: BLE001 - must not propagate through C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            def _eval(user, level, xi_level, nbatch, xi, s, init_s, init_level, use_init, emb):
+                try:
+                    x = np.ctypeslib.as_array(xi, shape=(nbatch, int(xs[xi_level])))
+                    init = np.ctypeslib.as_array(init_s, shape=(nbatch, int(xs[init_level]))) if use_init else None
+                    sv, ev = f_eval(level, xi_level, x, init, init_level if use_init else None)
+                    np.ctypeslib.as_array(s, shape=(nbatch, int(ss[level])))[...] = sv
+                    if emb:
+                        np.ctypeslib.as_array(emb, shape=(nbatch, int(xs[level])))[...] = ev
+                    return 0
+                except Exception:   # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            def _solve(user, level, nbatch, k, Qp, Cp):
+                try:
+                    kk = np.ctypeslib.as_array(k, shape=(nbatch, int(ss[level])))
+                    q, c = f_solve(level, kk)
+                    np.ctypeslib.as_array(Qp, shape=(nbatch,))[...] = q
+                    np.ctypeslib.as_array(Cp, shape=(nbatch,))[...] = c
+                    return 0
+                except Exception:   # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            cb.sample, cb.eval, cb.solve_fwd = CB_SAMPLE(_sample), CB_EVAL(_eval), CB_SOLVE(_solve)
+            cb.xi_size = xs.ctypes.data_as(C.POINTER(C.c_int32))
+            cb.sample_size = ss.ctypes.data_as(C.POINTER(C.c_int32))
+            cb.ndofs = nd.ctypes.data_as(C.POINTER(C.c_int32))
+            self._keep += [cb, cb.sample, cb.eval, cb.solve_fwd]
+            _hcheck(self.lib.pmc_mlmc_create_callbacks(nlevels, C.byref(cb), C.byref(p), C.byref(h)))
+        else:
+            assert sampler is not None and solver is not None
+            self._keep += [sampler, solver]
+            _hcheck(self.lib.pmc_mlmc_create(sampler.ctx.h, sampler.h, solver.h, nlevels, C.byref(p), C.byref(h)))
+        self.h = h
+
+    def set_farm(self, nranks: int, rank: int, reduce: Optional[Callable[[np.ndarray], None]] = None):
+        """reduce(buf) must SUM-all-reduce the numpy buffer in place (e.g. torch.distributed);
+        None with nranks > 1 uses the RCCL communicator of the device context."""
+        if reduce is not None:
+            def _red(buf, n, user):
+                try:
+                    reduce(np.ctypeslib.as_array(buf, shape=(n,)))
+                    return 0
+                except Exception:   # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            fn = REDUCE_FN(_red)
+        else:
+            fn = REDUCE_FN()
+        self._keep.append(fn)
+        _hcheck(self.lib.pmc_mlmc_set_farm(self.h, nranks, rank, fn, None))
+
+    def Run(self):
+        _hcheck(self.lib.pmc_mlmc_run(self.h))
+        return self.result()
+
+    def Reset(self):
+        _hcheck(self.lib.pmc_mlmc_reset(self.h))
+
+    def InitRun(self, nsamples: Sequence[int]):
+        a = np.ascontiguousarray(nsamples, np.int32)
+        assert len(a) == self.nlevels
+        _hcheck(self.lib.pmc_mlmc_init_run(self.h, a.ctypes.data_as(C.POINTER(C.c_int32))))
+        return self.result()
+
+    def result(self) -> dict:
+        r = pmc_mlmc_result()
+        _hcheck(self.lib.pmc_mlmc_result_get(self.h, C.byref(r)))
+        nl = r.nlevels
+        out = {k: getattr(r, k) for k in ("estimate", "eps2", "actual_mse", "estimator_variance", "bias2", "alpha",
+                                          "alpha_abs", "beta", "gamma")}
+        for k in ("eY", "eABSY", "eQ", "eABSQ", "eC", "varY", "varQ", "consistency", "kurtosis", "VC", "cost",
+                  "level_seconds"):
+            out[k] = np.ctypeslib.as_array(getattr(r, k), shape=(nl,)).copy()
+        out["sums"] = np.ctypeslib.as_array(r.sums, shape=(nl, NVAR)).copy()
+        out["nsamples"] = np.ctypeslib.as_array(r.nsamples, shape=(nl,)).copy()
+        out["missing"] = np.ctypeslib.as_array(r.nsamples_missing, shape=(nl,)).copy()
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pmc_mlmc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,89 @@
+"""Regenerates the fixtures under tests/golden/ (run in the build container, where
+/root/reference exists).  Fixtures are DATA only:
+  * meshes/*.json        - mesh data files the reference's tests/drivers read
+                           (/root/reference/meshes/*.mesh), converted to JSON arrays;
+  * kat.json             - the reference's RNG-free known answers
+                           (examples/CMakeLists.txt:62-66 DarcyDeterministicTest) and the
+                           closed-form Matern coefficients of src/Utilities.hpp:188-200;
+  * gold_sampler_hex.npz, gold_quad.npz, gold_darcy_hex.npz
+                         - SELF-GENERATED oracle outputs (sparse direct solves) for seeded
+                           inputs; they guard the oracle against drift, they are not
+                           reference outputs (the reference cannot be built here).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from parelagmc_amd.fe import (box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem,  # noqa: E402
+                              read_mfem_mesh)
+from oracle.darcy_oracle import DarcyOracle  # noqa: E402
+from oracle.sampler_oracle import SamplerOracle  # noqa: E402
+
+REF_MESHES = "/root/reference/meshes"
+
+
+def mesh_to_json(name):
+    m = read_mfem_mesh(os.path.join(REF_MESHES, name + ".mesh"))
+    d = dict(etype=m.etype, verts=m.verts.tolist(), elems=m.elems.tolist(), elem_attr=m.elem_attr.tolist(),
+             bdr=m.bdr.tolist(), bdr_attr=m.bdr_attr.tolist(), source=f"meshes/{name}.mesh")
+    with open(os.path.join(HERE, "meshes", name + ".json"), "w") as f:
+        json.dump(d, f)
+
+
+def main():
+    if os.path.isdir(REF_MESHES):
+        for name in ("inline_quad", "cube_hex", "cube_tet", "cube_tet_embed"):
+            mesh_to_json(name)
+    kat = {
+        "darcy_deterministic": {"source": "examples/CMakeLists.txt:62-66", "Q": [2.0, 2.0, 2.0],
+                                "dofs": [17152, 2240, 304],
+                                "mesh": "Build3DHexMesh 4x4x4 on [0,2]^3, 2 parallel refinements",
+                                "ess": [0, 1, 1, 1, 1, 0], "obs": [1, 0, 0, 0, 0, 0], "inflow": [0, 0, 0, 0, 0, 1]},
+        "matern_g": {"source": "src/Utilities.hpp:188-200", "cases": [
+            {"corlen": 0.1, "dim": 3, "g": 28.90067818451249},
+            {"corlen": 0.1, "dim": 2, "g": 50.13256549262001},
+            {"corlen": 100.0, "dim": 3, "g": 0.9139196898659948}]},
+    }
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f, indent=1)
+
+    rng = np.random.Generator(np.random.PCG64(20261003))
+    # GOLD-2: hex 4^3 -> 8^3 (2 levels), Gaussian
+    h = build_hierarchy(box_mesh([4, 4, 4], [2, 2, 2], "hex"), 1)
+    sp = build_sampler_problem(h, corlen=0.1)
+    so = SamplerOracle(sp)
+    xi = rng.standard_normal((2, sp.levels[0].n_s))
+    s00 = np.stack([so.eval(0, 0, x)[0] for x in xi])
+    s10 = np.stack([so.eval(1, 0, x)[0] for x in xi])      # coarse field from fine xi (Ps^T coupling)
+    xi1 = rng.standard_normal((2, sp.levels[1].n_s))
+    s11 = np.stack([so.eval(1, 1, x)[0] for x in xi1])
+    np.savez_compressed(os.path.join(HERE, "gold_sampler_hex.npz"), xi0=xi, s00=s00, s10=s10, xi1=xi1, s11=s11)
+    # GOLD-1: inline_quad, 1 level, d=2
+    hq = build_hierarchy(box_mesh([2, 2], [1.0, 1.0], "quad"), 0)
+    spq = build_sampler_problem(hq, corlen=0.1)
+    xq = rng.standard_normal((16, spq.levels[0].n_s))
+    sq = np.stack([SamplerOracle(spq).eval(0, 0, x)[0] for x in xq])
+    np.savez_compressed(os.path.join(HERE, "gold_quad.npz"), xi=xq, s=sq)
+    # GOLD-3: Darcy Q for lognormal k (both k_divides settings)
+    spl = build_sampler_problem(h, corlen=0.1, lognormal=True)
+    sol = SamplerOracle(spl)
+    out = {}
+    for kd in (True, False):
+        dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], k_divides=kd)
+        do = DarcyOracle(dp)
+        for lvl in range(2):
+            k = np.stack([sol.eval(lvl, 0, x)[0] for x in xi])
+            out[f"k_L{lvl}"] = k
+            out[f"Q_L{lvl}_{'div' if kd else 'mul'}"] = np.array([do.solve_fwd(lvl, kk)[0] for kk in k])
+    np.savez_compressed(os.path.join(HERE, "gold_darcy_hex.npz"), **out)
+    print("fixtures written")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+"""Setup-side FE builders: size identities, exactness, nestedness."""
+import numpy as np
+import pytest
+
+from conftest import golden_path
+from parelagmc_amd.fe import (box_mesh, build_hierarchy, build_spaces, kuhn_cube_tet, mass_contributions, mass_matrix,
+                              mesh_from_json, refine_uniform)
+
+
+def test_hex_dof_counts_match_reference_ctest(hex_hierarchy):
+    # examples/CMakeLists.txt:62-66: 17152 / 2240 / 304 global dofs on 16^3 / 8^3 / 4^3
+    assert [s.n_u + s.n_s for s in hex_hierarchy.spaces] == [17152, 2240, 304]
+
+
+def test_inline_quad_sizes():
+    m = mesh_from_json(golden_path("meshes", "inline_quad.json"))
+    s = build_spaces(m)
+    assert (s.n_s, s.n_u) == (4, 12)
+    fine, _ = refine_uniform(m)
+    fine, _ = refine_uniform(fine)
+    s2 = build_spaces(fine)
+    assert (s2.n_s, s2.n_u, s2.n_s + s2.n_u) == (64, 144, 208)
+
+
+@pytest.mark.parametrize("nref", [0, 1, 2, 3])
+def test_cube_tet_size_identities(nref):
+    m = mesh_from_json(golden_path("meshes", "cube_tet.json"))
+    for _ in range(nref):
+        m, _ = refine_uniform(m)
+    s = build_spaces(m)
+    assert s.n_s == 6 * 8 ** nref
+    assert s.n_u == (4 * s.n_s + 12 * 4 ** nref) // 2
+    assert abs(s.vol.sum() - 1.0) < 1e-12
+    assert (s.faces.face_bdr_attr > 0).sum() == 12 * 4 ** nref
+
+
+def test_cube_tet_embed_fixture():
+    m = mesh_from_json(golden_path("meshes", "cube_tet_embed.json"))
+    assert m.ne == 203 and (m.elem_attr == 1).sum() == 55 and len(m.bdr) == 46
+    s = build_spaces(m)
+    assert abs(s.vol.sum() - 27.0) < 1e-10          # [-1,2]^3
+    assert abs(s.vol[m.elem_attr == 1].sum() - 1.0) < 1e-10   # attr-1 region = [0,1]^3
+
+
+@pytest.mark.parametrize("mesh", ["hex", "tet", "quad"])
+def test_constant_fields_are_exact(mesh):
+    if mesh == "hex":
+        m = box_mesh([3, 2, 4], [1.5, 1.0, 2.0], "hex")
+    elif mesh == "quad":
+        m = box_mesh([3, 5], [1.5, 1.0], "quad")
+    else:
+        m, _ = refine_uniform(kuhn_cube_tet())
+    s = build_spaces(m)
+    M = mass_matrix(s.emass)
+    ft = s.faces
+    fv = m.verts[ft.face_verts]
+    d = m.dim
+    if d == 3:
+        nrm = np.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0])
+        if mesh == "tet":
+            nrm = nrm / 2.0
+        else:
+            # quads: sorted vertex ids are not cyclic; use the two edges from vertex 0 that span the face
+            e1, e2, e3 = fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0], fv[:, 3] - fv[:, 0]
+            c = [np.cross(e1, e2), np.cross(e1, e3), np.cross(e2, e3)]
+            a = np.stack([np.linalg.norm(x, axis=1) for x in c], 1)
+            pick = np.argmax(a, axis=1)
+            nrm = np.stack(c, 1)[np.arange(len(fv)), pick]
+    else:
+        t = fv[:, 1] - fv[:, 0]
+        nrm = np.stack([t[:, 1], -t[:, 0]], 1)
+    cen = m.verts[m.elems].mean(1)[ft.face_elem[:, 0]]
+    sgn = np.sign(np.einsum("fx,fx->f", nrm, fv.mean(1) - cen))
+    nrm = nrm * sgn[:, None]
+    c = np.array([0.3, -1.2, 0.7])[:d]
+    u = nrm @ c                                   # flux dofs of the constant field c
+    assert np.abs(s.B @ u).max() < 1e-12           # divergence free
+    assert abs(u @ (M @ u) - (c @ c) * s.vol.sum()) < 1e-10 * s.vol.sum()   # exact energy
+
+
+def test_hierarchy_is_nested(hex_hierarchy):
+    for i, P in enumerate(hex_hierarchy.P):
+        fine, coarse = hex_hierarchy.spaces[i], hex_hierarchy.spaces[i + 1]
+        assert P.shape == (fine.n_s, coarse.n_s)
+        assert np.all(np.asarray(P.sum(axis=1)).ravel() == 1.0)
+        assert np.allclose(P.T @ fine.vol, coarse.vol)        # children tile the parent
+
+
+def test_tet_hierarchy_is_nested():
+    h = build_hierarchy(kuhn_cube_tet(), 2)
+    for i, P in enumerate(h.P):
+        assert np.allclose(P.T @ h.spaces[i].vol, h.spaces[i + 1].vol)
+
+
+def test_mass_contributions_reproduce_mass_matrix(hex_hierarchy_small):
+    s = hex_hierarchy_small.spaces[0]
+    pat, c_ptr, c_elem, c_val = mass_contributions(s.emass)
+    rng = np.random.default_rng(0)
+    coef = rng.uniform(0.5, 2.0, s.n_s)
+    M = mass_matrix(s.emass, coef)
+    assert np.array_equal(M.indptr, pat.indptr) and np.array_equal(M.indices, pat.indices)
+    data = np.add.reduceat(coef[c_elem] * c_val, c_ptr[:-1])
+    assert np.allclose(data, M.data, rtol=1e-14, atol=0)
+    assert (np.diff(c_ptr) <= 2).all() and (np.diff(c_ptr) >= 1).all()   # a face pair shares <= 2 elements
+
+
+def test_box_mesh_boundary_attributes():
+    m = box_mesh([2, 2, 2], [2.0, 2.0, 2.0], "hex")
+    s = build_spaces(m)
+    fa = s.faces.face_bdr_attr
+    fc = m.verts[s.faces.face_verts].mean(1)
+    assert np.allclose(fc[fa == 1][:, 2], 0.0) and np.allclose(fc[fa == 6][:, 2], 2.0)
+    assert np.allclose(fc[fa == 2][:, 1], 0.0) and np.allclose(fc[fa == 4][:, 1], 2.0)
+    assert np.allclose(fc[fa == 5][:, 0], 0.0) and np.allclose(fc[fa == 3][:, 0], 2.0)
+    assert (fa > 0).sum() == 24

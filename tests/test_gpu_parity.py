@@ -1,0 +1,348 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  Run with -m gpu on an MI355X.
+
+Tolerances (fp64 everywhere): the GPU solves iteratively (MINRES, preconditioned-residual
+stopping rule), the oracle directly, so agreement is bounded by the solver tolerance:
+  rel_tol 1e-6 (reference default) -> fields agree to 1e-5 relative L2, QoIs to 1e-4 relative;
+  rel_tol 1e-12 (tightened)        -> fields agree to 1e-9 relative L2.
+Bit-level work (Philox integers) is compared through the resulting normals at 4 ulp."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = dict(rel_tol=1e-12, abs_tol=1e-30, max_iter=400)
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+@pytest.fixture(scope="module")
+def hexprob(hex_hierarchy):
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.sampler_oracle import SamplerOracle
+    sp = build_sampler_problem(hex_hierarchy, corlen=0.1)
+    dp = build_darcy_problem(hex_hierarchy, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    return sp, SamplerOracle(sp), dp, DarcyOracle(dp)
+
+
+# ---------------------------------------------------------------------------------- RNG (K1)
+def test_normal_fill_matches_restatement(gpu_ctx):
+    from oracle.rng_oracle import normal_fill
+    for n, nb, fid, stream in ((1, 1, 0, 0), (2, 3, 5, 1), (1001, 4, 2 ** 33 + 7, 2), (4096, 2, 123, 0)):
+        x = gpu_ctx.normal_fill(n, nbatch=nb, first_id=fid, stream=stream)
+        ref = np.stack([normal_fill(n, 20261003, fid + b, stream) for b in range(nb)])
+        assert np.max(np.abs(x - ref)) <= 4 * np.finfo(float).eps * max(1.0, np.abs(ref).max())
+    y = gpu_ctx.normal_fill(50000, mean=1.5, sigma2=4.0)
+    assert abs(y.mean() - 1.5) < 0.05 and abs(y.var() - 4.0) < 0.15
+    d = gpu_ctx.empty(3 * 77)
+    gpu_ctx.normal_fill(77, nbatch=3, first_id=9, out=d)
+    assert np.array_equal(d.download().reshape(3, 77), gpu_ctx.normal_fill(77, nbatch=3, first_id=9))
+
+
+# ---------------------------------------------------------------------------------- sampler
+@pytest.mark.parametrize("tol,bound", [(TIGHT, 1e-9), (dict(), 1e-5)])
+def test_sampler_matches_direct_solve_all_levels(gpu_ctx, hexprob, seeded_rng, tol, bound):
+    from parelagmc_amd import capi
+    sp, so, _, _ = hexprob
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**tol))
+    xi = seeded_rng.standard_normal((3, sp.levels[0].n_s))
+    for lvl in range(3):
+        s, st = smp.Eval(lvl, xi, xi_level=0, return_stats=True)
+        ref = np.stack([so.eval(lvl, 0, x)[0] for x in xi])
+        assert rel(s, ref) < bound
+        assert all(t[1] == 1 for t in st) and all(0 < t[0] <= 300 for t in st)
+    for lvl in (1, 2):          # xi drawn on the level itself
+        x = seeded_rng.standard_normal((2, sp.levels[lvl].n_s))
+        assert rel(smp.Eval(lvl, x), np.stack([so.eval(lvl, lvl, v)[0] for v in x])) < bound
+    smp.close()
+
+
+def test_sampler_golden_vectors(gpu_ctx, hex_hierarchy_small):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    g = np.load(golden_path("gold_sampler_hex.npz"))
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT))
+    assert rel(smp.Eval(0, g["xi0"], xi_level=0), g["s00"]) < 1e-9
+    assert rel(smp.Eval(1, g["xi0"], xi_level=0), g["s10"]) < 1e-9
+    assert rel(smp.Eval(1, g["xi1"], xi_level=1), g["s11"]) < 1e-9
+    smp.close()
+
+
+def test_inline_quad_config1(gpu_ctx):
+    """BASELINE config 1: PDESamplerTest on inline_quad, 1 level, 16 samples."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hierarchy, build_sampler_problem, mesh_from_json
+    g = np.load(golden_path("gold_quad.npz"))
+    sp = build_sampler_problem(build_hierarchy(mesh_from_json(golden_path("meshes", "inline_quad.json")), 0), corlen=0.1)
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT))
+    assert (smp.xi_size(0), smp.SampleSize(0)) == (4, 4)
+    assert rel(smp.Eval(0, g["xi"]), g["s"]) < 1e-10
+    smp.close()
+
+
+def test_warm_start_and_embed_output(gpu_ctx, hexprob, seeded_rng):
+    from parelagmc_amd import capi
+    sp, so, _, _ = hexprob
+    smp = capi.PDESampler(gpu_ctx, sp)
+    xi = seeded_rng.standard_normal((4, sp.levels[0].n_s))
+    sc, emb_c = smp.Eval(1, xi, xi_level=0, want_embed=True)
+    ref_c = np.stack([so.eval(1, 0, x)[1] for x in xi])
+    assert rel(emb_c, ref_c) < 1e-5 and rel(sc, ref_c) < 1e-5            # Gaussian: s == embed_s
+    s, emb, st = smp.Eval(0, xi, xi_level=0, init_s=emb_c, init_level=1, use_init=True, want_embed=True, return_stats=True)
+    ref = np.stack([so.eval(0, 0, x)[0] for x in xi])
+    assert rel(s, ref) < 1e-5 and rel(emb, ref) < 1e-5
+    assert all(t[1] == 1 for t in st)
+    # init on the same level with the exact solution: converges at once
+    _, st1 = smp.Eval(0, xi, xi_level=0, init_s=emb, init_level=0, use_init=True, return_stats=True)
+    assert all(t[0] <= 3 for t in st1)
+    smp.close()
+
+
+@pytest.mark.parametrize("nbatch", [1, 2, 3, 5, 16, 17, 33])
+def test_ragged_batches_equal_single_evaluations(gpu_ctx, hex_hierarchy_small, nbatch):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT))
+    xi = smp.Sample(0, first_id=100, nbatch=nbatch)
+    s = smp.Eval(0, xi)
+    one = np.stack([smp.Eval(0, xi[b:b + 1])[0] for b in range(nbatch)])
+    assert rel(s, one) < 1e-9
+    smp.close()
+
+
+def test_host_and_device_memory_paths_agree(gpu_ctx, hex_hierarchy_small):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    smp = capi.PDESampler(gpu_ctx, sp)
+    n = sp.levels[0].n_s
+    xi_h = smp.Sample(0, first_id=3, nbatch=5)
+    xi_d = gpu_ctx.empty(5 * n)
+    smp.Sample(0, first_id=3, nbatch=5, out=xi_d)
+    assert np.array_equal(xi_d.download().reshape(5, n), xi_h)
+    s_d = gpu_ctx.empty(5 * n)
+    smp.Eval(0, xi_d, xi_level=0, s_out=s_d)
+    assert np.array_equal(s_d.download().reshape(5, n), smp.Eval(0, xi_h))
+    smp.close()
+
+
+def test_lognormal_is_exp_of_gaussian(gpu_ctx, hexprob, seeded_rng):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    sp, so, _, _ = hexprob
+    import copy
+    spl = copy.copy(sp)
+    spl.lognormal = True
+    smp = capi.PDESampler(gpu_ctx, spl, capi.solver_opts(**TIGHT))
+    xi = seeded_rng.standard_normal((2, sp.levels[0].n_s))
+    s, emb = smp.Eval(1, xi, xi_level=0, want_embed=True)
+    assert np.allclose(s, np.exp(emb), rtol=1e-14)
+    assert rel(emb, np.stack([so.eval(1, 0, x)[1] for x in xi])) < 1e-9
+    smp.close()
+
+
+def test_linearity_and_zero_input(gpu_ctx, hexprob, seeded_rng):
+    from parelagmc_amd import capi
+    sp, _, _, _ = hexprob
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT))
+    a, b = seeded_rng.standard_normal((2, sp.levels[0].n_s))
+    sa, sb, sab = smp.Eval(0, a[None])[0], smp.Eval(0, b[None])[0], smp.Eval(0, (2.0 * a - 0.5 * b)[None])[0]
+    assert rel(sab, 2.0 * sa - 0.5 * sb) < 1e-9
+    z, st = smp.Eval(0, np.zeros((1, sp.levels[0].n_s)), return_stats=True)
+    assert np.all(z == 0.0) and st[0][0] == 0 and st[0][1] == 1
+    smp.close()
+
+
+def test_tet_hierarchy_with_preconditioner_only_levels(gpu_ctx, seeded_rng):
+    """config-2 shape at small size: cube_tet refined, ONE Monte Carlo level, the coarser
+    refinement levels only feed the V-cycle."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hierarchy, build_sampler_problem, mesh_from_json
+    from oracle.sampler_oracle import SamplerOracle
+    h = build_hierarchy(mesh_from_json(golden_path("meshes", "cube_tet.json")), 3)
+    sp = build_sampler_problem(h, corlen=0.1, n_mc_levels=1)
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT))
+    assert smp.nlevels == 1 and smp.xi_size(0) == 6 * 8 ** 3
+    xi = seeded_rng.standard_normal((2, sp.levels[0].n_s))
+    so = SamplerOracle(sp)
+    assert rel(smp.Eval(0, xi), np.stack([so.eval(0, 0, x)[0] for x in xi])) < 1e-9
+    with pytest.raises(capi.PmcError):
+        smp.Eval(1, xi, xi_level=0)           # level 1 is not a Monte Carlo level
+    smp.close()
+
+
+def test_embedded_gather_and_l2_projection(gpu_ctx, seeded_rng):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import box_mesh, build_hierarchy, build_sampler_problem, l2_projection_ops
+    from oracle.sampler_oracle import SamplerOracle
+    m = box_mesh([6, 6, 6], [3.0, 3.0, 3.0], "hex", origin=[-0.5, -0.5, -0.5])
+    cen = m.verts[m.elems].mean(1)
+    m.elem_attr[:] = np.where(np.all((cen > 0) & (cen < 2), axis=1), 1, 2)
+    h = build_hierarchy(m, 1)
+    sp = build_sampler_problem(h, corlen=0.1, embedded=True, lognormal=True)
+    so = SamplerOracle(sp)
+    l2 = l2_projection_ops(h, sp.orig_index)
+    ga = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT), projection="gather")
+    pr = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT), projection="l2", l2_ops=l2)
+    xi = seeded_rng.standard_normal((3, sp.levels[0].n_s))
+    for lvl in range(2):
+        assert ga.xi_size(lvl) == sp.levels[lvl].n_s and ga.SampleSize(lvl) == len(sp.orig_index[lvl])
+        a, emb = ga.Eval(lvl, xi, xi_level=0, want_embed=True)
+        b = pr.Eval(lvl, xi, xi_level=0)
+        ref = np.stack([so.eval(lvl, 0, x, projection=("gather", sp.orig_index[lvl]))[0] for x in xi])
+        assert rel(a, ref) < 1e-9 and rel(b, ref) < 1e-9
+        assert rel(a, b) < 1e-12             # reference invariant: matching == non-matching on aligned meshes
+        assert emb.shape == (3, sp.levels[lvl].n_s)
+    ga.close()
+    pr.close()
+
+
+def test_error_paths(gpu_ctx, hex_hierarchy_small):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    smp = capi.PDESampler(gpu_ctx, sp)
+    xi = np.zeros((1, sp.levels[1].n_s))
+    with pytest.raises(capi.PmcError):
+        smp.Eval(0, xi, xi_level=1)           # xi_level <= level violated (PARELAG_ASSERT, PDESampler.cpp:420)
+    with pytest.raises(capi.PmcError):
+        smp.Eval(5, xi, xi_level=1)
+    with pytest.raises(capi.PmcError):
+        smp.Eval(1, xi, xi_level=1, use_init=True)    # use_init without a field
+    smp.close()
+
+
+# ---------------------------------------------------------------------------------- Darcy
+def test_kat1_darcy_deterministic_on_gpu(gpu_ctx, hexprob):
+    """DarcyDeterministicTest (reference examples/CMakeLists.txt:62-66): Q = 2, dofs 17152/2240/304."""
+    from parelagmc_amd import capi
+    kat = json.load(open(golden_path("kat.json")))["darcy_deterministic"]
+    _, _, dp, _ = hexprob
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    for lvl in range(3):
+        Q, C = ds.SolveFwd(lvl, np.ones((1, dp.levels[lvl].n_p)))
+        assert abs(Q[0] - kat["Q"][lvl]) < 1e-9 and C[0] == kat["dofs"][lvl]
+        assert ds.GetGlobalNumberOfDofs(lvl) == kat["dofs"][lvl]
+    ds.close()
+
+
+@pytest.mark.parametrize("k_divides", [True, False])
+def test_darcy_lognormal_matches_direct_solve(gpu_ctx, hex_hierarchy, seeded_rng, k_divides):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem
+    from oracle.darcy_oracle import DarcyOracle
+    dp = build_darcy_problem(hex_hierarchy, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1],
+                             k_divides=k_divides)
+    do = DarcyOracle(dp)
+    for opts, qtol, stol in ((capi.solver_opts(**TIGHT), 1e-9, 1e-8), (capi.solver_opts(), 1e-4, 1e-3)):
+        ds = capi.DarcySolver(gpu_ctx, dp, opts)
+        for lvl in range(3):
+            k = np.exp(seeded_rng.standard_normal((3, dp.levels[lvl].n_p)))
+            Q, C, sol, st = ds.SolveFwd(lvl, k, want_solution=True, return_stats=True)
+            for b in range(3):
+                Qr, Cr, sr = do.solve_fwd(lvl, k[b], return_solution=True)
+                assert abs(Q[b] - Qr) < qtol * abs(Qr) and C[b] == Cr
+                assert rel(sol[b], sr) < stol
+            assert all(t[1] == 1 for t in st)
+        ds.close()
+
+
+def test_darcy_golden_and_batches(gpu_ctx, hex_hierarchy_small):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem
+    g = np.load(golden_path("gold_darcy_hex.npz"))
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    for lvl in range(2):
+        Q, _ = ds.SolveFwd(lvl, g[f"k_L{lvl}"])
+        assert np.allclose(Q, g[f"Q_L{lvl}_div"], rtol=1e-9)
+    k = np.exp(np.random.default_rng(5).standard_normal((19, dp.levels[0].n_p)))
+    Q, _ = ds.SolveFwd(0, k)                       # 16 + 2 + 1
+    Q1 = np.array([ds.SolveFwd(0, k[b:b + 1])[0][0] for b in range(19)])
+    assert np.allclose(Q, Q1, rtol=1e-9)
+    kd = gpu_ctx.array(k)
+    Qd, _ = ds.SolveFwd(0, kd, nbatch=19)
+    assert np.array_equal(Qd, Q)
+    ds.close()
+
+
+def test_darcy_nonzero_essential_data_and_volume_qoi(gpu_ctx, hex_hierarchy_small, seeded_rng):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem
+    from oracle.darcy_oracle import DarcyOracle
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], qoi="p_int")
+    for L in dp.levels:
+        L.ess_data = 0.05 * seeded_rng.standard_normal(L.n_u) * L.ess_mask     # inhomogeneous u.n data
+    do = DarcyOracle(dp)
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    for lvl in range(2):
+        k = np.exp(seeded_rng.standard_normal((2, dp.levels[lvl].n_p)))
+        Q, _, sol = ds.SolveFwd(lvl, k, want_solution=True)
+        for b in range(2):
+            Qr, _, sr = do.solve_fwd(lvl, k[b], return_solution=True)
+            assert abs(Q[b] - Qr) < 1e-8 * max(1.0, abs(Qr)) and rel(sol[b], sr) < 1e-8
+    ds.close()
+
+
+# ---------------------------------------------------------------------------------- whole realizations
+def test_mlmc_manager_on_device_matches_oracle_loop(gpu_ctx, hex_hierarchy_small):
+    """MLMC_Manager::InitRun on the device (Sample -> Eval -> SolveFwd per level pair) against the
+    same loop run with the CPU oracle on the same realizations (xi from the restated generator)."""
+    from oracle import mlmc_oracle as mo
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.rng_oracle import normal_fill
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT))
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    mgr = host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False, batch=4)
+    ns = [5, 9]
+    r = mgr.InitRun(ns)
+    so, do = SamplerOracle(sp), DarcyOracle(dp)
+    sums = np.zeros((2, mo.NVAR))
+    for i in range(ns[1]):
+        s, _ = so.eval(1, 1, normal_fill(sp.levels[1].n_s, 20261003, i, 1))
+        q, c = do.solve_fwd(1, s)
+        mo.accumulate(sums, 1, q, q, c)
+    for i in range(ns[0]):
+        xi = normal_fill(sp.levels[0].n_s, 20261003, i, 0)
+        qc, cc = do.solve_fwd(1, so.eval(1, 0, xi)[0])
+        q, c = do.solve_fwd(0, so.eval(0, 0, xi)[0])
+        mo.accumulate(sums, 0, q - qc, q, c + cc)
+    assert np.allclose(r["sums"], sums, rtol=1e-7, atol=1e-9)
+    ref = mo.compute_nsamples_mse(sums, ns, [L.ndofs for L in dp.levels], 1e-3, 0.5)
+    assert np.allclose(r["varY"], ref["varY"], rtol=1e-5) and r["estimate"] == pytest.approx(ref["estimate"], rel=1e-7)
+    mgr.close()
+    ds.close()
+    smp.close()
+
+
+# ---------------------------------------------------------------------------------- K5: block operator SpMV
+@pytest.mark.parametrize("nb", [1, 2, 4, 8, 16])
+def test_block_operator_spmv_matches_csr(gpu_ctx, hexprob, seeded_rng, nb):
+    """y = [M Bt; B -aW] x on the device (SELL-64 SpMM) against scipy's CSR product of the oracle's
+    block operator: same sums in a different order -> agreement at rounding level."""
+    from parelagmc_amd import capi
+    sp, so, _, _ = hexprob
+    smp = capi.PDESampler(gpu_ctx, sp)
+    for lvl in (0, 2):
+        A = so.block_operator(lvl).tocsr()
+        x = seeded_rng.standard_normal((nb, A.shape[0]))
+        y, ms, nbytes = smp.Mult(lvl, x, repeat=2)
+        ref = (A @ x.T).T
+        scale = (abs(A) @ np.abs(x.T)).T
+        assert np.max(np.abs(y - ref) / scale) < 8 * np.finfo(float).eps
+        assert ms > 0 and nbytes == 12 * A.nnz + 4 * A.shape[0] + nb * 16 * A.shape[0]
+        assert smp.GetNNZ(lvl) == A.nnz == sp.levels[lvl].nnz
+    smp.close()

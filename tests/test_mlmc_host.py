@@ -1,0 +1,177 @@
+"""Host logic of the MLMC / MC managers (libpmc_host.so) against the plain-Python restatement
+of MLMC_Manager (oracle/mlmc_oracle.py).  Plugins are Python callbacks: no GPU involved."""
+import numpy as np
+import pytest
+
+from oracle import mlmc_oracle as mo
+from oracle.rng_oracle import normal_fill
+from parelagmc_amd import host_api
+
+SIZES = [32, 16, 8]          # level 0 finest
+NDOFS = [1000, 140, 20]
+
+
+class SyntheticPlugin:
+    """Cheap analytic sampler/solver with the same call protocol as the real ones."""
+
+    def __init__(self, nlevels=3, seed=11):
+        self.nl = nlevels
+        self.seed = seed
+        self.calls = []
+
+    def sample(self, level, first_id, nbatch):
+        return np.stack([normal_fill(SIZES[level], self.seed, first_id + b, level) for b in range(nbatch)])
+
+    def _restrict(self, x, frm, to):
+        while frm < to:
+            x = x.reshape(x.shape[0], -1, 2).sum(axis=2) / np.sqrt(2.0)
+            frm += 1
+        return x
+
+    def eval(self, level, xi_level, xi, init, init_level):
+        assert xi_level <= level
+        g = 0.5 * self._restrict(xi, xi_level, level) + 0.01 * level
+        if init is not None:
+            assert init_level >= level and init.shape[1] == SIZES[init_level]
+        self.calls.append(("eval", level, xi_level, init is not None))
+        return np.exp(g), g
+
+    def solve(self, level, k):
+        assert k.shape[1] == SIZES[level]
+        q = np.log(k).mean(axis=1) * (1.0 + 0.3 * 2.0 ** (-2 * (self.nl - level))) + 1.0 / (1 + level)
+        return q, np.full(k.shape[0], float(NDOFS[level]))
+
+    def callbacks(self):
+        return dict(sample=self.sample, eval=self.eval, solve=self.solve, xi_size=SIZES[:self.nl],
+                    sample_size=SIZES[:self.nl], ndofs=NDOFS[:self.nl])
+
+
+def python_init_run(pl, nl, counts, nsamples, sums):
+    """MLMC_Manager::InitRun restated with the oracle's accumulate (src/MLMC_Manager.cpp:103-179)."""
+    for lvl in range(nl - 1, -1, -1):
+        for i in range(nsamples[lvl]):
+            sid = counts[lvl] + i
+            xi = pl.sample(lvl, sid, 1)
+            if lvl == nl - 1:
+                s, _ = pl.eval(lvl, lvl, xi, None, None)
+                q, c = pl.solve(lvl, s)
+                mo.accumulate(sums, lvl, q[0], q[0], c[0])
+            else:
+                sc, emb = pl.eval(lvl + 1, lvl, xi, None, None)
+                qc, cc = pl.solve(lvl + 1, sc)
+                s, _ = pl.eval(lvl, lvl, xi, emb, lvl + 1)
+                q, c = pl.solve(lvl, s)
+                mo.accumulate(sums, lvl, q[0] - qc[0], q[0], c[0] + cc[0])
+        counts[lvl] += nsamples[lvl]
+
+
+def test_exp_w_regression_matches_restatement():
+    rng = np.random.default_rng(3)
+    for n in (2, 3, 4, 6):
+        y = rng.uniform(0.1, 2.0, n) * rng.choice([-1, 1], n)
+        x = np.sort(rng.uniform(10, 1e6, n))[::-1].copy()
+        for skip in (0, 1):
+            assert host_api.exp_w_regression(y, x, skip) == pytest.approx(mo.exp_w_regression(y, x, skip), rel=1e-14, abs=0)
+    assert host_api.exp_w_regression([1.0], [2.0], 0) == 0.0
+
+
+@pytest.mark.parametrize("nl", [1, 2, 3])
+@pytest.mark.parametrize("batch", [1, 4, 16])
+def test_init_run_sums_and_statistics(nl, batch):
+    pl = SyntheticPlugin(nl)
+    mgr = host_api.MLMCManager(nl, callbacks=pl.callbacks(), wall_time=False, batch=batch, eps2=1e-3)
+    ns = [7, 12, 21][:nl]
+    r = mgr.InitRun(ns)
+    sums = np.zeros((nl, mo.NVAR))
+    counts = [0] * nl
+    ref_pl = SyntheticPlugin(nl)
+    python_init_run(ref_pl, nl, counts, ns, sums)
+    assert np.allclose(r["sums"], sums, rtol=1e-13, atol=1e-13)
+    assert list(r["nsamples"]) == ns
+    ref = mo.compute_nsamples_mse(sums, ns, NDOFS[:nl], 1e-3, 0.5)
+    for key in ("eY", "eABSY", "eQ", "eABSQ", "eC", "varY", "varQ", "kurtosis", "consistency", "VC"):
+        assert np.allclose(r[key], ref[key], rtol=1e-11, atol=1e-14), key
+    for a, b in (("alpha", "alpha"), ("alpha_abs", "alphaABS"), ("beta", "beta"), ("gamma", "gamma"),
+                 ("bias2", "bias2"), ("estimator_variance", "estimator_variance"), ("actual_mse", "actualMSE"),
+                 ("estimate", "estimate")):
+        assert r[a] == pytest.approx(ref[b], rel=1e-10, abs=1e-14), a
+    assert list(r["missing"]) == list(ref["missing"])
+    # second round continues the sample-id sequence and accumulates
+    r2 = mgr.InitRun([3] * nl)
+    python_init_run(ref_pl, nl, counts, [3] * nl, sums)
+    assert np.allclose(r2["sums"], sums, rtol=1e-13, atol=1e-13)
+    mgr.close()
+
+
+def test_call_protocol_matches_reference_loop():
+    """Coarsest level: Sample, Eval(l), SolveFwd(l).  Pairs: Eval(l+1, init=False), Eval(l, use_init=True)."""
+    pl = SyntheticPlugin(3)
+    mgr = host_api.MLMCManager(3, callbacks=pl.callbacks(), wall_time=False, batch=16)
+    mgr.InitRun([2, 2, 2])
+    assert pl.calls == [("eval", 2, 2, False), ("eval", 2, 1, False), ("eval", 1, 1, True),
+                        ("eval", 1, 0, False), ("eval", 0, 0, True)]
+    mgr.close()
+
+
+def test_run_reaches_target_variance_and_auto_eps():
+    pl = SyntheticPlugin(3)
+    mgr = host_api.MLMCManager(3, callbacks=pl.callbacks(), wall_time=False, batch=8, eps2=2e-4, init_nsamples=10)
+    r = mgr.Run()
+    assert r["estimator_variance"] <= 0.5 * 2e-4
+    assert (r["nsamples"] >= 10).all()
+    mgr.close()
+    mgr = host_api.MLMCManager(3, callbacks=pl.callbacks(), wall_time=False, batch=8, eps2=-1.0, init_nsamples=10)
+    r = mgr.Run()
+    assert r["eps2"] == pytest.approx(r["bias2"] / 0.5)       # auto_eps2 (src/MLMC_Manager.cpp:357-358)
+    assert r["estimator_variance"] <= 0.5 * r["eps2"]
+    mgr.close()
+
+
+def test_array_number_of_samples_and_wall_time_cost():
+    pl = SyntheticPlugin(3)
+    mgr = host_api.MLMCManager(3, callbacks=pl.callbacks(), wall_time=True, batch=4, array_nsamples=[4, 8, 16],
+                               eps2=1e9)
+    r = mgr.Run()                      # huge eps2 -> only the initial round
+    assert list(r["nsamples"]) == [4, 8, 16]
+    assert (r["cost"] > 0).all() and np.allclose(r["cost"], r["level_seconds"] / r["nsamples"])
+    mgr.close()
+
+
+def test_bad_arguments_are_reported():
+    pl = SyntheticPlugin(2)
+    with pytest.raises(Exception):
+        host_api.MLMCManager(2, callbacks=pl.callbacks(), batch=0)
+    mgr = host_api.MLMCManager(2, callbacks=pl.callbacks(), wall_time=False)
+    with pytest.raises(Exception):
+        mgr.InitRun([1, -1])
+    mgr.close()
+
+
+def test_oracle_backed_plugin_small_problem(hex_hierarchy_small):
+    """Realistic plugin: the CPU oracle's sampler + Darcy on 8^3/4^3 behind the same managers."""
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    so, do = SamplerOracle(sp), DarcyOracle(dp)
+    sizes = [L.n_s for L in sp.levels]
+
+    def sample(level, first_id, nb):
+        return np.stack([normal_fill(sizes[level], 5, first_id + b, level) for b in range(nb)])
+
+    def ev(level, xi_level, xi, init, init_level):
+        out = [so.eval(level, xi_level, x) for x in xi]
+        return np.stack([o[0] for o in out]), np.stack([o[1] for o in out])
+
+    def solve(level, k):
+        out = [do.solve_fwd(level, kk) for kk in k]
+        return np.array([o[0] for o in out]), np.array([o[1] for o in out])
+
+    mgr = host_api.MLMCManager(2, callbacks=dict(sample=sample, eval=ev, solve=solve, xi_size=sizes, sample_size=sizes,
+                                                 ndofs=[L.ndofs for L in dp.levels]), wall_time=False, batch=4)
+    r = mgr.InitRun([6, 10])
+    assert 1.0 < r["eQ"][0] < 4.0 and 1.0 < r["eQ"][1] < 4.0       # effective permeability around exp(.)*2
+    assert abs(r["eY"][0]) < abs(r["eQ"][0])                       # level correction smaller than the QoI
+    assert np.allclose(r["eC"], [dp.levels[0].ndofs + dp.levels[1].ndofs, dp.levels[1].ndofs])
+    mgr.close()
