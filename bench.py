@@ -42,7 +42,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PMC_CPU_CORES", "16"))))
 
 
-def cpu_baseline(problem, seed, nsamples_per_core=2):
+def cpu_baseline(problem, seed, nsamples_per_core=12):
     """Reference algorithm restated in C (oracle/c/pmc_ref.c), farmed over the host cores: a bounded
     sample of the same workload."""
     from oracle.cport import CPort
@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent batches in flight per GPU (one HIP stream + host thread each): the launch-latency-"
+                         "bound coarse-level kernels of one batch overlap the bandwidth-bound kernels of the other")
     ap.add_argument("--refine", type=int, default=5, help="uniform refinements of cube_tet (5 -> 595 968 DoF)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20261003)
@@ -90,17 +93,38 @@ def main():
 
     problem = build_problem(args.refine)
     L = problem.levels[0]
-    ctx = capi.Context(local_rank if world > 1 else 0, seed=args.seed)
-    ctx.seed(args.seed, nparts=world, mypart=rank)
-    smp = capi.PDESampler(ctx, problem)
-    nb, n = args.batch, L.n_s
-    xi_d, s_d = ctx.empty(nb * n), ctx.empty(nb * n)
+    import threading
+    dev = local_rank if world > 1 else 0
+    nb, n, ns = args.batch, L.n_s, max(1, args.streams)
+    lanes = []
+    for _ in range(ns):
+        c = capi.Context(dev, seed=args.seed)
+        c.seed(args.seed, nparts=world, mypart=rank)
+        lanes.append((c, capi.PDESampler(c, problem), c.empty(nb * n), c.empty(nb * n)))
+    ctx, smp = lanes[0][0], lanes[0][1]
+
+    def one_batch(lane, batch_index):
+        c, sm, xi_d, s_d = lanes[lane]
+        first = batch_index * nb          # realization ids are never repeated
+        sm.Sample(0, first_id=first, nbatch=nb, out=xi_d)
+        return sm.Eval(0, xi_d, xi_level=0, s_out=s_d, return_stats=True)[1]
 
     def step(i):
-        # realization ids: block-cyclic over ranks, never repeated
-        first = (i * world + rank) * nb
-        smp.Sample(0, first_id=first, nbatch=nb, out=xi_d)
-        return smp.Eval(0, xi_d, xi_level=0, s_out=s_d, return_stats=True)[1]
+        # a step = `streams` batches of nb realizations in flight at once; batch ids block-cyclic over ranks
+        res = [None] * ns
+        base = (i * world + rank) * ns
+
+        def work(lane):
+            res[lane] = one_batch(lane, base + lane)
+        if ns == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(k,)) for k in range(ns)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        return [t for r in res for t in r]
 
     def barrier():
         if world > 1:
@@ -126,7 +150,7 @@ def main():
         a = torch.from_numpy(acc).cuda()
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         acc = a.cpu().numpy()
-    total_samples = args.steps * nb * world
+    total_samples = args.steps * nb * ns * world
     value = total_samples / dt
 
     out = None
@@ -153,8 +177,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"PDESampler cube_tet r={args.refine}, {L.n_u + L.n_s} DoF "
                                    f"(n_s={L.n_s}, n_u={L.n_u}, nnz(A)={L.nnz}), 1 MC level, corlen 0.1, "
-                                   f"MINRES 300/1e-6/1e-12, batch {nb} realizations per step",
-                       "mean_minres_iterations": acc[0] / max(acc[1], 1.0), "batch": nb,
+                                   f"MINRES 300/1e-6/1e-12, {ns} x {nb} realizations per step",
+                       "mean_minres_iterations": acc[0] / max(acc[1], 1.0), "batch": nb, "streams": ns,
                        "parallelism": f"sample-farm x{world}"},
             "roofline": {"bound": "hbm", "kernel": f"sell_spmm_kernel<{nb},false,0,false> (block operator K5)",
                          "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": peak, "unit": "GB/s",
@@ -165,8 +189,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, args.seed)
-    smp.close()
-    ctx.close()
+    for c, sm, _, _ in lanes:
+        sm.close()
+        c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -62,13 +62,13 @@ typedef struct pmc_solver_opts {
     int32_t max_iter;
     double rel_tol;
     double abs_tol;
-    int32_t cheb_degree_M;    /* polynomial degree on the M block (default 3) */
+    int32_t cheb_degree_M;    /* polynomial degree on the M block (default 2) */
     double cheb_ratio_M;      /* targeted lambda_max/lambda_min of D^-1 M (default 8) */
     int32_t mg_smooth_degree; /* Chebyshev pre/post smoothing degree per level (default 2) */
-    double mg_smooth_ratio;   /* smoothing interval [lmax/ratio, lmax] (default 4) */
+    double mg_smooth_ratio;   /* smoothing interval [lmax/ratio, lmax] (default 8) */
     int32_t mg_coarse_degree; /* polynomial degree on the coarsest level (default 12) */
     double mg_coarse_ratio;   /* (default 100) */
-    int32_t check_every;      /* iterations between host convergence polls (default 4) */
+    int32_t check_every;      /* iterations between host convergence polls (default 2) */
 } pmc_solver_opts;
 
 /* Per-realization solver report; the reference returns -1 for iteration counts

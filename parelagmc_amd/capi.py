@@ -357,6 +357,8 @@ class PDESampler:
         """xi: (nbatch, n_xi) numpy (host) or DeviceArray/torch tensor (device, with nbatch=...).
         Returns s (and embed_s, stats) as numpy arrays for host inputs."""
         lib = self.ctx.lib
+        if not (0 <= level < self.nlevels):
+            raise PmcError(-1, f"Eval: level {level} out of range")
         if isinstance(xi, np.ndarray):
             xi = _f64(np.atleast_2d(xi))
             nbatch = xi.shape[0]

@@ -84,13 +84,15 @@ void pmc_solver_opts_default(pmc_solver_opts* o) {
     o->max_iter = 300;
     o->rel_tol = 1e-6;
     o->abs_tol = 1e-12;
-    o->cheb_degree_M = 3;
+    // tuned on MI355X (scripts/sweep.py, cube_tet r=5): degree 2 on M needs no more MINRES iterations than
+    // degree 3; smoothing interval [lmax/8, lmax]
+    o->cheb_degree_M = 2;
     o->cheb_ratio_M = 8.0;
     o->mg_smooth_degree = 2;
-    o->mg_smooth_ratio = 4.0;
+    o->mg_smooth_ratio = 8.0;
     o->mg_coarse_degree = 12;
     o->mg_coarse_ratio = 100.0;
-    o->check_every = 4;
+    o->check_every = 2;
 }
 
 int pmc_ctx_create(int device_id, pmc_ctx** out) {

@@ -331,15 +331,18 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     double* cxp = cx.p;
     double* cdp = cd.p;
     Multigrid* mgp = &mg;
-    PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z) {
+    PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z, double* dot_partial) {
         const int flips = cheb_flips(cpM.degree, true);
         double* start = (flips % 2 == 0) ? z : cxp;
         double* other = (flips % 2 == 0) ? cxp : z;
-        double* res = cheb_apply(s, nb_, Mv, l1, true, cpM, r, start, other, cdp, true);
+        int nblk_u = 0;
+        double* res = cheb_apply(s, nb_, Mv, l1, true, cpM, r, start, other, cdp, true, dot_partial, &nblk_u);
         if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
-        mgp->vcycle(s, nb_, level, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_);
+        const int nblk_s = mgp->vcycle(s, nb_, level, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_,
+                                       dot_partial ? dot_partial + (size_t)nblk_u * nb_ : nullptr);
+        return nblk_u + nblk_s;
     };
-    MinresResult res = minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol.p, true, opts, work);
+    MinresResult res = minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol.p, true, opts, work, 0, n);
     if (stats)
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
     // K15: Q = <obs, sol>

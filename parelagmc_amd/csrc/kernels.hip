@@ -11,6 +11,8 @@
 //   darcy_*                                    : K12-K15 per-sample M(k), BC elimination, Schur refresh, QoI
 #include "kernels.hpp"
 
+#include <algorithm>
+
 namespace pmc {
 
 static constexpr int kBlock = 256;
@@ -118,32 +120,56 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
     int slot = off + lane;
-#pragma unroll 2
-    for (int j = 0; j < width; ++j, slot += kWave) {
-        const int cj = cols[slot];
-        double vj = 0.0;
+
+    int cj = 0;
+    double vj = 0.0;
+    if (width > 0) {
+        cj = cols[slot];
         if constexpr (!BV) vj = vals[slot];
+    }
+    for (int j = 0; j < width; ++j, slot += kWave) {
+        // software pipeline: the next slice column's (value, index) pair is requested before this
+        // column's gathers, so its latency overlaps them
+        int cn = cj;
+        double vn = vj;
+        if (j + 1 < width) {
+            cn = cols[slot + kWave];
+            if constexpr (!BV) vn = vals[slot + kWave];
+        }
+        // phase 1: all cross-lane fetches, phase 2: all gathers (independent registers, so the T loads of a
+        // slice column are in flight together), phase 3: FMAs
+        int cc[T];
+        double aa[T];
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int src = rs * G + g;
-            const int cc = (T == 1) ? cj : __shfl(cj, src, kWave);
-            double xv[C];
-            load_c<C>(x + (size_t)cc * NB + t * C, xv);
-            if constexpr (BV) {
-                double av[C];
-                load_c<C>(vals + (size_t)(slot - lane + src) * NB + t * C, av);
+            cc[rs] = (T == 1) ? cj : __shfl(cj, src, kWave);
+            if constexpr (!BV) aa[rs] = (T == 1) ? vj : __shfl(vj, src, kWave);
+        }
+        double xv[T][C];
+        double av[T][C];
+        if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise re-serialises load -> wait -> fma
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[rs][c] = fma(av[c], xv[c], acc[rs][c]);
-            } else {
-                const double a = (T == 1) ? vj : __shfl(vj, src, kWave);
+        for (int rs = 0; rs < T; ++rs) {
+            load_c<C>(x + (size_t)cc[rs] * NB + t * C, xv[rs]);
+            if constexpr (BV) load_c<C>(vals + (size_t)(slot - lane + rs * G + g) * NB + t * C, av[rs]);
+        }
+        if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[rs][c] = fma(a, xv[c], acc[rs][c]);
+        for (int rs = 0; rs < T; ++rs) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if constexpr (BV) acc[rs][c] = fma(av[rs][c], xv[rs][c], acc[rs][c]);
+                else acc[rs][c] = fma(aa[rs], xv[rs][c], acc[rs][c]);
             }
         }
+        cj = cn;
+        vj = vn;
     }
 }
 
-// MODE 0: y = Ax   1: y += Ax   2: y = r - Ax ; DOT: partial sums of <dot_with, result>
+// MODE 0: y = Ax   1: y += Ax   2: y = r - Ax ; DOT: partial sums of <dot_with, result>.
+// Wavefronts stride over the slices (grid may be smaller than the slice count: bounded partial-sum count).
 template <int NB, bool BV, int MODE, bool DOT>
 __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ cols,
@@ -153,14 +179,14 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                                                            const double* __restrict__ dot_with,
                                                            double* __restrict__ partial) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
-    const int slice = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
-    double acc[T][C];
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    if (slice < nslices) {
+    for (int slice = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; slice < nslices;
+         slice += gridDim.x * (kBlock / kWave)) {
+        double acc[T][C];
         sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
@@ -191,92 +217,108 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
     if constexpr (DOT) reduce_cols_store<NB>(p, partial);
 }
 
-// Chebyshev / Jacobi step: d = a d + b dinv (r - A xin); xout = xin + d
-template <int NB, bool BV>
+// Chebyshev / Jacobi step: d = a d + b dinv (r - A xin); xout = xin + d ; DOT: partials of <r, xout>
+template <int NB, bool BV, bool DOT>
 __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ cols,
                                                            const double* __restrict__ vals,
                                                            const double* __restrict__ dinv,
                                                            const double* __restrict__ r,
                                                            const double* __restrict__ xin, double* __restrict__ d,
-                                                           double* __restrict__ xout, double a, double b) {
+                                                           double* __restrict__ xout, double a, double b,
+                                                           double* __restrict__ partial) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
-    const int slice = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
-    if (slice >= nslices) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
-    double acc[T][C];
-    sell_row_product<NB, BV>(slice_off, cols, vals, xin, slice, lane, acc);
+    double p[C];
 #pragma unroll
-    for (int rs = 0; rs < T; ++rs) {
-        const int row = slice * kWave + rs * G + g;
-        if (row >= nrows) continue;
-        const size_t at = (size_t)row * NB + t * C;
-        double rv[C], dv[C], xv[C], di[C];
-        load_c<C>(r + at, rv);
-        load_c<C>(xin + at, xv);
-        if (a != 0.0) {
-            load_c<C>(d + at, dv);
-        } else {
+    for (int c = 0; c < C; ++c) p[c] = 0.0;
+    for (int slice = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; slice < nslices;
+         slice += gridDim.x * (kBlock / kWave)) {
+        double acc[T][C];
+        sell_row_product<NB, BV>(slice_off, cols, vals, xin, slice, lane, acc);
 #pragma unroll
-            for (int c = 0; c < C; ++c) dv[c] = 0.0;
+        for (int rs = 0; rs < T; ++rs) {
+            const int row = slice * kWave + rs * G + g;
+            if (row >= nrows) continue;
+            const size_t at = (size_t)row * NB + t * C;
+            double rv[C], dv[C], xv[C], di[C];
+            load_c<C>(r + at, rv);
+            load_c<C>(xin + at, xv);
+            if (a != 0.0) {
+                load_c<C>(d + at, dv);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) dv[c] = 0.0;
+            }
+            if constexpr (BV) {
+                load_c<C>(dinv + at, di);
+            } else {
+                const double s = dinv[row];
+#pragma unroll
+                for (int c = 0; c < C; ++c) di[c] = s;
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                dv[c] = a * dv[c] + b * di[c] * (rv[c] - acc[rs][c]);
+                xv[c] += dv[c];
+                if constexpr (DOT) p[c] = fma(rv[c], xv[c], p[c]);
+            }
+            store_c<C>(d + at, dv);
+            store_c<C>(xout + at, xv);
         }
+    }
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+}
+
+// ---- flat element-wise kernels: thread i owns the C doubles at flat index i*C, i.e. row (i*C)/NB and
+// columns ((i*C) % NB) + c; consecutive lanes touch consecutive 16 B -> fully coalesced.  Grid-stride:
+// the stride gridDim*256 is a multiple of T, so a thread keeps its column pair.
+template <int NB, bool BV, bool DOT>
+__global__ __launch_bounds__(kBlock) void cheb_first_kernel(size_t nflat, const double* __restrict__ dinv,
+                                                            const double* __restrict__ r, double* __restrict__ d,
+                                                            double* __restrict__ x, double b,
+                                                            double* __restrict__ partial) {
+    constexpr int C = Lay<NB>::C;
+    double p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nflat; i += (size_t)gridDim.x * kBlock) {
+        const size_t e = i * C;
+        double rv[C], di[C], xv[C];
+        load_c<C>(r + e, rv);
         if constexpr (BV) {
-            load_c<C>(dinv + at, di);
+            load_c<C>(dinv + e, di);
         } else {
-            const double s = dinv[row];
+            const double s = dinv[e / NB];
 #pragma unroll
             for (int c = 0; c < C; ++c) di[c] = s;
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            dv[c] = a * dv[c] + b * di[c] * (rv[c] - acc[rs][c]);
-            xv[c] += dv[c];
+            xv[c] = b * di[c] * rv[c];
+            if constexpr (DOT) p[c] = fma(rv[c], xv[c], p[c]);
         }
-        store_c<C>(d + at, dv);
-        store_c<C>(xout + at, xv);
+        store_c<C>(d + e, xv);
+        store_c<C>(x + e, xv);
     }
-}
-
-// ---- flat element-wise kernels: thread i owns the C doubles at flat index i*C, i.e. row (i*C)/NB and
-// columns ((i*C) % NB) + c; consecutive lanes touch consecutive 16 B -> fully coalesced.
-template <int NB, bool BV>
-__global__ __launch_bounds__(kBlock) void cheb_first_kernel(size_t nflat, const double* __restrict__ dinv,
-                                                            const double* __restrict__ r, double* __restrict__ d,
-                                                            double* __restrict__ x, double b) {
-    constexpr int C = Lay<NB>::C;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nflat) return;
-    const size_t e = i * C;
-    double rv[C], di[C];
-    load_c<C>(r + e, rv);
-    if constexpr (BV) {
-        load_c<C>(dinv + e, di);
-    } else {
-        const double s = dinv[e / NB];
-#pragma unroll
-        for (int c = 0; c < C; ++c) di[c] = s;
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) rv[c] = b * di[c] * rv[c];
-    store_c<C>(d + e, rv);
-    store_c<C>(x + e, rv);
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
 }
 
 template <int NB>
 __global__ __launch_bounds__(kBlock) void dot_kernel(size_t nflat, const double* __restrict__ a,
                                                      const double* __restrict__ b, double* __restrict__ partial) {
     constexpr int C = Lay<NB>::C;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    if (i < nflat) {
+    // grid-stride: the stride gridDim*256 is a multiple of T, so a thread keeps its column pair
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nflat; i += (size_t)gridDim.x * kBlock) {
         double av[C], bv[C];
         load_c<C>(a + i * C, av);
         load_c<C>(b + i * C, bv);
 #pragma unroll
-        for (int c = 0; c < C; ++c) p[c] = av[c] * bv[c];
+        for (int c = 0; c < C; ++c) p[c] = fma(av[c], bv[c], p[c]);
     }
     reduce_cols_store<NB>(p, partial);
 }
@@ -330,16 +372,15 @@ template <int NB>
 __global__ __launch_bounds__(kBlock) void wdot_kernel(size_t nflat, const double* __restrict__ w,
                                                       const double* __restrict__ x, double* __restrict__ partial) {
     constexpr int C = Lay<NB>::C;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    if (i < nflat) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nflat; i += (size_t)gridDim.x * kBlock) {
         double xv[C];
         load_c<C>(x + i * C, xv);
         const double ww = w[(i * C) / NB];
 #pragma unroll
-        for (int c = 0; c < C; ++c) p[c] = ww * xv[c];
+        for (int c = 0; c < C; ++c) p[c] = fma(ww, xv[c], p[c]);
     }
     reduce_cols_store<NB>(p, partial);
 }
@@ -351,114 +392,118 @@ __global__ void fill_kernel(size_t n, double* __restrict__ x, double v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// MINRES scalar recurrences.  One block; column k handled by the threads of wavefront (k % 4)
-// in turn.  Restates the preconditioned MINRES of Paige & Saunders in the form MFEM's
-// MINRESSolver uses (normalised Lanczos vectors); the vectors are kept UNnormalised here and
-// the 1/beta factors are folded into the update coefficients.
-__device__ __forceinline__ double reduce_partials(const double* __restrict__ partial, int nblocks, int nb, int k) {
-    // all 256 threads participate, fixed order
-    __shared__ double lds[kBlock / kWave];
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) s += partial[(size_t)b * nb + k];
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
+// MINRES scalar recurrences.  One block of 256 threads; thread k < nb owns column k.  Restates the
+// preconditioned MINRES of Paige & Saunders in the form MFEM's MINRESSolver uses (normalised Lanczos
+// vectors); the vectors are kept UNnormalised here and the 1/beta factors are folded into the
+// update coefficients.
+//
+// Column sums of the per-block partials: thread t reads column t % nb of blocks t / nb, t / nb + 256/nb, ...
+// (coalesced), then thread k adds the 256/nb group sums of its column in a fixed order (deterministic).
+static constexpr int kScalBlock = 1024;
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ partial, int nblocks, int nb) {
+    __shared__ double lds[kScalBlock];
+    const int k = threadIdx.x % nb, q = threadIdx.x / nb, nq = kScalBlock / nb;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains keep the loads in flight
+    int b = q;
+    for (; b + 3 * nq < nblocks; b += 4 * nq) {
+        s0 += partial[(size_t)b * nb + k];
+        s1 += partial[(size_t)(b + nq) * nb + k];
+        s2 += partial[(size_t)(b + 2 * nq) * nb + k];
+        s3 += partial[(size_t)(b + 3 * nq) * nb + k];
+    }
+    for (; b < nblocks; b += nq) s0 += partial[(size_t)b * nb + k];
+    const double s = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = s;
+    lds[threadIdx.x] = s;
     __syncthreads();
     double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < kBlock / kWave; ++w) t += lds[w];
-    return t;
+    if (threadIdx.x < nb)
+        for (int g = 0; g < nq; ++g) t += lds[g * nb + threadIdx.x];
+    return t;   // valid for threadIdx.x < nb
 }
 
-__global__ __launch_bounds__(kBlock) void minres_init_kernel(k::MinresState* st, const double* __restrict__ partial,
-                                                             int nblocks, int nb, double rel_tol, double abs_tol) {
-    for (int k = 0; k < nb; ++k) {
-        const double d = reduce_partials(partial, nblocks, nb, k);
-        if (threadIdx.x == 0) {
-            const double beta = d > 0.0 ? sqrt(d) : 0.0;
-            st->beta[k] = beta;
-            st->beta_old[k] = 1.0;
-            st->eta[k] = beta;
-            st->eta0[k] = beta;
-            st->gamma0[k] = st->gamma1[k] = 1.0;
-            st->sigma0[k] = st->sigma1[k] = 0.0;
-            st->goal[k] = fmax(rel_tol * beta, abs_tol);
-            st->iters[k] = 0;
-            st->flag[k] = (d < 0.0 || d != d) ? -1 : 0;   // preconditioner not SPD / NaN
-            st->active[k] = (beta > st->goal[k] && st->flag[k] == 0) ? 1 : 0;
-        }
-    }
+__device__ __forceinline__ void count_active(k::MinresState* st, int nb, bool bump) {
     __syncthreads();
     if (threadIdx.x == 0) {
         int na = 0;
         for (int k = 0; k < nb; ++k) na += st->active[k];
         st->n_active = na;
-        st->it = 0;
+        st->it = bump ? st->it + 1 : 0;
     }
 }
 
+__global__ __launch_bounds__(kScalBlock) void minres_init_kernel(k::MinresState* st, const double* __restrict__ partial,
+                                                             int nblocks, int nb, double rel_tol, double abs_tol) {
+    const double d = reduce_partials(partial, nblocks, nb);
+    const int k = threadIdx.x;
+    if (k < nb) {
+        const double beta = d > 0.0 ? sqrt(d) : 0.0;
+        st->beta[k] = beta;
+        st->beta_old[k] = 1.0;
+        st->eta[k] = beta;
+        st->eta0[k] = beta;
+        st->gamma0[k] = st->gamma1[k] = 1.0;
+        st->sigma0[k] = st->sigma1[k] = 0.0;
+        st->goal[k] = fmax(rel_tol * beta, abs_tol);
+        st->iters[k] = 0;
+        st->flag[k] = (d < 0.0 || d != d) ? -1 : 0;   // preconditioner not SPD / NaN
+        st->active[k] = (beta > st->goal[k] && st->flag[k] == 0) ? 1 : 0;
+    }
+    count_active(st, nb, false);
+}
+
 // after q = A u1 and d1 = <u1, q>
-__global__ __launch_bounds__(kBlock) void minres_scal1_kernel(k::MinresState* st, const double* __restrict__ partial,
+__global__ __launch_bounds__(kScalBlock) void minres_scal1_kernel(k::MinresState* st, const double* __restrict__ partial,
                                                               int nblocks, int nb) {
-    for (int k = 0; k < nb; ++k) {
-        const double d1 = reduce_partials(partial, nblocks, nb, k);
-        if (threadIdx.x == 0) {
-            if (st->active[k]) {
-                const double beta = st->beta[k];
-                const double ib = 1.0 / beta;
-                const double alpha = d1 * ib * ib;
-                st->alpha[k] = alpha;
-                st->cV[0][k] = ib;                       // q / beta
-                st->cV[1][k] = -alpha * ib;              // - alpha v1
-                st->cV[2][k] = -beta / st->beta_old[k];  // - beta v0
-                st->delta[k] = st->gamma1[k] * alpha - st->gamma0[k] * st->sigma1[k] * beta;
-                st->rho3[k] = st->sigma0[k] * beta;
-                st->rho2[k] = st->sigma1[k] * alpha + st->gamma0[k] * st->gamma1[k] * beta;
-            } else {
-                st->cV[0][k] = st->cV[1][k] = st->cV[2][k] = 0.0;
-            }
-        }
+    const double d1 = reduce_partials(partial, nblocks, nb);
+    const int k = threadIdx.x;
+    if (k >= nb) return;
+    if (st->active[k]) {
+        const double beta = st->beta[k];
+        const double ib = 1.0 / beta;
+        const double alpha = d1 * ib * ib;
+        st->alpha[k] = alpha;
+        st->cV[0][k] = ib;                       // q / beta
+        st->cV[1][k] = -alpha * ib;              // - alpha v1
+        st->cV[2][k] = -beta / st->beta_old[k];  // - beta v0
+        st->delta[k] = st->gamma1[k] * alpha - st->gamma0[k] * st->sigma1[k] * beta;
+        st->rho3[k] = st->sigma0[k] * beta;
+        st->rho2[k] = st->sigma1[k] * alpha + st->gamma0[k] * st->gamma1[k] * beta;
+    } else {
+        st->cV[0][k] = st->cV[1][k] = st->cV[2][k] = 0.0;
     }
 }
 
 // after z_new = prec(v_new) and d2 = <v_new, z_new>
-__global__ __launch_bounds__(kBlock) void minres_scal2_kernel(k::MinresState* st, const double* __restrict__ partial,
+__global__ __launch_bounds__(kScalBlock) void minres_scal2_kernel(k::MinresState* st, const double* __restrict__ partial,
                                                               int nblocks, int nb) {
-    for (int k = 0; k < nb; ++k) {
-        const double d2 = reduce_partials(partial, nblocks, nb, k);
-        if (threadIdx.x == 0) {
-            if (st->active[k]) {
-                if (d2 < 0.0 || d2 != d2) st->flag[k] = -1;
-                const double beta_new = d2 > 0.0 ? sqrt(d2) : 0.0;
-                const double delta = st->delta[k];
-                const double rho1 = hypot(delta, beta_new);
-                const double ir = rho1 > 0.0 ? 1.0 / rho1 : 0.0;
-                st->cW[0][k] = ir / st->beta[k];
-                st->cW[1][k] = -st->rho3[k] * ir;
-                st->cW[2][k] = -st->rho2[k] * ir;
-                st->gamma0[k] = st->gamma1[k];
-                st->gamma1[k] = delta * ir;
-                st->cW[3][k] = st->gamma1[k] * st->eta[k];
-                st->sigma0[k] = st->sigma1[k];
-                st->sigma1[k] = beta_new * ir;
-                st->eta[k] = -st->sigma1[k] * st->eta[k];
-                st->beta_old[k] = st->beta[k];
-                st->beta[k] = beta_new;
-                st->iters[k] = st->it + 1;
-                if (fabs(st->eta[k]) <= st->goal[k] || beta_new == 0.0 || st->flag[k] != 0) st->active[k] = 0;
-            } else {
-                st->cW[0][k] = st->cW[1][k] = st->cW[2][k] = st->cW[3][k] = 0.0;
-            }
+    const double d2 = reduce_partials(partial, nblocks, nb);
+    const int k = threadIdx.x;
+    if (k < nb) {
+        if (st->active[k]) {
+            if (d2 < 0.0 || d2 != d2) st->flag[k] = -1;
+            const double beta_new = d2 > 0.0 ? sqrt(d2) : 0.0;
+            const double delta = st->delta[k];
+            const double rho1 = hypot(delta, beta_new);
+            const double ir = rho1 > 0.0 ? 1.0 / rho1 : 0.0;
+            st->cW[0][k] = ir / st->beta[k];
+            st->cW[1][k] = -st->rho3[k] * ir;
+            st->cW[2][k] = -st->rho2[k] * ir;
+            st->gamma0[k] = st->gamma1[k];
+            st->gamma1[k] = delta * ir;
+            st->cW[3][k] = st->gamma1[k] * st->eta[k];
+            st->sigma0[k] = st->sigma1[k];
+            st->sigma1[k] = beta_new * ir;
+            st->eta[k] = -st->sigma1[k] * st->eta[k];
+            st->beta_old[k] = st->beta[k];
+            st->beta[k] = beta_new;
+            st->iters[k] = st->it + 1;
+            if (fabs(st->eta[k]) <= st->goal[k] || beta_new == 0.0 || st->flag[k] != 0) st->active[k] = 0;
+        } else {
+            st->cW[0][k] = st->cW[1][k] = st->cW[2][k] = st->cW[3][k] = 0.0;
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int na = 0;
-        for (int k = 0; k < nb; ++k) na += st->active[k];
-        st->n_active = na;
-        st->it += 1;
-    }
+    count_active(st, nb, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -705,12 +750,10 @@ __global__ __launch_bounds__(kBlock) void diag_inv_kernel(int n, const int* __re
 }
 
 // out[k] = sum_b partial[b*nb+k]   (single block)
-__global__ __launch_bounds__(kBlock) void reduce_final_kernel(const double* __restrict__ partial, int nblocks, int nb,
+__global__ __launch_bounds__(kScalBlock) void reduce_final_kernel(const double* __restrict__ partial, int nblocks, int nb,
                                                               double* __restrict__ out) {
-    for (int k = 0; k < nb; ++k) {
-        const double s = reduce_partials(partial, nblocks, nb, k);
-        if (threadIdx.x == 0) out[k] = s;
-    }
+    const double s = reduce_partials(partial, nblocks, nb);
+    if (threadIdx.x < nb) out[threadIdx.x] = s;
 }
 
 // out[i*NB+k] = a[i] (broadcast a shared vector into an interleaved batch)
@@ -745,10 +788,12 @@ static inline void check_launch() { PMC_HIP(hipGetLastError()); }
 
 namespace k {
 
+static inline dim3 grid_bounded(dim3 g, bool bounded) { return bounded ? dim3(std::min(g.x, 512u)) : g; }
+
 int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate, double* dot_partial,
          const double* dot_with) {
     if (A.nrows == 0) return 0;
-    const dim3 g = grid_slices(A.nslices);
+    const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (A.bv) {
             if (dot_partial)
@@ -767,7 +812,7 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
         }
     });
     check_launch();
-    return (int)g.x;
+    return dot_partial ? (int)g.x : 0;
 }
 
 void residual(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out) {
@@ -782,49 +827,64 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
     check_launch();
 }
 
-void cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
-               const double* xin, double* d, double* xout, double a, double b) {
-    if (A.nrows == 0) return;
+int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
+              const double* xin, double* d, double* xout, double a, double b, double* dot_partial) {
+    if (A.nrows == 0) return 0;
     if (A.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "cheb_step: value/diagonal batching mismatch");
-    const dim3 g = grid_slices(A.nslices);
+    const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
-        if (A.bv)
-            sell_cheb_kernel<NB, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b);
-        else
-            sell_cheb_kernel<NB, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b);
+        if (A.bv) {
+            if (dot_partial)
+                sell_cheb_kernel<NB, true, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial);
+            else
+                sell_cheb_kernel<NB, true, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr);
+        } else {
+            if (dot_partial)
+                sell_cheb_kernel<NB, false, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial);
+            else
+                sell_cheb_kernel<NB, false, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr);
+        }
     });
     check_launch();
+    return dot_partial ? (int)g.x : 0;
 }
 
-void cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d, double* x,
-                double b) {
-    if (n == 0) return;
+int cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d, double* x,
+               double b, double* dot_partial) {
+    if (n == 0) return 0;
     const size_t nf = flat_count(n, nb);
+    const dim3 g = grid_bounded(grid_flat(n, nb), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
-        if (dinv_bv)
-            cheb_first_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(nf, dinv, r, d, x, b);
-        else
-            cheb_first_kernel<NB, false><<<grid_flat(n, nb), kBlock, 0, st>>>(nf, dinv, r, d, x, b);
+        if (dinv_bv) {
+            if (dot_partial) cheb_first_kernel<NB, true, true><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, dot_partial);
+            else cheb_first_kernel<NB, true, false><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, nullptr);
+        } else {
+            if (dot_partial) cheb_first_kernel<NB, false, true><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, dot_partial);
+            else cheb_first_kernel<NB, false, false><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, nullptr);
+        }
     });
     check_launch();
+    return dot_partial ? (int)g.x : 0;
 }
+
+static inline dim3 grid_dot(int n, int nb) { return dim3(std::min(grid_flat(n, nb).x, 1024u)); }
 
 int dot(hipStream_t st, int nb, int n, const double* a, const double* b, double* partial) {
-    const dim3 g = grid_flat(n, nb);
+    const dim3 g = grid_dot(n, nb);
     PMC_DISPATCH_NB(nb, { dot_kernel<NB><<<g, kBlock, 0, st>>>(flat_count(n, nb), a, b, partial); });
     check_launch();
     return (int)g.x;
 }
 
 int wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial) {
-    const dim3 g = grid_flat(n, nb);
+    const dim3 g = grid_dot(n, nb);
     PMC_DISPATCH_NB(nb, { wdot_kernel<NB><<<g, kBlock, 0, st>>>(flat_count(n, nb), w, x, partial); });
     check_launch();
     return (int)g.x;
 }
 
 void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, double* out) {
-    reduce_final_kernel<<<1, kBlock, 0, st>>>(partial, nblocks, nb, out);
+    reduce_final_kernel<<<1, kScalBlock, 0, st>>>(partial, nblocks, nb, out);
     check_launch();
 }
 
@@ -857,15 +917,15 @@ void copy(hipStream_t st, size_t n, const double* src, double* dst) {
 
 void minres_init(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks, double rel_tol,
                  double abs_tol) {
-    minres_init_kernel<<<1, kBlock, 0, st>>>(s, partial, nblocks, nb, rel_tol, abs_tol);
+    minres_init_kernel<<<1, kScalBlock, 0, st>>>(s, partial, nblocks, nb, rel_tol, abs_tol);
     check_launch();
 }
 void minres_scal1(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks) {
-    minres_scal1_kernel<<<1, kBlock, 0, st>>>(s, partial, nblocks, nb);
+    minres_scal1_kernel<<<1, kScalBlock, 0, st>>>(s, partial, nblocks, nb);
     check_launch();
 }
 void minres_scal2(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks) {
-    minres_scal2_kernel<<<1, kBlock, 0, st>>>(s, partial, nblocks, nb);
+    minres_scal2_kernel<<<1, kScalBlock, 0, st>>>(s, partial, nblocks, nb);
     check_launch();
 }
 

@@ -41,12 +41,13 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
           double* dot_partial, const double* dot_with);
 // out = r - A x
 void residual(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out);
-// Chebyshev / Jacobi step:  d = a*d + b*dinv.*(r - A xin);  xout = xin + d   (xin != xout)
-void cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
-               const double* xin, double* d, double* xout, double a, double b);
+// Chebyshev / Jacobi step:  d = a*d + b*dinv.*(r - A xin);  xout = xin + d   (xin != xout).
+// dot_partial != nullptr: also per-block partials of <r, xout>; returns the number of blocks written.
+int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
+              const double* xin, double* d, double* xout, double a, double b, double* dot_partial = nullptr);
 // first step from a zero guess: d = b*dinv.*r; x = d
-void cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d,
-                double* x, double b);
+int cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d,
+               double* x, double b, double* dot_partial = nullptr);
 // both return the number of partial blocks written
 int dot(hipStream_t st, int nb, int n, const double* a, const double* b, double* partial);
 int wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial);

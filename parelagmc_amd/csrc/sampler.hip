@@ -95,7 +95,20 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
         m.bv = false;
         sell_build(m.S, S, true, false, st);
         std::vector<double> dS = csr_diag(S);
-        m.lmax = gershgorin_scaled(S, dS) * 1.0001;
+        double lo = 0.0;
+        m.lmax = gershgorin_scaled(S, dS, &lo) * 1.0001;
+        // reaction-dominated level (alpha |e| dominates the flux coupling): spec(D^-1 S) lies in the narrow
+        // Gershgorin interval [lo, lmax]; a short Chebyshev polynomial on exactly that interval is an
+        // (almost) exact solve, so the V-cycle stops here.
+        // A small level (launch-latency bound below a few thousand rows) with a moderately narrow interval
+        // is also solved in place by a longer polynomial instead of descending further.
+        if (lo > 0.0 && (m.lmax / lo <= 3.5 || (L.n_s <= 4096 && m.lmax / lo <= 40.0))) {
+            m.is_last = true;
+            m.last_ratio = m.lmax / (lo * 0.999);
+            const double sk = std::sqrt(m.last_ratio);
+            const double sig = (sk - 1.0) / (sk + 1.0);
+            m.last_degree = std::min(16, std::max(2, (int)std::ceil(std::log(2.0 / 0.02) / std::log(1.0 / sig))));
+        }
         for (double& v : dS) v = 1.0 / v;
         m.dinv.upload(dS, st);
         if (l + 1 < nlevels) {
@@ -224,15 +237,19 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     double* cxp = cx.p;
     double* cdp = cd.p;
     Multigrid* mgp = &mg;
-    PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z) {
+    PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z, double* dot_partial) {
         const int flips = cheb_flips(cpM.degree, true);
         double* start = (flips % 2 == 0) ? z : cxp;
         double* other = (flips % 2 == 0) ? cxp : z;
-        double* res = cheb_apply(s, nb_, Mv, dinvM, false, cpM, r, start, other, cdp, true);
+        int nblk_u = 0;
+        double* res = cheb_apply(s, nb_, Mv, dinvM, false, cpM, r, start, other, cdp, true, dot_partial, &nblk_u);
         if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
-        mgp->vcycle(s, nb_, level, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_);
+        const int nblk_s = mgp->vcycle(s, nb_, level, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_,
+                                       dot_partial ? dot_partial + (size_t)nblk_u * nb_ : nullptr);
+        return nblk_u + nblk_s;   // <r, z> = u-block partials followed by s-block partials
     };
-    MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work);
+    // only the s-block of the solution is ever read (PDESampler.cpp:526): update only those rows
+    MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work, n_u, n_s);
     if (stats)
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
     // outputs (:526-533 and the embedded variants' maps)

@@ -8,7 +8,8 @@
 namespace pmc {
 
 double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
-                   const double* r, double* xa, double* xb, double* d, bool zero_guess) {
+                   const double* r, double* xa, double* xb, double* d, bool zero_guess, double* dot_partial,
+                   int* dot_blocks) {
     if (cp.degree < 1) throw Error(PMC_ERR_INVALID, "Chebyshev degree must be >= 1");
     const double lmax = cp.lmax, lmin = cp.lmax / cp.ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
@@ -17,20 +18,24 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
     double* cur = xa;
     double* oth = xb;
     int step = 0;
+    int nblk = 0;
+    double* dp = (cp.degree == 1) ? dot_partial : nullptr;
     if (zero_guess) {
-        k::cheb_first(st, nb, A.nrows, dinv, dinv_bv, r, d, cur, 1.0 / theta);
+        nblk = k::cheb_first(st, nb, A.nrows, dinv, dinv_bv, r, d, cur, 1.0 / theta, dp);
         step = 1;
     } else {
-        k::cheb_step(st, nb, A, dinv, dinv_bv, r, cur, d, oth, 0.0, 1.0 / theta);
+        nblk = k::cheb_step(st, nb, A, dinv, dinv_bv, r, cur, d, oth, 0.0, 1.0 / theta, dp);
         std::swap(cur, oth);
         step = 1;
     }
     for (; step < cp.degree; ++step) {
         const double rho = 1.0 / (2.0 * sigma - rho_old);
-        k::cheb_step(st, nb, A, dinv, dinv_bv, r, cur, d, oth, rho * rho_old, 2.0 * rho / delta);
+        dp = (step == cp.degree - 1) ? dot_partial : nullptr;
+        nblk = k::cheb_step(st, nb, A, dinv, dinv_bv, r, cur, d, oth, rho * rho_old, 2.0 * rho / delta, dp);
         std::swap(cur, oth);
         rho_old = rho;
     }
+    if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
     return cur;
 }
 
@@ -43,12 +48,15 @@ void MgLevel::ensure(int nb) {
     res.ensure(need);
 }
 
-double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target) {
+double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, double* dot_partial,
+                         int* dot_blocks) {
     MgLevel& lv = L[l];
     lv.ensure(nb);
     const SellView A = lv.sview();
-    const bool last = (l == (int)L.size() - 1);
-    const int flips = last ? cheb_flips(coarse_degree, true)
+    const bool last = (l == (int)L.size() - 1) || lv.is_last;
+    const int last_deg = lv.is_last ? lv.last_degree : coarse_degree;
+    const double last_rat = lv.is_last ? lv.last_ratio : coarse_ratio;
+    const int flips = last ? cheb_flips(last_deg, true)
                            : cheb_flips(smooth_degree, true) + cheb_flips(smooth_degree, false);
     double* start = lv.xa.p;
     double* other = lv.xb.p;
@@ -56,8 +64,8 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         if (flips % 2 == 0) start = target; else other = target;
     }
     if (last) {
-        ChebParams cp{coarse_degree, lv.lmax, coarse_ratio};
-        return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true);
+        ChebParams cp{last_deg, lv.lmax, last_rat};
+        return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true, dot_partial, dot_blocks);
     }
     ChebParams cp{smooth_degree, lv.lmax, smooth_ratio};
     double* x = cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true);
@@ -66,14 +74,16 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     MgLevel& lc = L[l + 1];
     lc.ensure(nb);
     k::spmm(st, nb, view(lv.Pt), lv.res.p, lc.r.p, false, nullptr, nullptr);
-    double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr);
+    double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr);
     k::spmm(st, nb, view(lv.P), xc, x, true, nullptr, nullptr);
-    return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, x, oth, lv.d.p, false);
+    return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, x, oth, lv.d.p, false, dot_partial, dot_blocks);
 }
 
-void Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout) {
-    double* res = cycle(st, nb, l0, l0, r, xout);
+int Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial) {
+    int nblk = 0;
+    double* res = cycle(st, nb, l0, l0, r, xout, dot_partial, &nblk);
     if (res != xout) throw Error(PMC_ERR_INTERNAL, "V-cycle result landed in the wrong buffer");
+    return nblk;
 }
 
 void MinresWork::ensure(int n, int nb) {
@@ -99,7 +109,7 @@ static void axpby(hipStream_t st, size_t n, double a, const double* x, double b,
 }
 
 MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, const double* b, double* x,
-                          bool zero_guess, const pmc_solver_opts& o, MinresWork& w) {
+                          bool zero_guess, const pmc_solver_opts& o, MinresWork& w, int x_row0, int x_nrows) {
     hipStream_t st = ctx.stream;
     const int n = A.n;
     const size_t len = (size_t)n * nb;
@@ -116,8 +126,10 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         A.apply(st, nb, x, v1, nullptr);
         axpby(st, len, 1.0, b, -1.0, v1);
     }
-    prec(st, nb, v1, u1);
-    int nblocks = k::dot(st, nb, n, v1, u1, w.partial.p);
+    if (x_row0 < 0 || x_nrows < 0 || x_row0 + x_nrows > n) throw Error(PMC_ERR_INTERNAL, "minres: bad solution row range");
+    const size_t xoff = (size_t)x_row0 * nb;
+    int nblocks = prec(st, nb, v1, u1, w.partial.p);
+    if (nblocks == 0) nblocks = k::dot(st, nb, n, v1, u1, w.partial.p);
     k::minres_init(st, nb, S, w.partial.p, nblocks, o.rel_tol, o.abs_tol);
     k::fill(st, len, v0, 0.0);
     k::fill(st, len, w0, 0.0);
@@ -148,10 +160,10 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         nblocks = A.apply(st, nb, u1, q, w.partial.p);
         k::minres_scal1(st, nb, S, w.partial.p, nblocks);
         k::lincomb3(st, nb, n, cV0, q, cV1, v1, cV2, v0);
-        prec(st, nb, v0, u0);
-        nblocks = k::dot(st, nb, n, v0, u0, w.partial.p);
+        nblocks = prec(st, nb, v0, u0, w.partial.p);
+        if (nblocks == 0) nblocks = k::dot(st, nb, n, v0, u0, w.partial.p);
         k::minres_scal2(st, nb, S, w.partial.p, nblocks);
-        k::minres_wx(st, nb, n, cW0, u1, cW1, w0, cW2, w1, cW3, x);
+        k::minres_wx(st, nb, x_nrows, cW0, u1 + xoff, cW1, w0, cW2, w1, cW3, x + xoff);
         std::swap(u0, u1);
         std::swap(v0, v1);
         std::swap(w0, w1);
@@ -174,13 +186,15 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     return out;
 }
 
-double gershgorin_scaled(const HostCsr& A, const std::vector<double>& diag) {
-    double lmax = 0.0;
+double gershgorin_scaled(const HostCsr& A, const std::vector<double>& diag, double* lmin) {
+    double lmax = 0.0, lo = 2.0;
     for (int i = 0; i < A.nrows; ++i) {
         double s = 0.0;
         for (int p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) s += std::fabs(A.vals[p]);
         lmax = std::max(lmax, s / diag[i]);
+        lo = std::min(lo, 2.0 - s / diag[i]);
     }
+    if (lmin) *lmin = lo;
     return lmax;
 }
 

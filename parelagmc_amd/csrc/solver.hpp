@@ -17,8 +17,10 @@ struct ChebParams {
 };
 // Runs `degree` steps.  xa holds the initial guess (ignored when zero_guess); the iterate ping-pongs
 // between xa and xb; returns the buffer holding the result.  d is work space.
+// dot_partial != nullptr: the last step also writes per-block partials of <r, result>; *dot_blocks gets their count.
 double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
-                   const double* r, double* xa, double* xb, double* d, bool zero_guess);
+                   const double* r, double* xa, double* xb, double* d, bool zero_guess,
+                   double* dot_partial = nullptr, int* dot_blocks = nullptr);
 // number of buffer flips cheb_apply performs
 inline int cheb_flips(int degree, bool zero_guess) { return zero_guess ? degree - 1 : degree; }
 
@@ -30,6 +32,13 @@ struct MgLevel {
     DevBuf<double> vals_bv;      // batched values (Darcy): nslots*kMaxBatch
     bool bv = false;
     double lmax = 2.0;
+    // Coarsest-level treatment: `is_last` levels end the recursion with a Chebyshev solve of degree
+    // last_degree on [lmax/last_ratio, lmax].  The last supplied level always is one; a level whose
+    // diagonally scaled spectrum is provably narrow (reaction-dominated sampler levels) is one too, so
+    // the V-cycle does not descend into launch-latency-bound tiny levels.
+    bool is_last = false;
+    int last_degree = 12;
+    double last_ratio = 100.0;
     Sell P, Pt;                  // to/from the next coarser level (absent on the last)
     DevBuf<double> r, xa, xb, d, res;
     void ensure(int nb);
@@ -42,11 +51,13 @@ struct Multigrid {
     double smooth_ratio = 4.0;
     int coarse_degree = 12;
     double coarse_ratio = 100.0;
-    // x = V(r) starting at level l0 with zero initial guess; result written to xout (n(l0)*nb)
-    void vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout);
+    // x = V(r) starting at level l0 with zero initial guess; result written to xout (n(l0)*nb).
+    // dot_partial != nullptr: also per-block partials of <r, xout>; returns their count.
+    int vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial = nullptr);
 
   private:
-    double* cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target);
+    double* cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, double* dot_partial,
+                  int* dot_blocks);
 };
 
 // Abstract pieces MINRES needs.
@@ -56,7 +67,9 @@ struct LinOp {
     // partial blocks written (0 when dot_partial == nullptr)
     std::function<int(hipStream_t, int nb, const double* x, double* y, double* dot_partial)> apply;
 };
-using PrecFn = std::function<void(hipStream_t, int nb, const double* r, double* z)>;
+// z = B^-1 r.  When dot_partial != nullptr the preconditioner may fuse <r, z> into its last kernels and
+// return the number of partial blocks it wrote (0 = not computed, the solver then runs a separate dot).
+using PrecFn = std::function<int(hipStream_t, int nb, const double* r, double* z, double* dot_partial)>;
 
 struct MinresWork {
     DevBuf<double> v0, v1, u0, u1, w0, w1, q, partial;
@@ -71,10 +84,13 @@ struct MinresResult {
 
 // Preconditioned MINRES on nb right-hand sides at once.  x holds the initial guess on entry when
 // !zero_guess.  b, x: n*nb interleaved device vectors.
+// Only rows [x_row0, x_row0 + x_nrows) of the solution are updated (the samplers need the s-block only,
+// which saves two thirds of the w / x vector traffic); pass 0, A.n for the full solution.
 MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, const double* b, double* x,
-                          bool zero_guess, const pmc_solver_opts& o, MinresWork& w);
+                          bool zero_guess, const pmc_solver_opts& o, MinresWork& w, int x_row0, int x_nrows);
 
-// Gershgorin bound of spec(D^-1 A) for D = diag(A) on the host (setup)
-double gershgorin_scaled(const HostCsr& A, const std::vector<double>& diag);
+// Gershgorin bounds of spec(D^-1 A) for D = diag(A) on the host (setup): returns lmax, sets *lmin
+// (may be <= 0 when a row is not strictly diagonally dominant)
+double gershgorin_scaled(const HostCsr& A, const std::vector<double>& diag, double* lmin = nullptr);
 
 }  // namespace pmc
