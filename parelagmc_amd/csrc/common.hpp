@@ -98,11 +98,17 @@ struct Sell {
     DevBuf<int> slice_off; // nslices+1
     DevBuf<int> cols;      // nslots
     DevBuf<double> vals;   // nslots (shared values) - empty for batched-value matrices
+    // Optional processing order of the slices (a permutation of 0..nslices-1).  For a block operator
+    // [u-rows; s-rows] it interleaves the u- and s-slices of the same mesh region, so the x entries both
+    // kinds of rows gather are fetched once while they are still in the XCD's L2.
+    DevBuf<int> sched;
     std::vector<int> h_slice_off, h_cols, h_src;  // host mirrors (h_src: slot -> csr nnz or -1)
     // algorithmic bytes of one SpMV with this matrix: 12 nnz + 12 nrows + 8 ncols
     double spmv_bytes() const { return 12.0 * nnz + 12.0 * nrows + 8.0 * ncols; }
 };
 void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st);
+// schedule that merges the slices of row block [0, n0) with those of [n0, nrows) by relative position
+void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st);
 
 // ---- context ------------------------------------------------------------------------------
 struct Ctx {

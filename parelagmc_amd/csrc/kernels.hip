@@ -168,10 +168,30 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
     }
 }
 
+// XCD-aware slice assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (block b runs
+// on XCD b % 8), and each XCD has its own 4 MiB L2.  Every workgroup takes one CONTIGUOUS chunk of slices, and
+// the chunks of the workgroups of one XCD are contiguous too, so an XCD sweeps one eighth of the rows and
+// the x entries its gathers touch (mesh neighbours = nearby indices) stay in that XCD's L2 instead of being
+// fetched by all eight.  Placement only affects speed, never results.
+__device__ __forceinline__ int first_slice(int nslices, int* slice_end) {
+    const int nblk = gridDim.x;
+    int rb = blockIdx.x;
+    if (nblk >= 8) {
+        const int per = nblk / 8, rem = nblk % 8;          // XCD x owns per + (x < rem) blocks
+        const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+        rb = xcd * per + (xcd < rem ? xcd : rem) + idx;
+    }
+    const int chunk = (nslices + nblk - 1) / nblk;
+    const int begin = rb * chunk;
+    *slice_end = min(begin + chunk, nslices);
+    return begin + (int)(threadIdx.x / kWave);
+}
+
 // MODE 0: y = Ax   1: y += Ax   2: y = r - Ax ; DOT: partial sums of <dot_with, result>.
 // Wavefronts stride over the slices (grid may be smaller than the slice count: bounded partial-sum count).
 template <int NB, bool BV, int MODE, bool DOT>
 __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+                                                           const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
                                                            const double* __restrict__ vals,
                                                            const double* __restrict__ x, double* __restrict__ y,
@@ -184,8 +204,9 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    for (int slice = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; slice < nslices;
-         slice += gridDim.x * (kBlock / kWave)) {
+    int slice_end;
+    for (int si = first_slice(nslices, &slice_end); si < slice_end; si += kBlock / kWave) {
+        const int slice = sched ? sched[si] : si;   // optional processing order (locality), see Sell::sched
         double acc[T][C];
         sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
 #pragma unroll
@@ -220,6 +241,7 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
 // Chebyshev / Jacobi step: d = a d + b dinv (r - A xin); xout = xin + d ; DOT: partials of <r, xout>
 template <int NB, bool BV, bool DOT>
 __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+                                                           const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
                                                            const double* __restrict__ vals,
                                                            const double* __restrict__ dinv,
@@ -233,8 +255,9 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    for (int slice = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; slice < nslices;
-         slice += gridDim.x * (kBlock / kWave)) {
+    int slice_end;
+    for (int si = first_slice(nslices, &slice_end); si < slice_end; si += kBlock / kWave) {
+        const int slice = sched ? sched[si] : si;
         double acc[T][C];
         sell_row_product<NB, BV>(slice_off, cols, vals, xin, slice, lane, acc);
 #pragma unroll
@@ -797,18 +820,18 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
     PMC_DISPATCH_NB(nb, {
         if (A.bv) {
             if (dot_partial)
-                sell_spmm_kernel<NB, true, 0, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+                sell_spmm_kernel<NB, true, 0, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
             else if (accumulate)
-                sell_spmm_kernel<NB, true, 1, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+                sell_spmm_kernel<NB, true, 1, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
             else
-                sell_spmm_kernel<NB, true, 0, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+                sell_spmm_kernel<NB, true, 0, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
         } else {
             if (dot_partial)
-                sell_spmm_kernel<NB, false, 0, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+                sell_spmm_kernel<NB, false, 0, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
             else if (accumulate)
-                sell_spmm_kernel<NB, false, 1, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+                sell_spmm_kernel<NB, false, 1, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
             else
-                sell_spmm_kernel<NB, false, 0, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+                sell_spmm_kernel<NB, false, 0, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
         }
     });
     check_launch();
@@ -820,9 +843,9 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
         if (A.bv)
-            sell_spmm_kernel<NB, true, 2, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, out, r, nullptr, nullptr);
+            sell_spmm_kernel<NB, true, 2, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr);
         else
-            sell_spmm_kernel<NB, false, 2, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, out, r, nullptr, nullptr);
+            sell_spmm_kernel<NB, false, 2, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr);
     });
     check_launch();
 }
@@ -835,14 +858,14 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
     PMC_DISPATCH_NB(nb, {
         if (A.bv) {
             if (dot_partial)
-                sell_cheb_kernel<NB, true, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial);
+                sell_cheb_kernel<NB, true, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial);
             else
-                sell_cheb_kernel<NB, true, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr);
+                sell_cheb_kernel<NB, true, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr);
         } else {
             if (dot_partial)
-                sell_cheb_kernel<NB, false, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial);
+                sell_cheb_kernel<NB, false, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial);
             else
-                sell_cheb_kernel<NB, false, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr);
+                sell_cheb_kernel<NB, false, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr);
         }
     });
     check_launch();

@@ -13,10 +13,11 @@ struct SellView {
     const int* cols = nullptr;
     const double* vals = nullptr;
     bool bv = false;
+    const int* sched = nullptr;   // optional slice processing order
 };
-inline SellView view(const Sell& S) { return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, S.vals.p, false}; }
+inline SellView view(const Sell& S) { return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, S.vals.p, false, S.sched.p}; }
 inline SellView view_bv(const Sell& S, const double* vals) {
-    return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, vals, true};
+    return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, vals, true, S.sched.p};
 }
 
 // capacity (in blocks) of a partial-sum buffer for (fused) dots over nrows rows: allocate dot_capacity*kMaxBatch doubles

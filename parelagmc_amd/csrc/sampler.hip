@@ -83,6 +83,7 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
         HostCsr A = csr_block2x2(M, Bt, B, maw.data());
         d.nnz = A.nnz();
         sell_build(d.A, A, true, false, st);
+        sell_schedule_two_blocks(d.A, L.n_u, st);
         sell_build(d.M, M, true, false, st);
         std::vector<double> dM = csr_diag(M);
         for (double v : dM) PMC_REQUIRE(v > 0.0, "sampler M must have a positive diagonal");

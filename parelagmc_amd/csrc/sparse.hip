@@ -149,4 +149,18 @@ void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipS
     if (!keep_src) { S.h_cols.clear(); S.h_cols.shrink_to_fit(); }
 }
 
+void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st) {
+    // slices [0, s0) lie (mostly) in the first row block, [s0, nslices) in the second
+    const int s0 = (n0 + 63) / 64, s1 = S.nslices - s0;
+    if (s0 <= 0 || s1 <= 0) return;
+    std::vector<std::pair<double, int>> key(S.nslices);
+    for (int k = 0; k < s0; ++k) key[k] = {(k + 0.5) / s0, k};
+    for (int j = 0; j < s1; ++j) key[s0 + j] = {(j + 0.5) / s1, s0 + j};
+    std::stable_sort(key.begin(), key.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    std::vector<int> order(S.nslices);
+    for (int i = 0; i < S.nslices; ++i) order[i] = key[i].second;
+    S.sched.upload(order, st);
+    PMC_HIP(hipStreamSynchronize(st));
+}
+
 }  // namespace pmc
