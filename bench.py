@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="independent batches in flight per GPU (one HIP stream + host thread each): the launch-latency-"
                          "bound coarse-level kernels of one batch overlap the bandwidth-bound kernels of the other")
     ap.add_argument("--refine", type=int, default=5, help="uniform refinements of cube_tet (5 -> 595 968 DoF)")
@@ -180,7 +180,7 @@ def main():
                                    f"MINRES 300/1e-6/1e-12, {ns} x {nb} realizations per step",
                        "mean_minres_iterations": acc[0] / max(acc[1], 1.0), "batch": nb, "streams": ns,
                        "parallelism": f"sample-farm x{world}"},
-            "roofline": {"bound": "hbm", "kernel": f"sell_spmm_kernel<{nb},false,0,false> (block operator K5)",
+            "roofline": {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, false, 1> (block operator K5)",
                          "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": peak, "unit": "GB/s",
                          "frac": k_bytes / (k_ms * 1e-3) / 1e9 / peak, "traffic": traffic,
                          "bytes_per_launch": k_bytes, "avg_kernel_ms": k_ms,

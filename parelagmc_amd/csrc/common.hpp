@@ -107,6 +107,8 @@ struct Sell {
     double spmv_bytes() const { return 12.0 * nnz + 12.0 * nrows + 8.0 * ncols; }
 };
 void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st);
+// values of A*diag(colscale) laid out on the SELL pattern S was built with (S must keep its host mirrors)
+std::vector<double> sell_scaled_values(const Sell& S, const HostCsr& A, const std::vector<double>& colscale);
 // schedule that merges the slices of row block [0, n0) with those of [n0, nrows) by relative position
 void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st);
 

@@ -332,7 +332,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     double* cdp = cd.p;
     Multigrid* mgp = &mg;
     PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z, double* dot_partial) {
-        const int flips = cheb_flips(cpM.degree, true);
+        const int flips = cheb_flips(cpM, true);
         double* start = (flips % 2 == 0) ? z : cxp;
         double* other = (flips % 2 == 0) ? cxp : z;
         int nblk_u = 0;

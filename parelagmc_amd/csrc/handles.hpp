@@ -12,6 +12,7 @@ struct SamplerLevel {
     Sell A;                 // [M Bt; B -aW]
     Sell M;
     DevBuf<double> dinvM;   // 1 / l1 row sums of M
+    DevBuf<double> M_scaled; // M D^-1 on M's SELL pattern
     DevBuf<double> w_sqrt;
     int proj = PMC_PROJ_NONE;
     int out_size = 0;

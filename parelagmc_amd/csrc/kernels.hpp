@@ -14,6 +14,7 @@ struct SellView {
     const double* vals = nullptr;
     bool bv = false;
     const int* sched = nullptr;   // optional slice processing order
+    int tag = 0;                  // 1 = block saddle-point operator (own kernel instantiation / profile row)
 };
 inline SellView view(const Sell& S) { return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, S.vals.p, false, S.sched.p}; }
 inline SellView view_bv(const Sell& S, const double* vals) {
@@ -46,6 +47,9 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
 // dot_partial != nullptr: also per-block partials of <r, xout>; returns the number of blocks written.
 int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
               const double* xin, double* d, double* xout, double a, double b, double* dot_partial = nullptr);
+// one-pass degree-2 polynomial from a zero guess: xout = dinv.*(c0 r - c1 As r), As = A D^-1 (shared values)
+int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, double* xout, double c0,
+          double c1, double* dot_partial = nullptr);
 // first step from a zero guess: d = b*dinv.*r; x = d
 int cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d,
                double* x, double b, double* dot_partial = nullptr);

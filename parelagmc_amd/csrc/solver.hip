@@ -15,6 +15,17 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
     const double sigma = theta / delta;
     double rho_old = 1.0 / sigma;
+    if (cheb_fused(cp, zero_guess)) {
+        const double rho1 = 1.0 / (2.0 * sigma - rho_old);
+        const double c0 = (1.0 + rho1 * rho_old) / theta + 2.0 * rho1 / delta;
+        const double c1 = 2.0 * rho1 / (delta * theta);
+        SellView As = A;
+        As.vals = cp.scaled_vals;
+        As.bv = false;
+        const int nblk = k::poly2(st, nb, As, dinv, r, xa, c0, c1, dot_partial);
+        if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
+        return xa;
+    }
     double* cur = xa;
     double* oth = xb;
     int step = 0;
@@ -56,18 +67,20 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
     const int last_deg = lv.is_last ? lv.last_degree : coarse_degree;
     const double last_rat = lv.is_last ? lv.last_ratio : coarse_ratio;
-    const int flips = last ? cheb_flips(last_deg, true)
-                           : cheb_flips(smooth_degree, true) + cheb_flips(smooth_degree, false);
+    const double* sv = lv.bv ? nullptr : lv.vals_scaled.p;
+    const ChebParams cp_last{last_deg, lv.lmax, last_rat, sv};
+    const ChebParams cp_smooth{smooth_degree, lv.lmax, smooth_ratio, sv};
+    const int flips = last ? cheb_flips(cp_last, true) : cheb_flips(cp_smooth, true) + cheb_flips(cp_smooth, false);
     double* start = lv.xa.p;
     double* other = lv.xb.p;
     if (target) {
         if (flips % 2 == 0) start = target; else other = target;
     }
     if (last) {
-        ChebParams cp{last_deg, lv.lmax, last_rat};
+        const ChebParams& cp = cp_last;
         return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true, dot_partial, dot_blocks);
     }
-    ChebParams cp{smooth_degree, lv.lmax, smooth_ratio};
+    const ChebParams& cp = cp_smooth;
     double* x = cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true);
     double* oth = (x == start) ? other : start;
     k::residual(st, nb, A, r, x, lv.res.p);

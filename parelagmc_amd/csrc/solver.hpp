@@ -14,7 +14,11 @@ struct ChebParams {
     int degree = 3;
     double lmax = 1.0;   // upper bound of spec(D^-1 A)
     double ratio = 8.0;  // interval [lmax/ratio, lmax]
+    // column-scaled values A D^-1 on A's pattern (shared-value matrices only); enables the one-pass
+    // degree-2 kernel for zero initial guesses
+    const double* scaled_vals = nullptr;
 };
+inline bool cheb_fused(const ChebParams& cp, bool zero_guess) { return zero_guess && cp.degree == 2 && cp.scaled_vals; }
 // Runs `degree` steps.  xa holds the initial guess (ignored when zero_guess); the iterate ping-pongs
 // between xa and xb; returns the buffer holding the result.  d is work space.
 // dot_partial != nullptr: the last step also writes per-block partials of <r, result>; *dot_blocks gets their count.
@@ -22,7 +26,10 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
                    const double* r, double* xa, double* xb, double* d, bool zero_guess,
                    double* dot_partial = nullptr, int* dot_blocks = nullptr);
 // number of buffer flips cheb_apply performs
-inline int cheb_flips(int degree, bool zero_guess) { return zero_guess ? degree - 1 : degree; }
+inline int cheb_flips(const ChebParams& cp, bool zero_guess) {
+    if (cheb_fused(cp, zero_guess)) return 0;
+    return zero_guess ? cp.degree - 1 : cp.degree;
+}
 
 // One level of the Schur-complement multigrid hierarchy.
 struct MgLevel {
@@ -30,6 +37,7 @@ struct MgLevel {
     Sell S;                      // pattern (+ shared values for the sampler)
     DevBuf<double> dinv;         // shared: n ; batched: n*kMaxBatch
     DevBuf<double> vals_bv;      // batched values (Darcy): nslots*kMaxBatch
+    DevBuf<double> vals_scaled;  // S D^-1 on S's pattern (sampler): one-pass pre-smoothing
     bool bv = false;
     double lmax = 2.0;
     // Coarsest-level treatment: `is_last` levels end the recursion with a Chebyshev solve of degree

@@ -149,6 +149,16 @@ void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipS
     if (!keep_src) { S.h_cols.clear(); S.h_cols.shrink_to_fit(); }
 }
 
+std::vector<double> sell_scaled_values(const Sell& S, const HostCsr& A, const std::vector<double>& colscale) {
+    PMC_REQUIRE((int64_t)S.h_src.size() == S.nslots, "sell_scaled_values: matrix was built without its slot map");
+    std::vector<double> v(S.nslots, 0.0);
+    for (int64_t s = 0; s < S.nslots; ++s) {
+        const int p = S.h_src[s];
+        if (p >= 0) v[s] = A.vals[p] * colscale[A.colind[p]];
+    }
+    return v;
+}
+
 void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st) {
     // slices [0, s0) lie (mostly) in the first row block, [s0, nslices) in the second
     const int s0 = (n0 + 63) / 64, s1 = S.nslices - s0;

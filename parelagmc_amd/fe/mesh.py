@@ -237,6 +237,10 @@ class FaceTable:
 def _row_keys(rows: np.ndarray, nv: int) -> np.ndarray:
     """Injective int64 key of sorted small-width rows."""
     rows = np.sort(rows, axis=1)
+    if rows.shape[1] == 4:
+        # quadrilateral faces of a conforming mesh share at most an edge, so the three smallest vertex
+        # ids identify a face uniquely (keeps the packed key inside 62 bits for large meshes)
+        rows = rows[:, :3]
     base = np.int64(nv + 1)
     w = rows.shape[1]
     if float(nv + 1) ** w >= 2.0 ** 62:
