@@ -84,8 +84,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # backend nccl = RCCL over xGMI; PMC_BENCH_BACKEND=gloo only exists to rehearse the multi-rank code
+        # path on a box with fewer GPUs than ranks (ranks then share devices round-robin)
+        backend = os.environ.get("PMC_BENCH_BACKEND", "nccl")
+        ndev = max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank % ndev)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -94,7 +98,8 @@ def main():
     problem = build_problem(args.refine)
     L = problem.levels[0]
     import threading
-    dev = local_rank if world > 1 else 0
+    dev = (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0
+    red_dev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     nb, n, ns = args.batch, L.n_s, max(1, args.streams)
     lanes = []
     for _ in range(ns):
@@ -144,10 +149,10 @@ def main():
     # the one exchange of a sample farm: SUM all-reduce of the accumulators (here: field statistics)
     acc = np.array([float(np.sum(iters)), float(len(iters)), dt])
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        a = torch.from_numpy(acc).cuda()
+        a = torch.from_numpy(acc).to(red_dev)
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         acc = a.cpu().numpy()
     total_samples = args.steps * nb * ns * world

@@ -363,8 +363,11 @@ int pmc_comm_destroy(pmc_ctx* c) {
 int pmc_allreduce_sum_f64(pmc_ctx* c, double* host_buf, int n) {
     return guarded([&] {
         PMC_REQUIRE(c != nullptr && (host_buf != nullptr || n == 0) && n >= 0, "pmc_allreduce_sum_f64: bad argument");
-        if (n == 0 || c->nranks == 1) return;
-        PMC_REQUIRE(c->nccl != nullptr, "pmc_allreduce_sum_f64: communicator not initialised");
+        if (n == 0) return;
+        if (c->nccl == nullptr) {
+            PMC_REQUIRE(c->nranks == 1, "pmc_allreduce_sum_f64: communicator not initialised");
+            return;   // single rank without a communicator: the sum is the buffer itself
+        }
         c->activate();
         c->comm_buf.ensure((size_t)n);
         PMC_HIP(hipMemcpyAsync(c->comm_buf.p, host_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));

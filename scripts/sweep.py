@@ -4,7 +4,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from bench import build_problem  # noqa: E402
 from parelagmc_amd import capi  # noqa: E402
 

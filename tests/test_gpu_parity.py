@@ -347,3 +347,18 @@ def test_block_operator_spmv_matches_csr(gpu_ctx, hexprob, seeded_rng, nb):
         assert ms > 0 and nbytes == 12 * A.nnz + 4 * A.shape[0] + nb * 16 * A.shape[0]
         assert smp.GetNNZ(lvl) == A.nnz == sp.levels[lvl].nnz
     smp.close()
+
+
+def test_native_rccl_allreduce_single_rank(gpu_ctx):
+    """pmc_comm_* / pmc_allreduce_sum_f64 go through RCCL even with one rank (the multi-rank collective
+    itself needs >= 2 GPUs; the driver's scaling run exercises it)."""
+    from parelagmc_amd import capi
+    ctx = capi.Context(0, seed=1)
+    buf = np.arange(30, dtype=np.float64)
+    assert np.array_equal(ctx.allreduce_sum(buf.copy()), buf)          # no communicator, one rank: identity
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 1, 0)
+    out = ctx.allreduce_sum(buf.copy())
+    assert np.array_equal(out, buf)
+    ctx.close()
