@@ -135,6 +135,15 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         d.ess_data.upload(L.ess_data, L.n_u, st);
         d.rhs_u0.upload(L.rhs, L.n_u, st);
         d.obs.upload(L.obs, L.n_u + L.n_p, st);
+        {
+            std::vector<int> rows;
+            std::vector<double> w;
+            for (int i = 0; i < L.n_u + L.n_p; ++i)
+                if (L.obs[i] != 0.0) { rows.push_back(i); w.push_back(L.obs[i]); }
+            d.n_obs = (int)rows.size();
+            d.obs_rows.upload(rows, st);
+            d.obs_w.upload(w, st);
+        }
 
         HostCsr Bfull = csr_from_c(L.B, true, "darcy B");
         PMC_REQUIRE(Bfull.nrows == L.n_p && Bfull.ncols == L.n_u, "darcy B: wrong shape");
@@ -203,6 +212,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         m.lmax = 2.0 * 1.0001;   // weakly diagonally dominant M-matrix: spec(D^-1 S) in (0, 2]
         sell_build(m.S, pattern[l], false, true, st);
         m.vals_bv.alloc((size_t)m.S.nslots * kMaxBatch);
+        m.vals_scaled.alloc((size_t)m.S.nslots * kMaxBatch);
         m.dinv.alloc((size_t)m.n * kMaxBatch);
         // own Schur lists mapped onto the (possibly larger) level pattern
         {
@@ -279,6 +289,8 @@ void Darcy::ensure(int level, int nb) {
     const size_t n = (size_t)d.n_u + d.n_p;
     d.coef.ensure((size_t)d.n_p * nb);
     d.mvals.ensure((size_t)d.M.nslots * nb);
+    d.mvals_scaled.ensure((size_t)d.M.nslots * nb);
+    sol_compact.ensure((size_t)std::max(d.n_obs, 1) * nb);
     d.diagM.ensure((size_t)d.n_u * nb);
     d.l1invM.ensure((size_t)d.n_u * nb);
     d.rhs_bc.ensure(n * nb);
@@ -305,14 +317,17 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     // K14: Schur complement values on the level hierarchy
     {
         MgLevel& m = mg.L[level];
+        k::scale_cols_bv(st, nb, d.M.nslots, d.M.cols.p, d.mvals.p, d.l1invM.p, d.mvals_scaled.p);
         k::refresh(st, nb, m.S.nslots, d.s_ptr.p, d.s_idx.p, d.s_w.p, d.diagM.p, true, m.vals_bv.p);
         k::diag_inv(st, nb, m.n, d.s_diag_slot.p, m.vals_bv.p, m.dinv.p);
+        k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
         for (int l = level; l + 1 < nlevels; ++l) {
             MgLevel& f = mg.L[l];
             MgLevel& c = mg.L[l + 1];
             DarcyLevel& dc = lv[l + 1];
             k::refresh(st, nb, c.S.nslots, dc.g_ptr.p, dc.g_idx.p, dc.g_w.p, f.vals_bv.p, false, c.vals_bv.p);
             k::diag_inv(st, nb, c.n, dc.s_diag_slot.p, c.vals_bv.p, c.dinv.p);
+            k::scale_cols_bv(st, nb, c.S.nslots, c.S.cols.p, c.vals_bv.p, c.dinv.p, c.vals_scaled.p);
         }
     }
     // operator [M(k) Bt; B 0] and block-diagonal preconditioner
@@ -321,12 +336,14 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     LinOp A;
     A.n = n;
     A.apply = [=](hipStream_t s, int nb_, const double* x, double* y, double* partial) {
-        k::spmm(s, nb_, Mv, x, y, false, nullptr, nullptr);
-        k::spmm(s, nb_, Btv, x + (size_t)n_u * nb_, y, true, nullptr, nullptr);
-        k::spmm(s, nb_, Bv, x, y + (size_t)n_u * nb_, false, nullptr, nullptr);
-        return partial ? k::dot(s, nb_, n, x, y, partial) : 0;
+        // u-rows: M(k) x_u + B^T x_p in one pass; p-rows: B x_u; <x, Ax> fused into both
+        const double* xp = x + (size_t)n_u * nb_;
+        const int nu_blk = k::pair_spmm(s, nb_, Mv, x, Btv, xp, y, partial, x);
+        const int np_blk = k::spmm(s, nb_, Bv, x, y + (size_t)n_u * nb_, false,
+                                   partial ? partial + (size_t)nu_blk * nb_ : nullptr, xp);
+        return nu_blk + np_blk;
     };
-    ChebParams cpM{opts.cheb_degree_M, 1.0, opts.cheb_ratio_M};
+    ChebParams cpM{opts.cheb_degree_M, 1.0, opts.cheb_ratio_M, d.mvals_scaled.p};
     const double* l1 = d.l1invM.p;
     double* cxp = cx.p;
     double* cdp = cd.p;
@@ -342,11 +359,17 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
                                        dot_partial ? dot_partial + (size_t)nblk_u * nb_ : nullptr);
         return nblk_u + nblk_s;
     };
-    MinresResult res = minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol.p, true, opts, work, 0, n);
+    // SolveFwd only needs Q = <obs, sol>: unless the solution itself is requested, MINRES maintains just the rows in
+    // the support of obs (compact w / x vectors)
+    const bool compact = (sol_d == nullptr) && d.n_obs > 0 && d.n_obs < n;
+    MinresResult res = compact ? minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol_compact.p, true, opts, work, 0, d.n_obs,
+                                              d.obs_rows.p)
+                               : minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol.p, true, opts, work, 0, n);
     if (stats)
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
     // K15: Q = <obs, sol>
-    const int qblocks = k::wdot(st, nb, n, d.obs.p, sol.p, qpartial.p);
+    const int qblocks = compact ? k::wdot(st, nb, d.n_obs, d.obs_w.p, sol_compact.p, qpartial.p)
+                                : k::wdot(st, nb, n, d.obs.p, sol.p, qpartial.p);
     k::reduce_final(st, nb, qblocks, qpartial.p, qout.p);
     PMC_HIP(hipMemcpyAsync(ctx.h_scal, qout.p, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
     if (sol_d) k::deinterleave(st, nb, n, sol.p, nullptr, nullptr, false, sol_d);

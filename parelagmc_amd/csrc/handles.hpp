@@ -64,7 +64,12 @@ struct DarcyLevel {
     DevBuf<int> g_ptr, g_idx;
     DevBuf<double> g_w;
     // per-realization values
-    DevBuf<double> coef, mvals, diagM, l1invM, rhs_bc;
+    DevBuf<double> coef, mvals, mvals_scaled, diagM, l1invM, rhs_bc;
+    // support of the observation functional (rows with obs != 0) and its weights: when the caller does not ask for
+    // the solution vector, MINRES only maintains these rows of it
+    DevBuf<int> obs_rows;
+    DevBuf<double> obs_w;
+    int n_obs = 0;
 };
 
 struct Darcy {
@@ -75,7 +80,7 @@ struct Darcy {
     std::vector<DarcyLevel> lv;
     Multigrid mg;                    // batched values
     MinresWork work;
-    DevBuf<double> sol, cx, cd, stage_k, stage_sol, qpartial, qout;
+    DevBuf<double> sol, sol_compact, cx, cd, stage_k, stage_sol, qpartial, qout;
 
     Darcy(Ctx& c, int nlevels, int n_mc, const pmc_darcy_level* in, bool k_divides, const pmc_solver_opts& o);
     void solve_fwd(int level, int nbatch, const double* k, double* Q, double* C, double* sol_out, int memspace,

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
 // collapse to  x2_i = dinv_i (c0 r_i - c1 (A D^-1 r)_i),  so with the column-scaled values As = A D^-1
 // (precomputed at create time) a single SpMM over r gives the result: 1 gather pass instead of the
 // 3 + 5 vector passes of cheb_first + cheb_step.  DOT: partials of <r, x2>.
-template <int NB, bool DOT>
+template <int NB, bool BV, bool DOT>
 __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                             const int* __restrict__ sched,
                                                             const int* __restrict__ cols,
@@ -319,24 +319,115 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
     for (int si = first_slice(nslices, &slice_end); si < slice_end; si += kBlock / kWave) {
         const int slice = sched ? sched[si] : si;
         double acc[T][C];
-        sell_row_product<NB, false>(slice_off, cols, vals_scaled, r, slice, lane, acc);
+        sell_row_product<NB, BV>(slice_off, cols, vals_scaled, r, slice, lane, acc);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
             if (row >= nrows) continue;
             const size_t at = (size_t)row * NB + t * C;
-            double rv[C], xv[C];
+            double rv[C], xv[C], di[C];
             load_c<C>(r + at, rv);
-            const double di = dinv[row];
+            if constexpr (BV) {
+                load_c<C>(dinv + at, di);
+            } else {
+                const double s = dinv[row];
+#pragma unroll
+                for (int c = 0; c < C; ++c) di[c] = s;
+            }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                xv[c] = di * (c0 * rv[c] - c1 * acc[rs][c]);
+                xv[c] = di[c] * (c0 * rv[c] - c1 * acc[rs][c]);
                 if constexpr (DOT) p[c] = fma(rv[c], xv[c], p[c]);
             }
             store_c<C>(xout + at, xv);
         }
     }
     if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+}
+
+// y = A1 x1 + A2 x2 over the SAME rows: A1 with per-realization values, A2 with shared values (the u-rows
+// [M(k) | B^T] of the Darcy operator in one pass); DOT: partials of <dot_with, y>.
+template <int NB, bool DOT>
+__global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
+    int nrows, int nslices, const int* __restrict__ off1, const int* __restrict__ cols1, const double* __restrict__ vals1,
+    const int* __restrict__ off2, const int* __restrict__ cols2, const double* __restrict__ vals2,
+    const double* __restrict__ x1, const double* __restrict__ x2, double* __restrict__ y,
+    const double* __restrict__ dot_with, double* __restrict__ partial) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = lane / T, t = lane % T;
+    double p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = 0.0;
+    int slice_end;
+    for (int slice = first_slice(nslices, &slice_end); slice < slice_end; slice += kBlock / kWave) {
+        double acc[T][C], acc2[T][C];
+        sell_row_product<NB, true>(off1, cols1, vals1, x1, slice, lane, acc);
+        sell_row_product<NB, false>(off2, cols2, vals2, x2, slice, lane, acc2);
+#pragma unroll
+        for (int rs = 0; rs < T; ++rs) {
+            const int row = slice * kWave + rs * G + g;
+            if (row >= nrows) continue;
+            const size_t at = (size_t)row * NB + t * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[rs][c] += acc2[rs][c];
+            store_c<C>(y + at, acc[rs]);
+            if constexpr (DOT) {
+                double w[C];
+                load_c<C>(dot_with + at, w);
+#pragma unroll
+                for (int c = 0; c < C; ++c) p[c] = fma(w[c], acc[rs][c], p[c]);
+            }
+        }
+    }
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+}
+
+// out[slot][k] = vals[slot][k] * colscale[cols[slot]][k]   (per-realization column scaling A(k) D(k)^-1)
+template <int NB>
+__global__ __launch_bounds__(kBlock) void scale_cols_bv_kernel(size_t nflat, const int* __restrict__ cols,
+                                                               const double* __restrict__ vals,
+                                                               const double* __restrict__ colscale,
+                                                               double* __restrict__ out) {
+    constexpr int C = Lay<NB>::C;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nflat; i += (size_t)gridDim.x * kBlock) {
+        const size_t e = i * C;
+        const size_t slot = e / NB;
+        const int k0 = (int)(e % NB);
+        double v[C], sc[C];
+        load_c<C>(vals + e, v);
+        load_c<C>(colscale + (size_t)cols[slot] * NB + k0, sc);
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] *= sc[c];
+        store_c<C>(out + e, v);
+    }
+}
+
+// MINRES w / x update restricted to an index list of rows: w, x are compact [nsel][NB], u is full
+template <int NB>
+__global__ __launch_bounds__(kBlock) void minres_wx_idx_kernel(size_t nflat, const int* __restrict__ rows,
+                                                               const double* __restrict__ c0, const double* __restrict__ u,
+                                                               const double* __restrict__ c1, double* __restrict__ w0,
+                                                               const double* __restrict__ c2, const double* __restrict__ w1,
+                                                               const double* __restrict__ c3, double* __restrict__ x) {
+    constexpr int C = Lay<NB>::C;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nflat) return;
+    const size_t e = i * C;
+    const size_t sel = e / NB;
+    const int k0 = (int)(e % NB);
+    double uv[C], w0v[C], w1v[C], xv[C];
+    load_c<C>(u + (size_t)rows[sel] * NB + k0, uv);
+    load_c<C>(w0 + e, w0v);
+    load_c<C>(w1 + e, w1v);
+    load_c<C>(x + e, xv);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        w0v[c] = c0[k0 + c] * uv[c] + c1[k0 + c] * w0v[c] + c2[k0 + c] * w1v[c];
+        xv[c] += c3[k0 + c] * w0v[c];
+    }
+    store_c<C>(w0 + e, w0v);
+    store_c<C>(x + e, xv);
 }
 
 // ---- flat element-wise kernels: thread i owns the C doubles at flat index i*C, i.e. row (i*C)/NB and
@@ -924,19 +1015,58 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
     return dot_partial ? (int)g.x : 0;
 }
 
-int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, double* xout, double c0,
-          double c1, double* dot_partial) {
+int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
+          double c0, double c1, double* dot_partial) {
     if (As.nrows == 0) return 0;
-    if (As.bv) throw Error(PMC_ERR_INTERNAL, "poly2: shared values only");
+    if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
-        if (dot_partial)
-            sell_poly2_kernel<NB, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial);
-        else
-            sell_poly2_kernel<NB, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr);
+        if (As.bv) {
+            if (dot_partial)
+                sell_poly2_kernel<NB, true, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial);
+            else
+                sell_poly2_kernel<NB, true, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr);
+        } else {
+            if (dot_partial)
+                sell_poly2_kernel<NB, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial);
+            else
+                sell_poly2_kernel<NB, false, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr);
+        }
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;
+}
+
+int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, const SellView& A2, const double* x2, double* y,
+              double* dot_partial, const double* dot_with) {
+    if (A1.nrows == 0) return 0;
+    if (!A1.bv || A2.bv || A1.nrows != A2.nrows || A1.nslices != A2.nslices)
+        throw Error(PMC_ERR_INTERNAL, "pair_spmm: operand mismatch");
+    const dim3 g = grid_bounded(grid_slices(A1.nslices), dot_partial != nullptr);
+    PMC_DISPATCH_NB(nb, {
+        if (dot_partial)
+            sell_pair_spmm_kernel<NB, true><<<g, kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial);
+        else
+            sell_pair_spmm_kernel<NB, false><<<g, kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr);
+    });
+    check_launch();
+    return dot_partial ? (int)g.x : 0;
+}
+
+void scale_cols_bv(hipStream_t st, int nb, int64_t nslots, const int* cols, const double* vals, const double* colscale,
+                   double* out) {
+    if (nslots == 0) return;
+    const size_t nf = (size_t)nslots * nb / (nb >= 2 ? 2 : 1);
+    const unsigned g = (unsigned)std::min<size_t>((nf + kBlock - 1) / kBlock, 8192);
+    PMC_DISPATCH_NB(nb, { scale_cols_bv_kernel<NB><<<g, kBlock, 0, st>>>(nf, cols, vals, colscale, out); });
+    check_launch();
+}
+
+void minres_wx_idx(hipStream_t st, int nb, int nsel, const int* rows, const double* c0, const double* u, const double* c1,
+                   double* w0, const double* c2, const double* w1, const double* c3, double* x) {
+    if (nsel == 0) return;
+    PMC_DISPATCH_NB(nb, { minres_wx_idx_kernel<NB><<<grid_flat(nsel, nb), kBlock, 0, st>>>(flat_count(nsel, nb), rows, c0, u, c1, w0, c2, w1, c3, x); });
+    check_launch();
 }
 
 int cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d, double* x,

@@ -48,8 +48,17 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
 int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
               const double* xin, double* d, double* xout, double a, double b, double* dot_partial = nullptr);
 // one-pass degree-2 polynomial from a zero guess: xout = dinv.*(c0 r - c1 As r), As = A D^-1 (shared values)
-int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, double* xout, double c0,
-          double c1, double* dot_partial = nullptr);
+int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
+          double c0, double c1, double* dot_partial = nullptr);
+// y = A1 x1 + A2 x2 (A1 per-realization values, A2 shared values, same rows); optional fused dot
+int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, const SellView& A2, const double* x2, double* y,
+              double* dot_partial, const double* dot_with);
+// out[slot][k] = vals[slot][k] * colscale[cols[slot]][k]
+void scale_cols_bv(hipStream_t st, int nb, int64_t nslots, const int* cols, const double* vals, const double* colscale,
+                   double* out);
+// MINRES w/x update on an index list of rows (w0, w1, x compact [nsel][nb]; u full)
+void minres_wx_idx(hipStream_t st, int nb, int nsel, const int* rows, const double* c0, const double* u, const double* c1,
+                   double* w0, const double* c2, const double* w1, const double* c3, double* x);
 // first step from a zero guess: d = b*dinv.*r; x = d
 int cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d,
                double* x, double b, double* dot_partial = nullptr);

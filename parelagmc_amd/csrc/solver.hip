@@ -21,8 +21,7 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
         const double c1 = 2.0 * rho1 / (delta * theta);
         SellView As = A;
         As.vals = cp.scaled_vals;
-        As.bv = false;
-        const int nblk = k::poly2(st, nb, As, dinv, r, xa, c0, c1, dot_partial);
+        const int nblk = k::poly2(st, nb, As, dinv, dinv_bv, r, xa, c0, c1, dot_partial);
         if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
         return xa;
     }
@@ -67,7 +66,7 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
     const int last_deg = lv.is_last ? lv.last_degree : coarse_degree;
     const double last_rat = lv.is_last ? lv.last_ratio : coarse_ratio;
-    const double* sv = lv.bv ? nullptr : lv.vals_scaled.p;
+    const double* sv = lv.vals_scaled.p;   // shared (sampler) or per-realization (Darcy) column-scaled values
     const ChebParams cp_last{last_deg, lv.lmax, last_rat, sv};
     const ChebParams cp_smooth{smooth_degree, lv.lmax, smooth_ratio, sv};
     const int flips = last ? cheb_flips(cp_last, true) : cheb_flips(cp_smooth, true) + cheb_flips(cp_smooth, false);
@@ -122,7 +121,8 @@ static void axpby(hipStream_t st, size_t n, double a, const double* x, double b,
 }
 
 MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, const double* b, double* x,
-                          bool zero_guess, const pmc_solver_opts& o, MinresWork& w, int x_row0, int x_nrows) {
+                          bool zero_guess, const pmc_solver_opts& o, MinresWork& w, int x_row0, int x_nrows,
+                          const int* x_rows) {
     hipStream_t st = ctx.stream;
     const int n = A.n;
     const size_t len = (size_t)n * nb;
@@ -132,14 +132,16 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     double* w0 = w.w0.p; double* w1 = w.w1.p; double* q = w.q.p;
 
     // v1 = b - A x0
+    if (x_rows && !zero_guess) throw Error(PMC_ERR_INTERNAL, "minres: compact solution needs a zero initial guess");
     if (zero_guess) {
-        k::fill(st, len, x, 0.0);
+        k::fill(st, x_rows ? (size_t)x_nrows * nb : len, x, 0.0);
         k::copy(st, len, b, v1);
     } else {
         A.apply(st, nb, x, v1, nullptr);
         axpby(st, len, 1.0, b, -1.0, v1);
     }
-    if (x_row0 < 0 || x_nrows < 0 || x_row0 + x_nrows > n) throw Error(PMC_ERR_INTERNAL, "minres: bad solution row range");
+    if (x_row0 < 0 || x_nrows < 0 || (!x_rows && x_row0 + x_nrows > n))
+        throw Error(PMC_ERR_INTERNAL, "minres: bad solution row range");
     const size_t xoff = (size_t)x_row0 * nb;
     int nblocks = prec(st, nb, v1, u1, w.partial.p);
     if (nblocks == 0) nblocks = k::dot(st, nb, n, v1, u1, w.partial.p);
@@ -176,7 +178,8 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         nblocks = prec(st, nb, v0, u0, w.partial.p);
         if (nblocks == 0) nblocks = k::dot(st, nb, n, v0, u0, w.partial.p);
         k::minres_scal2(st, nb, S, w.partial.p, nblocks);
-        k::minres_wx(st, nb, x_nrows, cW0, u1 + xoff, cW1, w0, cW2, w1, cW3, x + xoff);
+        if (x_rows) k::minres_wx_idx(st, nb, x_nrows, x_rows, cW0, u1, cW1, w0, cW2, w1, cW3, x);
+        else k::minres_wx(st, nb, x_nrows, cW0, u1 + xoff, cW1, w0, cW2, w1, cW3, x + xoff);
         std::swap(u0, u1);
         std::swap(v0, v1);
         std::swap(w0, w1);

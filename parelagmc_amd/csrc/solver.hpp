@@ -37,7 +37,7 @@ struct MgLevel {
     Sell S;                      // pattern (+ shared values for the sampler)
     DevBuf<double> dinv;         // shared: n ; batched: n*kMaxBatch
     DevBuf<double> vals_bv;      // batched values (Darcy): nslots*kMaxBatch
-    DevBuf<double> vals_scaled;  // S D^-1 on S's pattern (sampler): one-pass pre-smoothing
+    DevBuf<double> vals_scaled;  // S D^-1 on S's pattern (shared, or nslots*kMaxBatch when bv): one-pass pre-smoothing
     bool bv = false;
     double lmax = 2.0;
     // Coarsest-level treatment: `is_last` levels end the recursion with a Chebyshev solve of degree
@@ -93,9 +93,12 @@ struct MinresResult {
 // Preconditioned MINRES on nb right-hand sides at once.  x holds the initial guess on entry when
 // !zero_guess.  b, x: n*nb interleaved device vectors.
 // Only rows [x_row0, x_row0 + x_nrows) of the solution are updated (the samplers need the s-block only,
-// which saves two thirds of the w / x vector traffic); pass 0, A.n for the full solution.
+// which saves two thirds of the w / x vector traffic); pass 0, A.n for the full solution.  With x_rows != nullptr
+// (device index list of x_nrows rows, zero initial guess only) x is a COMPACT [x_nrows][nb] vector holding just those
+// rows of the solution (Darcy: the support of the observation functional).
 MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, const double* b, double* x,
-                          bool zero_guess, const pmc_solver_opts& o, MinresWork& w, int x_row0, int x_nrows);
+                          bool zero_guess, const pmc_solver_opts& o, MinresWork& w, int x_row0, int x_nrows,
+                          const int* x_rows = nullptr);
 
 // Gershgorin bounds of spec(D^-1 A) for D = diag(A) on the host (setup): returns lmax, sets *lmin
 // (may be <= 0 when a row is not strictly diagonally dominant)
