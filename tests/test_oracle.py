@@ -151,3 +151,18 @@ def test_marginal_variance_matches_matern_theory(seeded_rng):
     sigma2 = math.gamma(0.5 + 3.0) / math.gamma(0.5 + 1.5)
     assert abs(mean.mean()) < 4.0 * math.sqrt(sigma2 / N)
     assert abs(var.mean() / (sigma2 * cell_factor) - 1.0) < 0.05
+
+
+def test_c_port_of_reference_solver_matches_direct_solve(hex_hierarchy, seeded_rng):
+    """oracle/c/pmc_ref.c (MINRES + sym-GS x3 | V-cycle, the reference's MINRES-BJ-GS restated in C, also the
+    CPU baseline of bench.py) against the direct-solve oracle."""
+    from oracle.cport import CPort
+    sp = build_sampler_problem(hex_hierarchy, corlen=0.1)
+    so, cp = SamplerOracle(sp), CPort(sp)
+    xi = seeded_rng.standard_normal((3, sp.levels[0].n_s))
+    for lvl in range(3):
+        ref = np.stack([so.eval(lvl, 0, x)[0] for x in xi])
+        s, it = cp.eval(lvl, 0, xi, rel_tol=1e-12, abs_tol=1e-30, nthreads=2)
+        assert np.linalg.norm(s - ref) <= 1e-9 * np.linalg.norm(ref) and (it > 0).all()
+        s, it = cp.eval(lvl, 0, xi, nthreads=2)                     # reference tolerances 300 / 1e-6 / 1e-12
+        assert np.linalg.norm(s - ref) <= 1e-5 * np.linalg.norm(ref) and (it > 0).all() and (it <= 300).all()
