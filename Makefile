@@ -28,6 +28,6 @@ clean:
 HOSTLIB := parelagmc_amd/lib/libpmc_host.so
 HOSTSRC := parelagmc_amd/host/host.cpp
 $(HOSTLIB): $(HOSTSRC) parelagmc_amd/host/parelagmc.hpp include/pmc.h include/pmc_host.h $(LIB)
-	g++ -O2 -std=c++17 -fPIC -shared -Wall -o $@ $(HOSTSRC) -Lparelagmc_amd/lib -lpmc -Wl,-rpath,'$$ORIGIN'
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -pthread -o $@ $(HOSTSRC) -Lparelagmc_amd/lib -lpmc -Wl,-rpath,'$$ORIGIN'
 
 all: $(HOSTLIB)

@@ -72,6 +72,9 @@ typedef struct pmc_mlmc_result {
 /* manager over the device sampler + solver of pmc.h (device-resident vectors, no PCIe traffic) */
 int pmc_mlmc_create(pmc_ctx* ctx, pmc_sampler* sampler, pmc_darcy* solver, int nlevels,
                     const pmc_mlmc_params* params, pmc_mlmc** out);
+/* add a lane: another (ctx, sampler, solver) triple built from the same operators, i.e. another HIP stream
+ * that processes this rank's realizations concurrently (device-handle managers only) */
+int pmc_mlmc_add_lane(pmc_mlmc* m, pmc_ctx* ctx, pmc_sampler* sampler, pmc_darcy* solver);
 /* manager over arbitrary plugins */
 int pmc_mlmc_create_callbacks(int nlevels, const pmc_plugin_callbacks* cb, const pmc_mlmc_params* params,
                               pmc_mlmc** out);

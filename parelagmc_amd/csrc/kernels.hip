@@ -121,6 +121,40 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
         for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
     int slot = off + lane;
 
+    if constexpr (T == 1) {
+        // one lane per row (NB = 1, 2): take JU slice columns at a time so that JU (index, value) pairs and then
+        // JU gathers are in flight together instead of one dependent chain per column
+        constexpr int JU = 4;
+        for (int j = 0; j < width; j += JU, slot += JU * kWave) {
+            int cc[JU];
+            double aa[JU];
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                const bool ok = j + u < width;
+                const int at = ok ? slot + u * kWave : slot;   // out-of-range columns re-read column j, weight 0
+                cc[u] = cols[at];
+                if constexpr (BV) aa[u] = ok ? 1.0 : 0.0;
+                else aa[u] = ok ? vals[at] : 0.0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double xv[JU][C], av[JU][C];
+#pragma unroll
+            for (int u = 0; u < JU; ++u) {
+                load_c<C>(x + (size_t)cc[u] * NB, xv[u]);
+                if constexpr (BV) load_c<C>(vals + (size_t)(j + u < width ? slot + u * kWave : slot) * NB, av[u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < JU; ++u)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if constexpr (BV) acc[0][c] = fma(aa[u] * av[u][c], xv[u][c], acc[0][c]);
+                    else acc[0][c] = fma(aa[u], xv[u][c], acc[0][c]);
+                }
+        }
+        return;
+    }
+
     int cj = 0;
     double vj = 0.0;
     if (width > 0) {

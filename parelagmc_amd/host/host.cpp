@@ -8,6 +8,8 @@
 #include <iomanip>
 #include <iostream>
 #include <limits>
+#include <mutex>
+#include <thread>
 #include <sstream>
 
 namespace parelagmc {
@@ -204,10 +206,8 @@ MLMC_Manager::MLMC_Manager(pmc_ctx* ctx, int memspace, int nlevels_, PhysicalMLS
       sampler(sampler_),
       auto_eps2(p.eps2 < 0 ? 1 : 0),
       batch_(p.batch),
-      max_rounds_(p.max_rounds),
-      xi(ctx, memspace),
-      sparam(ctx, memspace),
-      init_s(ctx, memspace) {
+      max_rounds_(p.max_rounds) {
+    lanes_.emplace_back(new Lane(ctx, memspace, &sampler_, &pSolver_));
     if (nlevels < 1) throw std::invalid_argument("MLMC_Manager: nlevels < 1");
     if (batch_ < 1 || batch_ > 16) throw std::invalid_argument("MLMC_Manager: batch must be in 1..16");
     if (!(ratio > 0.0 && ratio < 1.0)) throw std::invalid_argument("MLMC_Manager: ratio must be in (0,1)");
@@ -238,43 +238,73 @@ void MLMC_Manager::Reset() {
 
 // One level of InitRun (src/MLMC_Manager.cpp:113-136 coarsest, :144-173 level pairs), for this
 // rank's share of the `nsamples` new realizations, `batch_` at a time.
+void MLMC_Manager::AddLane(pmc_ctx* ctx, PhysicalMLSolver& solver, MLSampler& smp) {
+    lanes_.emplace_back(new Lane(ctx, memspace_, &smp, &solver));
+}
+
 void MLMC_Manager::run_level(int ilevel, int nsamples) {
     const uint64_t base = (uint64_t)level_nsamples[ilevel];
-    double* psum = pending_.data() + (size_t)ilevel * NVAR;
-    std::vector<double> q(batch_), c(batch_), qc(batch_), cc(batch_);
     const int nblocks = (nsamples + batch_ - 1) / batch_;
+    const int nlanes = (int)lanes_.size();
+    std::vector<std::vector<double>> lane_sums(nlanes, std::vector<double>(NVAR, 0.0));
+    std::vector<std::string> lane_err(nlanes);
+    std::mutex log_mutex;
     const double t0 = now_s();
-    for (int blk = rank_; blk < nblocks; blk += nranks_) {
-        const int first = blk * batch_;
-        const int m = std::min(batch_, nsamples - first);
-        sampler.Sample(ilevel, xi, base + (uint64_t)first, m);
-        if (ilevel == nlevels - 1) {
-            sampler.Eval(ilevel, xi, sparam);
-            pSolver.SolveFwd(ilevel, sparam, q.data(), c.data());
-            for (int b = 0; b < m; ++b) qc[b] = 0.0;
-        } else {
-            sampler.Eval(ilevel + 1, xi, sparam, init_s, false);
-            pSolver.SolveFwd(ilevel + 1, sparam, qc.data(), cc.data());
-            sampler.Eval(ilevel, xi, sparam, init_s, true);
-            pSolver.SolveFwd(ilevel, sparam, q.data(), c.data());
+    // blocks of `batch_` consecutive realization ids: dealt round-robin to ranks, then to this rank's lanes
+    auto work = [&](int lane) {
+        try {
+            Lane& L = *lanes_[lane];
+            double* psum = lane_sums[lane].data();
+            std::vector<double> q(batch_), c(batch_), qc(batch_), cc(batch_);
+            for (int blk = rank_ + lane * nranks_; blk < nblocks; blk += nranks_ * nlanes) {
+                const int first = blk * batch_;
+                const int m = std::min(batch_, nsamples - first);
+                L.sampler->Sample(ilevel, L.xi, base + (uint64_t)first, m);
+                if (ilevel == nlevels - 1) {
+                    L.sampler->Eval(ilevel, L.xi, L.sparam);
+                    L.solver->SolveFwd(ilevel, L.sparam, q.data(), c.data());
+                    for (int b = 0; b < m; ++b) qc[b] = 0.0;
+                } else {
+                    L.sampler->Eval(ilevel + 1, L.xi, L.sparam, L.init_s, false);
+                    L.solver->SolveFwd(ilevel + 1, L.sparam, qc.data(), cc.data());
+                    L.sampler->Eval(ilevel, L.xi, L.sparam, L.init_s, true);
+                    L.solver->SolveFwd(ilevel, L.sparam, q.data(), c.data());
+                }
+                for (int b = 0; b < m; ++b) {
+                    const double y = (ilevel == nlevels - 1) ? q[b] : q[b] - qc[b];
+                    const double cost_b = (ilevel == nlevels - 1) ? c[b] : c[b] + cc[b];
+                    psum[Y3] += y * y * y;
+                    psum[Y4] += y * y * y * y;
+                    psum[Y2] += y * y;
+                    psum[Y] += y;
+                    psum[ABSY] += std::fabs(y);
+                    psum[Q2] += q[b] * q[b];
+                    psum[Q] += q[b];
+                    psum[ABSQ] += std::fabs(q[b]);
+                    psum[C] += cost_b;
+                    if (logger.is_open()) {
+                        std::lock_guard<std::mutex> lk(log_mutex);
+                        logger << std::setw(14) << ilevel << std::setw(14) << y << std::setw(14) << q[b] << std::setw(14)
+                               << qc[b] << std::setw(14) << cost_b << "\n";
+                    }
+                }
+            }
+        } catch (const std::exception& e) {
+            lane_err[lane] = e.what();
         }
-        for (int b = 0; b < m; ++b) {
-            const double y = (ilevel == nlevels - 1) ? q[b] : q[b] - qc[b];
-            const double cost_b = (ilevel == nlevels - 1) ? c[b] : c[b] + cc[b];
-            psum[Y3] += y * y * y;
-            psum[Y4] += y * y * y * y;
-            psum[Y2] += y * y;
-            psum[Y] += y;
-            psum[ABSY] += std::fabs(y);
-            psum[Q2] += q[b] * q[b];
-            psum[Q] += q[b];
-            psum[ABSQ] += std::fabs(q[b]);
-            psum[C] += cost_b;
-            if (logger.is_open())
-                logger << std::setw(14) << ilevel << std::setw(14) << y << std::setw(14) << q[b] << std::setw(14)
-                       << qc[b] << std::setw(14) << cost_b << "\n";
-        }
+    };
+    if (nlanes == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int l = 0; l < nlanes; ++l) th.emplace_back(work, l);
+        for (auto& t : th) t.join();
     }
+    for (const auto& e : lane_err)
+        if (!e.empty()) throw std::runtime_error(e);
+    double* psum = pending_.data() + (size_t)ilevel * NVAR;
+    for (int l = 0; l < nlanes; ++l)            // fixed order: deterministic for a fixed lane count
+        for (int v = 0; v < NVAR; ++v) psum[v] += lane_sums[l][v];
     pending_[(size_t)nlevels * NVAR + ilevel] += now_s() - t0;
 }
 
@@ -420,6 +450,8 @@ using namespace parelagmc;
 struct pmc_mlmc {
     std::unique_ptr<MLSampler> sampler;
     std::unique_ptr<PhysicalMLSolver> solver;
+    std::vector<std::unique_ptr<MLSampler>> lane_samplers;
+    std::vector<std::unique_ptr<PhysicalMLSolver>> lane_solvers;
     std::unique_ptr<MLMC_Manager> mgr;
     pmc_ctx* ctx = nullptr;
     std::vector<int64_t> ns, miss;
@@ -487,6 +519,16 @@ int pmc_mlmc_create_callbacks(int nlevels, const pmc_plugin_callbacks* cb, const
         m->solver.reset(new CallbackSolver(nlevels, *cb));
         m->mgr.reset(new MLMC_Manager(nullptr, PMC_MEM_HOST, nlevels, *m->solver, *m->sampler, p));
         *out = m.release();
+    });
+}
+
+int pmc_mlmc_add_lane(pmc_mlmc* m, pmc_ctx* ctx, pmc_sampler* sampler, pmc_darcy* solver) {
+    return hguard([&] {
+        if (!m || !ctx || !sampler || !solver) throw std::invalid_argument("pmc_mlmc_add_lane: NULL argument");
+        if (!m->ctx) throw std::invalid_argument("pmc_mlmc_add_lane: callback managers have a single lane");
+        m->lane_samplers.emplace_back(new PDESampler(ctx, sampler));
+        m->lane_solvers.emplace_back(new DarcySolver(ctx, solver));
+        m->mgr->AddLane(ctx, *m->lane_solvers.back(), *m->lane_samplers.back());
     });
 }
 

@@ -162,6 +162,9 @@ class MLMC_Manager {
     MLMC_Manager(pmc_ctx* ctx, int memspace, int nlevels, PhysicalMLSolver& pSolver, MLSampler& sampler,
                  const pmc_mlmc_params& params);
     void SetFarm(int nranks, int rank, std::function<void(double*, int)> reduce);
+    /// Additional plugin pair (own context / HIP stream) working on this rank's realizations concurrently:
+    /// the launch-latency-bound kernels of the small levels of one lane overlap the other lanes' work.
+    void AddLane(pmc_ctx* ctx, PhysicalMLSolver& solver, MLSampler& sampler);
     /// Run ML simulation by sampling v_init_nsamples then the missing samples until the estimator variance target is met
     void Run();
     /// Run ML simulation using level_nsamples_init[i] samples on level i
@@ -194,7 +197,14 @@ class MLMC_Manager {
     int nranks_ = 1, rank_ = 0;
     std::function<void(double*, int)> reduce_;
     std::vector<double> pending_;          // this round's local contributions (sums + counts + seconds)
-    Vector xi, sparam, init_s;
+    struct Lane {
+        MLSampler* sampler;
+        PhysicalMLSolver* solver;
+        Vector xi, sparam, init_s;
+        Lane(pmc_ctx* c, int ms, MLSampler* s, PhysicalMLSolver* p)
+            : sampler(s), solver(p), xi(c, ms), sparam(c, ms), init_s(c, ms) {}
+    };
+    std::vector<std::unique_ptr<Lane>> lanes_;
     std::ofstream logger;
 };
 

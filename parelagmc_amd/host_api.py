@@ -52,6 +52,7 @@ HOST_SYMBOLS = {
     "pmc_mlmc_create": (C.c_int, [_VP, _VP, _VP, C.c_int, C.POINTER(pmc_mlmc_params), C.POINTER(_VP)]),
     "pmc_mlmc_create_callbacks": (C.c_int, [C.c_int, C.POINTER(pmc_plugin_callbacks), C.POINTER(pmc_mlmc_params),
                                             C.POINTER(_VP)]),
+    "pmc_mlmc_add_lane": (C.c_int, [_VP, _VP, _VP, _VP]),
     "pmc_mlmc_destroy": (None, [_VP]),
     "pmc_mlmc_set_farm": (C.c_int, [_VP, C.c_int, C.c_int, REDUCE_FN, _VP]),
     "pmc_mlmc_run": (C.c_int, [_VP]),
@@ -171,6 +172,12 @@ class MLMCManager:
             self._keep += [sampler, solver]
             _hcheck(self.lib.pmc_mlmc_create(sampler.ctx.h, sampler.h, solver.h, nlevels, C.byref(p), C.byref(h)))
         self.h = h
+
+    def add_lane(self, sampler, solver):
+        """Another (context, sampler, solver) triple built from the same problem: one more HIP stream working on
+        this rank's realizations concurrently."""
+        self._keep += [sampler, solver]
+        _hcheck(self.lib.pmc_mlmc_add_lane(self.h, sampler.ctx.h, sampler.h, solver.h))
 
     def set_farm(self, nranks: int, rank: int, reduce: Optional[Callable[[np.ndarray], None]] = None):
         """reduce(buf) must SUM-all-reduce the numpy buffer in place (e.g. torch.distributed);

@@ -37,9 +37,21 @@ for lvl in range(3):
           f"({np.mean([t[0] for t in st2]):.0f} it, conv {all(t[1] == 1 for t in st2)})  Q mean {Q.mean():.4f} std {Q.std():.3f}", flush=True)
     Q1, _ = ds.SolveFwd(lvl, np.ones((1, dp.levels[lvl].n_p)))
     print(f"     k=1: Q = {Q1[0]:.8f}", flush=True)
-mgr = host_api.MLMCManager(3, sampler=smp, solver=ds, wall_time=True, batch=16)
-t0 = time.time()
-r = mgr.InitRun([32, 64, 128])
-dt = time.time() - t0
-print("InitRun [32,64,128]:", round(dt, 2), "s ->", round(224 / dt, 1), "realizations/s; estimate", r["estimate"], "eQ", r["eQ"], "varY", r["varY"],
-      "cost", r["cost"], "missing", r["missing"], flush=True)
+for nlanes in (1, 2, 4, 6):
+    mgr = host_api.MLMCManager(3, sampler=smp, solver=ds, wall_time=True, batch=16)
+    extra = []
+    for _ in range(nlanes - 1):
+        c2 = capi.Context(0, seed=5)
+        extra.append((c2, capi.PDESampler(c2, sp), capi.DarcySolver(c2, dp)))
+        mgr.add_lane(extra[-1][1], extra[-1][2])
+    ns = [64, 256, 1024]
+    mgr.InitRun([16 * nlanes] * 3)      # warm-up (allocations)
+    mgr.Reset()
+    t0 = time.time()
+    r = mgr.InitRun(ns)
+    dt = time.time() - t0
+    print(f"lanes={nlanes}: InitRun {ns}: {dt:.2f} s -> {sum(ns) / dt:.1f} realizations/s; estimate {r['estimate']:.6f} "
+          f"cost/sample {r['cost']} level_seconds {r['level_seconds']}", flush=True)
+    mgr.close()
+    for c2, s2, d2 in extra:
+        d2.close(); s2.close(); c2.close()

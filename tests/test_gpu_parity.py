@@ -438,3 +438,25 @@ def test_full_size_config2_properties(gpu_ctx):
     s_red = (1.0 / a) * winv * (L.B @ u) + (g / a) * winv * r
     assert rel(s[0], s_red) < 1e-6
     smp.close()
+
+
+def test_manager_lanes_give_the_same_sums(gpu_ctx, hex_hierarchy_small):
+    """Concurrent lanes (extra HIP streams with their own handles) only change who computes which block."""
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    out = []
+    for nlanes in (1, 3):
+        ctxs = [capi.Context(0, seed=99) for _ in range(nlanes)]
+        sm = [capi.PDESampler(c, sp) for c in ctxs]
+        dr = [capi.DarcySolver(c, dp) for c in ctxs]
+        mgr = host_api.MLMCManager(2, sampler=sm[0], solver=dr[0], wall_time=False, batch=4)
+        for i in range(1, nlanes):
+            mgr.add_lane(sm[i], dr[i])
+        out.append(mgr.InitRun([19, 37]))
+        mgr.close()
+        for c in ctxs:
+            c.close()
+    assert np.allclose(out[0]["sums"], out[1]["sums"], rtol=1e-12, atol=1e-13)
+    assert list(out[0]["nsamples"]) == list(out[1]["nsamples"]) == [19, 37]
