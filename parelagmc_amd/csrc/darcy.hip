@@ -276,6 +276,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         lv[l + 1].g_w.upload(w, st);
         PMC_HIP(hipStreamSynchronize(st));
     }
+    mg.build_tails(st);
     for (int l = 0; l < nlevels; ++l) {   // host mirrors no longer needed
         mg.L[l].S.h_src.clear(); mg.L[l].S.h_src.shrink_to_fit();
         mg.L[l].S.h_cols.clear(); mg.L[l].S.h_cols.shrink_to_fit();

@@ -12,6 +12,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
 
 namespace pmc {
 
@@ -961,6 +962,160 @@ __global__ __launch_bounds__(kBlock) void broadcast_kernel(int n, const double* 
     store_row<NB>(out + (size_t)i * NB, v);
 }
 
+// ------------------------------------------------------------------------------------------
+// V-cycle tail in LDS.  Small levels are launch-latency bound as separate kernels (a few us each, ~20
+// launches per V-cycle); here one workgroup per realization sweeps all of them with __syncthreads()
+// between phases.  Vectors live in LDS ([r | x | d] per level), matrices are read from global memory (L2).
+static constexpr int kTailThreads = 1024;
+static constexpr size_t kTailLdsBytes = 160 * 1024 - 1024;   // dynamic LDS budget (static reduction scratch on top)
+
+__device__ __forceinline__ double tail_row_dot(const int* __restrict__ off, const int* __restrict__ cols,
+                                               const double* __restrict__ vals, int vstride, int vk, int row,
+                                               const double* xl) {
+    const int slice = row >> 6, lane = row & 63;
+    const int o = off[slice];
+    const int width = (off[slice + 1] - o) >> 6;
+    double acc = 0.0;
+    int slot = o + lane;
+    // 8 (index, value) pairs are requested together, then the 8 LDS gathers: two memory latencies per 8 entries
+    // instead of one dependent chain per entry (rows have 1..8 entries on these levels)
+    for (int j0 = 0; j0 < width; j0 += 8, slot += 8 * kWave) {
+        int c[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = j0 + u < width;
+            const int at = ok ? slot + u * kWave : slot;
+            c[u] = cols[at];
+            v[u] = ok ? vals[(size_t)at * vstride + vk] : 0.0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma(v[u], xl[c[u]], acc);
+    }
+    return acc;
+}
+
+// Chebyshev iteration on one tail level, in place: x (zero or given) -> x.  All threads participate.
+// (A variant that cached each thread's matrix rows in registers across the steps spilled to scratch under
+// hipcc 7.2 and was not faster; the matrix is re-read from L2 every step.)
+__device__ void tail_cheb(const TailLevelDev& L, int bv, int nb, int k, int degree, double ratio, bool zero_guess,
+                          const double* r, double* x, double* d) {
+    const int n = L.n;
+    const int vstride = bv ? nb : 1, vk = bv ? k : 0;
+    const double lmax = L.lmax, lmin = lmax / ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho_old = 1.0 / sigma;
+    int step = 0;
+    if (zero_guess && degree == 2 && L.vals_scaled) {
+        const double rho1 = 1.0 / (2.0 * sigma - rho_old);
+        const double c0 = (1.0 + rho1 * rho_old) / theta + 2.0 * rho1 / delta, c1 = 2.0 * rho1 / (delta * theta);
+        for (int i = threadIdx.x; i < n; i += kTailThreads) {
+            const double acc = tail_row_dot(L.slice_off, L.cols, L.vals_scaled, vstride, vk, i, r);
+            x[i] = L.dinv[(size_t)i * vstride + vk] * (c0 * r[i] - c1 * acc);
+        }
+        __syncthreads();
+        return;
+    }
+    if (zero_guess) {
+        for (int i = threadIdx.x; i < n; i += kTailThreads) {
+            const double v = L.dinv[(size_t)i * vstride + vk] * r[i] / theta;
+            d[i] = v;
+            x[i] = v;
+        }
+        __syncthreads();
+        step = 1;
+    }
+    for (; step < degree; ++step) {
+        double a, b;
+        if (step == 0) {
+            a = 0.0;
+            b = 1.0 / theta;
+        } else {
+            const double rho = 1.0 / (2.0 * sigma - rho_old);
+            a = rho * rho_old;
+            b = 2.0 * rho / delta;
+            rho_old = rho;
+        }
+        for (int i = threadIdx.x; i < n; i += kTailThreads) {
+            const double acc = tail_row_dot(L.slice_off, L.cols, L.vals, vstride, vk, i, x);
+            const double dold = (a != 0.0) ? d[i] : 0.0;
+            d[i] = a * dold + b * L.dinv[(size_t)i * vstride + vk] * (r[i] - acc);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kTailThreads) x[i] += d[i];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(const TailParams* __restrict__ pp, int nb,
+                                                               const double* __restrict__ rin, double* __restrict__ xout,
+                                                               double* __restrict__ partial) {
+    extern __shared__ __align__(16) double lds[];
+    __shared__ double red[kTailThreads / kWave];
+    const TailParams& P = *pp;
+    const int k = blockIdx.x;
+    const int nlev = P.nlev;
+    {
+        const TailLevelDev& L0 = P.lev[0];
+        double* r0 = lds + L0.lds_off;
+        for (int i = threadIdx.x; i < L0.n; i += kTailThreads) r0[i] = rin[(size_t)i * nb + k];
+    }
+    __syncthreads();
+    // down sweep
+    int l = 0;
+    for (;; ++l) {
+        const TailLevelDev& L = P.lev[l];
+        double* r = lds + L.lds_off;
+        double* x = r + L.n;
+        double* d = x + L.n;
+        if (l == nlev - 1) {     // host guarantees last_degree > 0 on the final tail level
+            tail_cheb(L, P.bv, nb, k, L.last_degree, L.last_ratio, true, r, x, d);
+            break;
+        }
+        tail_cheb(L, P.bv, nb, k, P.smooth_degree, P.smooth_ratio, true, r, x, d);
+        const int vstride = P.bv ? nb : 1, vk = P.bv ? k : 0;
+        for (int i = threadIdx.x; i < L.n; i += kTailThreads)          // residual into d
+            d[i] = r[i] - tail_row_dot(L.slice_off, L.cols, L.vals, vstride, vk, i, x);
+        __syncthreads();
+        const TailLevelDev& Lc = P.lev[l + 1];
+        double* rc = lds + Lc.lds_off;
+        for (int i = threadIdx.x; i < Lc.n; i += kTailThreads)         // restriction r_c = P^T res
+            rc[i] = tail_row_dot(L.pt_off, L.pt_cols, L.pt_vals, 1, 0, i, d);
+        __syncthreads();
+    }
+    // up sweep
+    for (--l; l >= 0; --l) {
+        const TailLevelDev& L = P.lev[l];
+        double* r = lds + L.lds_off;
+        double* x = r + L.n;
+        double* d = x + L.n;
+        const double* xc = lds + P.lev[l + 1].lds_off + P.lev[l + 1].n;
+        for (int i = threadIdx.x; i < L.n; i += kTailThreads) x[i] += tail_row_dot(L.p_off, L.p_cols, L.p_vals, 1, 0, i, xc);
+        __syncthreads();
+        tail_cheb(L, P.bv, nb, k, P.smooth_degree, P.smooth_ratio, false, r, x, d);
+    }
+    const TailLevelDev& L0 = P.lev[0];
+    const double* r0 = lds + L0.lds_off;
+    const double* x0 = r0 + L0.n;
+    double p = 0.0;
+    for (int i = threadIdx.x; i < L0.n; i += kTailThreads) {
+        xout[(size_t)i * nb + k] = x0[i];
+        p = fma(r0[i], x0[i], p);
+    }
+    if (partial) {
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) p += __shfl_down(p, off, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = p;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < kTailThreads / kWave; ++w) s += red[w];
+            partial[k] = s;     // one partial block: partial[0*nb + k]
+        }
+    }
+}
+
 // ==========================================================================================
 // launchers
 #define PMC_DISPATCH_NB(nb, ...)                                          \
@@ -1236,6 +1391,22 @@ void refresh(hipStream_t st, int nb, int64_t nslots, const int* ptr, const int* 
 void diag_inv(hipStream_t st, int nb, int n, const int* diag_slot, const double* vals, double* dinv) {
     PMC_DISPATCH_NB(nb, { diag_inv_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, diag_slot, vals, dinv); });
     check_launch();
+}
+
+int mg_tail(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_doubles, const double* r, double* xout,
+            double* dot_partial) {
+    const size_t bytes = lds_doubles * sizeof(double);
+    if (bytes > kTailLdsBytes) throw Error(PMC_ERR_INTERNAL, "mg_tail: LDS request too large");
+    // one process drives one GPU; the attribute only has to be raised once (idempotent if two lanes race)
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load()) {
+        PMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mg_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kTailLdsBytes));
+        attr_set.store(true);
+    }
+    mg_tail_kernel<<<nb, kTailThreads, bytes, st>>>(dev_params, nb, r, xout, dot_partial);
+    check_launch();
+    return dot_partial ? 1 : 0;
 }
 
 }  // namespace k

@@ -97,3 +97,34 @@ void diag_inv(hipStream_t st, int nb, int n, const int* diag_slot, const double*
 
 }  // namespace k
 }  // namespace pmc
+
+// ---- small-level V-cycle tail: every level from some level on fits one workgroup's LDS ---------------
+namespace pmc {
+struct TailLevelDev {
+    int n, nslices;
+    const int* slice_off;
+    const int* cols;
+    const double* vals;         // shared [nslots] or per-realization [nslots][nb]
+    const double* vals_scaled;  // S D^-1 on the same pattern, may be null
+    const double* dinv;         // [n] or [n][nb]
+    int p_nslices, pt_nslices;  // transfers to / from the next coarser level (unused on the last tail level)
+    const int *p_off, *p_cols, *pt_off, *pt_cols;
+    const double *p_vals, *pt_vals;
+    double lmax;
+    int last_degree;            // > 0: this level ends the recursion with a Chebyshev solve of that degree
+    double last_ratio;
+    int lds_off;                // offset (in doubles) of this level's [r | x | d] block
+};
+static constexpr size_t kTailLdsDoubles = (160 * 1024 - 1024) / 8;
+struct TailParams {
+    int nlev, bv, smooth_degree;
+    double smooth_ratio;
+    TailLevelDev lev[8];
+};
+namespace k {
+// One workgroup per batch column runs the whole V-cycle over the tail levels in LDS.  r, xout: interleaved
+// vectors of the first tail level.  dot_partial != nullptr: writes <r, xout> per column as ONE partial block.
+int mg_tail(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_doubles, const double* r, double* xout,
+            double* dot_partial);
+}  // namespace k
+}  // namespace pmc

@@ -132,6 +132,7 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
         }
         PMC_HIP(hipStreamSynchronize(st));
     }
+    mg.build_tails(st);
 }
 
 void Sampler::set_projection(int level, int kind, const pmc_csr* Gt, const int32_t* idx, const double* inv_w,

@@ -58,10 +58,62 @@ void MgLevel::ensure(int nb) {
     res.ensure(need);
 }
 
+void Multigrid::build_tails(hipStream_t st) {
+    const int nl = (int)L.size();
+    tail.clear();
+    tail.resize(nl);
+    tail_lds.assign(nl, 0);
+    for (int l0 = 0; l0 < nl; ++l0) {
+        // per-realization values are interleaved [slot][nb]: one workgroup per column would pull 16x the bytes it uses
+        // through its L1 (measured: slower than the separate kernels), so the tail is for shared-value hierarchies
+        if (L[l0].bv) continue;
+        TailParams tp{};
+        tp.bv = L[l0].bv ? 1 : 0;
+        tp.smooth_degree = smooth_degree;
+        tp.smooth_ratio = smooth_ratio;
+        size_t off = 0;
+        int cnt = 0;
+        bool ok = true;
+        for (int l = l0; l < nl; ++l) {
+            if (cnt == 8) { ok = false; break; }
+            const MgLevel& m = L[l];
+            TailLevelDev& d = tp.lev[cnt++];
+            d.n = m.n;
+            d.nslices = m.S.nslices;
+            d.slice_off = m.S.slice_off.p;
+            d.cols = m.S.cols.p;
+            d.vals = m.bv ? m.vals_bv.p : m.S.vals.p;
+            d.vals_scaled = m.vals_scaled.p;
+            d.dinv = m.dinv.p;
+            d.lmax = m.lmax;
+            d.lds_off = (int)off;
+            off += 3 * (size_t)m.n;
+            const bool last = m.is_last || l == nl - 1;
+            d.last_degree = last ? (m.is_last ? m.last_degree : coarse_degree) : 0;
+            d.last_ratio = last ? (m.is_last ? m.last_ratio : coarse_ratio) : 1.0;
+            if (last) break;
+            d.p_nslices = m.P.nslices; d.p_off = m.P.slice_off.p; d.p_cols = m.P.cols.p; d.p_vals = m.P.vals.p;
+            d.pt_nslices = m.Pt.nslices; d.pt_off = m.Pt.slice_off.p; d.pt_cols = m.Pt.cols.p; d.pt_vals = m.Pt.vals.p;
+        }
+        if (!ok || off > kTailLdsDoubles) continue;
+        tp.nlev = cnt;
+        tail[l0].alloc(1);
+        PMC_HIP(hipMemcpyAsync(tail[l0].p, &tp, sizeof(tp), hipMemcpyHostToDevice, st));
+        PMC_HIP(hipStreamSynchronize(st));
+        tail_lds[l0] = off;
+    }
+}
+
 double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, double* dot_partial,
                          int* dot_blocks) {
     MgLevel& lv = L[l];
     lv.ensure(nb);
+    if (use_tail && l < (int)tail.size() && tail[l].p) {
+        double* out = target ? target : lv.xa.p;
+        const int nblk = k::mg_tail(st, nb, tail[l].p, tail_lds[l], r, out, dot_partial);
+        if (dot_blocks) *dot_blocks = nblk;
+        return out;
+    }
     const SellView A = lv.sview();
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
     const int last_deg = lv.is_last ? lv.last_degree : coarse_degree;

@@ -59,6 +59,12 @@ struct Multigrid {
     double smooth_ratio = 4.0;
     int coarse_degree = 12;
     double coarse_ratio = 100.0;
+    // Small-level tail: tail[l] (if non-empty) describes levels l.. that together fit one workgroup's LDS; the V-cycle
+    // then finishes in a single kernel from level l on.  Call build_tails() once all levels are set up.
+    std::vector<DevBuf<TailParams>> tail;
+    std::vector<size_t> tail_lds;
+    bool use_tail = true;
+    void build_tails(hipStream_t st);
     // x = V(r) starting at level l0 with zero initial guess; result written to xout (n(l0)*nb).
     // dot_partial != nullptr: also per-block partials of <r, xout>; returns their count.
     int vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial = nullptr);
