@@ -188,6 +188,11 @@ int64_t pmc_darcy_nnz(const pmc_darcy* d, int level);  /* GetNNZ()              
 int pmc_darcy_solve_fwd(pmc_darcy* d, int level, int nbatch, const double* k, double* Q, double* C,
                         double* sol_out, int memspace, pmc_stats* stats);
 
+/* SolveFwd_RtnPressure(level, k, P, C, Q, compute_Q) (src/DarcySolver.cpp:439-470): the pressure block of the
+ * solution, nbatch x n_p(level) in `memspace`; Q (host, may be NULL) is only written when compute_Q != 0. */
+int pmc_darcy_solve_fwd_pressure(pmc_darcy* d, int level, int nbatch, const double* k, double* p_out, double* C,
+                                 double* Q, int compute_Q, int memspace, pmc_stats* stats);
+
 /* ---- MLMC accumulators across GPUs (new: the reference's manager is serial,
  *      src/MLMC_Manager.hpp:24) ----------------------------------------------------------- */
 int pmc_comm_unique_id(void* id128);                                        /* 128 bytes    */

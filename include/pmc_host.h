@@ -83,6 +83,9 @@ void pmc_mlmc_destroy(pmc_mlmc* m);
 int pmc_mlmc_set_farm(pmc_mlmc* m, int nranks, int rank, pmc_reduce_fn reduce, void* user);
 int pmc_mlmc_run(pmc_mlmc* m);                               /* MLMC_Manager::Run      */
 int pmc_mlmc_reset(pmc_mlmc* m);                             /* zero sums and counters */
+/* resume: add the realizations recorded in a per-sample log (params.log_file of an earlier run; columns level, Y, Q,
+ * Q_c, cost as in the reference's MLMC.dat, src/MLMC_Manager.cpp:106-108) to the sums table and counters */
+int pmc_mlmc_replay_log(pmc_mlmc* m, const char* path, int64_t* nread);
 int pmc_mlmc_init_run(pmc_mlmc* m, const int32_t* nsamples); /* MLMC_Manager::InitRun  */
 int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* out);
 const char* pmc_host_last_error(void);

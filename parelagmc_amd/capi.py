@@ -93,6 +93,8 @@ SYMBOLS = {
     "pmc_darcy_nnz": (C.c_int64, [_VP, C.c_int]),
     "pmc_darcy_solve_fwd": (C.c_int, [_VP, C.c_int, C.c_int, _DP, C.POINTER(C.c_double), C.POINTER(C.c_double), _DP,
                                       C.c_int, C.POINTER(pmc_stats)]),
+    "pmc_darcy_solve_fwd_pressure": (C.c_int, [_VP, C.c_int, C.c_int, _DP, _DP, C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(pmc_stats)]),
     "pmc_comm_unique_id": (C.c_int, [_VP]),
     "pmc_comm_init": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     "pmc_comm_destroy": (C.c_int, [_VP]),
@@ -467,6 +469,20 @@ class DarcySolver:
         if return_stats:
             out.append([(s.iterations, s.converged, s.initial_norm, s.final_norm) for s in stats])
         return tuple(out)
+
+    def SolveFwd_RtnPressure(self, level, k, compute_Q=True):
+        """Returns (P, C, Q): pressure block (nbatch, n_p), dof counts, QoI (None unless compute_Q)."""
+        k = _f64(np.atleast_2d(k))
+        nb = k.shape[0]
+        n_p = self.problem.levels[level].n_p
+        P = np.empty((nb, n_p))
+        Q = np.empty(nb)
+        Cc = np.empty(nb)
+        stats = (pmc_stats * nb)()
+        _check(self.ctx.lib.pmc_darcy_solve_fwd_pressure(self.h, level, nb, k.ctypes.data, P.ctypes.data,
+                                                         _ptr(Cc, C.c_double), _ptr(Q, C.c_double),
+                                                         1 if compute_Q else 0, PMC_MEM_HOST, stats))
+        return P, Cc, (Q if compute_Q else None)
 
     def close(self):
         if getattr(self, "h", None):

@@ -327,6 +327,18 @@ int pmc_darcy_solve_fwd(pmc_darcy* d, int level, int nbatch, const double* kf, d
     });
 }
 
+int pmc_darcy_solve_fwd_pressure(pmc_darcy* d, int level, int nbatch, const double* kf, double* p_out, double* C,
+                                 double* Q, int compute_Q, int memspace, pmc_stats* stats) {
+    return guarded([&] {
+        PMC_REQUIRE(d != nullptr && p_out != nullptr, "SolveFwd_RtnPressure: NULL argument");
+        PMC_REQUIRE(nbatch >= 1, "SolveFwd_RtnPressure: bad batch");
+        std::vector<double> q(nbatch);
+        d->impl.solve_fwd(level, nbatch, kf, q.data(), C, p_out, memspace, stats, 2);
+        if (compute_Q && Q)
+            for (int b = 0; b < nbatch; ++b) Q[b] = q[b];
+    });
+}
+
 // ---- communicator -----------------------------------------------------------------------------
 int pmc_comm_unique_id(void* id128) {
     return guarded([&] {

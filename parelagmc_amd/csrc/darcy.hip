@@ -304,7 +304,8 @@ void Darcy::ensure(int level, int nb) {
     qout.ensure(kMaxBatch);
 }
 
-void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats) {
+void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats, int row0,
+                        int nrows) {
     hipStream_t st = ctx.stream;
     DarcyLevel& d = lv[level];
     const int n_u = d.n_u, n_p = d.n_p, n = n_u + n_p;
@@ -373,13 +374,13 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
                                 : k::wdot(st, nb, n, d.obs.p, sol.p, qpartial.p);
     k::reduce_final(st, nb, qblocks, qpartial.p, qout.p);
     PMC_HIP(hipMemcpyAsync(ctx.h_scal, qout.p, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
-    if (sol_d) k::deinterleave(st, nb, n, sol.p, nullptr, nullptr, false, sol_d);
+    if (sol_d) k::deinterleave(st, nb, nrows, sol.p + (size_t)row0 * nb, nullptr, nullptr, false, sol_d);
     PMC_HIP(hipStreamSynchronize(st));
     for (int kcol = 0; kcol < nb; ++kcol) Q_host[kcol] = ctx.h_scal[kcol];
 }
 
 void Darcy::solve_fwd(int level, int nbatch, const double* kf, double* Q, double* C, double* sol_out, int memspace,
-                      pmc_stats* stats) {
+                      pmc_stats* stats, int sol_kind) {
     PMC_REQUIRE(level >= 0 && level < n_mc, "SolveFwd: level out of range");
     PMC_REQUIRE(nbatch >= 1 && kf != nullptr && Q != nullptr, "SolveFwd: bad arguments");
     ctx.activate();
@@ -391,17 +392,20 @@ void Darcy::solve_fwd(int level, int nbatch, const double* kf, double* Q, double
         int nb = 16;
         while (nb > nbatch - done) nb >>= 1;
         const double* k_d = kf + (size_t)done * d.n_p;
-        double* sol_d = sol_out ? sol_out + (size_t)done * n : nullptr;
+        const int row0 = (sol_kind == 2) ? d.n_u : 0;
+        const size_t nout = (sol_kind == 2) ? (size_t)d.n_p : n;
+        double* sol_d = sol_out ? sol_out + (size_t)done * nout : nullptr;
         if (memspace == PMC_MEM_HOST) {
             ensure(level, nb);
             PMC_HIP(hipMemcpyAsync(stage_k.p, k_d, sizeof(double) * d.n_p * nb, hipMemcpyHostToDevice, st));
-            solve_chunk(level, nb, stage_k.p, Q + done, sol_d ? stage_sol.p : nullptr, stats ? stats + done : nullptr);
+            solve_chunk(level, nb, stage_k.p, Q + done, sol_d ? stage_sol.p : nullptr, stats ? stats + done : nullptr, row0,
+                        (int)nout);
             if (sol_d) {
-                PMC_HIP(hipMemcpyAsync(sol_d, stage_sol.p, sizeof(double) * n * nb, hipMemcpyDeviceToHost, st));
+                PMC_HIP(hipMemcpyAsync(sol_d, stage_sol.p, sizeof(double) * nout * nb, hipMemcpyDeviceToHost, st));
                 PMC_HIP(hipStreamSynchronize(st));
             }
         } else {
-            solve_chunk(level, nb, k_d, Q + done, sol_d, stats ? stats + done : nullptr);
+            solve_chunk(level, nb, k_d, Q + done, sol_d, stats ? stats + done : nullptr, row0, (int)nout);
         }
         if (C)
             for (int b = 0; b < nb; ++b) C[done + b] = (double)n;   // global true dofs (DarcySolver.cpp:429)

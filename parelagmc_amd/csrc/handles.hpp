@@ -83,12 +83,14 @@ struct Darcy {
     DevBuf<double> sol, sol_compact, cx, cd, stage_k, stage_sol, qpartial, qout;
 
     Darcy(Ctx& c, int nlevels, int n_mc, const pmc_darcy_level* in, bool k_divides, const pmc_solver_opts& o);
+    // sol_kind: 0 none, 1 full solution (n_u+n_p per realization), 2 pressure block only (n_p per realization)
     void solve_fwd(int level, int nbatch, const double* k, double* Q, double* C, double* sol_out, int memspace,
-                   pmc_stats* stats);
+                   pmc_stats* stats, int sol_kind = 1);
 
   private:
     void ensure(int level, int nb);
-    void solve_chunk(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats);
+    void solve_chunk(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats, int row0,
+                     int nrows);
 };
 
 }  // namespace pmc

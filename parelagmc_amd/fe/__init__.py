@@ -8,3 +8,4 @@ from .problems import (DarcyLevel, DarcyProblem, Hierarchy, SamplerLevel, Sample
                        build_darcy_problem, build_hierarchy, build_sampler_problem,
                        l2_projection_ops, matern_coefficient)
 from .rt0 import build_spaces, mass_contributions, mass_matrix, prolongation_p0  # noqa: F401
+from .transfer import box_intersection_gt, l2_projection_hierarchy  # noqa: F401

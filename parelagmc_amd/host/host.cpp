@@ -215,7 +215,10 @@ MLMC_Manager::MLMC_Manager(pmc_ctx* ctx, int memspace, int nlevels_, PhysicalMLS
     else v_init_nsamples.assign(nlevels, p.init_nsamples);
     M.resize(nlevels);
     for (int i = 0; i < nlevels; ++i) M[i] = pSolver.GetGlobalNumberOfDofs(i);
-    if (p.log_file && p.log_file[0]) logger.open(p.log_file);
+    if (p.log_file && p.log_file[0]) {
+        logger.open(p.log_file);
+        logger.precision(17);    // the per-sample log doubles as a checkpoint (ReplayLog), so it must round-trip
+    }
     Reset();
 }
 
@@ -284,8 +287,8 @@ void MLMC_Manager::run_level(int ilevel, int nsamples) {
                     psum[C] += cost_b;
                     if (logger.is_open()) {
                         std::lock_guard<std::mutex> lk(log_mutex);
-                        logger << std::setw(14) << ilevel << std::setw(14) << y << std::setw(14) << q[b] << std::setw(14)
-                               << qc[b] << std::setw(14) << cost_b << "\n";
+                        logger << std::setw(14) << ilevel << ' ' << std::setw(24) << y << ' ' << std::setw(24) << q[b] << ' '
+                               << std::setw(24) << qc[b] << ' ' << std::setw(14) << cost_b << "\n";
                     }
                 }
             }
@@ -328,6 +331,39 @@ void MLMC_Manager::InitRun(std::vector<int>& level_nsamples_init) {
     }
     if (logger.is_open()) logger << std::flush;
     computeNSamplesMSE();
+}
+
+// Rebuild sums / counters from a per-sample log written by an earlier run (same columns as the reference's
+// MLMC.dat, src/MLMC_Manager.cpp:106-108,133-135,170-172: level, Y, Q, Q_c, cost).  The reference never reads its log
+// back; this is the resume path SURVEY.md 5 asks for.  Returns the number of realizations read.
+int64_t MLMC_Manager::ReplayLog(const std::string& path) {
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("ReplayLog: cannot open " + path);
+    std::string line;
+    int64_t nread = 0;
+    while (std::getline(in, line)) {
+        if (line.empty() || line[0] == '%') continue;
+        std::istringstream ss(line);
+        int lvl;
+        double y, q, qc, c;
+        if (!(ss >> lvl >> y >> q >> qc >> c)) continue;       // truncated last line of an interrupted run
+        if (lvl < 0 || lvl >= nlevels) throw std::runtime_error("ReplayLog: level out of range");
+        S(lvl, Y3) += y * y * y;
+        S(lvl, Y4) += y * y * y * y;
+        S(lvl, Y2) += y * y;
+        S(lvl, Y) += y;
+        S(lvl, ABSY) += std::fabs(y);
+        S(lvl, Q2) += q * q;
+        S(lvl, Q) += q;
+        S(lvl, ABSQ) += std::fabs(q);
+        S(lvl, C) += c;
+        level_nsamples[lvl] += 1;
+        ++nread;
+    }
+    bool all = true;
+    for (int l = 0; l < nlevels; ++l) all = all && level_nsamples[l] > 1;
+    if (all) computeNSamplesMSE();
+    return nread;
 }
 
 void MLMC_Manager::Run() {
@@ -557,6 +593,13 @@ int pmc_mlmc_run(pmc_mlmc* m) {
     return hguard([&] {
         if (!m) throw std::invalid_argument("manager is NULL");
         m->mgr->Run();
+    });
+}
+int pmc_mlmc_replay_log(pmc_mlmc* m, const char* path, int64_t* nread) {
+    return hguard([&] {
+        if (!m || !path) throw std::invalid_argument("pmc_mlmc_replay_log: NULL argument");
+        const int64_t n = m->mgr->ReplayLog(path);
+        if (nread) *nread = n;
     });
 }
 int pmc_mlmc_reset(pmc_mlmc* m) {

@@ -170,6 +170,8 @@ class MLMC_Manager {
     /// Run ML simulation using level_nsamples_init[i] samples on level i
     void InitRun(std::vector<int>& level_nsamples_init);
     void Reset();
+    /// Resume: rebuild the sums table and sample counters from a per-sample log of an earlier run
+    int64_t ReplayLog(const std::string& path);
     void ShowMe(std::ostream& os) const;
 
     bool wallTime;   // public switch, src/MLMC_Manager.hpp:61

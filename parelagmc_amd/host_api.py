@@ -57,6 +57,7 @@ HOST_SYMBOLS = {
     "pmc_mlmc_set_farm": (C.c_int, [_VP, C.c_int, C.c_int, REDUCE_FN, _VP]),
     "pmc_mlmc_run": (C.c_int, [_VP]),
     "pmc_mlmc_reset": (C.c_int, [_VP]),
+    "pmc_mlmc_replay_log": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
     "pmc_mlmc_init_run": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
     "pmc_mlmc_result_get": (C.c_int, [_VP, C.POINTER(pmc_mlmc_result)]),
     "pmc_host_last_error": (C.c_char_p, []),
@@ -203,6 +204,11 @@ class MLMCManager:
 
     def Reset(self):
         _hcheck(self.lib.pmc_mlmc_reset(self.h))
+
+    def ReplayLog(self, path: str) -> int:
+        n = C.c_int64()
+        _hcheck(self.lib.pmc_mlmc_replay_log(self.h, path.encode(), C.byref(n)))
+        return n.value
 
     def InitRun(self, nsamples: Sequence[int]):
         a = np.ascontiguousarray(nsamples, np.int32)

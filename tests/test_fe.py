@@ -113,3 +113,26 @@ def test_box_mesh_boundary_attributes():
     assert np.allclose(fc[fa == 2][:, 1], 0.0) and np.allclose(fc[fa == 4][:, 1], 2.0)
     assert np.allclose(fc[fa == 5][:, 0], 0.0) and np.allclose(fc[fa == 3][:, 0], 2.0)
     assert (fa > 0).sum() == 24
+
+
+def test_nonmatching_box_projector_cube_hex_in_cube_hex_enlarge():
+    """Gt for the reference's non-matching hex pair (meshes/cube_hex.mesh, 4^3 cells of 0.5 on [0,2]^3, inside
+    meshes/cube_hex_enlarge.mesh, 5^3 cells of 0.6 on [-0.5,2.5]^3): partition of unity, total volume, and
+    coarse levels by RAP (L2ProjectionPDESampler.cpp:512-513) equal to the geometric intersection."""
+    from parelagmc_amd.fe import box_intersection_gt, l2_projection_hierarchy
+    o = mesh_from_json(golden_path("meshes", "cube_hex.json"))
+    e = mesh_from_json(golden_path("meshes", "cube_hex_enlarge.json"))
+    assert (o.ne, e.ne) == (64, 125)
+    ho, he = build_hierarchy(o, 2), build_hierarchy(e, 2)
+    ops = l2_projection_hierarchy(ho, he)
+    for lvl, (Gt, inv_w) in enumerate(ops):
+        assert Gt.shape == (ho.spaces[lvl].n_s, he.spaces[lvl].n_s)
+        assert np.allclose(np.asarray(Gt.sum(axis=1)).ravel() * inv_w, 1.0, rtol=1e-13)     # W_o^-1 Gt 1 = 1
+        assert abs(Gt.sum() - 8.0) < 1e-12
+        geo = box_intersection_gt(ho.spaces[lvl].mesh, he.spaces[lvl].mesh)
+        assert abs(Gt - geo).max() < 1e-14
+        assert (np.diff(Gt.indptr) >= 1).all() and (np.diff(Gt.indptr) <= 8).all()         # a cell meets <= 2 per axis
+    # the projection preserves the integral over the original domain of any embedded P0 field
+    f = np.random.default_rng(2).standard_normal(he.spaces[0].n_s)
+    proj = (ops[0][0] @ f) * ops[0][1]
+    assert abs(proj @ ho.spaces[0].vol - np.asarray(ops[0][0].sum(axis=0)).ravel() @ f) < 1e-12

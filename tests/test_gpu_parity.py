@@ -460,3 +460,43 @@ def test_manager_lanes_give_the_same_sums(gpu_ctx, hex_hierarchy_small):
             c.close()
     assert np.allclose(out[0]["sums"], out[1]["sums"], rtol=1e-12, atol=1e-13)
     assert list(out[0]["nsamples"]) == list(out[1]["nsamples"]) == [19, 37]
+
+
+def test_l2_projection_sampler_on_nonmatching_hex_pair(gpu_ctx, seeded_rng):
+    """L2ProjectionPDESampler on a genuinely non-matching pair: sample on cube_hex_enlarge (5^3 refined), project to
+    cube_hex (4^3 refined) with s = W_o^-1 G^T sbar (src/L2ProjectionPDESampler.cpp:738-750)."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hierarchy, build_sampler_problem, l2_projection_hierarchy, mesh_from_json
+    from oracle.sampler_oracle import SamplerOracle
+    ho = build_hierarchy(mesh_from_json(golden_path("meshes", "cube_hex.json")), 2)
+    he = build_hierarchy(mesh_from_json(golden_path("meshes", "cube_hex_enlarge.json")), 2)
+    sp = build_sampler_problem(he, corlen=0.1, lognormal=True)
+    ops = l2_projection_hierarchy(ho, he)
+    so = SamplerOracle(sp)
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT), projection="l2", l2_ops=ops)
+    xi = seeded_rng.standard_normal((3, sp.levels[0].n_s))
+    for lvl in range(3):
+        assert smp.xi_size(lvl) == he.spaces[lvl].n_s and smp.SampleSize(lvl) == ho.spaces[lvl].n_s
+        s, emb = smp.Eval(lvl, xi, xi_level=0, want_embed=True)
+        ref = np.stack([so.eval(lvl, 0, x, projection=("l2",) + ops[lvl])[0] for x in xi])
+        assert rel(s, ref) < 1e-9 and emb.shape[1] == he.spaces[lvl].n_s
+    smp.close()
+
+
+def test_solve_fwd_rtn_pressure(gpu_ctx, hex_hierarchy_small, seeded_rng):
+    """SolveFwd_RtnPressure (src/DarcySolver.cpp:439-470): pressure block of the solution, Q optional."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem
+    from oracle.darcy_oracle import DarcyOracle
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    do = DarcyOracle(dp)
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    for lvl in range(2):
+        k = np.exp(seeded_rng.standard_normal((3, dp.levels[lvl].n_p)))
+        P, C, Q = ds.SolveFwd_RtnPressure(lvl, k)
+        for b in range(3):
+            Qr, Cr, sr = do.solve_fwd(lvl, k[b], return_solution=True)
+            assert rel(P[b], sr[dp.levels[lvl].n_u:]) < 1e-8 and abs(Q[b] - Qr) < 1e-8 * abs(Qr) and C[b] == Cr
+        P2, _, Q2 = ds.SolveFwd_RtnPressure(lvl, k, compute_Q=False)
+        assert Q2 is None and np.array_equal(P2, P)
+    ds.close()

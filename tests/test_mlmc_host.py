@@ -175,3 +175,26 @@ def test_oracle_backed_plugin_small_problem(hex_hierarchy_small):
     assert abs(r["eY"][0]) < abs(r["eQ"][0])                       # level correction smaller than the QoI
     assert np.allclose(r["eC"], [dp.levels[0].ndofs + dp.levels[1].ndofs, dp.levels[1].ndofs])
     mgr.close()
+
+
+def test_log_replay_resumes_a_run(tmp_path):
+    """The per-sample log (the reference's MLMC.dat columns) is a checkpoint: replaying it into a fresh manager
+    restores sums, counters and the derived statistics, and later rounds continue the sample-id sequence."""
+    log = str(tmp_path / "MLMC.dat")
+    pl = SyntheticPlugin(3)
+    a = host_api.MLMCManager(3, callbacks=pl.callbacks(), wall_time=False, batch=4, log_file=log)
+    ra = a.InitRun([6, 9, 14])
+    a.close()
+    lines = [ln for ln in open(log) if not ln.startswith("%")]
+    assert len(lines) == 29 and len(lines[0].split()) == 5
+    b = host_api.MLMCManager(3, callbacks=SyntheticPlugin(3).callbacks(), wall_time=False, batch=4)
+    assert b.ReplayLog(log) == 29
+    rb = b.result()
+    assert np.allclose(rb["sums"], ra["sums"], rtol=1e-14, atol=1e-15) and list(rb["nsamples"]) == [6, 9, 14]
+    assert np.allclose(rb["varY"], ra["varY"], rtol=1e-12) and list(rb["missing"]) == list(ra["missing"])
+    # continuing from the checkpoint == continuing the original run
+    a2 = host_api.MLMCManager(3, callbacks=SyntheticPlugin(3).callbacks(), wall_time=False, batch=4)
+    a2.InitRun([6, 9, 14])
+    assert np.allclose(b.InitRun([2, 3, 4])["sums"], a2.InitRun([2, 3, 4])["sums"], rtol=1e-13)
+    b.close()
+    a2.close()
