@@ -69,6 +69,7 @@ typedef struct pmc_solver_opts {
     int32_t mg_coarse_degree; /* polynomial degree on the coarsest level (default 12) */
     double mg_coarse_ratio;   /* (default 100) */
     int32_t check_every;      /* iterations between host convergence polls (default 2) */
+    int32_t use_graph;        /* replay pairs of MINRES iterations as one hipGraph (default 0; needs check_every 2) */
 } pmc_solver_opts;
 
 /* Per-realization solver report; the reference returns -1 for iteration counts

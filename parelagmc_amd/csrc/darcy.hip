@@ -364,9 +364,15 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     // SolveFwd only needs Q = <obs, sol>: unless the solution itself is requested, MINRES maintains just the rows in
     // the support of obs (compact w / x vectors)
     const bool compact = (sol_d == nullptr) && d.n_obs > 0 && d.n_obs < n;
+    GraphHint hint;
+    hint.key = hash_mix(hash_mix(hash_mix(0xda, (uint64_t)level + 1), (uint64_t)nb), compact ? 1 : 2);
+    hint.sig = mg.signature(level);
+    for (const void* p : {(const void*)cx.p, (const void*)cd.p, (const void*)d.mvals.p, (const void*)d.mvals_scaled.p,
+                          (const void*)d.l1invM.p, (const void*)d.rhs_bc.p})
+        hint.sig = hash_ptr(hint.sig, p);
     MinresResult res = compact ? minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol_compact.p, true, opts, work, 0, d.n_obs,
-                                              d.obs_rows.p)
-                               : minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol.p, true, opts, work, 0, n);
+                                              d.obs_rows.p, hint)
+                               : minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol.p, true, opts, work, 0, n, nullptr, hint);
     if (stats)
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
     // K15: Q = <obs, sol>

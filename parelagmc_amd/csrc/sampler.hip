@@ -263,7 +263,10 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
         return nblk_u + nblk_s;   // <r, z> = u-block partials followed by s-block partials
     };
     // only the s-block of the solution is ever read (PDESampler.cpp:526): update only those rows
-    MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work, n_u, n_s);
+    GraphHint hint;
+    hint.key = hash_mix(hash_mix(0x5a, (uint64_t)level + 1), (uint64_t)nb);
+    hint.sig = hash_ptr(hash_ptr(mg.signature(level), cx.p), cd.p);
+    MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work, n_u, n_s, nullptr, hint);
     if (stats)
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
     // outputs (:526-533 and the embedded variants' maps)

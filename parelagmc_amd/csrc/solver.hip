@@ -150,6 +150,21 @@ int Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* x
     return nblk;
 }
 
+MinresWork::~MinresWork() {
+    for (auto& kv : graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+}
+
+uint64_t Multigrid::signature(int l0) const {
+    uint64_t h = 0x1234;
+    for (int l = l0; l < (int)L.size(); ++l) {
+        const MgLevel& m = L[l];
+        h = hash_ptr(h, m.r.p); h = hash_ptr(h, m.xa.p); h = hash_ptr(h, m.xb.p); h = hash_ptr(h, m.d.p);
+        h = hash_ptr(h, m.res.p); h = hash_ptr(h, m.vals_bv.p); h = hash_ptr(h, m.vals_scaled.p); h = hash_ptr(h, m.dinv.p);
+    }
+    return h;
+}
+
 void MinresWork::ensure(int n, int nb) {
     const size_t need = (size_t)n * nb;
     v0.ensure(need); v1.ensure(need); u0.ensure(need); u1.ensure(need);
@@ -174,7 +189,7 @@ static void axpby(hipStream_t st, size_t n, double a, const double* x, double b,
 
 MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, const double* b, double* x,
                           bool zero_guess, const pmc_solver_opts& o, MinresWork& w, int x_row0, int x_nrows,
-                          const int* x_rows) {
+                          const int* x_rows, GraphHint hint) {
     hipStream_t st = ctx.stream;
     const int n = A.n;
     const size_t len = (size_t)n * nb;
@@ -220,22 +235,82 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
 
     MinresResult out;
     const int every = o.check_every > 0 ? o.check_every : 1;
+    // one MINRES iteration with explicit roles of the ping-pong vectors
+    auto iteration = [&](double* u0_, double* u1_, double* v0_, double* v1_, double* w0_, double* w1_) {
+        int nblk = A.apply(st, nb, u1_, q, w.partial.p);
+        k::minres_scal1(st, nb, S, w.partial.p, nblk);
+        k::lincomb3(st, nb, n, cV0, q, cV1, v1_, cV2, v0_);
+        nblk = prec(st, nb, v0_, u0_, w.partial.p);
+        if (nblk == 0) nblk = k::dot(st, nb, n, v0_, u0_, w.partial.p);
+        k::minres_scal2(st, nb, S, w.partial.p, nblk);
+        if (x_rows) k::minres_wx_idx(st, nb, x_nrows, x_rows, cW0, u1_, cW1, w0_, cW2, w1_, cW3, x);
+        else k::minres_wx(st, nb, x_nrows, cW0, u1_ + xoff, cW1, w0_, cW2, w1_, cW3, x + xoff);
+    };
+    // two iterations return every vector to its original role
+    auto pair = [&]() {
+        iteration(u0, u1, v0, v1, w0, w1);
+        iteration(u1, u0, v1, v0, w1, w0);
+    };
     int it = 0;
     int n_active = poll();
-    while (n_active > 0 && it < o.max_iter) {
-        ++it;
-        nblocks = A.apply(st, nb, u1, q, w.partial.p);
-        k::minres_scal1(st, nb, S, w.partial.p, nblocks);
-        k::lincomb3(st, nb, n, cV0, q, cV1, v1, cV2, v0);
-        nblocks = prec(st, nb, v0, u0, w.partial.p);
-        if (nblocks == 0) nblocks = k::dot(st, nb, n, v0, u0, w.partial.p);
-        k::minres_scal2(st, nb, S, w.partial.p, nblocks);
-        if (x_rows) k::minres_wx_idx(st, nb, x_nrows, x_rows, cW0, u1, cW1, w0, cW2, w1, cW3, x);
-        else k::minres_wx(st, nb, x_nrows, cW0, u1 + xoff, cW1, w0, cW2, w1, cW3, x + xoff);
-        std::swap(u0, u1);
-        std::swap(v0, v1);
-        std::swap(w0, w1);
-        if (it % every == 0 || it == o.max_iter) n_active = poll();
+    const bool graphs = hint.key != 0 && o.use_graph != 0 && every == 2;
+    if (graphs) {
+        // hipGraph path: the first pair runs eagerly (it also performs every lazy allocation), later pairs replay one
+        // captured graph - ~70 kernel launches become a single hipGraphLaunch, which is what the launch-bound small
+        // levels need; the convergence poll stays between replays.
+        if (n_active > 0 && it + 2 <= o.max_iter) {
+            pair();
+            it += 2;
+            n_active = poll();
+        }
+        if (n_active > 0 && it + 2 <= o.max_iter) {
+            uint64_t sig = hash_mix(hint.sig, (uint64_t)nb);
+            sig = hash_mix(sig, (uint64_t)n);
+            for (const void* p : {(const void*)b, (const void*)x, (const void*)v0, (const void*)v1, (const void*)u0,
+                                  (const void*)u1, (const void*)w0, (const void*)w1, (const void*)q,
+                                  (const void*)w.partial.p, (const void*)S, (const void*)x_rows})
+                sig = hash_ptr(sig, p);
+            sig = hash_mix(sig, ((uint64_t)x_row0 << 32) ^ (uint64_t)x_nrows);
+            MinresWork::GraphEntry& ge = w.graphs[hint.key];
+            if (ge.exec && ge.sig != sig) {
+                PMC_HIP(hipGraphExecDestroy(ge.exec));
+                ge.exec = nullptr;
+            }
+            if (!ge.exec) {
+                hipGraph_t graph = nullptr;
+                PMC_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                try {
+                    pair();
+                } catch (...) {
+                    (void)hipStreamEndCapture(st, &graph);
+                    if (graph) (void)hipGraphDestroy(graph);
+                    throw;
+                }
+                PMC_HIP(hipStreamEndCapture(st, &graph));
+                PMC_HIP(hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+                PMC_HIP(hipGraphDestroy(graph));
+                ge.sig = sig;
+            }
+            while (n_active > 0 && it + 2 <= o.max_iter) {
+                PMC_HIP(hipGraphLaunch(ge.exec, st));
+                it += 2;
+                n_active = poll();
+            }
+        }
+        if (n_active > 0 && it < o.max_iter) {   // odd max_iter: one last eager iteration
+            iteration(u0, u1, v0, v1, w0, w1);
+            ++it;
+            n_active = poll();
+        }
+    } else {
+        while (n_active > 0 && it < o.max_iter) {
+            ++it;
+            iteration(u0, u1, v0, v1, w0, w1);
+            std::swap(u0, u1);
+            std::swap(v0, v1);
+            std::swap(w0, w1);
+            if (it % every == 0 || it == o.max_iter) n_active = poll();
+        }
     }
     out.iterations = it;
     static_assert(sizeof(k::MinresState) <= 4096 * sizeof(double), "pinned scratch too small");

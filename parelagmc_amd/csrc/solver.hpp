@@ -1,6 +1,7 @@
 // Krylov solver and preconditioner building blocks (host orchestration of kernels.hip).
 #pragma once
 #include <functional>
+#include <map>
 
 #include "kernels.hpp"
 
@@ -65,6 +66,8 @@ struct Multigrid {
     std::vector<size_t> tail_lds;
     bool use_tail = true;
     void build_tails(hipStream_t st);
+    // hash of the work-buffer pointers a V-cycle from level l0 touches (for GraphHint::sig)
+    uint64_t signature(int l0) const;
     // x = V(r) starting at level l0 with zero initial guess; result written to xout (n(l0)*nb).
     // dot_partial != nullptr: also per-block partials of <r, xout>; returns their count.
     int vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial = nullptr);
@@ -85,9 +88,30 @@ struct LinOp {
 // return the number of partial blocks it wrote (0 = not computed, the solver then runs a separate dot).
 using PrecFn = std::function<int(hipStream_t, int nb, const double* r, double* z, double* dot_partial)>;
 
+// Caller-side identity of one solver configuration for hipGraph reuse: `key` names the configuration (handle, level,
+// batch width, ...), `sig` hashes every device pointer the caller's operator / preconditioner closures use, so a
+// reallocation anywhere invalidates the cached graph.  key == 0: never use graphs.
+struct GraphHint {
+    uint64_t key = 0, sig = 0;
+};
+inline uint64_t hash_mix(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    return h;
+}
+inline uint64_t hash_ptr(uint64_t h, const void* p) { return hash_mix(h, (uint64_t)(uintptr_t)p); }
+
 struct MinresWork {
     DevBuf<double> v0, v1, u0, u1, w0, w1, q, partial;
     DevBuf<k::MinresState> state;
+    struct GraphEntry {
+        uint64_t sig = 0;
+        hipGraphExec_t exec = nullptr;
+    };
+    std::map<uint64_t, GraphEntry> graphs;   // two MINRES iterations per graph, see minres_solve
+    MinresWork() = default;
+    MinresWork(const MinresWork&) = delete;
+    MinresWork& operator=(const MinresWork&) = delete;
+    ~MinresWork();
     void ensure(int n, int nb);
 };
 
@@ -104,7 +128,7 @@ struct MinresResult {
 // rows of the solution (Darcy: the support of the observation functional).
 MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, const double* b, double* x,
                           bool zero_guess, const pmc_solver_opts& o, MinresWork& w, int x_row0, int x_nrows,
-                          const int* x_rows = nullptr);
+                          const int* x_rows = nullptr, GraphHint hint = GraphHint());
 
 // Gershgorin bounds of spec(D^-1 A) for D = diag(A) on the host (setup): returns lmax, sets *lmin
 // (may be <= 0 when a row is not strictly diagonally dominant)

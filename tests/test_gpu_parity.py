@@ -500,3 +500,27 @@ def test_solve_fwd_rtn_pressure(gpu_ctx, hex_hierarchy_small, seeded_rng):
         P2, _, Q2 = ds.SolveFwd_RtnPressure(lvl, k, compute_Q=False)
         assert Q2 is None and np.array_equal(P2, P)
     ds.close()
+
+
+def test_hipgraph_replay_gives_identical_results(gpu_ctx, hex_hierarchy_small):
+    """use_graph = 1 replays pairs of MINRES iterations as one hipGraph: same kernels, same order, same results."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    res = []
+    for g in (0, 1):
+        smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(use_graph=g))
+        ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(use_graph=g))
+        xi = smp.Sample(0, first_id=7, nbatch=5)
+        out = []
+        for _ in range(2):                       # second call reuses the cached graph
+            s, st = smp.Eval(0, xi, return_stats=True)
+            Q, _, st2 = ds.SolveFwd(0, s, return_stats=True)
+            out.append((s, Q, [t[0] for t in st], [t[0] for t in st2]))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        res.append(out[0])
+        ds.close()
+        smp.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
