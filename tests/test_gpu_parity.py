@@ -524,3 +524,50 @@ def test_hipgraph_replay_gives_identical_results(gpu_ctx, hex_hierarchy_small):
         smp.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
+
+
+def test_config5_shape_spe10_box_l2projection_mlmc(gpu_ctx):
+    """BASELINE config 5 shape at small size: SPE10-like box 1200 x 2200 x 170 with anisotropic hex cells, sampler on an
+    enlarged box (+1 coarse cell per side, aligned -> Gt is the volume-weighted selection), L2ProjectionPDESampler,
+    correlation length 100, BCs of examples/example_parameterlists/spe10_3D_parameters.xml:45-49 (essential 1 0 1 0 1 1,
+    observation 0 1 0 0 0 0, inflow 0 0 0 1 0 0: flow along y), 3 levels, MLMC_Manager::InitRun on the device against
+    the same loop with the CPU oracle."""
+    from oracle import mlmc_oracle as mo
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.rng_oracle import normal_fill
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import (box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem,
+                                  l2_projection_hierarchy)
+    nx, ny, nz = 3, 5, 2
+    hx, hy, hz = 1200.0 / nx, 2200.0 / ny, 170.0 / nz
+    orig = box_mesh([nx, ny, nz], [1200.0, 2200.0, 170.0], "hex")
+    emb = box_mesh([nx + 2, ny + 2, nz + 2], [1200.0 + 2 * hx, 2200.0 + 2 * hy, 170.0 + 2 * hz], "hex", origin=[-hx, -hy, -hz])
+    ho, he = build_hierarchy(orig, 2), build_hierarchy(emb, 2)
+    sp = build_sampler_problem(he, corlen=100.0, lognormal=True)
+    ops = l2_projection_hierarchy(ho, he)
+    assert all(np.diff(G.indptr).max() == 1 for G, _ in ops)              # aligned: one embedded cell per original cell
+    dp = build_darcy_problem(ho, [1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0])
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT), projection="l2", l2_ops=ops)
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    # k == 1: Darcy flux through y = 0 is k * dp/L * area = 1/2200 * 1200*170
+    Q1, _ = ds.SolveFwd(0, np.ones((1, dp.levels[0].n_p)))
+    assert abs(Q1[0] - 1200.0 * 170.0 / 2200.0) < 1e-6 * Q1[0]
+    mgr = host_api.MLMCManager(3, sampler=smp, solver=ds, wall_time=False, batch=4)
+    ns = [3, 4, 6]
+    r = mgr.InitRun(ns)
+    so, do = SamplerOracle(sp), DarcyOracle(dp)
+    sums = np.zeros((3, mo.NVAR))
+    for lvl in (2, 1, 0):
+        for i in range(ns[lvl]):
+            xi = normal_fill(sp.levels[lvl].n_s, 20261003, i, lvl)
+            q, c = do.solve_fwd(lvl, so.eval(lvl, lvl, xi, projection=("l2",) + ops[lvl])[0])
+            if lvl == 2:
+                mo.accumulate(sums, lvl, q, q, c)
+            else:
+                qc, cc = do.solve_fwd(lvl + 1, so.eval(lvl + 1, lvl, xi, projection=("l2",) + ops[lvl + 1])[0])
+                mo.accumulate(sums, lvl, q - qc, q, c + cc)
+    assert np.allclose(r["sums"], sums, rtol=1e-6, atol=1e-8 * np.abs(sums).max())
+    mgr.close()
+    ds.close()
+    smp.close()
