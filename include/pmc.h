@@ -70,6 +70,8 @@ typedef struct pmc_solver_opts {
     double mg_coarse_ratio;   /* (default 100) */
     int32_t check_every;      /* iterations between host convergence polls (default 2) */
     int32_t use_graph;        /* replay pairs of MINRES iterations as one hipGraph (default 0; needs check_every 2) */
+    double schur_scale;       /* gamma in S = aW + gamma * B diag(M)^-1 B^T (default 1): diag(M) under-/over-estimates M by
+                                 the spectrum of diag(M)^-1 M, gamma recentres that interval                              */
 } pmc_solver_opts;
 
 /* Per-realization solver report; the reference returns -1 for iteration counts

@@ -93,6 +93,7 @@ void pmc_solver_opts_default(pmc_solver_opts* o) {
     o->mg_coarse_degree = 12;
     o->mg_coarse_ratio = 100.0;
     o->check_every = 2;
+    o->schur_scale = 1.0;
     o->use_graph = 0;   // measured: no gain single-stream (kernels are latency-, not launch-bound), slower with 4 lanes
 }
 

@@ -97,7 +97,9 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
         }
         d.w_sqrt.upload(wsq, st);
         // Schur complement level
-        HostCsr S = schur_host(B, Bt, dM, aw.data());
+        std::vector<double> dMs(dM);
+        for (double& v : dMs) v /= o.schur_scale;
+        HostCsr S = schur_host(B, Bt, dMs, aw.data());
         MgLevel& m = mg.L[l];
         m.n = L.n_s;
         m.bv = false;

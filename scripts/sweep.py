@@ -14,8 +14,9 @@ ctx = capi.Context(0, seed=1)
 n = problem.levels[0].n_s
 nb = 16
 xi_d, s_d = ctx.empty(nb * n), ctx.empty(nb * n)
-for degM, ratM, sdeg, srat in [(2, 8, 2, 6), (2, 8, 2, 8), (2, 8, 2, 10), (2, 8, 2, 15), (2, 8, 3, 8), (2, 8, 3, 12), (2, 8, 3, 20), (2, 3, 2, 8), (2, 15, 2, 8), (2, 8, 4, 20), (1, 8, 3, 12)]:
-    opts = capi.solver_opts(cheb_degree_M=degM, cheb_ratio_M=float(ratM), mg_smooth_degree=sdeg, mg_smooth_ratio=float(srat))
+for gam in (0.6, 0.8, 1.0, 1.2, 1.5, 2.0):
+    degM, ratM, sdeg, srat = 2, 8, 2, 8
+    opts = capi.solver_opts(schur_scale=gam)
     smp = capi.PDESampler(ctx, problem, opts)
     smp.Sample(0, first_id=0, nbatch=nb, out=xi_d)
     smp.Eval(0, xi_d, xi_level=0, s_out=s_d)
@@ -26,6 +27,6 @@ for degM, ratM, sdeg, srat in [(2, 8, 2, 6), (2, 8, 2, 8), (2, 8, 2, 10), (2, 8,
         st = smp.Eval(0, xi_d, xi_level=0, s_out=s_d, return_stats=True)[1]
     ms = ctx.timer_stop() / reps
     it = np.mean([t[0] for t in st])
-    print(f"degM={degM} ratM={ratM} sdeg={sdeg} srat={srat}: {ms:7.2f} ms/batch  iters {it:5.1f}  {ms / it * 1e3:6.1f} us/it  "
+    print(f"gamma={gam} degM={degM} ratM={ratM} sdeg={sdeg} srat={srat}: {ms:7.2f} ms/batch  iters {it:5.1f}  {ms / it * 1e3:6.1f} us/it  "
           f"{nb / ms * 1e3:7.1f} samples/s  conv {all(t[1] == 1 for t in st)}", flush=True)
     smp.close()
