@@ -95,8 +95,8 @@ def mlmc_config3(seed, lanes=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batches in flight per GPU (one HIP stream + host thread each): the launch-latency-"

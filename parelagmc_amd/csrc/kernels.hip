@@ -7,7 +7,7 @@
 //        K8 V-cycle smoothing/residual/transfer, K3/K4 restriction/prolongation, K11 projection
 //   minres_* / lincomb3 / dot                  : K6 MINRES vector operations
 //   normal_fill                                : K1 NormalDistributionSampler
-//   rhs_interleave / finish_field              : K2 white-noise RHS, K9 exp, K10 gather
+//   interleave / deinterleave                  : K2 white-noise RHS scaling, K9 exp, K10 gather (fused with the layout change)
 //   darcy_*                                    : K12-K15 per-sample M(k), BC elimination, Schur refresh, QoI
 #include "kernels.hpp"
 
