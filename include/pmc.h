@@ -184,6 +184,7 @@ int pmc_darcy_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_darcy
                      int k_divides, const pmc_solver_opts* opts, pmc_darcy** out);
 void pmc_darcy_destroy(pmc_darcy* d);
 int pmc_darcy_num_dofs(const pmc_darcy* d, int level); /* GetGlobalNumberOfDofs() */
+int pmc_darcy_num_pressure_dofs(const pmc_darcy* d, int level); /* GetSizeOfStochasticData(): entries of k */
 int64_t pmc_darcy_nnz(const pmc_darcy* d, int level);  /* GetNNZ()                */
 /* SolveFwd(level, k, Q, C) (src/DarcySolver.cpp:416-437).  k: nbatch x n_p(level) in
  * `memspace`; Q, C: host arrays of nbatch; sol_out (may be NULL): nbatch x (n_u+n_p) in
@@ -195,6 +196,15 @@ int pmc_darcy_solve_fwd(pmc_darcy* d, int level, int nbatch, const double* k, do
  * solution, nbatch x n_p(level) in `memspace`; Q (host, may be NULL) is only written when compute_Q != 0. */
 int pmc_darcy_solve_fwd_pressure(pmc_darcy* d, int level, int nbatch, const double* k, double* p_out, double* C,
                                  double* Q, int compute_Q, int memspace, pmc_stats* stats);
+
+/* Bayesian observation operator (src/BayesianInverseProblem.cpp:178-186, ComputeG): Gobs is nobs x n_p(level), row i
+ * = the observation functional g_obs_i (e.g. the indicator of the cells around an observation point, restricted to the
+ * level).  pmc_darcy_compute_G solves like SolveFwd and returns G[b*nobs + i] = <g_i, p_b> / sum(g_i) (host array) plus
+ * Q and C (host, may be NULL); only the rows of the solution that Q and G read are maintained by the Krylov solver. */
+int pmc_darcy_set_observations(pmc_darcy* d, int level, const pmc_csr* Gobs);
+int pmc_darcy_num_observations(const pmc_darcy* d, int level);
+int pmc_darcy_compute_G(pmc_darcy* d, int level, int nbatch, const double* k, double* G, double* C, double* Q,
+                        int memspace, pmc_stats* stats);
 
 /* ---- MLMC accumulators across GPUs (new: the reference's manager is serial,
  *      src/MLMC_Manager.hpp:24) ----------------------------------------------------------- */

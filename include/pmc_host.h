@@ -90,6 +90,13 @@ int pmc_mlmc_init_run(pmc_mlmc* m, const int32_t* nsamples); /* MLMC_Manager::In
 int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* out);
 const char* pmc_host_last_error(void);
 
+/* BayesianInverseProblem::ComputeLikelihood / ComputeLikelihoodAndQ / ComputeR (src/BayesianInverseProblem.cpp:188-218)
+ * for nbatch realizations:  G = ComputeG(k) on the device (pmc_darcy_compute_G),
+ *   likelihood = exp(-|G - G_obs|^2 / (2 noise)),   R = Q * likelihood.
+ * likelihood, C: host arrays of nbatch; Q, R: host arrays or NULL. */
+int pmc_bayes_likelihood(pmc_darcy* solver, int level, int nbatch, const double* k, int memspace, const double* G_obs,
+                         int nobs, double noise, double* likelihood, double* C, double* Q, double* R);
+
 /* expWRegression (src/Utilities.cpp:257-283), exported for the host-logic tests */
 double pmc_exp_w_regression(const double* y, const double* x, int n, int skip_n_last);
 

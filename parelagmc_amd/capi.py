@@ -91,11 +91,16 @@ SYMBOLS = {
                                    C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
     "pmc_darcy_destroy": (None, [_VP]),
     "pmc_darcy_num_dofs": (C.c_int, [_VP, C.c_int]),
+    "pmc_darcy_num_pressure_dofs": (C.c_int, [_VP, C.c_int]),
     "pmc_darcy_nnz": (C.c_int64, [_VP, C.c_int]),
     "pmc_darcy_solve_fwd": (C.c_int, [_VP, C.c_int, C.c_int, _DP, C.POINTER(C.c_double), C.POINTER(C.c_double), _DP,
                                       C.c_int, C.POINTER(pmc_stats)]),
     "pmc_darcy_solve_fwd_pressure": (C.c_int, [_VP, C.c_int, C.c_int, _DP, _DP, C.POINTER(C.c_double),
                                                C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(pmc_stats)]),
+    "pmc_darcy_set_observations": (C.c_int, [_VP, C.c_int, C.POINTER(pmc_csr)]),
+    "pmc_darcy_num_observations": (C.c_int, [_VP, C.c_int]),
+    "pmc_darcy_compute_G": (C.c_int, [_VP, C.c_int, C.c_int, _DP, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.c_int, C.POINTER(pmc_stats)]),
     "pmc_comm_unique_id": (C.c_int, [_VP]),
     "pmc_comm_init": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     "pmc_comm_destroy": (C.c_int, [_VP]),
@@ -470,6 +475,26 @@ class DarcySolver:
         if return_stats:
             out.append([(s.iterations, s.converged, s.initial_norm, s.final_norm) for s in stats])
         return tuple(out)
+
+    def SetObservations(self, level, Gobs):
+        """Gobs: scipy sparse (nobs, n_p): rows are the observation functionals g_obs_i of the level."""
+        keep = _Keep()
+        g = keep.csr(Gobs)
+        _check(self.ctx.lib.pmc_darcy_set_observations(self.h, level, C.byref(g)))
+
+    def ComputeG(self, level, k, nbatch=None):
+        """BayesianInverseProblem::ComputeG: returns (G (nbatch, nobs), C, Q)."""
+        if isinstance(k, np.ndarray):
+            k = _f64(np.atleast_2d(k))
+            nbatch = k.shape[0]
+        nobs = self.ctx.lib.pmc_darcy_num_observations(self.h, level)
+        G = np.empty((nbatch, nobs))
+        Q = np.empty(nbatch)
+        Cc = np.empty(nbatch)
+        pk, ms = _addr(k)
+        _check(self.ctx.lib.pmc_darcy_compute_G(self.h, level, nbatch, pk, _ptr(G, C.c_double), _ptr(Cc, C.c_double),
+                                                _ptr(Q, C.c_double), ms, None))
+        return G, Cc, Q
 
     def SolveFwd_RtnPressure(self, level, k, compute_Q=True):
         """Returns (P, C, Q): pressure block (nbatch, n_p), dof counts, QoI (None unless compute_Q)."""

@@ -317,6 +317,10 @@ int pmc_darcy_num_dofs(const pmc_darcy* d, int level) {
     if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
     return d->impl.lv[level].n_u + d->impl.lv[level].n_p;
 }
+int pmc_darcy_num_pressure_dofs(const pmc_darcy* d, int level) {
+    if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
+    return d->impl.lv[level].n_p;
+}
 int64_t pmc_darcy_nnz(const pmc_darcy* d, int level) {
     if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
     return d->impl.lv[level].nnz;
@@ -338,6 +342,24 @@ int pmc_darcy_solve_fwd_pressure(pmc_darcy* d, int level, int nbatch, const doub
         d->impl.solve_fwd(level, nbatch, kf, q.data(), C, p_out, memspace, stats, 2);
         if (compute_Q && Q)
             for (int b = 0; b < nbatch; ++b) Q[b] = q[b];
+    });
+}
+
+int pmc_darcy_set_observations(pmc_darcy* d, int level, const pmc_csr* Gobs) {
+    return guarded([&] {
+        PMC_REQUIRE(d != nullptr, "darcy is NULL");
+        d->impl.set_observations(level, Gobs);
+    });
+}
+int pmc_darcy_num_observations(const pmc_darcy* d, int level) {
+    if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
+    return d->impl.lv[level].n_gobs;
+}
+int pmc_darcy_compute_G(pmc_darcy* d, int level, int nbatch, const double* kf, double* G, double* C, double* Q,
+                        int memspace, pmc_stats* stats) {
+    return guarded([&] {
+        PMC_REQUIRE(d != nullptr, "darcy is NULL");
+        d->impl.compute_G(level, nbatch, kf, G, C, Q, memspace, stats);
     });
 }
 

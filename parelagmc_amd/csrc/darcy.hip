@@ -304,8 +304,73 @@ void Darcy::ensure(int level, int nb) {
     qout.ensure(kMaxBatch);
 }
 
+void Darcy::set_observations(int level, const pmc_csr* Gc) {
+    PMC_REQUIRE(level >= 0 && level < n_mc && Gc != nullptr, "set_observations: bad arguments");
+    DarcyLevel& d = lv[level];
+    HostCsr G = csr_from_c(*Gc, true, "observation functionals");
+    PMC_REQUIRE(G.ncols == d.n_p && G.nrows >= 1, "set_observations: Gobs must be nobs x n_p");
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    // union of supp(obs) and the pressure dofs any g_i touches, as sorted row indices of the full solution vector
+    std::vector<double> obs_h((size_t)d.n_u + d.n_p);
+    PMC_HIP(hipMemcpyAsync(obs_h.data(), d.obs.p, sizeof(double) * obs_h.size(), hipMemcpyDeviceToHost, st));
+    PMC_HIP(hipStreamSynchronize(st));
+    std::vector<char> mark(obs_h.size(), 0);
+    for (size_t i = 0; i < obs_h.size(); ++i) mark[i] = obs_h[i] != 0.0;
+    for (int c : G.colind) mark[(size_t)d.n_u + c] = 1;
+    std::vector<int> rows, pos(obs_h.size(), -1);
+    std::vector<double> w;
+    for (size_t i = 0; i < mark.size(); ++i)
+        if (mark[i]) { pos[i] = (int)rows.size(); rows.push_back((int)i); w.push_back(obs_h[i]); }
+    std::vector<double> norm(G.nrows);
+    for (int i = 0; i < G.nrows; ++i) {
+        double s = 0.0;
+        for (int p = G.rowptr[i]; p < G.rowptr[i + 1]; ++p) s += G.vals[p];
+        PMC_REQUIRE(s != 0.0, "set_observations: an observation functional sums to zero");
+        norm[i] = 1.0 / s;                      // G_i = <g_i, p> / sum(g_i)
+    }
+    HostCsr Gcmp = G;
+    Gcmp.ncols = (int)rows.size();
+    for (int& c : Gcmp.colind) c = pos[(size_t)d.n_u + c];
+    sell_build(d.Gobs, Gcmp, true, false, st);
+    d.g_rows.upload(rows, st);
+    d.g_obs_w.upload(w, st);
+    d.g_norm.upload(norm, st);
+    d.n_gobs = G.nrows;
+    d.n_grows = (int)rows.size();
+    PMC_HIP(hipStreamSynchronize(st));
+}
+
+void Darcy::compute_G(int level, int nbatch, const double* kf, double* G, double* C, double* Q, int memspace,
+                      pmc_stats* stats) {
+    PMC_REQUIRE(level >= 0 && level < n_mc, "ComputeG: level out of range");
+    PMC_REQUIRE(nbatch >= 1 && kf != nullptr && G != nullptr, "ComputeG: bad arguments");
+    DarcyLevel& d = lv[level];
+    PMC_REQUIRE(d.n_gobs > 0, "ComputeG: no observation functionals set on this level");
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    std::vector<double> q(16);
+    int done = 0;
+    while (done < nbatch) {
+        int nb = 16;
+        while (nb > nbatch - done) nb >>= 1;
+        const double* k_d = kf + (size_t)done * d.n_p;
+        if (memspace == PMC_MEM_HOST) {
+            ensure(level, nb);
+            PMC_HIP(hipMemcpyAsync(stage_k.p, k_d, sizeof(double) * d.n_p * nb, hipMemcpyHostToDevice, st));
+            k_d = stage_k.p;
+        }
+        solve_chunk(level, nb, k_d, q.data(), nullptr, stats ? stats + done : nullptr, 0, 0, G + (size_t)done * d.n_gobs);
+        for (int b = 0; b < nb; ++b) {
+            if (Q) Q[done + b] = q[b];
+            if (C) C[done + b] = (double)((size_t)d.n_u + d.n_p);
+        }
+        done += nb;
+    }
+}
+
 void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats, int row0,
-                        int nrows) {
+                        int nrows, double* G_host) {
     hipStream_t st = ctx.stream;
     DarcyLevel& d = lv[level];
     const int n_u = d.n_u, n_p = d.n_p, n = n_u + n_p;
@@ -363,24 +428,37 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     };
     // SolveFwd only needs Q = <obs, sol>: unless the solution itself is requested, MINRES maintains just the rows in
     // the support of obs (compact w / x vectors)
-    const bool compact = (sol_d == nullptr) && d.n_obs > 0 && d.n_obs < n;
+    const bool gmode = G_host != nullptr;
+    const bool compact = gmode || ((sol_d == nullptr) && d.n_obs > 0 && d.n_obs < n);
+    const int ncomp = gmode ? d.n_grows : d.n_obs;
+    const int* comp_rows = gmode ? d.g_rows.p : d.obs_rows.p;
+    const double* comp_w = gmode ? d.g_obs_w.p : d.obs_w.p;
+    sol_compact.ensure((size_t)std::max(ncomp, 1) * nb);
     GraphHint hint;
-    hint.key = hash_mix(hash_mix(hash_mix(0xda, (uint64_t)level + 1), (uint64_t)nb), compact ? 1 : 2);
+    hint.key = hash_mix(hash_mix(hash_mix(0xda, (uint64_t)level + 1), (uint64_t)nb), gmode ? 3 : (compact ? 1 : 2));
     hint.sig = mg.signature(level);
     for (const void* p : {(const void*)cx.p, (const void*)cd.p, (const void*)d.mvals.p, (const void*)d.mvals_scaled.p,
                           (const void*)d.l1invM.p, (const void*)d.rhs_bc.p})
         hint.sig = hash_ptr(hint.sig, p);
-    MinresResult res = compact ? minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol_compact.p, true, opts, work, 0, d.n_obs,
-                                              d.obs_rows.p, hint)
+    MinresResult res = compact ? minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol_compact.p, true, opts, work, 0, ncomp,
+                                              comp_rows, hint)
                                : minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol.p, true, opts, work, 0, n, nullptr, hint);
     if (stats)
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
     // K15: Q = <obs, sol>
-    const int qblocks = compact ? k::wdot(st, nb, d.n_obs, d.obs_w.p, sol_compact.p, qpartial.p)
+    const int qblocks = compact ? k::wdot(st, nb, ncomp, comp_w, sol_compact.p, qpartial.p)
                                 : k::wdot(st, nb, n, d.obs.p, sol.p, qpartial.p);
     k::reduce_final(st, nb, qblocks, qpartial.p, qout.p);
     PMC_HIP(hipMemcpyAsync(ctx.h_scal, qout.p, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
     if (sol_d) k::deinterleave(st, nb, nrows, sol.p + (size_t)row0 * nb, nullptr, nullptr, false, sol_d);
+    if (gmode) {
+        // G_i = <g_i, p> / sum(g_i) for every realization (BayesianInverseProblem::ComputeG), on the compact solution
+        gtmp.ensure((size_t)d.n_gobs * nb);
+        gout.ensure((size_t)d.n_gobs * nb);
+        k::spmm(st, nb, view(d.Gobs), sol_compact.p, gtmp.p, false, nullptr, nullptr);
+        k::deinterleave(st, nb, d.n_gobs, gtmp.p, nullptr, d.g_norm.p, false, gout.p);
+        PMC_HIP(hipMemcpyAsync(G_host, gout.p, sizeof(double) * d.n_gobs * nb, hipMemcpyDeviceToHost, st));
+    }
     PMC_HIP(hipStreamSynchronize(st));
     for (int kcol = 0; kcol < nb; ++kcol) Q_host[kcol] = ctx.h_scal[kcol];
 }
@@ -405,13 +483,13 @@ void Darcy::solve_fwd(int level, int nbatch, const double* kf, double* Q, double
             ensure(level, nb);
             PMC_HIP(hipMemcpyAsync(stage_k.p, k_d, sizeof(double) * d.n_p * nb, hipMemcpyHostToDevice, st));
             solve_chunk(level, nb, stage_k.p, Q + done, sol_d ? stage_sol.p : nullptr, stats ? stats + done : nullptr, row0,
-                        (int)nout);
+                        (int)nout, nullptr);
             if (sol_d) {
                 PMC_HIP(hipMemcpyAsync(sol_d, stage_sol.p, sizeof(double) * nout * nb, hipMemcpyDeviceToHost, st));
                 PMC_HIP(hipStreamSynchronize(st));
             }
         } else {
-            solve_chunk(level, nb, k_d, Q + done, sol_d, stats ? stats + done : nullptr, row0, (int)nout);
+            solve_chunk(level, nb, k_d, Q + done, sol_d, stats ? stats + done : nullptr, row0, (int)nout, nullptr);
         }
         if (C)
             for (int b = 0; b < nb; ++b) C[done + b] = (double)n;   // global true dofs (DarcySolver.cpp:429)

@@ -70,6 +70,12 @@ struct DarcyLevel {
     DevBuf<int> obs_rows;
     DevBuf<double> obs_w;
     int n_obs = 0;
+    // Bayesian observation functionals g_i (src/BayesianInverseProblem.cpp:178-186): rows of Gobs act on the pressure
+    // block.  MINRES then maintains the union of supp(obs) and supp(g_i); Gobs is stored on that compact numbering.
+    int n_gobs = 0, n_grows = 0;
+    Sell Gobs;
+    DevBuf<int> g_rows;
+    DevBuf<double> g_obs_w, g_norm;
 };
 
 struct Darcy {
@@ -80,7 +86,9 @@ struct Darcy {
     std::vector<DarcyLevel> lv;
     Multigrid mg;                    // batched values
     MinresWork work;
-    DevBuf<double> sol, sol_compact, cx, cd, stage_k, stage_sol, qpartial, qout;
+    DevBuf<double> sol, sol_compact, cx, cd, stage_k, stage_sol, qpartial, qout, gtmp, gout;
+    void set_observations(int level, const pmc_csr* Gobs);
+    void compute_G(int level, int nbatch, const double* k, double* G, double* C, double* Q, int memspace, pmc_stats* stats);
 
     Darcy(Ctx& c, int nlevels, int n_mc, const pmc_darcy_level* in, bool k_divides, const pmc_solver_opts& o);
     // sol_kind: 0 none, 1 full solution (n_u+n_p per realization), 2 pressure block only (n_p per realization)
@@ -90,7 +98,7 @@ struct Darcy {
   private:
     void ensure(int level, int nb);
     void solve_chunk(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats, int row0,
-                     int nrows);
+                     int nrows, double* G_host);
 };
 
 }  // namespace pmc

@@ -134,6 +134,40 @@ int DarcySolver::GetNumberOfDofs(int l) const { return pmc_darcy_num_dofs(h_, l)
 int DarcySolver::GetGlobalNumberOfDofs(int l) const { return pmc_darcy_num_dofs(h_, l); }
 int DarcySolver::GetNNZ(int l) const { return (int)pmc_darcy_nnz(h_, l); }
 
+// ---- BayesianInverseProblem --------------------------------------------------------------------------
+void BayesianInverseProblem::ComputeG(int ilevel, Vector& k, std::vector<double>& G, double* C, double* Q,
+                                      bool compute_Q) {
+    const int nobs = pmc_darcy_num_observations(solver_, ilevel);
+    if (nobs != (int)G_obs_.size()) throw std::runtime_error("BayesianInverseProblem: observation count mismatch");
+    G.resize((size_t)k.Batch() * nobs);
+    std::vector<double> q(k.Batch());
+    check(pmc_darcy_compute_G(solver_, ilevel, k.Batch(), k.GetData(), G.data(), C, q.data(), k.MemSpace(), nullptr),
+          "BayesianInverseProblem::ComputeG");
+    if (compute_Q && Q)
+        for (int b = 0; b < k.Batch(); ++b) Q[b] = q[b];
+}
+void BayesianInverseProblem::ComputeLikelihoodAndQ(int ilevel, Vector& k, double* likelihood, double* C, double* Q) {
+    std::vector<double> G;
+    ComputeG(ilevel, k, G, C, Q, Q != nullptr);
+    const int nobs = (int)G_obs_.size();
+    for (int b = 0; b < k.Batch(); ++b) {
+        double s = 0.0;
+        for (int i = 0; i < nobs; ++i) {
+            const double d = G[(size_t)b * nobs + i] - G_obs_[i];
+            s += d * d;
+        }
+        likelihood[b] = std::exp((-1. / (noise_ * 2)) * s);      // BayesianInverseProblem.cpp:196
+    }
+}
+void BayesianInverseProblem::ComputeLikelihood(int ilevel, Vector& k, double* likelihood, double* C) {
+    ComputeLikelihoodAndQ(ilevel, k, likelihood, C, nullptr);
+}
+void BayesianInverseProblem::ComputeR(int ilevel, Vector& k, double* R, double* C) {
+    std::vector<double> q(k.Batch());
+    ComputeLikelihoodAndQ(ilevel, k, R, C, q.data());
+    for (int b = 0; b < k.Batch(); ++b) R[b] *= q[b];
+}
+
 // ---- callback plugins ---------------------------------------------------------------------------
 CallbackSampler::CallbackSampler(int nlevels, const pmc_plugin_callbacks& cb) : cb_(cb) {
     if (!cb.sample || !cb.eval || !cb.xi_size || !cb.sample_size) throw std::invalid_argument("sampler callbacks missing");
@@ -638,6 +672,31 @@ int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* r) {
         r->nsamples = g.level_nsamples.data();
         r->nsamples_missing = g.level_nsamples_missing.data();
         r->level_seconds = g.level_seconds.data();
+    });
+}
+
+int pmc_bayes_likelihood(pmc_darcy* solver, int level, int nbatch, const double* k, int memspace, const double* G_obs,
+                         int nobs, double noise, double* likelihood, double* C, double* Q, double* R) {
+    return hguard([&] {
+        if (!solver || !k || !G_obs || !likelihood || nbatch < 1 || nobs < 1 || !(noise > 0.0))
+            throw std::invalid_argument("pmc_bayes_likelihood: bad argument");
+        // a non-owning batch view of k
+        struct View : Vector {
+            View(double* p, int n, int nb, int ms) : Vector(nullptr, ms) { Adopt(p, n, nb); }
+            ~View() { Release(); }
+        };
+        BayesianInverseProblem prob(solver, noise, std::vector<double>(G_obs, G_obs + nobs));
+        std::vector<double> G, q(nbatch);
+        std::vector<double> cdummy(nbatch);
+        // ComputeG needs the per-realization size of k = n_p(level): recover it from the solver
+        int n_k = pmc_darcy_num_pressure_dofs(solver, level);
+        if (n_k <= 0) throw std::invalid_argument("pmc_bayes_likelihood: level out of range");
+        View kv(const_cast<double*>(k), n_k, nbatch, memspace);
+        prob.ComputeLikelihoodAndQ(level, kv, likelihood, C ? C : cdummy.data(), q.data());
+        for (int b = 0; b < nbatch; ++b) {
+            if (Q) Q[b] = q[b];
+            if (R) R[b] = q[b] * likelihood[b];
+        }
     });
 }
 

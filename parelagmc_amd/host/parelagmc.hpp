@@ -37,6 +37,8 @@ class Vector {
     ~Vector();
     void SetSize(int size, int nbatch = 1);   // reallocates when the capacity is too small
     void Swap(Vector& o);                     // exchange storage (same context and memory space)
+    void Adopt(double* p, int size, int nbatch) { data_ = p; size_ = size; nbatch_ = nbatch; cap_ = (size_t)size * nbatch; }
+    void Release() { data_ = nullptr; cap_ = 0; }   // forget adopted storage without freeing it
     int Size() const { return size_; }
     int Batch() const { return nbatch_; }
     int MemSpace() const { return memspace_; }
@@ -150,6 +152,26 @@ class CallbackSolver : public PhysicalMLSolver {
   private:
     pmc_plugin_callbacks cb_;
     std::vector<int> ndofs_;
+};
+
+/// Bayesian inverse problem on top of the forward solver (src/BayesianInverseProblem.hpp): observation operator G,
+/// Gaussian likelihood with noise variance `noise`, ratio integrand R = Q * likelihood.  The observation functionals
+/// live in the solver handle (pmc_darcy_set_observations).
+class BayesianInverseProblem {
+  public:
+    BayesianInverseProblem(pmc_darcy* solver, double noise, std::vector<double> G_obs)
+        : solver_(solver), noise_(noise), G_obs_(std::move(G_obs)) {}
+    /// G (k.Batch() x size_obs_data), C and optionally Q
+    void ComputeG(int ilevel, Vector& k_over_k_ref, std::vector<double>& G, double* C, double* Q, bool compute_Q);
+    void ComputeLikelihood(int ilevel, Vector& k_over_k_ref, double* likelihood, double* C);
+    void ComputeLikelihoodAndQ(int ilevel, Vector& k_over_k_ref, double* likelihood, double* C, double* Q);
+    void ComputeR(int ilevel, Vector& k_over_k_ref, double* R, double* C);
+    int SizeOfObservationalData() const { return (int)G_obs_.size(); }
+
+  private:
+    pmc_darcy* solver_;
+    double noise_;
+    std::vector<double> G_obs_;
 };
 
 double expWRegression(const std::vector<double>& y, const std::vector<double>& x, int skip_n_last);

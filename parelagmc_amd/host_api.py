@@ -60,6 +60,8 @@ HOST_SYMBOLS = {
     "pmc_mlmc_replay_log": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
     "pmc_mlmc_init_run": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
     "pmc_mlmc_result_get": (C.c_int, [_VP, C.POINTER(pmc_mlmc_result)]),
+    "pmc_bayes_likelihood": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_int, _DPTR, C.c_int, C.c_double, _DPTR, _DPTR, _DPTR,
+                                       _DPTR]),
     "pmc_host_last_error": (C.c_char_p, []),
     "pmc_exp_w_regression": (C.c_double, [_DPTR, _DPTR, C.c_int, C.c_int]),
 }
@@ -92,6 +94,19 @@ def exp_w_regression(y, x, skip_n_last):
     y = np.ascontiguousarray(y, np.float64)
     x = np.ascontiguousarray(x, np.float64)
     return load_host_library().pmc_exp_w_regression(y.ctypes.data_as(_DPTR), x.ctypes.data_as(_DPTR), len(y), skip_n_last)
+
+
+def bayes_likelihood(solver, level, k, G_obs, noise):
+    """BayesianInverseProblem::ComputeLikelihoodAndQ / ComputeR for a batch: returns (likelihood, C, Q, R)."""
+    lib = load_host_library()
+    k = np.ascontiguousarray(np.atleast_2d(k), np.float64)
+    G_obs = np.ascontiguousarray(G_obs, np.float64)
+    nb = k.shape[0]
+    like, Cc, Q, R = (np.empty(nb) for _ in range(4))
+    _hcheck(lib.pmc_bayes_likelihood(solver.h, level, nb, k.ctypes.data, capi.PMC_MEM_HOST, G_obs.ctypes.data_as(_DPTR),
+                                     len(G_obs), float(noise), like.ctypes.data_as(_DPTR), Cc.ctypes.data_as(_DPTR),
+                                     Q.ctypes.data_as(_DPTR), R.ctypes.data_as(_DPTR)))
+    return like, Cc, Q, R
 
 
 class MLMCManager:

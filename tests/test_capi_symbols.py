@@ -12,7 +12,7 @@ from parelagmc_amd import capi, host_api
 def _declared(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pmc_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(pmc_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def _exported(lib):

@@ -571,3 +571,35 @@ def test_config5_shape_spe10_box_l2projection_mlmc(gpu_ctx):
     mgr.close()
     ds.close()
     smp.close()
+
+
+def test_bayesian_observation_operator_and_likelihood(gpu_ctx, hex_hierarchy_small, seeded_rng):
+    """BayesianInverseProblem::ComputeG / ComputeLikelihoodAndQ / ComputeR (src/BayesianInverseProblem.cpp:178-218) on
+    the device (pmc_darcy_compute_G + pmc_bayes_likelihood) against the oracle."""
+    from oracle.bayes_oracle import compute_G, likelihood, observation_functionals
+    from oracle.darcy_oracle import DarcyOracle
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem
+    h = hex_hierarchy_small
+    dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    do = DarcyOracle(dp)
+    pts = np.array([[0.5, 0.5, 0.5], [1.5, 1.0, 0.4], [1.0, 1.6, 1.7]])
+    Gobs = observation_functionals(h, pts, eps=0.3)
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    noise = 0.01
+    for lvl in range(2):
+        ds.SetObservations(lvl, Gobs[lvl])
+        k = np.exp(0.5 * seeded_rng.standard_normal((5, dp.levels[lvl].n_p)))
+        G, C, Q = ds.ComputeG(lvl, k)
+        ref = [compute_G(do, Gobs, lvl, kk) for kk in k]
+        assert np.allclose(G, np.stack([r[0] for r in ref]), rtol=1e-8, atol=1e-10)
+        assert np.allclose(Q, [r[2] for r in ref], rtol=1e-8) and np.all(C == dp.levels[lvl].ndofs)
+        G_obs = ref[0][0] + 0.02 * seeded_rng.standard_normal(3)
+        like, C2, Q2, R = host_api.bayes_likelihood(ds, lvl, k, G_obs, noise)
+        like_ref = np.array([likelihood(r[0], G_obs, noise) for r in ref])
+        assert np.allclose(like, like_ref, rtol=1e-6) and np.allclose(R, like_ref * np.array([r[2] for r in ref]), rtol=1e-6)
+        assert np.allclose(Q2, Q, rtol=1e-12) and 0.0 < like.max() <= 1.0
+    # the plain SolveFwd path is unaffected by the registered observations
+    Q3, _ = ds.SolveFwd(0, np.ones((1, dp.levels[0].n_p)))
+    assert abs(Q3[0] - 2.0) < 1e-9
+    ds.close()
