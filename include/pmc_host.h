@@ -97,6 +97,36 @@ const char* pmc_host_last_error(void);
 int pmc_bayes_likelihood(pmc_darcy* solver, int level, int nbatch, const double* k, int memspace, const double* G_obs,
                          int nobs, double noise, double* likelihood, double* C, double* Q, double* R);
 
+/* ---- ML_BayesRatio_Manager / SL_BayesRatio_Manager (src/ML_BayesRatio_Manager.hpp:315-728, src/SL_BayesRatio_Manager.hpp)
+ * Multilevel ratio estimator E[Q * likelihood] / E[likelihood]: per realization two INDEPENDENT prior draws, one for
+ * Z = likelihood and one for R = Q * likelihood, each evaluated on level l and (same xi) on level l+1; the same
+ * variance / bias / sample-allocation statistics as MLMC_Manager, computed for R and Z and combined by max.  nlevels == 1
+ * is the single-level manager.  Sums use the reference's enum order (:66-69), 20 columns per level. */
+#define PMC_RATIO_NVAR 20
+typedef struct pmc_ratio pmc_ratio;
+/* likelihood and R = Q*likelihood of nbatch realizations of k (host pointers) */
+typedef int (*pmc_cb_likelihood)(void* user, int level, int nbatch, const double* k, double* likelihood, double* R,
+                                 double* C);
+typedef struct pmc_ratio_result {
+    int32_t nlevels;
+    double R_estimate, Z_estimate, ratio_estimate, eps2, actual_mse, estimator_variance, estimator_variance_R,
+        estimator_variance_Z, bias2, bias2_R, bias2_Z, alpha_R, alpha_abs_R, beta_R, alpha_Z, alpha_abs_Z, beta_Z, gamma;
+    const double *eR, *varR, *eYR, *varYR, *eABS_YR, *eZ, *varZ, *eYZ, *varYZ, *eABS_YZ, *eC, *cost;
+    const double* sums;          /* nlevels x PMC_RATIO_NVAR */
+    const int64_t *nsamples, *nsamples_missing;
+} pmc_ratio_result;
+/* device version: prior = sampler, forward problem = solver with observation functionals set on every level */
+int pmc_ratio_create(pmc_ctx* ctx, pmc_sampler* sampler, pmc_darcy* solver, int nlevels, const double* G_obs, int nobs,
+                     double noise, const pmc_mlmc_params* params, pmc_ratio** out);
+/* plugin version: cb->sample / cb->eval give the prior, `like` the likelihood and ratio integrand */
+int pmc_ratio_create_callbacks(int nlevels, const pmc_plugin_callbacks* cb, pmc_cb_likelihood like,
+                               const pmc_mlmc_params* params, pmc_ratio** out);
+void pmc_ratio_destroy(pmc_ratio* m);
+int pmc_ratio_set_farm(pmc_ratio* m, int nranks, int rank, pmc_reduce_fn reduce, void* user);
+int pmc_ratio_run(pmc_ratio* m);
+int pmc_ratio_init_run(pmc_ratio* m, const int32_t* nsamples);
+int pmc_ratio_result_get(pmc_ratio* m, pmc_ratio_result* out);
+
 /* expWRegression (src/Utilities.cpp:257-283), exported for the host-logic tests */
 double pmc_exp_w_regression(const double* y, const double* x, int n, int skip_n_last);
 

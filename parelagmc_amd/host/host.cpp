@@ -511,6 +511,244 @@ void MLMC_Manager::ShowMe(std::ostream& os) const {
     os << std::string(79, '=') << std::endl;
 }
 
+
+// ---- ML_BayesRatio_Manager ------------------------------------------------------------------------------
+namespace {
+// bias model shared by R and Z (ML_BayesRatio_Manager.hpp:649-680, same as MLMC_Manager.cpp:339-355)
+double bias2_of(int nlevels, const std::vector<double>& M, const std::vector<double>& eABS, double alphaABS) {
+    if (nlevels == 1) return 0.;
+    const double m = M[0] / M[1];
+    if (nlevels > 3)
+        return std::max(std::pow(m, 2. * alphaABS) * eABS[1] * eABS[1], eABS[0] * eABS[0]) /
+               (std::pow(std::pow(m, -2. * alphaABS) - 1., 2));
+    if (nlevels == 3) return (eABS[0] * eABS[0]) / (std::pow(std::pow(m, -alphaABS) - 1., 2));
+    return eABS[0] * eABS[0];
+}
+}  // namespace
+
+ML_BayesRatio_Manager::ML_BayesRatio_Manager(pmc_ctx* ctx, int memspace, int nlevels_, BayesRatioProblem& problem_,
+                                             const pmc_mlmc_params& p)
+    : wallTime(p.wall_time != 0),
+      nlevels(nlevels_),
+      eps2(p.eps2),
+      ratio(p.ratio),
+      problem(problem_),
+      auto_eps2(p.eps2 < 0 ? 1 : 0),
+      init_nsamples_(p.init_nsamples),
+      batch_(p.batch),
+      max_rounds_(p.max_rounds),
+      zxi(ctx, memspace),
+      xi(ctx, memspace),
+      zparam(ctx, memspace),
+      sparam(ctx, memspace) {
+    if (nlevels < 1) throw std::invalid_argument("ML_BayesRatio_Manager: nlevels < 1");
+    if (batch_ < 1 || batch_ > 16) throw std::invalid_argument("ML_BayesRatio_Manager: batch must be in 1..16");
+    if (!(ratio > 0.0 && ratio < 1.0)) throw std::invalid_argument("ML_BayesRatio_Manager: ratio must be in (0,1)");
+    M.resize(nlevels);
+    for (int i = 0; i < nlevels; ++i) M[i] = problem.GetGlobalNumberOfDofs(i);
+    Reset();
+}
+
+void ML_BayesRatio_Manager::SetFarm(int nranks, int rank, std::function<void(double*, int)> reduce) {
+    if (nranks < 1 || rank < 0 || rank >= nranks) throw std::invalid_argument("SetFarm: bad rank");
+    if (nranks > 1 && !reduce) throw std::invalid_argument("SetFarm: reduction missing");
+    nranks_ = nranks;
+    rank_ = rank;
+    reduce_ = std::move(reduce);
+}
+
+void ML_BayesRatio_Manager::Reset() {
+    auto z = [&](std::vector<double>& v) { v.assign(nlevels, 0.0); };
+    sums.assign((size_t)nlevels * NVAR, 0.0);
+    z(eR); z(varR); z(eYR); z(varYR); z(eABS_YR); z(eZ); z(varZ); z(eYZ); z(varYZ); z(eABS_YZ); z(eC); z(cost);
+    z(level_seconds);
+    level_nsamples.assign(nlevels, 0);
+    level_nsamples_missing.assign(nlevels, 0);
+    ml_estimator_variance = ml_estimator_variance_R = ml_estimator_variance_Z = std::numeric_limits<double>::infinity();
+    expected_discretization_error2 = expected_discretization_error2_R = expected_discretization_error2_Z = actualMSE =
+        std::numeric_limits<double>::infinity();
+}
+
+// One level of InitRun (ML_BayesRatio_Manager.hpp:323-372 coarsest, :375-430 level pairs).  Realization i of the level
+// uses prior draw 2i for Z and 2i+1 for R (two independent samples, :334-341).
+void ML_BayesRatio_Manager::run_level(int ilevel, int nsamples) {
+    const uint64_t base = (uint64_t)level_nsamples[ilevel];
+    double* psum = pending_.data() + (size_t)ilevel * NVAR;
+    std::vector<double> z(batch_), r(batch_), zc(batch_), rc(batch_), c(batch_), ctot(batch_), tmp(batch_);
+    const int nblocks = (nsamples + batch_ - 1) / batch_;
+    const bool coarsest = (ilevel == nlevels - 1);
+    const double t0 = now_s();
+    for (int blk = rank_; blk < nblocks; blk += nranks_) {
+        const int first = blk * batch_;
+        const int m = std::min(batch_, nsamples - first);
+        std::fill(ctot.begin(), ctot.end(), 0.0);
+        std::fill(zc.begin(), zc.end(), 0.0);
+        std::fill(rc.begin(), rc.end(), 0.0);
+        const uint64_t id0 = base + (uint64_t)first;
+        // two independent prior draws per realization (:334-341): Z draws use the id range [2^62 + id0, ...), R draws
+        // [id0, ...) - disjoint counter ranges of the generator, hence independent streams
+        problem.SamplePrior(ilevel, zxi, ((uint64_t)1 << 62) + id0, m);
+        problem.EvalPrior(ilevel, zxi, zparam);
+        problem.ComputeLikelihoodAndR(ilevel, zparam, z.data(), tmp.data(), c.data());
+        for (int b = 0; b < m; ++b) ctot[b] += c[b];
+        problem.SamplePrior(ilevel, xi, id0, m);
+        problem.EvalPrior(ilevel, xi, sparam);
+        problem.ComputeLikelihoodAndR(ilevel, sparam, tmp.data(), r.data(), c.data());
+        for (int b = 0; b < m; ++b) ctot[b] += c[b];
+        if (!coarsest) {
+            problem.EvalPrior(ilevel + 1, zxi, zparam);
+            problem.ComputeLikelihoodAndR(ilevel + 1, zparam, zc.data(), tmp.data(), c.data());
+            for (int b = 0; b < m; ++b) ctot[b] += c[b];
+            problem.EvalPrior(ilevel + 1, xi, sparam);
+            problem.ComputeLikelihoodAndR(ilevel + 1, sparam, tmp.data(), rc.data(), c.data());
+            for (int b = 0; b < m; ++b) ctot[b] += c[b];
+        }
+        for (int b = 0; b < m; ++b) {
+            const double y_r = coarsest ? r[b] : r[b] - rc[b];
+            const double y_z = coarsest ? z[b] : z[b] - zc[b];
+            psum[R] += r[b];
+            psum[ABS_R] += std::fabs(r[b]);
+            psum[R2] += r[b] * r[b];
+            psum[YR] += y_r;
+            psum[ABS_YR] += std::fabs(y_r);
+            psum[YR2] += y_r * y_r;
+            psum[Z] += z[b];
+            psum[ABS_Z] += std::fabs(z[b]);
+            psum[Z2] += z[b] * z[b];
+            psum[YZ] += y_z;
+            psum[ABS_YZ] += std::fabs(y_z);
+            psum[YZ2] += y_z * y_z;
+            psum[C] += ctot[b];
+        }
+    }
+    pending_[(size_t)nlevels * NVAR + ilevel] += now_s() - t0;
+}
+
+void ML_BayesRatio_Manager::InitRun(std::vector<int>& level_nsamples_init) {
+    if ((int)level_nsamples_init.size() != nlevels) throw std::invalid_argument("InitRun: wrong number of levels");
+    pending_.assign((size_t)nlevels * (NVAR + 1), 0.0);
+    for (int ilevel = nlevels - 1; ilevel >= 0; --ilevel) {
+        const int ns = level_nsamples_init[ilevel];
+        if (ns < 0) throw std::invalid_argument("InitRun: negative sample count");
+        if (ns > 0) run_level(ilevel, ns);
+    }
+    if (nranks_ > 1) reduce_(pending_.data(), (int)pending_.size());
+    for (size_t i = 0; i < (size_t)nlevels * NVAR; ++i) sums[i] += pending_[i];
+    for (int l = 0; l < nlevels; ++l) {
+        level_seconds[l] += pending_[(size_t)nlevels * NVAR + l];
+        level_nsamples[l] += level_nsamples_init[l];
+    }
+    computeNSamplesMSE();
+}
+
+void ML_BayesRatio_Manager::Run() {
+    Reset();
+    std::vector<int> v_init(nlevels, init_nsamples_);
+    InitRun(v_init);
+    std::vector<int> grain(nlevels, 0);
+    int rounds = 0;
+    while (ml_estimator_variance > ratio * eps2) {
+        if (++rounds > max_rounds_) throw std::runtime_error("ML_BayesRatio_Manager::Run: round limit reached");
+        for (int i = 0; i < nlevels; ++i) {
+            const int64_t miss = level_nsamples_missing[i];
+            grain[i] = (int)std::min<int64_t>(miss, (int64_t)init_nsamples_ + grain[i] + miss / 10);
+        }
+        InitRun(grain);
+    }
+}
+
+void ML_BayesRatio_Manager::computeNSamplesMSE() {
+    for (int l = 0; l < nlevels; ++l) {
+        const double n = (double)level_nsamples[l];
+        eR[l] = S(l, R) / n;  varR[l] = S(l, R2) / n;  eYR[l] = S(l, YR) / n;  varYR[l] = S(l, YR2) / n;
+        eABS_YR[l] = S(l, ABS_YR) / n;
+        eZ[l] = S(l, Z) / n;  varZ[l] = S(l, Z2) / n;  eYZ[l] = S(l, YZ) / n;  varYZ[l] = S(l, YZ2) / n;
+        eABS_YZ[l] = S(l, ABS_YZ) / n;
+        eC[l] = S(l, C) / n;
+        const double f = n / (n - 1.0);
+        varR[l] = (varR[l] - eR[l] * eR[l]) * f;
+        varYR[l] = (varYR[l] - eYR[l] * eYR[l]) * f;
+        varZ[l] = (varZ[l] - eZ[l] * eZ[l]) * f;
+        varYZ[l] = (varYZ[l] - eYZ[l] * eYZ[l]) * f;
+    }
+    if (wallTime)
+        for (int l = 0; l < nlevels; ++l) cost[l] = level_seconds[l] / (double)level_nsamples[l];
+    else
+        cost = eC;
+    alpha_R = expWRegression(eYR, M, 1);
+    alphaABS_R = expWRegression(eABS_YR, M, 1);
+    beta_R = expWRegression(varYR, M, 1);
+    alpha_Z = expWRegression(eYZ, M, 1);
+    alphaABS_Z = expWRegression(eABS_YZ, M, 1);
+    beta_Z = expWRegression(varYZ, M, 1);
+    gamma = expWRegression(cost, M, 0);
+    expected_discretization_error2_R = bias2_of(nlevels, M, eABS_YR, alphaABS_R);
+    expected_discretization_error2_Z = bias2_of(nlevels, M, eABS_YZ, alphaABS_Z);
+    expected_discretization_error2 = std::max(expected_discretization_error2_R, expected_discretization_error2_Z);
+    if (auto_eps2) eps2 = expected_discretization_error2 / (1. - ratio);
+    ml_estimator_variance_Z = ml_estimator_variance_R = 0.;
+    for (int l = 0; l < nlevels; ++l) {
+        ml_estimator_variance_Z += varYZ[l] / (double)level_nsamples[l];
+        ml_estimator_variance_R += varYR[l] / (double)level_nsamples[l];
+    }
+    ml_estimator_variance = std::max(ml_estimator_variance_Z, ml_estimator_variance_R);
+    actualMSE = expected_discretization_error2 + ml_estimator_variance;
+    double prop_R = 0., prop_Z = 0.;
+    for (int i = 0; i < nlevels; ++i) {
+        prop_R += std::sqrt(varYR[i] * cost[i]);
+        prop_Z += std::sqrt(varYZ[i] * cost[i]);
+    }
+    prop_R /= ratio * eps2;
+    prop_Z /= ratio * eps2;
+    for (int i = 0; i < nlevels; ++i) {
+        const double mr = std::ceil(prop_R * std::sqrt(varYR[i] / cost[i]) - (double)level_nsamples[i]);
+        const double mz = std::ceil(prop_Z * std::sqrt(varYZ[i] / cost[i]) - (double)level_nsamples[i]);
+        const double mm = std::max(std::isfinite(mr) ? mr : 0.0, std::isfinite(mz) ? mz : 0.0);
+        level_nsamples_missing[i] = mm > 0.0 ? (int64_t)std::min(mm, 2.0e9) : 0;
+    }
+}
+
+// device-backed problem: prior = PDESampler, forward problem + observations = DarcySolver handle
+class DeviceBayesRatioProblem : public BayesRatioProblem {
+  public:
+    DeviceBayesRatioProblem(pmc_ctx* ctx, pmc_sampler* smp, pmc_darcy* solver, double noise, std::vector<double> G_obs)
+        : sampler_(ctx, smp), solver_(solver), bip_(solver, noise, std::move(G_obs)) {}
+    void SamplePrior(int level, Vector& xi, uint64_t first_id, int nbatch) override { sampler_.Sample(level, xi, first_id, nbatch); }
+    void EvalPrior(int level, const Vector& xi, Vector& s) override { sampler_.Eval(level, xi, s); }
+    void ComputeLikelihoodAndR(int level, Vector& s, double* like, double* R, double* C) override {
+        std::vector<double> q(s.Batch());
+        bip_.ComputeLikelihoodAndQ(level, s, like, C, q.data());
+        for (int b = 0; b < s.Batch(); ++b) R[b] = q[b] * like[b];
+    }
+    int GetGlobalNumberOfDofs(int level) const override { return pmc_darcy_num_dofs(solver_, level); }
+
+  private:
+    PDESampler sampler_;
+    pmc_darcy* solver_;
+    BayesianInverseProblem bip_;
+};
+
+class CallbackBayesRatioProblem : public BayesRatioProblem {
+  public:
+    CallbackBayesRatioProblem(int nlevels, const pmc_plugin_callbacks& cb, pmc_cb_likelihood like)
+        : prior_(nlevels, cb), cb_(cb), like_(like) {
+        if (!like || !cb.ndofs) throw std::invalid_argument("likelihood callback / ndofs missing");
+        ndofs_.assign(cb.ndofs, cb.ndofs + nlevels);
+    }
+    void SamplePrior(int level, Vector& xi, uint64_t first_id, int nbatch) override { prior_.Sample(level, xi, first_id, nbatch); }
+    void EvalPrior(int level, const Vector& xi, Vector& s) override { prior_.Eval(level, xi, s); }
+    void ComputeLikelihoodAndR(int level, Vector& s, double* like, double* R, double* C) override {
+        if (like_(cb_.user, level, s.Batch(), s.GetData(), like, R, C) != 0) throw std::runtime_error("likelihood callback failed");
+    }
+    int GetGlobalNumberOfDofs(int level) const override { return ndofs_.at(level); }
+
+  private:
+    CallbackSampler prior_;
+    pmc_plugin_callbacks cb_;
+    pmc_cb_likelihood like_;
+    std::vector<int> ndofs_;
+};
+
 }  // namespace parelagmc
 
 // =================================================================================================
@@ -697,6 +935,103 @@ int pmc_bayes_likelihood(pmc_darcy* solver, int level, int nbatch, const double*
             if (Q) Q[b] = q[b];
             if (R) R[b] = q[b] * likelihood[b];
         }
+    });
+}
+
+struct pmc_ratio {
+    std::unique_ptr<BayesRatioProblem> problem;
+    std::unique_ptr<ML_BayesRatio_Manager> mgr;
+    pmc_ctx* ctx = nullptr;
+};
+
+int pmc_ratio_create(pmc_ctx* ctx, pmc_sampler* sampler, pmc_darcy* solver, int nlevels, const double* G_obs, int nobs,
+                     double noise, const pmc_mlmc_params* params, pmc_ratio** out) {
+    return hguard([&] {
+        if (!ctx || !sampler || !solver || !G_obs || !out || nobs < 1 || !(noise > 0.0))
+            throw std::invalid_argument("pmc_ratio_create: bad argument");
+        pmc_mlmc_params p;
+        pmc_mlmc_params_default(&p);
+        if (params) p = *params;
+        std::unique_ptr<pmc_ratio> m(new pmc_ratio());
+        m->ctx = ctx;
+        m->problem.reset(new DeviceBayesRatioProblem(ctx, sampler, solver, noise, std::vector<double>(G_obs, G_obs + nobs)));
+        m->mgr.reset(new ML_BayesRatio_Manager(ctx, PMC_MEM_DEVICE, nlevels, *m->problem, p));
+        *out = m.release();
+    });
+}
+int pmc_ratio_create_callbacks(int nlevels, const pmc_plugin_callbacks* cb, pmc_cb_likelihood like,
+                               const pmc_mlmc_params* params, pmc_ratio** out) {
+    return hguard([&] {
+        if (!cb || !like || !out) throw std::invalid_argument("pmc_ratio_create_callbacks: NULL argument");
+        pmc_mlmc_params p;
+        pmc_mlmc_params_default(&p);
+        if (params) p = *params;
+        std::unique_ptr<pmc_ratio> m(new pmc_ratio());
+        m->problem.reset(new CallbackBayesRatioProblem(nlevels, *cb, like));
+        m->mgr.reset(new ML_BayesRatio_Manager(nullptr, PMC_MEM_HOST, nlevels, *m->problem, p));
+        *out = m.release();
+    });
+}
+void pmc_ratio_destroy(pmc_ratio* m) { delete m; }
+int pmc_ratio_set_farm(pmc_ratio* m, int nranks, int rank, pmc_reduce_fn reduce, void* user) {
+    return hguard([&] {
+        if (!m) throw std::invalid_argument("manager is NULL");
+        std::function<void(double*, int)> fn;
+        if (reduce) {
+            fn = [reduce, user](double* b, int n) {
+                if (reduce(b, n, user) != 0) throw std::runtime_error("reduce callback failed");
+            };
+        } else if (nranks > 1) {
+            pmc_ctx* ctx = m->ctx;
+            if (!ctx) throw std::invalid_argument("pmc_ratio_set_farm: no reduction and no device context");
+            fn = [ctx](double* b, int n) {
+                if (pmc_allreduce_sum_f64(ctx, b, n) != PMC_OK) throw std::runtime_error(pmc_last_error());
+            };
+        }
+        m->mgr->SetFarm(nranks, rank, fn);
+    });
+}
+int pmc_ratio_run(pmc_ratio* m) {
+    return hguard([&] {
+        if (!m) throw std::invalid_argument("manager is NULL");
+        m->mgr->Run();
+    });
+}
+int pmc_ratio_init_run(pmc_ratio* m, const int32_t* nsamples) {
+    return hguard([&] {
+        if (!m || !nsamples) throw std::invalid_argument("pmc_ratio_init_run: NULL argument");
+        std::vector<int> v(nsamples, nsamples + m->mgr->nlevels);
+        m->mgr->InitRun(v);
+    });
+}
+int pmc_ratio_result_get(pmc_ratio* m, pmc_ratio_result* r) {
+    return hguard([&] {
+        if (!m || !r) throw std::invalid_argument("pmc_ratio_result_get: NULL argument");
+        ML_BayesRatio_Manager& g = *m->mgr;
+        double er = 0, ez = 0;
+        for (double x : g.eYR) er += x;
+        for (double x : g.eYZ) ez += x;
+        r->nlevels = g.nlevels;
+        r->R_estimate = er;
+        r->Z_estimate = ez;
+        r->ratio_estimate = er / ez;
+        r->eps2 = g.eps2;
+        r->actual_mse = g.actualMSE;
+        r->estimator_variance = g.ml_estimator_variance;
+        r->estimator_variance_R = g.ml_estimator_variance_R;
+        r->estimator_variance_Z = g.ml_estimator_variance_Z;
+        r->bias2 = g.expected_discretization_error2;
+        r->bias2_R = g.expected_discretization_error2_R;
+        r->bias2_Z = g.expected_discretization_error2_Z;
+        r->alpha_R = g.alpha_R; r->alpha_abs_R = g.alphaABS_R; r->beta_R = g.beta_R;
+        r->alpha_Z = g.alpha_Z; r->alpha_abs_Z = g.alphaABS_Z; r->beta_Z = g.beta_Z;
+        r->gamma = g.gamma;
+        r->eR = g.eR.data(); r->varR = g.varR.data(); r->eYR = g.eYR.data(); r->varYR = g.varYR.data();
+        r->eABS_YR = g.eABS_YR.data(); r->eZ = g.eZ.data(); r->varZ = g.varZ.data(); r->eYZ = g.eYZ.data();
+        r->varYZ = g.varYZ.data(); r->eABS_YZ = g.eABS_YZ.data(); r->eC = g.eC.data(); r->cost = g.cost.data();
+        r->sums = g.sums.data();
+        r->nsamples = g.level_nsamples.data();
+        r->nsamples_missing = g.level_nsamples_missing.data();
     });
 }
 

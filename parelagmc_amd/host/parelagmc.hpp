@@ -232,6 +232,52 @@ class MLMC_Manager {
     std::ofstream logger;
 };
 
+/// What the ratio managers call (the reference's BayesianInverseProblem seen from ML_BayesRatio_Manager):
+/// prior draws plus likelihood and ratio integrand.
+class BayesRatioProblem {
+  public:
+    virtual ~BayesRatioProblem() = default;
+    virtual void SamplePrior(int level, Vector& xi, uint64_t first_id, int nbatch) = 0;
+    virtual void EvalPrior(int level, const Vector& xi, Vector& s) = 0;
+    /// likelihood[b] and R[b] = Q[b] * likelihood[b]; C[b] = cost (dofs)
+    virtual void ComputeLikelihoodAndR(int level, Vector& s, double* likelihood, double* R, double* C) = 0;
+    virtual int GetGlobalNumberOfDofs(int level) const = 0;
+};
+
+/// Multilevel (nlevels > 1) / single-level (nlevels == 1) ratio estimator, src/ML_BayesRatio_Manager.hpp.
+class ML_BayesRatio_Manager {
+  public:
+    enum { YZ2 = 0, YZ = 1, ABS_YZ = 2, Z2 = 3, Z = 4, ABS_Z = 5, YR2 = 6, YR = 7, ABS_YR = 8, R2 = 9, R = 10,
+           ABS_R = 11, YRatio2 = 12, YRatio = 13, ABS_YRatio = 14, Ratio2 = 15, Ratio = 16, ABS_Ratio = 17, C = 18,
+           T = 19, NVAR = 20 };
+    ML_BayesRatio_Manager(pmc_ctx* ctx, int memspace, int nlevels, BayesRatioProblem& problem,
+                          const pmc_mlmc_params& params);
+    void SetFarm(int nranks, int rank, std::function<void(double*, int)> reduce);
+    void Run();
+    void InitRun(std::vector<int>& level_nsamples_init);
+    void Reset();
+
+    bool wallTime;
+    int nlevels;
+    double eps2, ratio;
+    double ml_estimator_variance, ml_estimator_variance_R, ml_estimator_variance_Z;
+    double expected_discretization_error2, expected_discretization_error2_R, expected_discretization_error2_Z, actualMSE;
+    double alpha_R = 0, alphaABS_R = 0, beta_R = 0, alpha_Z = 0, alphaABS_Z = 0, beta_Z = 0, gamma = 0;
+    std::vector<double> sums, eR, varR, eYR, varYR, eABS_YR, eZ, varZ, eYZ, varYZ, eABS_YZ, eC, M, cost, level_seconds;
+    std::vector<int64_t> level_nsamples, level_nsamples_missing;
+
+  private:
+    void computeNSamplesMSE();
+    void run_level(int ilevel, int nsamples);
+    double& S(int l, int v) { return sums[(size_t)l * NVAR + v]; }
+    BayesRatioProblem& problem;
+    int auto_eps2, init_nsamples_, batch_, max_rounds_;
+    int nranks_ = 1, rank_ = 0;
+    std::function<void(double*, int)> reduce_;
+    std::vector<double> pending_;
+    Vector zxi, xi, zparam, sparam;
+};
+
 /// Single-level Monte Carlo manager (src/MC_Manager.hpp): the nlevels == 1 case of the above.
 class MC_Manager : public MLMC_Manager {
   public:

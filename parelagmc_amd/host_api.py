@@ -62,6 +62,15 @@ HOST_SYMBOLS = {
     "pmc_mlmc_result_get": (C.c_int, [_VP, C.POINTER(pmc_mlmc_result)]),
     "pmc_bayes_likelihood": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_int, _DPTR, C.c_int, C.c_double, _DPTR, _DPTR, _DPTR,
                                        _DPTR]),
+    "pmc_ratio_create": (C.c_int, [_VP, _VP, _VP, C.c_int, _DPTR, C.c_int, C.c_double, C.POINTER(pmc_mlmc_params),
+                                   C.POINTER(_VP)]),
+    "pmc_ratio_create_callbacks": (C.c_int, [C.c_int, C.POINTER(pmc_plugin_callbacks), _VP, C.POINTER(pmc_mlmc_params),
+                                             C.POINTER(_VP)]),
+    "pmc_ratio_destroy": (None, [_VP]),
+    "pmc_ratio_set_farm": (C.c_int, [_VP, C.c_int, C.c_int, REDUCE_FN, _VP]),
+    "pmc_ratio_run": (C.c_int, [_VP]),
+    "pmc_ratio_init_run": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
+    "pmc_ratio_result_get": (C.c_int, [_VP, _VP]),
     "pmc_host_last_error": (C.c_char_p, []),
     "pmc_exp_w_regression": (C.c_double, [_DPTR, _DPTR, C.c_int, C.c_int]),
 }
@@ -107,6 +116,150 @@ def bayes_likelihood(solver, level, k, G_obs, noise):
                                      len(G_obs), float(noise), like.ctypes.data_as(_DPTR), Cc.ctypes.data_as(_DPTR),
                                      Q.ctypes.data_as(_DPTR), R.ctypes.data_as(_DPTR)))
     return like, Cc, Q, R
+
+
+CB_LIKE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                      C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+class pmc_ratio_result(C.Structure):
+    _fields_ = [("nlevels", C.c_int32)] + [(n, C.c_double) for n in
+                ("R_estimate", "Z_estimate", "ratio_estimate", "eps2", "actual_mse", "estimator_variance",
+                 "estimator_variance_R", "estimator_variance_Z", "bias2", "bias2_R", "bias2_Z", "alpha_R", "alpha_abs_R",
+                 "beta_R", "alpha_Z", "alpha_abs_Z", "beta_Z", "gamma")] + \
+               [(n, _DPTR) for n in ("eR", "varR", "eYR", "varYR", "eABS_YR", "eZ", "varZ", "eYZ", "varYZ", "eABS_YZ", "eC",
+                                     "cost")] + \
+               [("sums", _DPTR), ("nsamples", _LPTR), ("nsamples_missing", _LPTR)]
+
+
+RATIO_NVAR = 20
+
+
+class RatioManager:
+    """parelagmc::ML_BayesRatio_Manager (SL_BayesRatio_Manager for nlevels == 1)."""
+
+    def __init__(self, nlevels, sampler=None, solver=None, G_obs=None, noise=None, callbacks=None, likelihood=None,
+                 eps2=0.001, ratio=0.5, init_nsamples=10, wall_time=True, batch=16, max_rounds=1000):
+        self.lib = load_host_library()
+        self.nlevels = nlevels
+        p = pmc_mlmc_params()
+        self.lib.pmc_mlmc_params_default(C.byref(p))
+        p.eps2, p.ratio, p.init_nsamples = eps2, ratio, init_nsamples
+        p.wall_time, p.batch, p.max_rounds = (1 if wall_time else 0), batch, max_rounds
+        self._keep = []
+        h = _VP()
+        if callbacks is not None:
+            cb, keep = _make_callbacks(callbacks)
+            self._keep += keep
+
+            def _like(user, level, nbatch, k, like, R, Cp):
+                try:
+                    kk = np.ctypeslib.as_array(k, shape=(nbatch, int(callbacks["sample_size"][level])))
+                    l, r, c = likelihood(level, kk)
+                    np.ctypeslib.as_array(like, shape=(nbatch,))[...] = l
+                    np.ctypeslib.as_array(R, shape=(nbatch,))[...] = r
+                    np.ctypeslib.as_array(Cp, shape=(nbatch,))[...] = c
+                    return 0
+                except Exception:   # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            fn = CB_LIKE(_like)
+            self._keep.append(fn)
+            _hcheck(self.lib.pmc_ratio_create_callbacks(nlevels, C.byref(cb), fn, C.byref(p), C.byref(h)))
+        else:
+            g = np.ascontiguousarray(G_obs, np.float64)
+            self._keep += [sampler, solver, g]
+            _hcheck(self.lib.pmc_ratio_create(sampler.ctx.h, sampler.h, solver.h, nlevels, g.ctypes.data_as(_DPTR), len(g),
+                                              float(noise), C.byref(p), C.byref(h)))
+        self.h = h
+
+    def set_farm(self, nranks, rank, reduce=None):
+        if reduce is not None:
+            def _red(buf, n, user):
+                try:
+                    reduce(np.ctypeslib.as_array(buf, shape=(n,)))
+                    return 0
+                except Exception:   # noqa: BLE001
+                    return 1
+            fn = REDUCE_FN(_red)
+        else:
+            fn = REDUCE_FN()
+        self._keep.append(fn)
+        _hcheck(self.lib.pmc_ratio_set_farm(self.h, nranks, rank, fn, None))
+
+    def InitRun(self, nsamples):
+        a = np.ascontiguousarray(nsamples, np.int32)
+        _hcheck(self.lib.pmc_ratio_init_run(self.h, a.ctypes.data_as(C.POINTER(C.c_int32))))
+        return self.result()
+
+    def Run(self):
+        _hcheck(self.lib.pmc_ratio_run(self.h))
+        return self.result()
+
+    def result(self):
+        r = pmc_ratio_result()
+        _hcheck(self.lib.pmc_ratio_result_get(self.h, C.byref(r)))
+        nl = r.nlevels
+        out = {n: getattr(r, n) for n, t in pmc_ratio_result._fields_ if t is C.c_double}
+        for n in ("eR", "varR", "eYR", "varYR", "eABS_YR", "eZ", "varZ", "eYZ", "varYZ", "eABS_YZ", "eC", "cost"):
+            out[n] = np.ctypeslib.as_array(getattr(r, n), shape=(nl,)).copy()
+        out["sums"] = np.ctypeslib.as_array(r.sums, shape=(nl, RATIO_NVAR)).copy()
+        out["nsamples"] = np.ctypeslib.as_array(r.nsamples, shape=(nl,)).copy()
+        out["missing"] = np.ctypeslib.as_array(r.nsamples_missing, shape=(nl,)).copy()
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pmc_ratio_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _make_callbacks(callbacks):
+    """pmc_plugin_callbacks from a dict of Python callables (sample, eval, [solve]) + sizes; returns (struct, keepalive)."""
+    cb = pmc_plugin_callbacks()
+    xs = np.ascontiguousarray(callbacks["xi_size"], np.int32)
+    ss = np.ascontiguousarray(callbacks["sample_size"], np.int32)
+    nd = np.ascontiguousarray(callbacks["ndofs"], np.int32)
+    f_sample, f_eval = callbacks["sample"], callbacks["eval"]
+
+    def _sample(user, level, first_id, nbatch, xi):
+        try:
+            np.ctypeslib.as_array(xi, shape=(nbatch, int(xs[level])))[...] = f_sample(level, int(first_id), nbatch)
+            return 0
+        except Exception:   # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _eval(user, level, xi_level, nbatch, xi, s, init_s, init_level, use_init, emb):
+        try:
+            x = np.ctypeslib.as_array(xi, shape=(nbatch, int(xs[xi_level])))
+            init = np.ctypeslib.as_array(init_s, shape=(nbatch, int(xs[init_level]))) if use_init else None
+            sv, ev = f_eval(level, xi_level, x, init, init_level if use_init else None)
+            np.ctypeslib.as_array(s, shape=(nbatch, int(ss[level])))[...] = sv
+            if emb:
+                np.ctypeslib.as_array(emb, shape=(nbatch, int(xs[level])))[...] = ev
+            return 0
+        except Exception:   # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _solve(user, level, nbatch, k, Qp, Cp):
+        return 1     # the ratio managers never call SolveFwd directly
+
+    cb.sample, cb.eval, cb.solve_fwd = CB_SAMPLE(_sample), CB_EVAL(_eval), CB_SOLVE(_solve)
+    cb.xi_size = xs.ctypes.data_as(C.POINTER(C.c_int32))
+    cb.sample_size = ss.ctypes.data_as(C.POINTER(C.c_int32))
+    cb.ndofs = nd.ctypes.data_as(C.POINTER(C.c_int32))
+    return cb, [xs, ss, nd, cb, cb.sample, cb.eval, cb.solve_fwd]
 
 
 class MLMCManager:

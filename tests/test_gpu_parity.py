@@ -603,3 +603,54 @@ def test_bayesian_observation_operator_and_likelihood(gpu_ctx, hex_hierarchy_sma
     Q3, _ = ds.SolveFwd(0, np.ones((1, dp.levels[0].n_p)))
     assert abs(Q3[0] - 2.0) < 1e-9
     ds.close()
+
+
+def test_ratio_manager_on_device_matches_oracle_loop(gpu_ctx, hex_hierarchy_small):
+    """ML_BayesRatio_Manager::InitRun on the device (two independent prior draws, likelihood / R via the device
+    observation operator) against the same loop with the CPU oracle."""
+    from oracle import ratio_oracle as ro
+    from oracle.bayes_oracle import compute_G, likelihood, observation_functionals
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.rng_oracle import normal_fill
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    h = hex_hierarchy_small
+    sp = build_sampler_problem(h, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    so, do = SamplerOracle(sp), DarcyOracle(dp)
+    Gobs = observation_functionals(h, np.array([[0.5, 0.5, 0.5], [1.4, 1.2, 0.6]]), eps=0.3)
+    noise = 0.05
+    G_obs = compute_G(do, Gobs, 0, so.eval(0, 0, normal_fill(sp.levels[0].n_s, 20261003, 12345, 0))[0])[0]
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT))
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    for lvl in range(2):
+        ds.SetObservations(lvl, Gobs[lvl])
+    mgr = host_api.RatioManager(2, sampler=smp, solver=ds, G_obs=G_obs, noise=noise, wall_time=False, batch=4)
+    ns = [3, 5]
+    r = mgr.InitRun(ns)
+
+    def like_r(lvl, xi_lvl, xi):
+        s = so.eval(lvl, xi_lvl, xi)[0]
+        G, C, Q = compute_G(do, Gobs, lvl, s)
+        l = likelihood(G, G_obs, noise)
+        return l, l * Q, C
+    sums = np.zeros((2, ro.NVAR))
+    for lvl in (1, 0):
+        for i in range(ns[lvl]):
+            zxi = normal_fill(sp.levels[lvl].n_s, 20261003, (1 << 62) + i, lvl)
+            xi = normal_fill(sp.levels[lvl].n_s, 20261003, i, lvl)
+            z, _, c1 = like_r(lvl, lvl, zxi)
+            _, rr, c2 = like_r(lvl, lvl, xi)
+            if lvl == 1:
+                ro.accumulate(sums, lvl, rr, rr, z, z, c1 + c2)
+            else:
+                zc, _, c3 = like_r(1, 0, zxi)
+                _, rc, c4 = like_r(1, 0, xi)
+                ro.accumulate(sums, lvl, rr, rr - rc, z, z - zc, c1 + c2 + c3 + c4)
+    assert np.allclose(r["sums"], sums, rtol=1e-6, atol=1e-9)
+    st = ro.compute(sums, ns, [L.ndofs for L in dp.levels], 1e-3, 0.5)
+    assert r["ratio_estimate"] == pytest.approx(st["ratio_estimate"], rel=1e-6)
+    mgr.close()
+    ds.close()
+    smp.close()

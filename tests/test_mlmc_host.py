@@ -198,3 +198,58 @@ def test_log_replay_resumes_a_run(tmp_path):
     assert np.allclose(b.InitRun([2, 3, 4])["sums"], a2.InitRun([2, 3, 4])["sums"], rtol=1e-13)
     b.close()
     a2.close()
+
+
+# ---------------------------------------------------------------------------------- ratio estimator (Bayesian)
+def _synthetic_likelihood(nl):
+    def like(level, k):
+        g = np.log(k).mean(axis=1)
+        l = np.exp(-0.5 * (g - 0.1) ** 2 / 0.05) * (1.0 + 0.1 * 2.0 ** (-(nl - level)))
+        q = g * 2.0 + 1.0 / (1 + level)
+        return l, l * q, np.full(k.shape[0], float(NDOFS[level]))
+    return like
+
+
+@pytest.mark.parametrize("nl", [1, 2, 3])
+def test_ratio_manager_sums_and_statistics(nl):
+    """ML_BayesRatio_Manager::InitRun / computeNSamplesMSE (src/ML_BayesRatio_Manager.hpp:315-433,560-728) against the
+    Python restatement; two independent prior draws per realization, coarse level evaluated on the same draws."""
+    from oracle import ratio_oracle as ro
+    pl = SyntheticPlugin(nl)
+    like = _synthetic_likelihood(nl)
+    mgr = host_api.RatioManager(nl, callbacks=pl.callbacks(), likelihood=like, wall_time=False, batch=4, eps2=1e-3)
+    ns = [5, 8, 13][:nl]
+    r = mgr.InitRun(ns)
+    sums = np.zeros((nl, ro.NVAR))
+    ref = SyntheticPlugin(nl)
+    for lvl in range(nl - 1, -1, -1):
+        for i in range(ns[lvl]):
+            zxi, xi = ref.sample(lvl, (1 << 62) + i, 1), ref.sample(lvl, i, 1)
+            zl, _, c1 = like(lvl, ref.eval(lvl, lvl, zxi, None, None)[0])
+            _, rr, c2 = like(lvl, ref.eval(lvl, lvl, xi, None, None)[0])
+            ctot, zc, rc = c1[0] + c2[0], 0.0, 0.0
+            if lvl < nl - 1:
+                zcl, _, c3 = like(lvl + 1, ref.eval(lvl + 1, lvl, zxi, None, None)[0])
+                _, rcl, c4 = like(lvl + 1, ref.eval(lvl + 1, lvl, xi, None, None)[0])
+                zc, rc, ctot = zcl[0], rcl[0], ctot + c3[0] + c4[0]
+                ro.accumulate(sums, lvl, rr[0], rr[0] - rc, zl[0], zl[0] - zc, ctot)
+            else:
+                ro.accumulate(sums, lvl, rr[0], rr[0], zl[0], zl[0], ctot)
+    assert np.allclose(r["sums"], sums, rtol=1e-12, atol=1e-14)
+    st = ro.compute(sums, ns, NDOFS[:nl], 1e-3, 0.5)
+    for key in ("eR", "varR", "eYR", "varYR", "eABS_YR", "eZ", "varZ", "eYZ", "varYZ", "eABS_YZ", "eC"):
+        assert np.allclose(r[key], st[key], rtol=1e-10, atol=1e-14), key
+    assert r["ratio_estimate"] == pytest.approx(st["ratio_estimate"], rel=1e-10)
+    assert r["bias2"] == pytest.approx(st["bias2"], rel=1e-9, abs=1e-16)
+    assert r["estimator_variance"] == pytest.approx(st["estimator_variance"], rel=1e-10)
+    assert list(r["missing"]) == st["missing"]
+    mgr.close()
+
+
+def test_ratio_manager_run_converges():
+    pl = SyntheticPlugin(3)
+    mgr = host_api.RatioManager(3, callbacks=pl.callbacks(), likelihood=_synthetic_likelihood(3), wall_time=False, batch=8,
+                                eps2=5e-4, init_nsamples=10)
+    r = mgr.Run()
+    assert r["estimator_variance"] <= 0.5 * 5e-4 and np.isfinite(r["ratio_estimate"])
+    mgr.close()
