@@ -72,6 +72,10 @@ typedef struct pmc_solver_opts {
     int32_t use_graph;        /* replay pairs of MINRES iterations as one hipGraph (default 0; needs check_every 2) */
     double schur_scale;       /* gamma in S = aW + gamma * B diag(M)^-1 B^T (default 1): diag(M) under-/over-estimates M by
                                  the spectrum of diag(M)^-1 M, gamma recentres that interval                              */
+    int32_t mg_coarsening;    /* hierarchy of the Schur-complement V-cycle: 0 = the caller's levels (P of the level structs),
+                                 1 = smoothed aggregation built internally from S itself (what BoomerAMG does in the reference:
+                                 strength-based, robust on stretched cells), 2 = choose 1 when the cells are strongly anisotropic
+                                 (median strongest/weakest coupling per row > 10), else 0 (default 2)                       */
 } pmc_solver_opts;
 
 /* Per-realization solver report; the reference returns -1 for iteration counts

@@ -94,6 +94,7 @@ void pmc_solver_opts_default(pmc_solver_opts* o) {
     o->mg_coarse_ratio = 100.0;
     o->check_every = 2;
     o->schur_scale = 1.0;
+    o->mg_coarsening = 2;
     o->use_graph = 0;   // measured: no gain single-stream (kernels are latency-, not launch-bound), slower with 4 lanes
 }
 

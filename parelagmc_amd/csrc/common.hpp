@@ -86,6 +86,21 @@ std::vector<double> csr_diag(const HostCsr& a);
 // vertical/horizontal assembly of the saddle-point operator [M Bt; B D] (D diagonal or absent)
 HostCsr csr_block2x2(const HostCsr& M, const HostCsr& Bt, const HostCsr& B, const double* d11);
 
+// algebraic coarsening helpers (setup): piecewise-constant aggregation
+HostCsr csr_galerkin_agg(const HostCsr& A, const std::vector<int>& agg, int nc);
+int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg);
+int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg);
+HostCsr prolongator_from_agg(const std::vector<int>& agg, int nc);
+
+HostCsr csr_spgemm(const HostCsr& A, const HostCsr& B);
+double csr_anisotropy(const HostCsr& K);
+struct AmgLevelHost {
+    HostCsr S;   // operator of this level
+    HostCsr P;   // prolongator from the next coarser level (empty on the last level)
+};
+std::vector<AmgLevelHost> sa_hierarchy(const HostCsr& K0, const std::vector<double>& w0, int passes, double theta,
+                                       int min_size, int max_levels);
+
 // ---- SELL-64 device matrix ---------------------------------------------------------------
 // Rows are grouped in slices of 64 (one wavefront); inside a slice entries are stored
 // column-major: slot(s, j, lane) = slice_off[s] + j*64 + lane, so a wavefront's loads of

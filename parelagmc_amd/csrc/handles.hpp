@@ -5,6 +5,9 @@
 namespace pmc {
 
 HostCsr schur_host(const HostCsr& B, const HostCsr& Bt, const std::vector<double>& dM, const double* diag_add);
+// device V-cycle hierarchy (shared values) from a host smoothed-aggregation hierarchy of diag(w) + K
+std::unique_ptr<Multigrid> build_sa_chain(const HostCsr& K, const std::vector<double>& w, const pmc_solver_opts& o,
+                                          hipStream_t st);
 
 struct SamplerLevel {
     int n_u = 0, n_s = 0;
@@ -28,7 +31,9 @@ struct Sampler {
     bool lognormal;
     pmc_solver_opts opts;
     std::vector<SamplerLevel> lv;
-    Multigrid mg;
+    Multigrid mg;                                  // caller's levels: transfers between MC levels + geometric V-cycle
+    std::vector<std::unique_ptr<Multigrid>> amg;   // per MC level: internal smoothed-aggregation hierarchy (if selected)
+    double anisotropy = 1.0;
     MinresWork work;
     DevBuf<double> rhs, sol, tA, tB, cx, cd, stage_in, stage_out, stage_emb;
 

@@ -34,6 +34,47 @@ HostCsr schur_host(const HostCsr& B, const HostCsr& Bt, const std::vector<double
     return S;
 }
 
+std::unique_ptr<Multigrid> build_sa_chain(const HostCsr& K, const std::vector<double>& w, const pmc_solver_opts& o,
+                                          hipStream_t st) {
+    std::vector<AmgLevelHost> lv = sa_hierarchy(K, w, /*passes=*/2, /*theta=*/0.25, /*min_size=*/256, /*max_levels=*/14);
+    std::unique_ptr<Multigrid> mg(new Multigrid());
+    mg->smooth_degree = o.mg_smooth_degree;
+    mg->smooth_ratio = o.mg_smooth_ratio;
+    mg->coarse_degree = o.mg_coarse_degree;
+    mg->coarse_ratio = o.mg_coarse_ratio;
+    mg->L.resize(lv.size());
+    for (size_t l = 0; l < lv.size(); ++l) {
+        MgLevel& m = mg->L[l];
+        const HostCsr& S = lv[l].S;
+        m.n = S.nrows;
+        m.bv = false;
+        sell_build(m.S, S, true, true, st);
+        std::vector<double> dS = csr_diag(S);
+        double lo = 0.0;
+        m.lmax = gershgorin_scaled(S, dS, &lo) * 1.0001;
+        if (lo > 0.0 && (m.lmax / lo <= 3.5 || (m.n <= 4096 && m.lmax / lo <= 40.0))) {
+            m.is_last = true;
+            m.last_ratio = m.lmax / (lo * 0.999);
+            const double sk = std::sqrt(m.last_ratio);
+            const double sig = (sk - 1.0) / (sk + 1.0);
+            m.last_degree = std::min(16, std::max(2, (int)std::ceil(std::log(2.0 / 0.02) / std::log(1.0 / sig))));
+        }
+        for (double& v : dS) v = 1.0 / v;
+        m.dinv.upload(dS, st);
+        m.vals_scaled.upload(sell_scaled_values(m.S, S, dS), st);
+        PMC_HIP(hipStreamSynchronize(st));
+        m.S.h_src.clear(); m.S.h_src.shrink_to_fit();
+        m.S.h_cols.clear(); m.S.h_cols.shrink_to_fit();
+        if (m.is_last) { mg->L.resize(l + 1); break; }
+        if (l + 1 < lv.size()) {
+            sell_build(m.P, lv[l].P, true, false, st);
+            sell_build(m.Pt, csr_transpose(lv[l].P), true, false, st);
+        }
+    }
+    mg->build_tails(st);
+    return mg;
+}
+
 static std::vector<double> l1_inverse(const HostCsr& M) {
     std::vector<double> d(M.nrows);
     for (int i = 0; i < M.nrows; ++i) {
@@ -100,6 +141,15 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
         std::vector<double> dMs(dM);
         for (double& v : dMs) v /= o.schur_scale;
         HostCsr S = schur_host(B, Bt, dMs, aw.data());
+        if (l < n_mc && o.mg_coarsening != 0) {
+            // internal algebraic hierarchy for this Monte Carlo level (always when asked for, on stretched cells in auto mode)
+            HostCsr K = schur_host(B, Bt, dMs, nullptr);
+            if (l == 0) anisotropy = csr_anisotropy(K);
+            if (o.mg_coarsening == 1 || anisotropy > 10.0) {
+                if ((int)amg.size() < n_mc) amg.resize(n_mc);
+                amg[l] = build_sa_chain(K, aw, o, st);
+            }
+        }
         MgLevel& m = mg.L[l];
         m.n = L.n_s;
         m.bv = false;
@@ -252,7 +302,9 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     ChebParams cpM{opts.cheb_degree_M, 1.0, opts.cheb_ratio_M, d.M_scaled.p};
     double* cxp = cx.p;
     double* cdp = cd.p;
-    Multigrid* mgp = &mg;
+    const bool use_amg = level < (int)amg.size() && amg[level];
+    Multigrid* mgp = use_amg ? amg[level].get() : &mg;
+    const int mg_l0 = use_amg ? 0 : level;
     PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z, double* dot_partial) {
         const int flips = cheb_flips(cpM, true);
         double* start = (flips % 2 == 0) ? z : cxp;
@@ -260,14 +312,14 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
         int nblk_u = 0;
         double* res = cheb_apply(s, nb_, Mv, dinvM, false, cpM, r, start, other, cdp, true, dot_partial, &nblk_u);
         if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
-        const int nblk_s = mgp->vcycle(s, nb_, level, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_,
+        const int nblk_s = mgp->vcycle(s, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_,
                                        dot_partial ? dot_partial + (size_t)nblk_u * nb_ : nullptr);
         return nblk_u + nblk_s;   // <r, z> = u-block partials followed by s-block partials
     };
     // only the s-block of the solution is ever read (PDESampler.cpp:526): update only those rows
     GraphHint hint;
     hint.key = hash_mix(hash_mix(0x5a, (uint64_t)level + 1), (uint64_t)nb);
-    hint.sig = hash_ptr(hash_ptr(mg.signature(level), cx.p), cd.p);
+    hint.sig = hash_ptr(hash_ptr(mgp->signature(mg_l0), cx.p), cd.p);
     MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work, n_u, n_s, nullptr, hint);
     if (stats)
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];

@@ -174,3 +174,270 @@ void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st) {
 }
 
 }  // namespace pmc
+
+// ---- algebraic coarsening of the Schur complement (setup, host) ---------------------------------------------------
+namespace pmc {
+
+// C = P^T A P for a piecewise-constant P given as agg[i] = coarse index of fine row i (values 1).
+HostCsr csr_galerkin_agg(const HostCsr& A, const std::vector<int>& agg, int nc) {
+    std::vector<std::vector<std::pair<int, double>>> rows(nc);
+    // accumulate per coarse row with a marker array
+    std::vector<int> marker(nc, -1);
+    std::vector<int> members_ptr(nc + 1, 0);
+    for (int i = 0; i < A.nrows; ++i) members_ptr[agg[i] + 1]++;
+    for (int c = 0; c < nc; ++c) members_ptr[c + 1] += members_ptr[c];
+    std::vector<int> members(A.nrows), fill(members_ptr.begin(), members_ptr.end() - 1);
+    for (int i = 0; i < A.nrows; ++i) members[fill[agg[i]]++] = i;
+    HostCsr C;
+    C.nrows = C.ncols = nc;
+    C.rowptr.assign(nc + 1, 0);
+    std::vector<std::pair<int, double>> row;
+    for (int c = 0; c < nc; ++c) {
+        row.clear();
+        for (int m = members_ptr[c]; m < members_ptr[c + 1]; ++m) {
+            const int i = members[m];
+            for (int p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) {
+                const int cj = agg[A.colind[p]];
+                if (marker[cj] < 0) { marker[cj] = (int)row.size(); row.emplace_back(cj, A.vals[p]); }
+                else row[marker[cj]].second += A.vals[p];
+            }
+        }
+        std::sort(row.begin(), row.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        for (auto& cv : row) { C.colind.push_back(cv.first); C.vals.push_back(cv.second); marker[cv.first] = -1; }
+        C.rowptr[c + 1] = (int)C.colind.size();
+    }
+    return C;
+}
+
+// One pass of pairwise matching along the strongest negative coupling (Notay-style): every unmatched row joins its
+// strongest unmatched neighbour j with -a_ij >= theta * max_k(-a_ik), otherwise it stays alone.  Returns the number of
+// aggregates; agg[i] = aggregate of row i.  On anisotropic operators this coarsens along the strong direction only.
+int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg) {
+    const int n = A.nrows;
+    agg.assign(n, -1);
+    // visit rows by increasing number of strong neighbours... plain index order keeps the mesh ordering's locality
+    int nc = 0;
+    for (int i = 0; i < n; ++i) {
+        if (agg[i] >= 0) continue;
+        double smax = 0.0;
+        for (int p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p)
+            if (A.colind[p] != i) smax = std::max(smax, -A.vals[p]);
+        int best = -1;
+        double bval = 0.0;
+        for (int p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) {
+            const int j = A.colind[p];
+            if (j == i || agg[j] >= 0) continue;
+            const double s = -A.vals[p];
+            if (s >= theta * smax && s > bval) { bval = s; best = j; }
+        }
+        agg[i] = nc;
+        if (best >= 0) agg[best] = nc;
+        ++nc;
+    }
+    return nc;
+}
+
+// `passes` rounds of pairwise matching (aggregates of up to 2^passes rows).  K = the coupling part of the operator that
+// steers the matching; returns agg and the number of aggregates.
+int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg) {
+    std::vector<int> cur;
+    int nc = pairwise_match(K, theta, cur);
+    agg = cur;
+    HostCsr Kc = K;
+    for (int pass = 1; pass < passes; ++pass) {
+        Kc = csr_galerkin_agg(Kc, cur, nc);
+        std::vector<int> nxt;
+        const int nc2 = pairwise_match(Kc, theta, nxt);
+        if (nc2 == nc) break;
+        for (int& a : agg) a = nxt[a];
+        cur = nxt;
+        nc = nc2;
+    }
+    return nc;
+}
+
+HostCsr prolongator_from_agg(const std::vector<int>& agg, int nc) {
+    HostCsr P;
+    P.nrows = (int)agg.size();
+    P.ncols = nc;
+    P.rowptr.resize(P.nrows + 1);
+    P.colind.resize(P.nrows);
+    P.vals.assign(P.nrows, 1.0);
+    for (int i = 0; i < P.nrows; ++i) { P.rowptr[i] = i; P.colind[i] = agg[i]; }
+    P.rowptr[P.nrows] = P.nrows;
+    return P;
+}
+
+}  // namespace pmc
+
+// ---- smoothed-aggregation hierarchy for the Schur complement (setup, host) -------------------------------------------
+namespace pmc {
+
+HostCsr csr_spgemm(const HostCsr& A, const HostCsr& B) {
+    PMC_REQUIRE(A.ncols == B.nrows, "spgemm: shape mismatch");
+    HostCsr C;
+    C.nrows = A.nrows;
+    C.ncols = B.ncols;
+    C.rowptr.assign(A.nrows + 1, 0);
+    std::vector<int> marker(B.ncols, -1);
+    std::vector<std::pair<int, double>> row;
+    for (int i = 0; i < A.nrows; ++i) {
+        row.clear();
+        for (int p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) {
+            const int k = A.colind[p];
+            const double a = A.vals[p];
+            for (int q = B.rowptr[k]; q < B.rowptr[k + 1]; ++q) {
+                const int j = B.colind[q];
+                if (marker[j] < 0) { marker[j] = (int)row.size(); row.emplace_back(j, a * B.vals[q]); }
+                else row[marker[j]].second += a * B.vals[q];
+            }
+        }
+        std::sort(row.begin(), row.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        for (auto& cv : row) { C.colind.push_back(cv.first); C.vals.push_back(cv.second); marker[cv.first] = -1; }
+        PMC_REQUIRE(C.colind.size() < (size_t)2147483647, "spgemm: result exceeds int32 nonzeros");
+        C.rowptr[i + 1] = (int)C.colind.size();
+    }
+    return C;
+}
+
+static HostCsr csr_add_diag(const HostCsr& K, const std::vector<double>& w) {
+    if (w.empty()) return K;
+    HostCsr S = K;
+    for (int i = 0; i < S.nrows; ++i) {
+        bool found = false;
+        for (int p = S.rowptr[i]; p < S.rowptr[i + 1]; ++p)
+            if (S.colind[p] == i) { S.vals[p] += w[i]; found = true; }
+        PMC_REQUIRE(found, "Schur coupling matrix lacks a diagonal entry");
+    }
+    return S;
+}
+
+// median over rows of (largest / smallest) nonzero off-diagonal magnitude: ~1 for isotropic meshes, >> 1 for
+// stretched cells
+double csr_anisotropy(const HostCsr& K) {
+    std::vector<double> ratio;
+    ratio.reserve(K.nrows);
+    for (int i = 0; i < K.nrows; ++i) {
+        double mx = 0.0, mn = 1e300;
+        for (int p = K.rowptr[i]; p < K.rowptr[i + 1]; ++p) {
+            if (K.colind[p] == i) continue;
+            const double a = std::fabs(K.vals[p]);
+            if (a == 0.0) continue;
+            mx = std::max(mx, a);
+            mn = std::min(mn, a);
+        }
+        if (mx > 0.0) ratio.push_back(mx / mn);
+    }
+    if (ratio.empty()) return 1.0;
+    std::nth_element(ratio.begin(), ratio.begin() + ratio.size() / 2, ratio.end());
+    return ratio[ratio.size() / 2];
+}
+
+// Smoothed aggregation (Vanek, Mandel, Brezina) on S = diag(w) + K: pairwise-matching aggregates of up to 2^passes rows
+// along strong couplings, tentative piecewise-constant prolongator smoothed by one damped Jacobi step with the
+// strength-filtered operator, Galerkin coarse operators.  K and diag(w) are coarsened separately so the caller can
+// keep treating them differently.  levels[0] holds the input operator.
+std::vector<AmgLevelHost> sa_hierarchy(const HostCsr& K0, const std::vector<double>& w0, int passes, double theta,
+                                       int min_size, int max_levels) {
+    std::vector<AmgLevelHost> out;
+    HostCsr K = K0;
+    HostCsr Wm;           // mass part as a general matrix on coarse levels (diagonal on level 0)
+    bool w_is_diag = true;
+    std::vector<double> w = w0;
+    for (int lvl = 0;; ++lvl) {
+        AmgLevelHost L;
+        if (w_is_diag) {
+            L.S = csr_add_diag(K, w);
+        } else {
+            // S = Wm + K: union pattern via spgemm-free merge (both sorted)
+            HostCsr S;
+            S.nrows = S.ncols = K.nrows;
+            S.rowptr.assign(K.nrows + 1, 0);
+            for (int i = 0; i < K.nrows; ++i) {
+                int a = K.rowptr[i], b = Wm.rowptr[i];
+                const int ae = K.rowptr[i + 1], be = Wm.rowptr[i + 1];
+                while (a < ae || b < be) {
+                    const int ca = a < ae ? K.colind[a] : 2147483647, cb = b < be ? Wm.colind[b] : 2147483647;
+                    if (ca == cb) { S.colind.push_back(ca); S.vals.push_back(K.vals[a++] + Wm.vals[b++]); }
+                    else if (ca < cb) { S.colind.push_back(ca); S.vals.push_back(K.vals[a++]); }
+                    else { S.colind.push_back(cb); S.vals.push_back(Wm.vals[b++]); }
+                }
+                S.rowptr[i + 1] = (int)S.colind.size();
+            }
+            L.S = std::move(S);
+        }
+        const int n = L.S.nrows;
+        if (n <= min_size || lvl + 1 >= max_levels) { out.push_back(std::move(L)); break; }
+        std::vector<int> agg;
+        const int nc = aggregate_rows(K, passes, theta, agg);
+        if (nc * 10 > n * 9 || nc < 1) { out.push_back(std::move(L)); break; }      // coarsening stalled
+        // strength-filtered operator (weak off-diagonals lumped onto the diagonal), damped-Jacobi smoothing of P_tent
+        const HostCsr& S = L.S;
+        std::vector<double> df(n, 0.0), rowabs(n, 0.0);
+        std::vector<char> keep(S.colind.size(), 1);
+        for (int i = 0; i < n; ++i) {
+            double smax = 0.0;
+            for (int p = S.rowptr[i]; p < S.rowptr[i + 1]; ++p)
+                if (S.colind[p] != i) smax = std::max(smax, -S.vals[p]);
+            for (int p = S.rowptr[i]; p < S.rowptr[i + 1]; ++p) {
+                if (S.colind[p] == i) { df[i] += S.vals[p]; continue; }
+                if (-S.vals[p] < theta * smax) { keep[p] = 0; df[i] += S.vals[p]; }
+            }
+        }
+        double lam = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double s = std::fabs(df[i]);
+            for (int p = S.rowptr[i]; p < S.rowptr[i + 1]; ++p)
+                if (S.colind[p] != i && keep[p]) s += std::fabs(S.vals[p]);
+            PMC_REQUIRE(df[i] > 0.0, "smoothed aggregation: filtered operator lost its positive diagonal");
+            lam = std::max(lam, s / df[i]);
+        }
+        const double omega = 4.0 / (3.0 * lam);
+        HostCsr P;
+        P.nrows = n;
+        P.ncols = nc;
+        P.rowptr.assign(n + 1, 0);
+        {
+            std::vector<int> marker(nc, -1);
+            std::vector<std::pair<int, double>> row;
+            for (int i = 0; i < n; ++i) {
+                row.clear();
+                auto add = [&](int c, double v) {
+                    if (marker[c] < 0) { marker[c] = (int)row.size(); row.emplace_back(c, v); }
+                    else row[marker[c]].second += v;
+                };
+                add(agg[i], 1.0 - omega);            // (I - omega D_f^-1 S_f): diagonal part = 1 - omega * df/df
+                for (int p = S.rowptr[i]; p < S.rowptr[i + 1]; ++p)
+                    if (S.colind[p] != i && keep[p]) add(agg[S.colind[p]], -omega * S.vals[p] / df[i]);
+                std::sort(row.begin(), row.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+                for (auto& cv : row) { P.colind.push_back(cv.first); P.vals.push_back(cv.second); marker[cv.first] = -1; }
+                P.rowptr[i + 1] = (int)P.colind.size();
+            }
+        }
+        const HostCsr Pt = csr_transpose(P);
+        HostCsr Kc = csr_spgemm(Pt, csr_spgemm(K, P));
+        HostCsr Wc;
+        if (w_is_diag) {
+            if (!w.empty()) {
+                HostCsr WP = P;
+                for (int i = 0; i < n; ++i)
+                    for (int p = WP.rowptr[i]; p < WP.rowptr[i + 1]; ++p) WP.vals[p] *= w[i];
+                Wc = csr_spgemm(Pt, WP);
+            }
+        } else {
+            Wc = csr_spgemm(Pt, csr_spgemm(Wm, P));
+        }
+        L.P = std::move(P);
+        out.push_back(std::move(L));
+        K = std::move(Kc);
+        if (!w.empty() || !w_is_diag) {
+            Wm = std::move(Wc);
+            w_is_diag = false;
+            w.clear();
+            if (Wm.nrows == 0) { w_is_diag = true; }     // no mass part at all (Darcy)
+        }
+    }
+    return out;
+}
+
+}  // namespace pmc
