@@ -87,6 +87,79 @@ HostCsr drop_columns(const HostCsr& B, const unsigned char* mask) {
     return o;
 }
 
+std::vector<int> diag_slots(const Sell& S, const HostCsr& pat) {
+    std::vector<int> ds(pat.nrows, -1);
+    std::vector<int> n2s = nnz_to_slot(S, pat.nnz());
+    for (int e = 0; e < pat.nrows; ++e)
+        for (int p = pat.rowptr[e]; p < pat.rowptr[e + 1]; ++p)
+            if (pat.colind[p] == e) ds[e] = n2s[p];
+    for (int v : ds) PMC_REQUIRE(v >= 0, "darcy: Schur pattern lacks a diagonal entry");
+    return ds;
+}
+
+// chain of one MC level: own Schur lists `own` (over diag(M)), prolongators from the k == 1 operator K1
+std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, const pmc_solver_opts& o, hipStream_t st) {
+    std::vector<AmgLevelHost> lvh = sa_hierarchy(K1, std::vector<double>(), /*passes=*/2, /*theta=*/0.25,
+                                                 /*min_size=*/256, /*max_levels=*/14);
+    std::unique_ptr<DarcyChain> ch(new DarcyChain());
+    Multigrid& mg = ch->mg;
+    mg.smooth_degree = o.mg_smooth_degree;
+    mg.smooth_ratio = o.mg_smooth_ratio;
+    mg.coarse_degree = o.mg_coarse_degree;
+    mg.coarse_ratio = o.mg_coarse_ratio;
+    const int nl = (int)lvh.size();
+    mg.L.resize(nl);
+    ch->cl.resize(nl);
+    Symbolic sym = own;                      // lists of the current level; idx refers to the source array of its refresh
+    for (int j = 0; j < nl; ++j) {
+        MgLevel& m = mg.L[j];
+        DarcyChainLevel& c = ch->cl[j];
+        const HostCsr& pat = sym.pat;
+        m.n = pat.nrows;
+        m.bv = true;
+        m.lmax = 1.0;                        // dinv carries the per-realization Gershgorin bound (k::gersh_scale_bv)
+        sell_build(m.S, pat, false, true, st);
+        m.vals_bv.alloc((size_t)m.S.nslots * kMaxBatch);
+        m.vals_scaled.alloc((size_t)m.S.nslots * kMaxBatch);
+        m.dinv.alloc((size_t)m.n * kMaxBatch);
+        {
+            std::vector<int> ptr, idx;
+            std::vector<double> w;
+            lists_to_slots(m.S, sym, ptr, idx, w);
+            c.ptr.upload(ptr, st);
+            c.idx.upload(idx, st);
+            c.w.upload(w, st);
+            c.diag_slot.upload(diag_slots(m.S, pat), st);
+        }
+        PMC_HIP(hipStreamSynchronize(st));
+        if (j + 1 == nl) break;
+        const HostCsr& P = lvh[j].P;
+        PMC_REQUIRE(P.nrows == m.n, "darcy: aggregation prolongator of the wrong height");
+        sell_build(m.P, P, true, false, st);
+        sell_build(m.Pt, csr_transpose(P), true, false, st);
+        // S_{j+1} = P^T S_j P as lists over the SELL slots of S_j
+        std::vector<int> n2s = nnz_to_slot(m.S, pat.nnz());
+        std::vector<Triple> tr;
+        tr.reserve((size_t)pat.nnz() * 4);
+        for (int e = 0; e < pat.nrows; ++e)
+            for (int p = pat.rowptr[e]; p < pat.rowptr[e + 1]; ++p) {
+                const int e2 = pat.colind[p];
+                for (int a = P.rowptr[e]; a < P.rowptr[e + 1]; ++a)
+                    for (int b = P.rowptr[e2]; b < P.rowptr[e2 + 1]; ++b)
+                        tr.push_back({P.colind[a], P.colind[b], n2s[p], P.vals[a] * P.vals[b]});
+            }
+        Symbolic next = build_symbolic(P.ncols, tr);
+        PMC_HIP(hipStreamSynchronize(st));
+        sym = std::move(next);
+    }
+    for (int j = 0; j < nl; ++j) {
+        mg.L[j].S.h_src.clear(); mg.L[j].S.h_src.shrink_to_fit();
+        mg.L[j].S.h_cols.clear(); mg.L[j].S.h_cols.shrink_to_fit();
+    }
+    mg.build_tails(st);
+    return ch;
+}
+
 }  // namespace
 
 Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kdiv, const pmc_solver_opts& o)
@@ -175,6 +248,23 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
             }
         }
         schur[l] = build_symbolic(L.n_p, tr);
+        if (l < n_mc && o.mg_coarsening != 0) {
+            // algebraic hierarchy of this MC level, prolongators from the k == 1 operator (c(1) = 1 either way)
+            std::vector<double> dM1(L.n_u, 1.0);
+            for (int i = 0; i < Mp.nrows; ++i)
+                for (int p = Mp.rowptr[i]; p < Mp.rowptr[i + 1]; ++p)
+                    if (Mp.colind[p] == i) {
+                        double sdiag = 0.0;
+                        for (int t = L.c_ptr[p]; t < L.c_ptr[p + 1]; ++t) sdiag += L.c_val[t];
+                        dM1[i] = sdiag;
+                    }
+            HostCsr K1 = schur_host(B, Bt, dM1, nullptr);
+            if (l == 0) anisotropy = csr_anisotropy(K1);
+            if (o.mg_coarsening == 1 || anisotropy > 10.0) {
+                if ((int)chains.size() < n_mc) chains.resize(n_mc);
+                chains[l] = build_chain(schur[l], K1, o, st);
+            }
+        }
         if (l + 1 < nlevels) {
             Pl[l] = csr_from_c(L.P, true, "darcy P");
             PMC_REQUIRE(Pl[l].nrows == L.n_p && Pl[l].ncols == in[l + 1].n_p, "darcy P: wrong shape");
@@ -246,16 +336,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
             d.s_w.upload(w, st);
         }
         // diagonal slots
-        {
-            std::vector<int> ds(m.n, -1);
-            const HostCsr& pat = pattern[l];
-            std::vector<int> n2s = nnz_to_slot(m.S, pat.nnz());
-            for (int e = 0; e < pat.nrows; ++e)
-                for (int p = pat.rowptr[e]; p < pat.rowptr[e + 1]; ++p)
-                    if (pat.colind[p] == e) ds[e] = n2s[p];
-            for (int v : ds) PMC_REQUIRE(v >= 0, "darcy: Schur pattern lacks a diagonal entry");
-            d.s_diag_slot.upload(ds, st);
-        }
+        d.s_diag_slot.upload(diag_slots(m.S, pattern[l]), st);
         if (l + 1 < nlevels) {
             HostCsr Pt = csr_transpose(Pl[l]);
             sell_build(m.P, Pl[l], true, false, st);
@@ -382,9 +463,21 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
                       d.rhs_u0.p, d.mvals.p, d.diagM.p, d.l1invM.p, d.rhs_bc.p);
     k::broadcast(st, nb, n_p, d.rhs_p.p, d.rhs_bc.p + (size_t)n_u * nb);
     // K14: Schur complement values on the level hierarchy
-    {
+    DarcyChain* chain = (level < (int)chains.size()) ? chains[level].get() : nullptr;
+    k::scale_cols_bv(st, nb, d.M.nslots, d.M.cols.p, d.mvals.p, d.l1invM.p, d.mvals_scaled.p);
+    if (chain) {
+        gwork.ensure(kMaxBatch);
+        for (size_t j = 0; j < chain->cl.size(); ++j) {
+            MgLevel& m = chain->mg.L[j];
+            DarcyChainLevel& c = chain->cl[j];
+            const double* src = (j == 0) ? d.diagM.p : chain->mg.L[j - 1].vals_bv.p;
+            k::refresh(st, nb, m.S.nslots, c.ptr.p, c.idx.p, c.w.p, src, j == 0, m.vals_bv.p);
+            k::diag_inv(st, nb, m.n, c.diag_slot.p, m.vals_bv.p, m.dinv.p);
+            k::gersh_scale_bv(st, nb, view_bv(m.S, m.vals_bv.p), m.dinv.p, gwork.p);
+            k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
+        }
+    } else {
         MgLevel& m = mg.L[level];
-        k::scale_cols_bv(st, nb, d.M.nslots, d.M.cols.p, d.mvals.p, d.l1invM.p, d.mvals_scaled.p);
         k::refresh(st, nb, m.S.nslots, d.s_ptr.p, d.s_idx.p, d.s_w.p, d.diagM.p, true, m.vals_bv.p);
         k::diag_inv(st, nb, m.n, d.s_diag_slot.p, m.vals_bv.p, m.dinv.p);
         k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
@@ -414,7 +507,8 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     const double* l1 = d.l1invM.p;
     double* cxp = cx.p;
     double* cdp = cd.p;
-    Multigrid* mgp = &mg;
+    Multigrid* mgp = chain ? &chain->mg : &mg;
+    const int mg_l0 = chain ? 0 : level;
     PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z, double* dot_partial) {
         const int flips = cheb_flips(cpM, true);
         double* start = (flips % 2 == 0) ? z : cxp;
@@ -422,7 +516,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
         int nblk_u = 0;
         double* res = cheb_apply(s, nb_, Mv, l1, true, cpM, r, start, other, cdp, true, dot_partial, &nblk_u);
         if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
-        const int nblk_s = mgp->vcycle(s, nb_, level, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_,
+        const int nblk_s = mgp->vcycle(s, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_,
                                        dot_partial ? dot_partial + (size_t)nblk_u * nb_ : nullptr);
         return nblk_u + nblk_s;
     };
@@ -436,7 +530,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     sol_compact.ensure((size_t)std::max(ncomp, 1) * nb);
     GraphHint hint;
     hint.key = hash_mix(hash_mix(hash_mix(0xda, (uint64_t)level + 1), (uint64_t)nb), gmode ? 3 : (compact ? 1 : 2));
-    hint.sig = mg.signature(level);
+    hint.sig = mgp->signature(mg_l0);
     for (const void* p : {(const void*)cx.p, (const void*)cd.p, (const void*)d.mvals.p, (const void*)d.mvals_scaled.p,
                           (const void*)d.l1invM.p, (const void*)d.rhs_bc.p})
         hint.sig = hash_ptr(hint.sig, p);

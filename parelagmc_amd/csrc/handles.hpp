@@ -83,6 +83,18 @@ struct DarcyLevel {
     DevBuf<double> g_obs_w, g_norm;
 };
 
+// Internal algebraic hierarchy of one Monte Carlo level (mg_coarsening): smoothed-aggregation prolongators frozen at
+// k == 1, operators S_0(k) = B diag(M(k))^-1 B^T and S_{j+1}(k) = P_j^T S_j(k) P_j refreshed per realization on fixed
+// patterns through contribution lists (the same refresh kernel as the geometric hierarchy).
+struct DarcyChainLevel {
+    DevBuf<int> ptr, idx, diag_slot;   // per SELL slot: list into diag(M) (level 0, reciprocal) or the finer level's slots
+    DevBuf<double> w;
+};
+struct DarcyChain {
+    Multigrid mg;
+    std::vector<DarcyChainLevel> cl;
+};
+
 struct Darcy {
     Ctx& ctx;
     int nlevels, n_mc;
@@ -90,6 +102,9 @@ struct Darcy {
     pmc_solver_opts opts;
     std::vector<DarcyLevel> lv;
     Multigrid mg;                    // batched values
+    std::vector<std::unique_ptr<DarcyChain>> chains;   // per MC level, empty unless algebraic coarsening is selected
+    double anisotropy = 1.0;
+    DevBuf<double> gwork;
     MinresWork work;
     DevBuf<double> sol, sol_compact, cx, cd, stage_k, stage_sol, qpartial, qout, gtmp, gout;
     void set_observations(int level, const pmc_csr* Gobs);

@@ -943,6 +943,52 @@ __global__ __launch_bounds__(kBlock) void diag_inv_kernel(int n, const int* __re
     store_row<NB>(dinv + (size_t)row * NB, v);
 }
 
+// Per-realization Gershgorin bound of D^-1 S on batched values:  g[k] = max_i dinv[i][k] * sum_j |S_ij(k)|  (atomic max
+// on the bit pattern of the non-negative doubles; g zeroed by the launcher), then dinv[i][k] /= 1.0001 g[k] so that the
+// Chebyshev smoothers run on (0, 1] for every realization of the batch.
+template <int NB>
+__global__ __launch_bounds__(kBlock) void gersh_bv_kernel(int nrows, const int* __restrict__ slice_off,
+                                                          const double* __restrict__ vals, const double* __restrict__ dinv,
+                                                          unsigned long long* __restrict__ g) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    double acc[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc[k] = 0.0;
+    if (row < nrows) {
+        const int slice = row >> 6, lane = row & 63;
+        const int off = slice_off[slice];
+        const int width = (slice_off[slice + 1] - off) >> 6;
+        for (int j = 0; j < width; ++j) {
+            double v[NB];
+            load_row<NB>(vals + ((size_t)off + (size_t)j * 64 + lane) * NB, v);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) acc[k] += fabs(v[k]);
+        }
+        double d[NB];
+        load_row<NB>(dinv + (size_t)row * NB, d);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc[k] *= fabs(d[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        double v = acc[k];
+        for (int o = kWave / 2; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, kWave));
+        if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(g + k, (unsigned long long)__double_as_longlong(v));
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(kBlock) void gersh_scale_kernel(int nrows, const unsigned long long* __restrict__ g,
+                                                             double* __restrict__ dinv) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nrows) return;
+    double d[NB];
+    load_row<NB>(dinv + (size_t)row * NB, d);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) d[k] /= 1.0001 * __longlong_as_double((long long)g[k]);
+    store_row<NB>(dinv + (size_t)row * NB, d);
+}
+
 // out[k] = sum_b partial[b*nb+k]   (single block)
 __global__ __launch_bounds__(kScalBlock) void reduce_final_kernel(const double* __restrict__ partial, int nblocks, int nb,
                                                               double* __restrict__ out) {
@@ -1378,6 +1424,17 @@ void darcy_assemble(hipStream_t st, int nb, const SellView& Mp, const int* slot_
                                                        c_val, coef, ess, ess_data, rhs0, mvals, diag, l1inv, rhs_bc);
     });
     check_launch();
+}
+
+void gersh_scale_bv(hipStream_t st, int nb, const SellView& S, double* dinv, double* gwork) {
+    unsigned long long* g = reinterpret_cast<unsigned long long*>(gwork);
+    PMC_HIP(hipMemsetAsync(g, 0, sizeof(unsigned long long) * kMaxBatch, st));
+    const int grid = (S.nrows + kBlock - 1) / kBlock;
+    PMC_DISPATCH_NB(nb, {
+        gersh_bv_kernel<NB><<<grid, kBlock, 0, st>>>(S.nrows, S.slice_off, S.vals, dinv, g);
+        gersh_scale_kernel<NB><<<grid, kBlock, 0, st>>>(S.nrows, g, dinv);
+    });
+    PMC_HIP(hipGetLastError());
 }
 
 void refresh(hipStream_t st, int nb, int64_t nslots, const int* ptr, const int* idx, const double* w, const double* src,

@@ -91,6 +91,9 @@ void darcy_coef(hipStream_t st, int nb, int n, const double* kfield, bool k_divi
 void darcy_assemble(hipStream_t st, int nb, const SellView& Mp, const int* slot_src, const int* c_ptr, const int* c_elem,
                     const double* c_val, const double* coef, const unsigned char* ess, const double* ess_data,
                     const double* rhs0, double* mvals, double* diag, double* l1inv, double* rhs_bc);
+// per-realization Gershgorin scaling of dinv (batched values): afterwards spec(diag(dinv) S) lies in (0, 1] for every
+// realization; gwork = kMaxBatch doubles of scratch
+void gersh_scale_bv(hipStream_t st, int nb, const SellView& S, double* dinv, double* gwork);
 void refresh(hipStream_t st, int nb, int64_t nslots, const int* ptr, const int* idx, const double* w, const double* src,
              bool recip, double* out);
 void diag_inv(hipStream_t st, int nb, int n, const int* diag_slot, const double* vals, double* dinv);

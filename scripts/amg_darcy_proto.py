@@ -1,0 +1,89 @@
+"""CPU prototype: Schur-block V-cycle variants for the Darcy saddle system on a stretched (SPE10-shaped) box with a
+log-normal coefficient.  Development aid for the algebraic coarsening option of the Darcy solver."""
+import os
+import sys
+import numpy as np
+import scipy.sparse as sp
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from amg_proto import MG, aggregate, cheb, level_tuple, my_minres  # noqa: E402
+from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy  # noqa: E402
+from oracle.darcy_oracle import DarcyOracle  # noqa: E402
+
+
+def sa_prolongator(S, agg, nc, theta=0.25):
+    P = sp.csr_matrix((np.ones(len(agg)), (np.arange(len(agg)), agg)), shape=(len(agg), nc))
+    Sc = S.tocoo()
+    off = Sc.row != Sc.col
+    rowmax = np.zeros(S.shape[0]); np.maximum.at(rowmax, Sc.row[off], -Sc.data[off])
+    weak = off & (-Sc.data < theta * rowmax[Sc.row])
+    lump = np.zeros(S.shape[0]); np.add.at(lump, Sc.row[weak], Sc.data[weak])
+    data = Sc.data.copy(); data[weak] = 0.0
+    Sf = sp.csr_matrix((data, (Sc.row, Sc.col)), shape=S.shape); Sf.eliminate_zeros()
+    Sf = Sf + sp.diags(lump)
+    df = Sf.diagonal()
+    lam = (abs(Sf) @ np.ones(S.shape[0]) / df).max()
+    return (P - (4.0 / (3.0 * lam)) * (sp.diags(1.0 / df) @ (Sf @ P))).tocsr()
+
+
+def main():
+    nref = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    sigma = float(sys.argv[2]) if len(sys.argv) > 2 else 1.8
+    h = build_hierarchy(box_mesh([7, 27, 10], [1200.0, 2200.0, 170.0], "hex"), nref)
+    dp = build_darcy_problem(h, [1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0], n_mc_levels=1)
+    orc = DarcyOracle(dp)
+    L = dp.levels[0]
+    rng = np.random.default_rng(1)
+    # rough log-normal field (cellwise iid is harsher than the Matern draws)
+    k = np.exp(sigma * rng.standard_normal(L.n_p))
+    for kname, kk in (("k=1", np.ones(L.n_p)), (f"lognormal sigma={sigma}", k)):
+        A, rhs = orc.assemble(0, kk)
+        n_u = L.n_u
+        A = A.tocsr()
+        M = A[:n_u, :n_u].tocsr(); B = A[n_u:, :n_u].tocsr()
+        l1 = 1.0 / (abs(M) @ np.ones(n_u))
+        S = (B @ sp.diags(1.0 / M.diagonal()) @ B.T).tocsr()
+        A1, _ = orc.assemble(0, np.ones(L.n_p))
+        A1 = A1.tocsr(); M1 = A1[:n_u, :n_u]; B1 = A1[n_u:, :n_u]
+        S1 = (B1 @ sp.diags(1.0 / M1.diagonal()) @ B1.T).tocsr()
+        variants = {}
+        # geometric Galerkin 1/2 P^T S P
+        geo = []
+        Sc = S
+        for lv in dp.levels[:-1]:
+            geo.append(level_tuple(Sc, lv.P))
+            Sc = (0.5 * lv.P.T @ Sc @ lv.P).tocsr()
+        geo.append(level_tuple(Sc, None))
+        variants["geometric"] = geo
+        for mode in ("plain(k=1)", "SA(k=1)", "SA(k)"):
+            lvls = []
+            Sc, Sref = S, (S if mode == "SA(k)" else S1)
+            while True:
+                if Sc.shape[0] <= 200 or len(lvls) >= 12:
+                    lvls.append(level_tuple(Sc, None)); break
+                agg, nc = aggregate(Sref, 2)
+                if mode.startswith("plain"):
+                    P = sp.csr_matrix((np.ones(len(agg)), (np.arange(len(agg)), agg)), shape=(len(agg), nc))
+                else:
+                    P = sa_prolongator(Sref, agg, nc)
+                if len(lvls) == 0:
+                    T = (Sc @ P).tocsr()
+                    print(f"  {mode}: n {Sc.shape[0]} -> {nc}, nnz/row P {P.nnz / P.shape[0]:.1f}  S*P {T.nnz / T.shape[0]:.1f}  "
+                          f"PtSP {(P.T @ T).nnz / nc:.1f}")
+                lvls.append(level_tuple(Sc, P))
+                Sc = (P.T @ Sc @ P).tocsr()
+                Sref = (P.T @ Sref @ P).tocsr()
+            variants[mode] = lvls
+        for name, lv in variants.items():
+            mg = MG(lv)
+
+            def prec(r):
+                z = np.empty_like(r)
+                z[:n_u] = cheb(M, l1, 1.0, 8.0, 2, r[:n_u])
+                z[n_u:] = mg.v(0, r[n_u:])
+                return z
+            x, nit = my_minres(A, prec, rhs, 1e-6, 400)
+            print(f"{kname} {name}: iterations {nit} resid {np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs):.2e}", flush=True)
+
+
+main()

@@ -200,4 +200,5 @@ def main():
         print(f"{name}: minres iterations {nit} resid {np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs):.2e}", flush=True)
 
 
-main()
+if __name__ == "__main__":
+    main()

@@ -12,14 +12,18 @@ print("dofs", [L.ndofs for L in dp.levels], flush=True)
 ctx = capi.Context(0, seed=3)
 smp0 = capi.PDESampler(ctx, sp, opts=capi.solver_opts(mg_coarsening=0))
 smp = capi.PDESampler(ctx, sp, opts=capi.solver_opts(mg_coarsening=1))
-ds = capi.DarcySolver(ctx, dp)
+ds0 = capi.DarcySolver(ctx, dp, opts=capi.solver_opts(mg_coarsening=0))
+ds = capi.DarcySolver(ctx, dp, opts=capi.solver_opts(mg_coarsening=1))
 for lvl in range(min(3, nref + 1)):
     xi = smp.Sample(lvl, first_id=0, nbatch=4)
     s0, st0 = smp0.Eval(lvl, xi, return_stats=True)
     s, st = smp.Eval(lvl, xi, return_stats=True)
     print(f"L{lvl}: geometric iters {[t[0] for t in st0]}  SA iters {[t[0] for t in st]}  rel diff "
           f"{np.abs(np.log(s) - np.log(s0)).max() / np.abs(np.log(s0)).max():.2e}", flush=True)
+    Qg, _, stg = ds0.SolveFwd(lvl, s, return_stats=True)
     Q, C, st2 = ds.SolveFwd(lvl, s, return_stats=True)
+    print(f"L{lvl}: darcy geometric iters {[t[0] for t in stg]} conv {[t[1] for t in stg]} Q {Qg}", flush=True)
+    print(f"L{lvl}: darcy SA        iters {[t[0] for t in st2]} conv {[t[1] for t in st2]} Q {Q}", flush=True)
     Q1, _, st3 = ds.SolveFwd(lvl, np.ones((1, dp.levels[lvl].n_p)), return_stats=True)
     print(f"L{lvl}: sampler iters {[t[0] for t in st]} conv {[t[1] for t in st]} | darcy iters {[t[0] for t in st2]} conv {[t[1] for t in st2]} "
           f"| k=1: Q={Q1[0]:.6f} (exact {1200 * 170 / 2200:.6f}) iters {st3[0][0]}", flush=True)

@@ -654,3 +654,52 @@ def test_ratio_manager_on_device_matches_oracle_loop(gpu_ctx, hex_hierarchy_smal
     mgr.close()
     ds.close()
     smp.close()
+
+
+# ---------------------------------------------------------------------------------- algebraic coarsening
+def test_stretched_cells_algebraic_coarsening(gpu_ctx, seeded_rng):
+    """Stretched hex cells (150 x 92 x 14, SPE10-like): the internal smoothed-aggregation hierarchy of the Schur block
+    (mg_coarsening 1, and the default auto mode which must select it here) gives the oracle's fields / QoIs and needs
+    fewer MINRES iterations than the caller-level (geometric) V-cycle.  The reference gets the same robustness from
+    BoomerAMG inside its block preconditioner (src/PDESampler.cpp:300-309, src/DarcySolver.cpp:585-601)."""
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem
+    h = build_hierarchy(box_mesh([4, 12, 6], [1200.0, 2200.0, 170.0], "hex"), 1)
+    sp = build_sampler_problem(h, corlen=100.0, lognormal=True)
+    dp = build_darcy_problem(h, [1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0])
+    so, do = SamplerOracle(sp), DarcyOracle(dp)
+    its = {}
+    for mode in (0, 1, 2):
+        o = capi.solver_opts(mg_coarsening=mode, **TIGHT)
+        smp = capi.PDESampler(gpu_ctx, sp, o)
+        ds = capi.DarcySolver(gpu_ctx, dp, o)
+        for lvl in (0, 1):
+            xi = np.random.default_rng(5 + lvl).standard_normal((3, sp.levels[lvl].n_s))
+            s, st = smp.Eval(lvl, xi, return_stats=True)
+            ref = np.stack([so.eval(lvl, lvl, x)[0] for x in xi])
+            assert rel(np.log(s), np.log(ref)) < 1e-8
+            Q, C, st2 = ds.SolveFwd(lvl, ref, return_stats=True)
+            for b in range(3):
+                Qr, _ = do.solve_fwd(lvl, ref[b])
+                assert abs(Q[b] - Qr) < 1e-8 * abs(Qr)
+            assert all(t[1] == 1 for t in st) and all(t[1] == 1 for t in st2)
+            its[mode, lvl] = (max(t[0] for t in st), max(t[0] for t in st2))
+        ds.close()
+        smp.close()
+    for lvl in (0, 1):
+        assert its[2, lvl] == its[1, lvl]                                  # auto mode picked the algebraic hierarchy
+    assert its[1, 0][0] < 0.7 * its[0, 0][0] and its[1, 0][1] < 0.7 * its[0, 0][1]
+    # isotropic cells: auto mode keeps the caller's levels
+    h2 = build_hierarchy(box_mesh([4, 4, 4], [1.0, 1.0, 1.0], "hex"), 1)
+    sp2 = build_sampler_problem(h2, corlen=0.1)
+    xi = seeded_rng.standard_normal((2, sp2.levels[0].n_s))
+    got = []
+    for mode in (0, 2, 1):
+        smp = capi.PDESampler(gpu_ctx, sp2, capi.solver_opts(mg_coarsening=mode))
+        s, st = smp.Eval(0, xi, return_stats=True)
+        got.append((s, [t[0] for t in st]))
+        smp.close()
+    assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1]
+    assert rel(got[2][0], got[0][0]) < 1e-5
