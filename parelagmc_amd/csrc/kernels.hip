@@ -11,6 +11,8 @@
 //   darcy_*                                    : K12-K15 per-sample M(k), BC elimination, Schur refresh, QoI
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <atomic>
 
@@ -336,14 +338,17 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
 // collapse to  x2_i = dinv_i (c0 r_i - c1 (A D^-1 r)_i),  so with the column-scaled values As = A D^-1
 // (precomputed at create time) a single SpMM over r gives the result: 1 gather pass instead of the
 // 3 + 5 vector passes of cheb_first + cheb_step.  DOT: partials of <r, x2>.
+// From a NONZERO guess x0 the same polynomial acts on the residual: x2 = x0 + p2(r - A x0); then r is that residual,
+// xadd = x0 (may alias xout: no gathers on it) and the dot is taken with dot_with (the right-hand side).
 template <int NB, bool BV, bool DOT>
 __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                             const int* __restrict__ sched,
                                                             const int* __restrict__ cols,
                                                             const double* __restrict__ vals_scaled,
                                                             const double* __restrict__ dinv,
-                                                            const double* __restrict__ r, double* __restrict__ xout,
-                                                            double c0, double c1, double* __restrict__ partial) {
+                                                            const double* __restrict__ r, double* xout,
+                                                            double c0, double c1, double* __restrict__ partial,
+                                                            const double* xadd, const double* __restrict__ dot_with) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
@@ -370,9 +375,17 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
                 for (int c = 0; c < C; ++c) di[c] = s;
             }
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                xv[c] = di[c] * (c0 * rv[c] - c1 * acc[rs][c]);
-                if constexpr (DOT) p[c] = fma(rv[c], xv[c], p[c]);
+            for (int c = 0; c < C; ++c) xv[c] = di[c] * (c0 * rv[c] - c1 * acc[rs][c]);
+            if (xadd) {
+                double x0[C];
+                load_c<C>(xadd + at, x0);
+#pragma unroll
+                for (int c = 0; c < C; ++c) xv[c] += x0[c];
+            }
+            if constexpr (DOT) {
+                if (dot_with) load_c<C>(dot_with + at, rv);
+#pragma unroll
+                for (int c = 0; c < C; ++c) p[c] = fma(rv[c], xv[c], p[c]);
             }
             store_c<C>(xout + at, xv);
         }
@@ -1182,7 +1195,17 @@ static inline void check_launch() { PMC_HIP(hipGetLastError()); }
 
 namespace k {
 
-static inline dim3 grid_bounded(dim3 g, bool bounded) { return bounded ? dim3(std::min(g.x, 512u)) : g; }
+// kernels with a fused dot write one partial per block; the bound trades occupancy of the SpMM against the length of
+// the single-block final reduction (PMC_DOT_GRID overrides it for tuning runs)
+static unsigned dot_grid_bound() {
+    static const unsigned v = [] {
+        const char* e = getenv("PMC_DOT_GRID");
+        const long x = e ? atol(e) : 0;
+        return x >= 8 ? (unsigned)x : 4096u;
+    }();
+    return v;
+}
+static inline dim3 grid_bounded(dim3 g, bool bounded) { return bounded ? dim3(std::min(g.x, dot_grid_bound())) : g; }
 
 template <int NB, int TAG>
 static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double* x, double* y, bool accumulate,
@@ -1251,21 +1274,21 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
 }
 
 int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
-          double c0, double c1, double* dot_partial) {
+          double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with) {
     if (As.nrows == 0) return 0;
     if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (As.bv) {
             if (dot_partial)
-                sell_poly2_kernel<NB, true, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial);
+                sell_poly2_kernel<NB, true, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with);
             else
-                sell_poly2_kernel<NB, true, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr);
+                sell_poly2_kernel<NB, true, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with);
         } else {
             if (dot_partial)
-                sell_poly2_kernel<NB, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial);
+                sell_poly2_kernel<NB, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with);
             else
-                sell_poly2_kernel<NB, false, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr);
+                sell_poly2_kernel<NB, false, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with);
         }
     });
     check_launch();

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <cstdlib>
+
 #include "handles.hpp"
 
 namespace pmc {
@@ -357,16 +359,41 @@ void Sampler::apply_operator(int level, int nb, const double* x, double* y, int 
     SellView Av = view(d.A);
     Av.tag = 1;
     k::spmm(st, nb, Av, xi.p, yi.p, false, nullptr, nullptr);   // untimed first touch
-    PMC_HIP(hipEventRecord(ctx.ev0, st));
-    for (int r = 0; r < repeat; ++r) k::spmm(st, nb, Av, xi.p, yi.p, false, nullptr, nullptr);
-    PMC_HIP(hipEventRecord(ctx.ev1, st));
+    // tuning probes: PMC_PROBE_FLUSH_MB = bytes overwritten between launches (evicts the operator from L2 / Infinity
+    // Cache, i.e. the state in which MINRES finds it), PMC_PROBE_DOT = time the fused <x, Ax> variant
+    const char* e_flush = getenv("PMC_PROBE_FLUSH_MB");
+    const char* e_dot = getenv("PMC_PROBE_DOT");
+    const size_t flush_bytes = e_flush ? (size_t)atol(e_flush) << 20 : 0;
+    DevBuf<double> flush, part;
+    if (flush_bytes) flush.alloc(flush_bytes / sizeof(double));
+    if (e_dot && atoi(e_dot)) part.alloc((size_t)dot_capacity((int)n) * kMaxBatch);
+    double total_ms = 0.0;
+    if (!flush_bytes) {
+        PMC_HIP(hipEventRecord(ctx.ev0, st));
+        for (int r = 0; r < repeat; ++r) k::spmm(st, nb, Av, xi.p, yi.p, false, part.p, part.p ? xi.p : nullptr);
+        PMC_HIP(hipEventRecord(ctx.ev1, st));
+    } else {
+        for (int r = 0; r < repeat; ++r) {
+            PMC_HIP(hipMemsetAsync(flush.p, r & 0xff, flush_bytes, st));
+            PMC_HIP(hipEventRecord(ctx.ev0, st));
+            k::spmm(st, nb, Av, xi.p, yi.p, false, part.p, part.p ? xi.p : nullptr);
+            PMC_HIP(hipEventRecord(ctx.ev1, st));
+            PMC_HIP(hipStreamSynchronize(st));
+            float ms1 = 0.f;
+            PMC_HIP(hipEventElapsedTime(&ms1, ctx.ev0, ctx.ev1));
+            total_ms += ms1;
+        }
+    }
     k::deinterleave(st, nb, (int)n, yi.p, nullptr, nullptr, false, yd);
     if (memspace == PMC_MEM_HOST) PMC_HIP(hipMemcpyAsync(y, stage.p, sizeof(double) * n * nb, hipMemcpyDeviceToHost, st));
     PMC_HIP(hipStreamSynchronize(st));
     if (avg_ms) {
-        float ms = 0.f;
-        PMC_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
-        *avg_ms = (double)ms / repeat;
+        if (!flush_bytes) {
+            float ms = 0.f;
+            PMC_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+            total_ms = ms;
+        }
+        *avg_ms = total_ms / repeat;
     }
     if (bytes) *bytes = 12.0 * d.A.nnz + 4.0 * d.A.nrows + (double)nb * 8.0 * ((double)d.A.nrows + d.A.ncols);
 }

@@ -21,7 +21,14 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
         const double c1 = 2.0 * rho1 / (delta * theta);
         SellView As = A;
         As.vals = cp.scaled_vals;
-        const int nblk = k::poly2(st, nb, As, dinv, dinv_bv, r, xa, c0, c1, dot_partial);
+        int nblk;
+        if (zero_guess) {
+            nblk = k::poly2(st, nb, As, dinv, dinv_bv, r, xa, c0, c1, dot_partial);
+        } else {
+            // x2 = x0 + p2(r - A x0): residual into the work vector, polynomial of it accumulated onto x0 in place
+            k::residual(st, nb, A, r, xa, d);
+            nblk = k::poly2(st, nb, As, dinv, dinv_bv, d, xa, c0, c1, dot_partial, xa, r);
+        }
         if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
         return xa;
     }

@@ -19,7 +19,8 @@ struct ChebParams {
     // degree-2 kernel for zero initial guesses
     const double* scaled_vals = nullptr;
 };
-inline bool cheb_fused(const ChebParams& cp, bool zero_guess) { return zero_guess && cp.degree == 2 && cp.scaled_vals; }
+// degree 2 with column-scaled values runs as one polynomial pass (on r from a zero guess, on the residual otherwise)
+inline bool cheb_fused(const ChebParams& cp, bool /*zero_guess*/) { return cp.degree == 2 && cp.scaled_vals; }
 // Runs `degree` steps.  xa holds the initial guess (ignored when zero_guess); the iterate ping-pongs
 // between xa and xb; returns the buffer holding the result.  d is work space.
 // dot_partial != nullptr: the last step also writes per-block partials of <r, result>; *dot_blocks gets their count.
