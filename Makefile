@@ -26,8 +26,8 @@ clean:
 
 # host-side managers (plain C++, links against libpmc.so next to it)
 HOSTLIB := parelagmc_amd/lib/libpmc_host.so
-HOSTSRC := parelagmc_amd/host/host.cpp
+HOSTSRC := parelagmc_amd/host/host.cpp parelagmc_amd/host/mortar.cpp
 $(HOSTLIB): $(HOSTSRC) parelagmc_amd/host/parelagmc.hpp include/pmc.h include/pmc_host.h $(LIB)
-	g++ -O2 -std=c++17 -fPIC -shared -Wall -pthread -o $@ $(HOSTSRC) -Lparelagmc_amd/lib -lpmc -Wl,-rpath,'$$ORIGIN'
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -pthread -Iinclude -o $@ $(HOSTSRC) -Lparelagmc_amd/lib -lpmc -Wl,-rpath,'$$ORIGIN'
 
 all: $(HOSTLIB)

@@ -127,6 +127,26 @@ int pmc_ratio_run(pmc_ratio* m);
 int pmc_ratio_init_run(pmc_ratio* m, const int32_t* nsamples);
 int pmc_ratio_result_get(pmc_ratio* m, pmc_ratio_result* out);
 
+/* ---- P0 x P0 mortar matrix between two NON-MATCHING meshes:  G[i,j] = | A_i  n  B_j |  (setup side, host only).
+ * Replaces ParMortarAssembler::Assemble (src/transfer/ParMortarAssembler.cpp:1127-1144) as used for Gt by
+ * L2ProjectionPDESampler::BuildHierarchy (src/L2ProjectionPDESampler.cpp:488-505) with A = original mesh, B = enlarged
+ * mesh; the coarser levels follow by RAP(orig_Ps, Gt, Ps) (:512-513).  Elements: triangles / quadrilaterals (dim 2),
+ * tetrahedra / hexahedra in MFEM vertex order (dim 3); they are split into simplices and intersected exactly. */
+typedef struct pmc_mesh_view {
+    int32_t dim, nverts, nelems, verts_per_elem;
+    const double* verts;   /* nverts x dim, row-major         */
+    const int32_t* elems;  /* nelems x verts_per_elem          */
+} pmc_mesh_view;
+typedef struct pmc_mortar pmc_mortar;
+/* rel_tol: intersections below rel_tol * min(|A_i|, |B_j|) are dropped (<= 0: 1e-12) */
+int pmc_mortar_assemble(const pmc_mesh_view* a, const pmc_mesh_view* b, double rel_tol, pmc_mortar** out);
+int64_t pmc_mortar_nnz(const pmc_mortar* m);
+/* copies the CSR arrays (rowptr: nelems_a + 1) and the element measures of both meshes; NULL pointers are skipped */
+int pmc_mortar_get(const pmc_mortar* m, int32_t* rowptr, int32_t* colind, double* vals, double* measure_a,
+                   double* measure_b);
+void pmc_mortar_destroy(pmc_mortar* m);
+const char* pmc_mortar_last_error(void);
+
 /* expWRegression (src/Utilities.cpp:257-283), exported for the host-logic tests */
 double pmc_exp_w_regression(const double* y, const double* x, int n, int skip_n_last);
 

@@ -2,10 +2,14 @@
 
 Host-only numpy/scipy code that produces the CSR operators the C-ABI consumes; it stands in
 for the MFEM/ParELAG setup calls of the reference drivers and is outside every timed region."""
-from .mesh import (Mesh, box_mesh, build_faces, kuhn_cube_tet, mesh_from_json, read_mfem_mesh,  # noqa: F401
+from .mesh import (Mesh, box_mesh, build_faces, element_volumes, kuhn_cube_tet, mesh_from_json,  # noqa: F401
+                   read_mfem_mesh,
                    refine_uniform)
 from .problems import (DarcyLevel, DarcyProblem, Hierarchy, SamplerLevel, SamplerProblem,  # noqa: F401
                        build_darcy_problem, build_hierarchy, build_sampler_problem,
                        l2_projection_ops, matern_coefficient)
 from .rt0 import build_spaces, mass_contributions, mass_matrix, prolongation_p0  # noqa: F401
-from .transfer import box_intersection_gt, l2_projection_hierarchy  # noqa: F401
+from .transfer import (box_intersection_gt, clipped_intersection_gt, intersection_gt,  # noqa: F401
+                       l2_projection_hierarchy)
+from .output import (compute_l2_error, compute_max_error, prolongate_to_fine_grid, read_gridfunction_p0,  # noqa: F401
+                     save_field_glvis, save_mesh_glvis, write_mfem_mesh)

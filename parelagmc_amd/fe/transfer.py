@@ -1,4 +1,4 @@
-"""L2 (mortar) projector between NON-MATCHING meshes of axis-aligned boxes (setup side).
+"""L2 (mortar) projector between NON-MATCHING meshes (setup side).
 
 The reference assembles ``Gt[i,j] = |e_orig,i  ∩  e_embed,j|`` for P0 x P0 with a general polytope-clipping
 mortar assembler (/root/reference/src/transfer/ParMortarAssembler.cpp:1127-1144, used by
@@ -6,7 +6,8 @@ src/L2ProjectionPDESampler.cpp:488-505) and obtains the coarse levels by ``RAP(o
 For quadrilateral / hexahedral meshes whose elements are axis-aligned boxes (meshes/cube_hex.mesh inside
 meshes/cube_hex_enlarge.mesh: 4^3 cells of size 0.5 on [0,2]^3 inside 5^3 cells of size 0.6 on [-0.5,2.5]^3) the
 intersection volume is the product of the per-axis interval overlaps, which is what this module computes - exactly,
-without clipping.  Simplicial pairs still need the general assembler (not built).
+without clipping.  Every other pair (triangles, tetrahedra, general quadrilaterals / hexahedra, mixed) goes through the
+simplex-clipping assembler of libpmc_host.so (``pmc_mortar_assemble``, host/mortar.cpp).
 """
 from __future__ import annotations
 
@@ -65,12 +66,34 @@ def box_intersection_gt(orig: Mesh, embed: Mesh, tol: float = 1e-12) -> sp.csr_m
     return sp.csr_matrix((ov[keep], (ii[keep], jj[keep])), shape=(orig.ne, embed.ne))
 
 
-def l2_projection_hierarchy(h_orig, h_embed):
+def clipped_intersection_gt(orig: Mesh, embed: Mesh, rel_tol: float = 1e-12) -> sp.csr_matrix:
+    """Gt for arbitrary (convex-element) mesh pairs through the C ABI of libpmc_host.so."""
+    from ..host_api import mortar_gt
+    if orig.dim != embed.dim:
+        raise ValueError("meshes of different dimension")
+    G, _, _ = mortar_gt(orig.verts, orig.elems, embed.verts, embed.elems, rel_tol)
+    return G
+
+
+def intersection_gt(orig: Mesh, embed: Mesh, method: str = "auto") -> sp.csr_matrix:
+    """method: 'box' (axis-aligned boxes, interval products), 'clip' (general), 'auto' (box when both meshes qualify)."""
+    if method not in ("auto", "box", "clip"):
+        raise ValueError("method must be auto, box or clip")
+    if method in ("auto", "box"):
+        try:
+            return box_intersection_gt(orig, embed)
+        except ValueError:
+            if method == "box":
+                raise
+    return clipped_intersection_gt(orig, embed)
+
+
+def l2_projection_hierarchy(h_orig, h_embed, method: str = "auto"):
     """Per level (Gt, 1/|e_orig|): the finest level by geometry, coarser ones by RAP with the P0 prolongators as in
     L2ProjectionPDESampler.cpp:512-513.  Both hierarchies must have the same number of levels."""
     if h_orig.nlevels != h_embed.nlevels:
         raise ValueError("original and embedded hierarchies need the same number of levels")
-    Gt = box_intersection_gt(h_orig.spaces[0].mesh, h_embed.spaces[0].mesh)
+    Gt = intersection_gt(h_orig.spaces[0].mesh, h_embed.spaces[0].mesh, method)
     out = [(Gt, 1.0 / h_orig.spaces[0].vol)]
     for lvl in range(h_orig.nlevels - 1):
         Gt = (h_orig.P[lvl].T @ Gt @ h_embed.P[lvl]).tocsr()

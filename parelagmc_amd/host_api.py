@@ -72,6 +72,11 @@ HOST_SYMBOLS = {
     "pmc_ratio_init_run": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
     "pmc_ratio_result_get": (C.c_int, [_VP, _VP]),
     "pmc_host_last_error": (C.c_char_p, []),
+    "pmc_mortar_assemble": (C.c_int, [_VP, _VP, C.c_double, C.POINTER(_VP)]),
+    "pmc_mortar_nnz": (C.c_int64, [_VP]),
+    "pmc_mortar_get": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "pmc_mortar_destroy": (None, [_VP]),
+    "pmc_mortar_last_error": (C.c_char_p, []),
     "pmc_exp_w_regression": (C.c_double, [_DPTR, _DPTR, C.c_int, C.c_int]),
 }
 
@@ -103,6 +108,40 @@ def exp_w_regression(y, x, skip_n_last):
     y = np.ascontiguousarray(y, np.float64)
     x = np.ascontiguousarray(x, np.float64)
     return load_host_library().pmc_exp_w_regression(y.ctypes.data_as(_DPTR), x.ctypes.data_as(_DPTR), len(y), skip_n_last)
+
+
+class pmc_mesh_view(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("nverts", C.c_int32), ("nelems", C.c_int32), ("verts_per_elem", C.c_int32),
+                ("verts", C.c_void_p), ("elems", C.c_void_p)]
+
+
+def mortar_gt(verts_a, elems_a, verts_b, elems_b, rel_tol=1e-12):
+    """P0 x P0 mortar matrix G[i,j] = |A_i n B_j| between two non-matching meshes (pmc_mortar_assemble).  Returns
+    (G as scipy CSR, |A_i|, |B_j|)."""
+    import scipy.sparse as sp
+    lib = load_host_library()
+    keep = []
+
+    def view(v, e):
+        v = np.ascontiguousarray(v, np.float64)
+        e = np.ascontiguousarray(e, np.int32)
+        keep.extend((v, e))
+        return pmc_mesh_view(v.shape[1], v.shape[0], e.shape[0], e.shape[1], v.ctypes.data, e.ctypes.data)
+    va, vb = view(verts_a, elems_a), view(verts_b, elems_b)
+    h = _VP()
+    rc = lib.pmc_mortar_assemble(C.byref(va), C.byref(vb), float(rel_tol), C.byref(h))
+    if rc != 0:
+        raise capi.PmcError(rc, lib.pmc_mortar_last_error().decode("utf-8", "replace"))
+    try:
+        nnz = lib.pmc_mortar_nnz(h)
+        rowptr = np.empty(va.nelems + 1, np.int32)
+        colind = np.empty(nnz, np.int32)
+        vals = np.empty(nnz)
+        ma, mb = np.empty(va.nelems), np.empty(vb.nelems)
+        lib.pmc_mortar_get(h, rowptr.ctypes.data, colind.ctypes.data, vals.ctypes.data, ma.ctypes.data, mb.ctypes.data)
+    finally:
+        lib.pmc_mortar_destroy(h)
+    return sp.csr_matrix((vals, colind, rowptr), shape=(va.nelems, vb.nelems)), ma, mb
 
 
 def bayes_likelihood(solver, level, k, G_obs, noise):

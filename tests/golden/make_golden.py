@@ -38,7 +38,8 @@ def mesh_to_json(name):
 
 def main():
     if os.path.isdir(REF_MESHES):
-        for name in ("inline_quad", "cube_hex", "cube_tet", "cube_tet_embed", "cube_hex_enlarge"):
+        for name in ("inline_quad", "cube_hex", "cube_tet", "cube_tet_embed", "cube_hex_enlarge", "cube_tet_enlarge", "square",
+                     "square_enlarge"):
             mesh_to_json(name)
     kat = {
         "darcy_deterministic": {"source": "examples/CMakeLists.txt:62-66", "Q": [2.0, 2.0, 2.0],

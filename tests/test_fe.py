@@ -136,3 +136,31 @@ def test_nonmatching_box_projector_cube_hex_in_cube_hex_enlarge():
     f = np.random.default_rng(2).standard_normal(he.spaces[0].n_s)
     proj = (ops[0][0] @ f) * ops[0][1]
     assert abs(proj @ ho.spaces[0].vol - np.asarray(ops[0][0].sum(axis=0)).ravel() @ f) < 1e-12
+
+
+def test_glvis_output_round_trip(tmp_path):
+    """SaveMeshGLVis / SaveFieldGLVis / ComputeL2Error / ComputeMaxError (src/PDESampler.cpp:613-672): the mesh file
+    reads back identically, the field file holds the level's coefficients prolongated to the finest grid."""
+    from parelagmc_amd.fe import (build_hierarchy, compute_l2_error, compute_max_error, read_gridfunction_p0,
+                                  read_mfem_mesh, save_field_glvis, save_mesh_glvis)
+    for name in ("cube_tet", "inline_quad"):
+        h = build_hierarchy(mesh_from_json(golden_path("meshes", name + ".json")), 2)
+        mp = save_mesh_glvis(h, str(tmp_path / f"{name}_mesh"))
+        assert mp.endswith(".000000")
+        m0, m = h.spaces[0].mesh, read_mfem_mesh(mp)
+        assert m.etype == m0.etype and np.array_equal(m.elems, m0.elems) and np.array_equal(m.bdr_attr, m0.bdr_attr)
+        assert np.allclose(m.verts, m0.verts, rtol=1e-7, atol=1e-12)
+        for lvl in range(3):
+            c = np.random.default_rng(lvl).standard_normal(h.spaces[lvl].n_s)
+            fp = save_field_glvis(h, lvl, c, str(tmp_path / f"{name}_field"), save_vtk=(lvl == 1))
+            assert fp.endswith(f"_L{lvl:02d}.000000")
+            x = read_gridfunction_p0(fp)
+            fine = c
+            for k in range(lvl - 1, -1, -1):
+                fine = h.P[k] @ fine
+            assert x.shape == (h.spaces[0].n_s,) and np.allclose(x, fine, rtol=1e-7)
+            # piecewise constants on nested meshes: the L2 distance to a constant is the same on every grid
+            assert np.isclose(compute_l2_error(h, lvl, c, 0.25), np.sum(h.spaces[lvl].vol * (c - 0.25) ** 2), rtol=1e-12)
+            assert compute_max_error(c, 0.25) == max(c.max() - 0.25, 0.25 - c.min())
+        vtk = open(str(tmp_path / f"{name}_field_L01.000000.vtk")).read()
+        assert "UNSTRUCTURED_GRID" in vtk and f"CELL_DATA {h.spaces[0].n_s}" in vtk

@@ -703,3 +703,29 @@ def test_stretched_cells_algebraic_coarsening(gpu_ctx, seeded_rng):
         smp.close()
     assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1]
     assert rel(got[2][0], got[0][0]) < 1e-5
+
+
+def test_l2_projection_sampler_on_nonmatching_tet_pair(gpu_ctx, seeded_rng):
+    """L2ProjectionPDESampler on the reference's simplicial pair: sample on cube_tet_enlarge ([-0.5,1.5]^3, 48 tets,
+    refined twice), project to cube_tet ([0,1]^3, 6 tets refined three times) with Gt from the clipping mortar assembler
+    (pmc_mortar_assemble) on the finest level and RAP below (src/L2ProjectionPDESampler.cpp:488-513, 738-750)."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import (build_hierarchy, build_sampler_problem, l2_projection_hierarchy, mesh_from_json,
+                                  refine_uniform)
+    from oracle.sampler_oracle import SamplerOracle
+    ho = build_hierarchy(refine_uniform(mesh_from_json(golden_path("meshes", "cube_tet.json")))[0], 2)
+    he = build_hierarchy(mesh_from_json(golden_path("meshes", "cube_tet_enlarge.json")), 2)
+    sp = build_sampler_problem(he, corlen=0.2, lognormal=True)
+    ops = l2_projection_hierarchy(ho, he)
+    for lvl in range(3):                                  # every original element is covered: rows sum to its volume
+        assert np.allclose(np.asarray(ops[lvl][0].sum(axis=1)).ravel() * ops[lvl][1], 1.0, rtol=1e-11)
+    assert np.diff(ops[0][0].indptr).max() > 1
+    so = SamplerOracle(sp)
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT), projection="l2", l2_ops=ops)
+    xi = seeded_rng.standard_normal((3, sp.levels[0].n_s))
+    for lvl in range(3):
+        assert smp.xi_size(lvl) == he.spaces[lvl].n_s and smp.SampleSize(lvl) == ho.spaces[lvl].n_s
+        s = smp.Eval(lvl, xi, xi_level=0)
+        ref = np.stack([so.eval(lvl, 0, x, projection=("l2",) + ops[lvl])[0] for x in xi])
+        assert rel(s, ref) < 1e-9
+    smp.close()

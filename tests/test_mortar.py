@@ -1,0 +1,98 @@
+"""P0 x P0 mortar matrix between non-matching meshes (pmc_mortar_assemble) against the half-space /
+convex-hull oracle, the interval-product assembler for boxes and size-independent properties.  The mesh pairs are the
+reference's own data files (meshes/cube_tet.mesh in cube_tet_enlarge.mesh, square.mesh in square_enlarge.mesh,
+cube_hex.mesh in cube_hex_enlarge.mesh - the pairs its L2ProjectionPDESampler drivers read)."""
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+
+def _mesh(name):
+    from parelagmc_amd.fe import mesh_from_json
+    return mesh_from_json(golden_path("meshes", name + ".json"))
+
+
+def _gt(a, b):
+    from parelagmc_amd.host_api import mortar_gt
+    return mortar_gt(a.verts, a.elems, b.verts, b.elems)
+
+
+def _oracle(a, b):
+    from oracle.mortar_oracle import mortar_gt
+    return mortar_gt(a.verts, a.elems, a.etype, b.verts, b.elems, b.etype)
+
+
+def test_tets_in_enlarged_tets_match_halfspace_oracle():
+    from parelagmc_amd.fe import element_volumes, refine_uniform
+    a = refine_uniform(_mesh("cube_tet"))[0]               # 48 tets on [0,1]^3
+    b = _mesh("cube_tet_enlarge")                          # 48 tets on [-0.5,1.5]^3, not aligned with a
+    G, ma, mb = _gt(a, b)
+    assert np.allclose(ma, element_volumes(a), rtol=1e-13) and np.allclose(mb, element_volumes(b), rtol=1e-13)
+    R = _oracle(a, b)
+    assert abs(G - R).max() < 1e-12 and (G != 0).nnz == (R != 0).nnz
+    assert np.allclose(np.asarray(G.sum(axis=1)).ravel(), ma, rtol=1e-12)      # b covers a
+    assert abs(G.sum() - 1.0) < 1e-12
+    assert np.all(np.asarray(G.sum(axis=0)).ravel() <= mb * (1 + 1e-12))
+    assert np.diff(G.indptr).max() > 1                                           # genuinely non-matching
+
+
+def test_triangles_in_enlarged_triangles():
+    a, b = _mesh("square"), _mesh("square_enlarge")        # unstructured triangulations, 328 in 648
+    G, ma, mb = _gt(a, b)
+    assert np.allclose(np.asarray(G.sum(axis=1)).ravel(), ma, rtol=1e-11)
+    assert abs(G.sum() - 1.0) < 1e-12
+    assert np.all(np.asarray(G.sum(axis=0)).ravel() <= mb * (1 + 1e-11))
+    sub = np.arange(0, a.ne, 9)
+    asub = type(a)(a.etype, a.verts, a.elems[sub], a.elem_attr[sub], a.bdr, a.bdr_attr)
+    R = _oracle(asub, b)
+    assert abs(G[sub] - R).max() < 1e-12
+
+
+def test_boxes_agree_with_interval_products_and_hierarchy_rap():
+    from parelagmc_amd.fe import (box_intersection_gt, build_hierarchy, clipped_intersection_gt, l2_projection_hierarchy)
+    a, b = _mesh("cube_hex"), _mesh("cube_hex_enlarge")
+    G = clipped_intersection_gt(a, b)
+    Gb = box_intersection_gt(a, b)
+    assert abs(G - Gb).max() < 1e-13 and (G != 0).nnz == (Gb != 0).nnz
+    # coarse levels by RAP == geometry on the coarse meshes (nested refinements)
+    ha, hb = build_hierarchy(a, 1), build_hierarchy(b, 1)
+    ops = l2_projection_hierarchy(ha, hb, method="clip")
+    assert abs(ops[1][0] - Gb).max() < 1e-13
+    assert abs(ops[0][0] - box_intersection_gt(ha.spaces[0].mesh, hb.spaces[0].mesh)).max() < 1e-13
+
+
+def test_aligned_and_mixed_element_types():
+    from parelagmc_amd.fe import box_mesh, build_hierarchy, element_volumes, refine_uniform
+    h = box_mesh([3, 2, 2], [1.5, 1.0, 2.0], "hex")
+    G, ma, _ = _gt(h, h)                                   # a mesh against itself: the mass matrix of P0
+    assert abs(G - __import__("scipy.sparse").sparse.diags(ma)).max() < 1e-13 and G.nnz == h.ne
+    h = box_mesh([3, 2, 5], [1.0, 1.0, 1.0], "hex")
+    t = refine_uniform(_mesh("cube_tet"))[0]               # 48 tets filling the same unit cube, unrelated to the grid
+    G2, mt, mh = _gt(t, h)
+    assert np.allclose(np.asarray(G2.sum(axis=1)).ravel(), mt, rtol=1e-12)
+    assert np.allclose(np.asarray(G2.sum(axis=0)).ravel(), mh, rtol=1e-12)
+    q = box_mesh([4, 3], [1.0, 1.0], "quad")
+    tri = _mesh("square")                                  # unstructured triangles on the same unit square
+    G3, mq, mtr = _gt(q, tri)
+    assert np.allclose(np.asarray(G3.sum(axis=1)).ravel(), mq, rtol=1e-12)
+    assert np.allclose(np.asarray(G3.sum(axis=0)).ravel(), mtr, rtol=1e-12)
+    # refined (nested) tets against their parents: every child lies in exactly one parent
+    hh = build_hierarchy(_mesh("cube_tet"), 2)
+    Gc, mc, mp = _gt(hh.spaces[0].mesh, hh.spaces[1].mesh)
+    assert Gc.nnz == hh.spaces[0].mesh.ne and abs(Gc - hh.P[0].multiply(element_volumes(hh.spaces[0].mesh)[:, None])).max() < 1e-13
+
+
+def test_disjoint_meshes_and_errors():
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import box_mesh
+    from parelagmc_amd.host_api import mortar_gt
+    a = box_mesh([2, 2], [1.0, 1.0], "quad")
+    b = box_mesh([2, 2], [1.0, 1.0], "quad", origin=[3.0, 0.0])
+    G, _, _ = _gt(a, b)
+    assert G.nnz == 0
+    c = box_mesh([2, 2, 2], [1.0, 1.0, 1.0], "hex")
+    with pytest.raises(capi.PmcError):
+        mortar_gt(a.verts, a.elems, c.verts, c.elems)
+    with pytest.raises(capi.PmcError):
+        mortar_gt(a.verts, a.elems[:, :2], a.verts, a.elems)
