@@ -114,6 +114,9 @@ typedef struct pmc_ratio_result {
     const double *eR, *varR, *eYR, *varYR, *eABS_YR, *eZ, *varZ, *eYZ, *varYZ, *eABS_YZ, *eC, *cost;
     const double* sums;          /* nlevels x PMC_RATIO_NVAR */
     const int64_t *nsamples, *nsamples_missing;
+    /* Ratio columns (q = r/z, y = q - q_c): what the *_Splitting managers estimate and allocate samples by */
+    double alpha, alpha_abs, beta;
+    const double *eRatio, *varRatio, *eYRatio, *varYRatio, *eABS_YRatio;
 } pmc_ratio_result;
 /* device version: prior = sampler, forward problem = solver with observation functionals set on every level */
 int pmc_ratio_create(pmc_ctx* ctx, pmc_sampler* sampler, pmc_darcy* solver, int nlevels, const double* G_obs, int nobs,
@@ -123,6 +126,10 @@ int pmc_ratio_create_callbacks(int nlevels, const pmc_plugin_callbacks* cb, pmc_
                                const pmc_mlmc_params* params, pmc_ratio** out);
 void pmc_ratio_destroy(pmc_ratio* m);
 int pmc_ratio_set_farm(pmc_ratio* m, int nranks, int rank, pmc_reduce_fn reduce, void* user);
+/* on != 0: ML_BayesRatio_Splitting_Manager / SL_BayesRatio_Splitting_Manager (src/ML_BayesRatio_Splitting_Manager.hpp:
+ * 297-432 InitRun, :595-737 computeNSamplesMSE): estimate E[R/Z] by the level differences r/z - r_c/z_c; variance,
+ * bias and sample allocation follow the Ratio columns; ratio_estimate = sum_l E[Y_Ratio,l] */
+int pmc_ratio_set_splitting(pmc_ratio* m, int on);
 int pmc_ratio_run(pmc_ratio* m);
 int pmc_ratio_init_run(pmc_ratio* m, const int32_t* nsamples);
 int pmc_ratio_result_get(pmc_ratio* m, pmc_ratio_result* out);

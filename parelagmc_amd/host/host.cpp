@@ -561,6 +561,7 @@ void ML_BayesRatio_Manager::Reset() {
     auto z = [&](std::vector<double>& v) { v.assign(nlevels, 0.0); };
     sums.assign((size_t)nlevels * NVAR, 0.0);
     z(eR); z(varR); z(eYR); z(varYR); z(eABS_YR); z(eZ); z(varZ); z(eYZ); z(varYZ); z(eABS_YZ); z(eC); z(cost);
+    z(eRatio); z(varRatio); z(eYRatio); z(varYRatio); z(eABS_YRatio);
     z(level_seconds);
     level_nsamples.assign(nlevels, 0);
     level_nsamples_missing.assign(nlevels, 0);
@@ -618,6 +619,18 @@ void ML_BayesRatio_Manager::run_level(int ilevel, int nsamples) {
             psum[YZ] += y_z;
             psum[ABS_YZ] += std::fabs(y_z);
             psum[YZ2] += y_z * y_z;
+            if (splitting) {
+                // "divide, then subtract" (ML_BayesRatio_Splitting_Manager.hpp:329,386-397); the plain ratio manager
+                // leaves these columns at zero
+                const double q = r[b] / z[b];
+                const double y = coarsest ? q : q - rc[b] / zc[b];
+                psum[Ratio] += q;
+                psum[ABS_Ratio] += std::fabs(q);
+                psum[Ratio2] += q * q;
+                psum[YRatio] += y;
+                psum[ABS_YRatio] += std::fabs(y);
+                psum[YRatio2] += y * y;
+            }
             psum[C] += ctot[b];
         }
     }
@@ -670,6 +683,9 @@ void ML_BayesRatio_Manager::computeNSamplesMSE() {
         varYR[l] = (varYR[l] - eYR[l] * eYR[l]) * f;
         varZ[l] = (varZ[l] - eZ[l] * eZ[l]) * f;
         varYZ[l] = (varYZ[l] - eYZ[l] * eYZ[l]) * f;
+        eRatio[l] = S(l, Ratio) / n;  eYRatio[l] = S(l, YRatio) / n;  eABS_YRatio[l] = S(l, ABS_YRatio) / n;
+        varRatio[l] = (S(l, Ratio2) / n - eRatio[l] * eRatio[l]) * f;
+        varYRatio[l] = (S(l, YRatio2) / n - eYRatio[l] * eYRatio[l]) * f;
     }
     if (wallTime)
         for (int l = 0; l < nlevels; ++l) cost[l] = level_seconds[l] / (double)level_nsamples[l];
@@ -682,6 +698,31 @@ void ML_BayesRatio_Manager::computeNSamplesMSE() {
     alphaABS_Z = expWRegression(eABS_YZ, M, 1);
     beta_Z = expWRegression(varYZ, M, 1);
     gamma = expWRegression(cost, M, 0);
+    alpha = expWRegression(eYRatio, M, 1);
+    alphaABS = expWRegression(eABS_YRatio, M, 1);
+    beta = expWRegression(varYRatio, M, 1);
+    if (splitting) {
+        // ML_BayesRatio_Splitting_Manager.hpp:668-716: everything is driven by the Ratio columns
+        expected_discretization_error2_R = bias2_of(nlevels, M, eABS_YR, alphaABS_R);
+        expected_discretization_error2_Z = bias2_of(nlevels, M, eABS_YZ, alphaABS_Z);
+        expected_discretization_error2 = bias2_of(nlevels, M, eABS_YRatio, alphaABS);
+        if (auto_eps2) eps2 = expected_discretization_error2 / (1. - ratio);
+        ml_estimator_variance = ml_estimator_variance_Z = ml_estimator_variance_R = 0.;
+        for (int l = 0; l < nlevels; ++l) {
+            ml_estimator_variance += varYRatio[l] / (double)level_nsamples[l];
+            ml_estimator_variance_Z += varYZ[l] / (double)level_nsamples[l];
+            ml_estimator_variance_R += varYR[l] / (double)level_nsamples[l];
+        }
+        actualMSE = expected_discretization_error2 + ml_estimator_variance;
+        double prop = 0.;
+        for (int i = 0; i < nlevels; ++i) prop += std::sqrt(varYRatio[i] * cost[i]);
+        prop /= ratio * eps2;
+        for (int i = 0; i < nlevels; ++i) {
+            const double mm = std::ceil(prop * std::sqrt(varYRatio[i] / cost[i]) - (double)level_nsamples[i]);
+            level_nsamples_missing[i] = (std::isfinite(mm) && mm > 0.0) ? (int64_t)std::min(mm, 2.0e9) : 0;
+        }
+        return;
+    }
     expected_discretization_error2_R = bias2_of(nlevels, M, eABS_YR, alphaABS_R);
     expected_discretization_error2_Z = bias2_of(nlevels, M, eABS_YZ, alphaABS_Z);
     expected_discretization_error2 = std::max(expected_discretization_error2_R, expected_discretization_error2_Z);
@@ -991,6 +1032,12 @@ int pmc_ratio_set_farm(pmc_ratio* m, int nranks, int rank, pmc_reduce_fn reduce,
         m->mgr->SetFarm(nranks, rank, fn);
     });
 }
+int pmc_ratio_set_splitting(pmc_ratio* m, int on) {
+    return hguard([&] {
+        if (!m) throw std::invalid_argument("manager is NULL");
+        m->mgr->SetSplitting(on != 0);
+    });
+}
 int pmc_ratio_run(pmc_ratio* m) {
     return hguard([&] {
         if (!m) throw std::invalid_argument("manager is NULL");
@@ -1014,7 +1061,9 @@ int pmc_ratio_result_get(pmc_ratio* m, pmc_ratio_result* r) {
         r->nlevels = g.nlevels;
         r->R_estimate = er;
         r->Z_estimate = ez;
-        r->ratio_estimate = er / ez;
+        double eq = 0;
+        for (double x : g.eYRatio) eq += x;
+        r->ratio_estimate = g.splitting ? eq : er / ez;   // "Ratio Estimate": eYRatio.Sum() vs R / Z
         r->eps2 = g.eps2;
         r->actual_mse = g.actualMSE;
         r->estimator_variance = g.ml_estimator_variance;
@@ -1026,6 +1075,9 @@ int pmc_ratio_result_get(pmc_ratio* m, pmc_ratio_result* r) {
         r->alpha_R = g.alpha_R; r->alpha_abs_R = g.alphaABS_R; r->beta_R = g.beta_R;
         r->alpha_Z = g.alpha_Z; r->alpha_abs_Z = g.alphaABS_Z; r->beta_Z = g.beta_Z;
         r->gamma = g.gamma;
+        r->alpha = g.alpha; r->alpha_abs = g.alphaABS; r->beta = g.beta;
+        r->eRatio = g.eRatio.data(); r->varRatio = g.varRatio.data(); r->eYRatio = g.eYRatio.data();
+        r->varYRatio = g.varYRatio.data(); r->eABS_YRatio = g.eABS_YRatio.data();
         r->eR = g.eR.data(); r->varR = g.varR.data(); r->eYR = g.eYR.data(); r->varYR = g.varYR.data();
         r->eABS_YR = g.eABS_YR.data(); r->eZ = g.eZ.data(); r->varZ = g.varZ.data(); r->eYZ = g.eYZ.data();
         r->varYZ = g.varYZ.data(); r->eABS_YZ = g.eABS_YZ.data(); r->eC = g.eC.data(); r->cost = g.cost.data();

@@ -245,6 +245,10 @@ class BayesRatioProblem {
 };
 
 /// Multilevel (nlevels > 1) / single-level (nlevels == 1) ratio estimator, src/ML_BayesRatio_Manager.hpp.
+/// SetSplitting(true) turns it into ML_BayesRatio_Splitting_Manager / SL_BayesRatio_Splitting_Manager
+/// (src/ML_BayesRatio_Splitting_Manager.hpp): the same draws, but the estimated quantity is E[R/Z] with the
+/// level difference r/z - r_c/z_c ("divide, then subtract"), and the variance / bias / sample allocation follow the
+/// Ratio columns of the sums table instead of max(R, Z).
 class ML_BayesRatio_Manager {
   public:
     enum { YZ2 = 0, YZ = 1, ABS_YZ = 2, Z2 = 3, Z = 4, ABS_Z = 5, YR2 = 6, YR = 7, ABS_YR = 8, R2 = 9, R = 10,
@@ -253,13 +257,17 @@ class ML_BayesRatio_Manager {
     ML_BayesRatio_Manager(pmc_ctx* ctx, int memspace, int nlevels, BayesRatioProblem& problem,
                           const pmc_mlmc_params& params);
     void SetFarm(int nranks, int rank, std::function<void(double*, int)> reduce);
+    void SetSplitting(bool on) { splitting = on; }
     void Run();
     void InitRun(std::vector<int>& level_nsamples_init);
     void Reset();
 
     bool wallTime;
+    bool splitting = false;
     int nlevels;
     double eps2, ratio;
+    double alpha = 0, alphaABS = 0, beta = 0;   // rates of the Ratio columns (splitting manager)
+    std::vector<double> eRatio, varRatio, eYRatio, varYRatio, eABS_YRatio;
     double ml_estimator_variance, ml_estimator_variance_R, ml_estimator_variance_Z;
     double expected_discretization_error2, expected_discretization_error2_R, expected_discretization_error2_Z, actualMSE;
     double alpha_R = 0, alphaABS_R = 0, beta_R = 0, alpha_Z = 0, alphaABS_Z = 0, beta_Z = 0, gamma = 0;

@@ -68,6 +68,7 @@ HOST_SYMBOLS = {
                                              C.POINTER(_VP)]),
     "pmc_ratio_destroy": (None, [_VP]),
     "pmc_ratio_set_farm": (C.c_int, [_VP, C.c_int, C.c_int, REDUCE_FN, _VP]),
+    "pmc_ratio_set_splitting": (C.c_int, [_VP, C.c_int]),
     "pmc_ratio_run": (C.c_int, [_VP]),
     "pmc_ratio_init_run": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
     "pmc_ratio_result_get": (C.c_int, [_VP, _VP]),
@@ -168,17 +169,20 @@ class pmc_ratio_result(C.Structure):
                  "beta_R", "alpha_Z", "alpha_abs_Z", "beta_Z", "gamma")] + \
                [(n, _DPTR) for n in ("eR", "varR", "eYR", "varYR", "eABS_YR", "eZ", "varZ", "eYZ", "varYZ", "eABS_YZ", "eC",
                                      "cost")] + \
-               [("sums", _DPTR), ("nsamples", _LPTR), ("nsamples_missing", _LPTR)]
+               [("sums", _DPTR), ("nsamples", _LPTR), ("nsamples_missing", _LPTR)] + \
+               [(n, C.c_double) for n in ("alpha", "alpha_abs", "beta")] + \
+               [(n, _DPTR) for n in ("eRatio", "varRatio", "eYRatio", "varYRatio", "eABS_YRatio")]
 
 
 RATIO_NVAR = 20
 
 
 class RatioManager:
-    """parelagmc::ML_BayesRatio_Manager (SL_BayesRatio_Manager for nlevels == 1)."""
+    """parelagmc::ML_BayesRatio_Manager (SL_BayesRatio_Manager for nlevels == 1); splitting=True gives
+    ML_BayesRatio_Splitting_Manager / SL_BayesRatio_Splitting_Manager."""
 
     def __init__(self, nlevels, sampler=None, solver=None, G_obs=None, noise=None, callbacks=None, likelihood=None,
-                 eps2=0.001, ratio=0.5, init_nsamples=10, wall_time=True, batch=16, max_rounds=1000):
+                 eps2=0.001, ratio=0.5, init_nsamples=10, wall_time=True, batch=16, max_rounds=1000, splitting=False):
         self.lib = load_host_library()
         self.nlevels = nlevels
         p = pmc_mlmc_params()
@@ -212,6 +216,8 @@ class RatioManager:
             _hcheck(self.lib.pmc_ratio_create(sampler.ctx.h, sampler.h, solver.h, nlevels, g.ctypes.data_as(_DPTR), len(g),
                                               float(noise), C.byref(p), C.byref(h)))
         self.h = h
+        if splitting:
+            _hcheck(self.lib.pmc_ratio_set_splitting(self.h, 1))
 
     def set_farm(self, nranks, rank, reduce=None):
         if reduce is not None:
@@ -241,7 +247,8 @@ class RatioManager:
         _hcheck(self.lib.pmc_ratio_result_get(self.h, C.byref(r)))
         nl = r.nlevels
         out = {n: getattr(r, n) for n, t in pmc_ratio_result._fields_ if t is C.c_double}
-        for n in ("eR", "varR", "eYR", "varYR", "eABS_YR", "eZ", "varZ", "eYZ", "varYZ", "eABS_YZ", "eC", "cost"):
+        for n in ("eR", "varR", "eYR", "varYR", "eABS_YR", "eZ", "varZ", "eYZ", "varYZ", "eABS_YZ", "eC", "cost", "eRatio",
+                  "varRatio", "eYRatio", "varYRatio", "eABS_YRatio"):
             out[n] = np.ctypeslib.as_array(getattr(r, n), shape=(nl,)).copy()
         out["sums"] = np.ctypeslib.as_array(r.sums, shape=(nl, RATIO_NVAR)).copy()
         out["nsamples"] = np.ctypeslib.as_array(r.nsamples, shape=(nl,)).copy()

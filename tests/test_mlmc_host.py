@@ -246,6 +246,52 @@ def test_ratio_manager_sums_and_statistics(nl):
     mgr.close()
 
 
+@pytest.mark.parametrize("nl", [1, 3])
+def test_ratio_splitting_manager_sums_and_statistics(nl):
+    """ML_BayesRatio_Splitting_Manager / SL_BayesRatio_Splitting_Manager ("divide, then subtract":
+    src/ML_BayesRatio_Splitting_Manager.hpp:297-432 InitRun, :595-737 computeNSamplesMSE) against the restatement."""
+    from oracle import ratio_oracle as ro
+    pl = SyntheticPlugin(nl)
+    like = _synthetic_likelihood(nl)
+    mgr = host_api.RatioManager(nl, callbacks=pl.callbacks(), likelihood=like, wall_time=False, batch=4, eps2=1e-3,
+                                splitting=True)
+    ns = [6, 9, 14][:nl]
+    r = mgr.InitRun(ns)
+    sums = np.zeros((nl, ro.NVAR))
+    ref = SyntheticPlugin(nl)
+    for lvl in range(nl - 1, -1, -1):
+        for i in range(ns[lvl]):
+            zxi, xi = ref.sample(lvl, (1 << 62) + i, 1), ref.sample(lvl, i, 1)
+            zl, _, c1 = like(lvl, ref.eval(lvl, lvl, zxi, None, None)[0])
+            _, rr, c2 = like(lvl, ref.eval(lvl, lvl, xi, None, None)[0])
+            q = rr[0] / zl[0]
+            if lvl < nl - 1:
+                zcl, _, c3 = like(lvl + 1, ref.eval(lvl + 1, lvl, zxi, None, None)[0])
+                _, rcl, c4 = like(lvl + 1, ref.eval(lvl + 1, lvl, xi, None, None)[0])
+                ro.accumulate(sums, lvl, rr[0], rr[0] - rcl[0], zl[0], zl[0] - zcl[0], c1[0] + c2[0] + c3[0] + c4[0])
+                ro.accumulate_ratio(sums, lvl, q, q - rcl[0] / zcl[0])
+            else:
+                ro.accumulate(sums, lvl, rr[0], rr[0], zl[0], zl[0], c1[0] + c2[0])
+                ro.accumulate_ratio(sums, lvl, q, q)
+    assert np.allclose(r["sums"], sums, rtol=1e-12, atol=1e-14)
+    st = ro.compute_splitting(sums, ns, NDOFS[:nl], 1e-3, 0.5)
+    for key in ("eRatio", "varRatio", "eYRatio", "varYRatio", "eABS_YRatio", "eC"):
+        assert np.allclose(r[key], st[key], rtol=1e-10, atol=1e-14), key
+    assert r["ratio_estimate"] == pytest.approx(st["ratio_estimate"], rel=1e-10)
+    assert r["bias2"] == pytest.approx(st["bias2"], rel=1e-9, abs=1e-16)
+    assert r["estimator_variance"] == pytest.approx(st["estimator_variance"], rel=1e-10)
+    if nl > 2:
+        assert r["alpha"] == pytest.approx(st["alpha"], rel=1e-9) and r["beta"] == pytest.approx(st["beta"], rel=1e-9)
+    assert list(r["missing"]) == st["missing"]
+    mgr.close()
+    # adaptive loop terminates on the Ratio variance
+    mgr = host_api.RatioManager(nl, callbacks=SyntheticPlugin(nl).callbacks(), likelihood=like, wall_time=False, batch=8,
+                                eps2=2e-3, init_nsamples=10, splitting=True)
+    r = mgr.Run()
+    assert r["estimator_variance"] <= 0.5 * 2e-3 and np.isfinite(r["ratio_estimate"])
+    mgr.close()
+
+
 def test_ratio_manager_run_converges():
     pl = SyntheticPlugin(3)
     mgr = host_api.RatioManager(3, callbacks=pl.callbacks(), likelihood=_synthetic_likelihood(3), wall_time=False, batch=8,
