@@ -170,6 +170,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    if rank == 0:
+        smp.set_operator_timing(True)     # HIP events around every K5 launch of lane 0's MINRES loops
+        smp.operator_time()
     t0 = time.perf_counter()
     iters = []
     for i in range(args.steps):
@@ -177,6 +180,9 @@ def main():
         iters += [t[0] for t in st]
     barrier()
     dt = time.perf_counter() - t0
+    if rank == 0:
+        loop_ms, loop_launches = smp.operator_time()
+        smp.set_operator_timing(False)
     # the one exchange of a sample farm: SUM all-reduce of the accumulators (here: field statistics)
     acc = np.array([float(np.sum(iters)), float(len(iters)), dt])
     if world > 1:
@@ -222,7 +228,15 @@ def main():
                          "frac": k_bytes / (k_ms * 1e-3) / 1e9 / peak, "traffic": traffic,
                          "bytes_per_launch": k_bytes, "avg_kernel_ms": k_ms,
                          "spmv_nb1": {"achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "bytes_per_launch": k1_bytes,
-                                      "avg_kernel_ms": k1_ms, "frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / peak}},
+                                      "avg_kernel_ms": k1_ms, "frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / peak},
+                         # the same operator with its fused <u, Au>, every launch of lane 0 inside the timed region
+                         # (HIP events on that lane's stream); with streams > 1 other lanes' kernels share the GPU
+                         # during these launches, so this is a lower bound on what the kernel itself sustains
+                         "in_loop": {"kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, true, 1>",
+                                     "launches": loop_launches, "concurrent_streams": ns,
+                                     "avg_kernel_ms": loop_ms / max(loop_launches, 1),
+                                     "achieved": k_bytes / (loop_ms / max(loop_launches, 1) * 1e-3) / 1e9,
+                                     "frac": k_bytes / (loop_ms / max(loop_launches, 1) * 1e-3) / 1e9 / peak}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, args.seed)

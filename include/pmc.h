@@ -63,7 +63,8 @@ typedef struct pmc_solver_opts {
     double rel_tol;
     double abs_tol;
     int32_t cheb_degree_M;    /* polynomial degree on the M block (default 2) */
-    double cheb_ratio_M;      /* targeted lambda_max/lambda_min of D^-1 M (default 8) */
+    double cheb_ratio_M;      /* Chebyshev interval lambda_max/lambda_min of the l1-scaled M-block; <= 0 (default): measured at
+                                 create time by a host Lanczos run on M (Darcy: on M(k == 1))                              */
     int32_t mg_smooth_degree; /* Chebyshev pre/post smoothing degree per level (default 2) */
     double mg_smooth_ratio;   /* smoothing interval [lmax/ratio, lmax] (default 8) */
     int32_t mg_coarse_degree; /* polynomial degree on the coarsest level (default 12) */
@@ -182,6 +183,12 @@ int pmc_sampler_eval(pmc_sampler* s, int level, int xi_level, int nbatch, const 
  * 12 nnz + 4 nrows + nbatch * 8 * (nrows + ncols). */
 int pmc_sampler_apply_operator(pmc_sampler* s, int level, int nbatch, const double* x, double* y, int memspace,
                                int repeat, double* avg_ms, double* bytes);
+
+/* In-situ timing of the K5 launches inside the MINRES loop of pmc_sampler_eval: with on != 0 every operator launch is
+ * bracketed by HIP events on the solve's own stream (adds two event records per iteration; hipGraph replay is not
+ * timed).  pmc_sampler_operator_time returns and clears the accumulated kernel time [ms] and launch count. */
+int pmc_sampler_set_operator_timing(pmc_sampler* s, int on);
+int pmc_sampler_operator_time(pmc_sampler* s, double* total_ms, int64_t* launches);
 
 /* ---- DarcySolver ------------------------------------------------------------------------ */
 int pmc_darcy_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_darcy_level* levels,

@@ -87,6 +87,8 @@ SYMBOLS = {
                                    C.POINTER(pmc_stats)]),
     "pmc_sampler_apply_operator": (C.c_int, [_VP, C.c_int, C.c_int, _DP, _DP, C.c_int, C.c_int, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double)]),
+    "pmc_sampler_set_operator_timing": (C.c_int, [_VP, C.c_int]),
+    "pmc_sampler_operator_time": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pmc_darcy_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_darcy_level), C.c_int,
                                    C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
     "pmc_darcy_destroy": (None, [_VP]),
@@ -394,6 +396,16 @@ class PDESampler:
         if return_stats:
             out.append([(s.iterations, s.converged, s.initial_norm, s.final_norm) for s in stats])
         return out[0] if len(out) == 1 else tuple(out)
+
+    def set_operator_timing(self, on: bool):
+        """Bracket every K5 launch of the MINRES loop with HIP events (in-situ kernel time for the roofline)."""
+        _check(self.ctx.lib.pmc_sampler_set_operator_timing(self.h, 1 if on else 0))
+
+    def operator_time(self):
+        """(total ms, launches) of the timed K5 launches since the last call."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        _check(self.ctx.lib.pmc_sampler_operator_time(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def Mult(self, level, x, repeat=1):
         """y = [M Bt; B -aW] x (the block operator's Mult).  x: (nbatch, n_u+n_s) numpy or a

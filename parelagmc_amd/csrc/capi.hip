@@ -87,7 +87,7 @@ void pmc_solver_opts_default(pmc_solver_opts* o) {
     // tuned on MI355X (scripts/sweep.py, cube_tet r=5): degree 2 on M needs no more MINRES iterations than
     // degree 3; smoothing interval [lmax/8, lmax]
     o->cheb_degree_M = 2;
-    o->cheb_ratio_M = 8.0;
+    o->cheb_ratio_M = 0.0;
     o->mg_smooth_degree = 2;
     o->mg_smooth_ratio = 8.0;
     o->mg_coarse_degree = 12;
@@ -238,7 +238,7 @@ int pmc_sampler_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_sampl
         pmc_solver_opts_default(&o);
         if (opts) o = *opts;
         PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 1 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
-                        o.cheb_ratio_M > 1.0 && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
+                        (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
                     "solver options out of range");
         *out = new pmc_sampler(*c, nlevels, n_mc_levels, levels, alpha, matern_g, lognormal != 0, o);
         for (int l = 0; l < (*out)->impl.nlevels; ++l) (*out)->impl.lv[l].out_size = (*out)->impl.lv[l].n_s;
@@ -293,6 +293,23 @@ int pmc_sampler_apply_operator(pmc_sampler* s, int level, int nbatch, const doub
     });
 }
 
+int pmc_sampler_set_operator_timing(pmc_sampler* s, int on) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr, "sampler is NULL");
+        s->impl.work.time_operator = on != 0;
+    });
+}
+
+int pmc_sampler_operator_time(pmc_sampler* s, double* total_ms, int64_t* launches) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr, "sampler is NULL");
+        if (total_ms) *total_ms = s->impl.work.op_ms;
+        if (launches) *launches = s->impl.work.op_launches;
+        s->impl.work.op_ms = 0.0;
+        s->impl.work.op_launches = 0;
+    });
+}
+
 // ---- Darcy ------------------------------------------------------------------------------------
 int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_level* levels, int k_divides,
                      const pmc_solver_opts* opts, pmc_darcy** out) {
@@ -303,7 +320,7 @@ int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_l
         pmc_solver_opts_default(&o);
         if (opts) o = *opts;
         PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 1 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
-                        o.cheb_ratio_M > 1.0 && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
+                        (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
                     "solver options out of range");
         *out = new pmc_darcy(*c, nlevels, n_mc_levels, levels, k_divides != 0, o);
     });

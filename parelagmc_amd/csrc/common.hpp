@@ -94,6 +94,10 @@ HostCsr prolongator_from_agg(const std::vector<int>& agg, int nc);
 
 HostCsr csr_spgemm(const HostCsr& A, const HostCsr& B);
 double csr_anisotropy(const HostCsr& K);
+// lambda_min(D^-1 M) estimate (host Lanczos) and the M-block Chebyshev ratio derived from it
+double lanczos_lambda_min_scaled(const HostCsr& M, const std::vector<double>& dinv, int steps);
+double mass_block_ratio(const HostCsr& M, const std::vector<double>& l1inv);
+
 struct AmgLevelHost {
     HostCsr S;   // operator of this level
     HostCsr P;   // prolongator from the next coarser level (empty on the last level)

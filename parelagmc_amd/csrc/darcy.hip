@@ -201,6 +201,29 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         PMC_REQUIRE(has_diag_all, "darcy M_pattern must store the diagonal");
         sell_build(d.M, Mp, false, true, st);
         d.slot_src.upload(d.M.h_src, st);
+        if (o.cheb_ratio_M > 1.0) {
+            d.ratio_M = o.cheb_ratio_M;
+        } else {
+            // interval of the M-block smoother from M(k == 1) after the essential elimination; the element-wise lower
+            // bound behind it does not depend on the coefficient (M(k) and its l1 diagonal are the same positive
+            // combination of element matrices)
+            HostCsr M1 = Mp;
+            for (int i = 0; i < M1.nrows; ++i)
+                for (int p = M1.rowptr[i]; p < M1.rowptr[i + 1]; ++p) {
+                    const int j = M1.colind[p];
+                    double v = 0.0;
+                    for (int t = L.c_ptr[p]; t < L.c_ptr[p + 1]; ++t) v += L.c_val[t];
+                    if (L.ess_mask[i] || L.ess_mask[j]) v = (i == j) ? 1.0 : 0.0;
+                    M1.vals[p] = v;
+                }
+            std::vector<double> l1(M1.nrows);
+            for (int i = 0; i < M1.nrows; ++i) {
+                double sabs = 0.0;
+                for (int p = M1.rowptr[i]; p < M1.rowptr[i + 1]; ++p) sabs += std::fabs(M1.vals[p]);
+                l1[i] = 1.0 / sabs;
+            }
+            d.ratio_M = mass_block_ratio(M1, l1);
+        }
         d.c_ptr.upload(L.c_ptr, nnzM + 1, st);
         d.c_elem.upload(L.c_elem, ncontrib, st);
         d.c_val.upload(L.c_val, ncontrib, st);
@@ -503,7 +526,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
                                    partial ? partial + (size_t)nu_blk * nb_ : nullptr, xp);
         return nu_blk + np_blk;
     };
-    ChebParams cpM{opts.cheb_degree_M, 1.0, opts.cheb_ratio_M, d.mvals_scaled.p};
+    ChebParams cpM{opts.cheb_degree_M, 1.0, d.ratio_M, d.mvals_scaled.p};
     const double* l1 = d.l1invM.p;
     double* cxp = cx.p;
     double* cdp = cd.p;

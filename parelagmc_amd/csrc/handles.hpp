@@ -10,6 +10,7 @@ std::unique_ptr<Multigrid> build_sa_chain(const HostCsr& K, const std::vector<do
                                           hipStream_t st);
 
 struct SamplerLevel {
+    double ratio_M = 8.0;            // Chebyshev interval lambda_max/lambda_min of the l1-scaled M-block
     int n_u = 0, n_s = 0;
     int64_t nnz = 0;
     Sell A;                 // [M Bt; B -aW]
@@ -54,6 +55,7 @@ struct Sampler {
 
 struct DarcyLevel {
     int n_u = 0, n_p = 0, n_coef = 0;
+    double ratio_M = 8.0;            // Chebyshev interval of the l1-scaled M-block (from M(k == 1) unless given)
     int64_t nnz = 0;
     Sell M;                          // pattern only; values are per-realization
     DevBuf<int> slot_src, c_ptr, c_elem;

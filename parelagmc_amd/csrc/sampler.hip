@@ -132,6 +132,7 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
         for (double v : dM) PMC_REQUIRE(v > 0.0, "sampler M must have a positive diagonal");
         {
             std::vector<double> l1 = l1_inverse(M);
+            d.ratio_M = o.cheb_ratio_M > 1.0 ? o.cheb_ratio_M : mass_block_ratio(M, l1);
             d.dinvM.upload(l1, st);
             d.M_scaled.upload(sell_scaled_values(d.M, M, l1), st);
             PMC_HIP(hipStreamSynchronize(st));
@@ -301,7 +302,7 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     };
     const SellView Mv = view(d.M);
     const double* dinvM = d.dinvM.p;
-    ChebParams cpM{opts.cheb_degree_M, 1.0, opts.cheb_ratio_M, d.M_scaled.p};
+    ChebParams cpM{opts.cheb_degree_M, 1.0, d.ratio_M, d.M_scaled.p};
     double* cxp = cx.p;
     double* cdp = cd.p;
     const bool use_amg = level < (int)amg.size() && amg[level];

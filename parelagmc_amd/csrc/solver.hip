@@ -160,6 +160,7 @@ int Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* x
 MinresWork::~MinresWork() {
     for (auto& kv : graphs)
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
 }
 
 uint64_t Multigrid::signature(int l0) const {
@@ -243,8 +244,22 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     MinresResult out;
     const int every = o.check_every > 0 ? o.check_every : 1;
     // one MINRES iteration with explicit roles of the ping-pong vectors
+    size_t ev_used = 0;
+    const bool timing = w.time_operator && !(hint.key != 0 && o.use_graph != 0);
     auto iteration = [&](double* u0_, double* u1_, double* v0_, double* v1_, double* w0_, double* w1_) {
+        if (timing) {
+            while (w.ev.size() < ev_used + 2) {
+                hipEvent_t e;
+                PMC_HIP(hipEventCreate(&e));
+                w.ev.push_back(e);
+            }
+            PMC_HIP(hipEventRecord(w.ev[ev_used], st));
+        }
         int nblk = A.apply(st, nb, u1_, q, w.partial.p);
+        if (timing) {
+            PMC_HIP(hipEventRecord(w.ev[ev_used + 1], st));
+            ev_used += 2;
+        }
         k::minres_scal1(st, nb, S, w.partial.p, nblk);
         k::lincomb3(st, nb, n, cV0, q, cV1, v1_, cV2, v0_);
         nblk = prec(st, nb, v0_, u0_, w.partial.p);
@@ -323,6 +338,12 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     static_assert(sizeof(k::MinresState) <= 4096 * sizeof(double), "pinned scratch too small");
     PMC_HIP(hipMemcpyAsync(ctx.h_scal, S, sizeof(k::MinresState), hipMemcpyDeviceToHost, st));
     PMC_HIP(hipStreamSynchronize(st));
+    for (size_t e = 0; e + 1 < ev_used; e += 2) {
+        float ms = 0.f;
+        PMC_HIP(hipEventElapsedTime(&ms, w.ev[e], w.ev[e + 1]));
+        w.op_ms += ms;
+        ++w.op_launches;
+    }
     k::MinresState hs;
     std::memcpy(&hs, ctx.h_scal, sizeof(hs));
     for (int kcol = 0; kcol < nb; ++kcol) {

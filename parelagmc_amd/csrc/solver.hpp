@@ -109,6 +109,11 @@ struct MinresWork {
         hipGraphExec_t exec = nullptr;
     };
     std::map<uint64_t, GraphEntry> graphs;   // two MINRES iterations per graph, see minres_solve
+    // optional in-situ timing of the operator launches (K5) with HIP events on the solve's own stream
+    bool time_operator = false;
+    std::vector<hipEvent_t> ev;
+    double op_ms = 0.0;
+    int64_t op_launches = 0;
     MinresWork() = default;
     MinresWork(const MinresWork&) = delete;
     MinresWork& operator=(const MinresWork&) = delete;

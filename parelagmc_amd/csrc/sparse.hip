@@ -440,4 +440,76 @@ std::vector<AmgLevelHost> sa_hierarchy(const HostCsr& K0, const std::vector<doub
     return out;
 }
 
+
+// Smallest eigenvalue of D^-1 M (D^-1 = dinv > 0, M symmetric positive definite) by `steps` Lanczos iterations on the
+// symmetrically scaled matrix (three-term recurrence, no stored basis) and bisection on the tridiagonal matrix.  The
+// Ritz value approaches the eigenvalue from above; it sizes the Chebyshev interval of the M-block smoother, where an
+// over-estimate only weakens the polynomial on the few modes below it (it stays positive definite).
+double lanczos_lambda_min_scaled(const HostCsr& M, const std::vector<double>& dinv, int steps) {
+    const int n = M.nrows;
+    if (n == 0) return 1.0;
+    std::vector<double> sd(n), v(n), vold(n, 0.0), w(n), t(n);
+    for (int i = 0; i < n; ++i) sd[i] = std::sqrt(dinv[i]);
+    uint64_t state = 0x9e3779b97f4a7c15ull;
+    double nrm = 0.0;
+    for (int i = 0; i < n; ++i) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        v[i] = (double)((state >> 11) & 0xfffff) / 1048576.0 - 0.5;
+        nrm += v[i] * v[i];
+    }
+    nrm = std::sqrt(nrm);
+    for (double& x : v) x /= nrm;
+    std::vector<double> al, be;
+    double beta = 0.0;
+    steps = std::min(steps, n);
+    for (int k = 0; k < steps; ++k) {
+        for (int i = 0; i < n; ++i) t[i] = sd[i] * v[i];
+        for (int i = 0; i < n; ++i) {
+            double acc = 0.0;
+            for (int p = M.rowptr[i]; p < M.rowptr[i + 1]; ++p) acc += M.vals[p] * t[M.colind[p]];
+            w[i] = sd[i] * acc;
+        }
+        double alpha = 0.0;
+        for (int i = 0; i < n; ++i) alpha += w[i] * v[i];
+        for (int i = 0; i < n; ++i) w[i] -= alpha * v[i] + beta * vold[i];
+        al.push_back(alpha);
+        double b2 = 0.0;
+        for (int i = 0; i < n; ++i) b2 += w[i] * w[i];
+        beta = std::sqrt(b2);
+        if (beta < 1e-14 * std::fabs(alpha) || k + 1 == steps) break;
+        be.push_back(beta);
+        for (int i = 0; i < n; ++i) { vold[i] = v[i]; v[i] = w[i] / beta; }
+    }
+    // smallest eigenvalue of the tridiagonal (al, be): bisection with the Sturm count
+    const int m = (int)al.size();
+    double lo = 1e300, hi = -1e300;
+    for (int i = 0; i < m; ++i) {
+        const double r = (i > 0 ? std::fabs(be[i - 1]) : 0.0) + (i + 1 < m ? std::fabs(be[i]) : 0.0);
+        lo = std::min(lo, al[i] - r);
+        hi = std::max(hi, al[i] + r);
+    }
+    auto count_below = [&](double x) {
+        int cnt = 0;
+        double q = al[0] - x;
+        if (q < 0) ++cnt;
+        for (int i = 1; i < m; ++i) {
+            if (q == 0.0) q = 1e-300;
+            q = al[i] - x - be[i - 1] * be[i - 1] / q;
+            if (q < 0) ++cnt;
+        }
+        return cnt;
+    };
+    for (int it = 0; it < 200 && hi - lo > 1e-12 * std::max(1.0, std::fabs(hi)); ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (count_below(mid) >= 1) hi = mid; else lo = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
+// Chebyshev interval ratio lambda_max / lambda_min of the l1-scaled M-block (lambda_max <= 1 by construction)
+double mass_block_ratio(const HostCsr& M, const std::vector<double>& l1inv) {
+    const double lmin = lanczos_lambda_min_scaled(M, l1inv, 40);
+    const double ratio = 1.0 / std::max(lmin, 1.0 / 64.0);
+    return std::min(64.0, std::max(1.5, ratio));
+}
 }  // namespace pmc
