@@ -348,7 +348,9 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
                                                             const double* __restrict__ dinv,
                                                             const double* __restrict__ r, double* xout,
                                                             double c0, double c1, double* __restrict__ partial,
-                                                            const double* xadd, const double* __restrict__ dot_with) {
+                                                            const double* xadd, const double* __restrict__ dot_with,
+                                                            const int* __restrict__ padd_idx,
+                                                            const double* __restrict__ padd_x) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
@@ -381,6 +383,12 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
                 load_c<C>(xadd + at, x0);
 #pragma unroll
                 for (int c = 0; c < C; ++c) xv[c] += x0[c];
+            }
+            if (padd_idx) {   // + (P xc)_row for an injection-type prolongator: xc[parent[row]]
+                double pc[C];
+                load_c<C>(padd_x + (size_t)padd_idx[row] * NB + t * C, pc);
+#pragma unroll
+                for (int c = 0; c < C; ++c) xv[c] += pc[c];
             }
             if constexpr (DOT) {
                 if (dot_with) load_c<C>(dot_with + at, rv);
@@ -1274,21 +1282,22 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
 }
 
 int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
-          double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with) {
+          double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with, const int* padd_idx,
+          const double* padd_x) {
     if (As.nrows == 0) return 0;
     if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (As.bv) {
             if (dot_partial)
-                sell_poly2_kernel<NB, true, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with);
+                sell_poly2_kernel<NB, true, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
             else
-                sell_poly2_kernel<NB, true, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with);
+                sell_poly2_kernel<NB, true, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x);
         } else {
             if (dot_partial)
-                sell_poly2_kernel<NB, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with);
+                sell_poly2_kernel<NB, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
             else
-                sell_poly2_kernel<NB, false, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with);
+                sell_poly2_kernel<NB, false, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x);
         }
     });
     check_launch();

@@ -50,7 +50,7 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
 // one-pass degree-2 polynomial from a zero guess: xout = dinv.*(c0 r - c1 As r), As = A D^-1 (shared values)
 int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
           double c0, double c1, double* dot_partial = nullptr, const double* xadd = nullptr,
-          const double* dot_with = nullptr);
+          const double* dot_with = nullptr, const int* padd_idx = nullptr, const double* padd_x = nullptr);
 // y = A1 x1 + A2 x2 (A1 per-realization values, A2 shared values, same rows); optional fused dot
 int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, const SellView& A2, const double* x2, double* y,
               double* dot_partial, const double* dot_with);

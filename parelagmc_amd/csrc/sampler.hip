@@ -184,6 +184,18 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
             HostCsr Pt = csr_transpose(P);
             sell_build(m.P, P, true, false, st);
             sell_build(m.Pt, Pt, true, false, st);
+            // injection-type prolongator (P0 on nested meshes): coarse correction folded into the post-smoothing
+            bool injection = true;
+            std::vector<int> parent(P.nrows, 0);
+            for (int i = 0; i < P.nrows && injection; ++i) {
+                injection = (P.rowptr[i + 1] - P.rowptr[i] == 1) && P.vals[P.rowptr[i]] == 1.0;
+                if (injection) parent[i] = P.colind[P.rowptr[i]];
+            }
+            if (injection) {
+                sell_build(m.SP, csr_spgemm(S, P), true, false, st);
+                m.parent.upload(parent, st);
+                m.has_sp = true;
+            }
         }
         PMC_HIP(hipStreamSynchronize(st));
     }

@@ -56,6 +56,22 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
     return cur;
 }
 
+int cheb_post_from_residual(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv,
+                            const ChebParams& cp, const double* r, const double* res, double* x, const int* parent,
+                            const double* xc, double* dot_partial) {
+    if (!(cp.degree == 2 && cp.scaled_vals)) throw Error(PMC_ERR_INTERNAL, "fused post-smoothing needs degree 2");
+    const double lmax = cp.lmax, lmin = cp.lmax / cp.ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+    const double sigma = theta / delta;
+    const double rho_old = 1.0 / sigma;
+    const double rho1 = 1.0 / (2.0 * sigma - rho_old);
+    const double c0 = (1.0 + rho1 * rho_old) / theta + 2.0 * rho1 / delta;
+    const double c1 = 2.0 * rho1 / (delta * theta);
+    SellView As = A;
+    As.vals = cp.scaled_vals;
+    return k::poly2(st, nb, As, dinv, dinv_bv, res, x, c0, c1, dot_partial, x, r, parent, xc);
+}
+
 void MgLevel::ensure(int nb) {
     const size_t need = (size_t)n * nb;
     r.ensure(need);
@@ -146,6 +162,14 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     lc.ensure(nb);
     k::spmm(st, nb, view(lv.Pt), lv.res.p, lc.r.p, false, nullptr, nullptr);
     double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr);
+    if (lv.has_sp && !lv.bv && cheb_fused(cp, false)) {
+        // r - S (x + P xc) = res - (S P) xc, in place; then x <- x + P xc + p2(that residual) in one pass
+        k::residual(st, nb, view(lv.SP), lv.res.p, xc, lv.res.p);
+        const int nblk = cheb_post_from_residual(st, nb, A, lv.dinv.p, lv.bv, cp, r, lv.res.p, x, lv.parent.p, xc,
+                                                 dot_partial);
+        if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
+        return x;
+    }
     k::spmm(st, nb, view(lv.P), xc, x, true, nullptr, nullptr);
     return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, x, oth, lv.d.p, false, dot_partial, dot_blocks);
 }
@@ -168,6 +192,7 @@ uint64_t Multigrid::signature(int l0) const {
     for (int l = l0; l < (int)L.size(); ++l) {
         const MgLevel& m = L[l];
         h = hash_ptr(h, m.r.p); h = hash_ptr(h, m.xa.p); h = hash_ptr(h, m.xb.p); h = hash_ptr(h, m.d.p);
+        h = hash_ptr(h, m.SP.vals.p); h = hash_ptr(h, m.parent.p);
         h = hash_ptr(h, m.res.p); h = hash_ptr(h, m.vals_bv.p); h = hash_ptr(h, m.vals_scaled.p); h = hash_ptr(h, m.dinv.p);
     }
     return h;

@@ -27,6 +27,11 @@ inline bool cheb_fused(const ChebParams& cp, bool /*zero_guess*/) { return cp.de
 double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
                    const double* r, double* xa, double* xb, double* d, bool zero_guess,
                    double* dot_partial = nullptr, int* dot_blocks = nullptr);
+// Post-smoothing of a V-cycle level from an already formed residual `res` = r - A (x + P xc) without x + P xc in memory:
+// x <- x + xc[parent] + p2(res); degree 2 with scaled values only.  Returns the partial-block count of <r, x>.
+int cheb_post_from_residual(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv,
+                            const ChebParams& cp, const double* r, const double* res, double* x, const int* parent,
+                            const double* xc, double* dot_partial);
 // number of buffer flips cheb_apply performs
 inline int cheb_flips(const ChebParams& cp, bool zero_guess) {
     if (cheb_fused(cp, zero_guess)) return 0;
@@ -50,6 +55,12 @@ struct MgLevel {
     int last_degree = 12;
     double last_ratio = 100.0;
     Sell P, Pt;                  // to/from the next coarser level (absent on the last)
+    // Injection-type prolongators (one unit entry per row: P0 on nested meshes) with shared values: the coarse
+    // correction never materialises on this level.  SP = S P lets the post-smoothing residual be formed from the
+    // pre-restriction one, r - S (x + P xc) = res - SP xc, and `parent` adds xc[parent[i]] inside the smoother pass.
+    Sell SP;
+    DevBuf<int> parent;
+    bool has_sp = false;
     DevBuf<double> r, xa, xb, d, res;
     void ensure(int nb);
     SellView sview() const { return bv ? view_bv(S, vals_bv.p) : view(S); }
