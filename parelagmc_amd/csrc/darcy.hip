@@ -156,6 +156,7 @@ std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, 
         mg.L[j].S.h_src.clear(); mg.L[j].S.h_src.shrink_to_fit();
         mg.L[j].S.h_cols.clear(); mg.L[j].S.h_cols.shrink_to_fit();
     }
+    mg.enable_bv_tail();
     mg.build_tails(st);
     return ch;
 }
@@ -380,6 +381,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         lv[l + 1].g_w.upload(w, st);
         PMC_HIP(hipStreamSynchronize(st));
     }
+    mg.enable_bv_tail();
     mg.build_tails(st);
     for (int l = 0; l < nlevels; ++l) {   // host mirrors no longer needed
         mg.L[l].S.h_src.clear(); mg.L[l].S.h_src.shrink_to_fit();
@@ -499,6 +501,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
             k::gersh_scale_bv(st, nb, view_bv(m.S, m.vals_bv.p), m.dinv.p, gwork.p);
             k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
         }
+        chain->mg.refresh_bv_tail(st, nb);
     } else {
         MgLevel& m = mg.L[level];
         k::refresh(st, nb, m.S.nslots, d.s_ptr.p, d.s_idx.p, d.s_w.p, d.diagM.p, true, m.vals_bv.p);
@@ -512,6 +515,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
             k::diag_inv(st, nb, c.n, dc.s_diag_slot.p, c.vals_bv.p, c.dinv.p);
             k::scale_cols_bv(st, nb, c.S.nslots, c.S.cols.p, c.vals_bv.p, c.dinv.p, c.vals_scaled.p);
         }
+        mg.refresh_bv_tail(st, nb);
     }
     // operator [M(k) Bt; B 0] and block-diagonal preconditioner
     const SellView Mv = view_bv(d.M, d.mvals.p);

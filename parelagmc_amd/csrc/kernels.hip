@@ -1037,7 +1037,7 @@ static constexpr int kTailThreads = 1024;
 static constexpr size_t kTailLdsBytes = 160 * 1024 - 1024;   // dynamic LDS budget (static reduction scratch on top)
 
 __device__ __forceinline__ double tail_row_dot(const int* __restrict__ off, const int* __restrict__ cols,
-                                               const double* __restrict__ vals, int vstride, int vk, int row,
+                                               const double* __restrict__ vals, int vstride, size_t vk, int row,
                                                const double* xl) {
     const int slice = row >> 6, lane = row & 63;
     const int o = off[slice];
@@ -1069,7 +1069,10 @@ __device__ __forceinline__ double tail_row_dot(const int* __restrict__ off, cons
 __device__ void tail_cheb(const TailLevelDev& L, int bv, int nb, int k, int degree, double ratio, bool zero_guess,
                           const double* r, double* x, double* d) {
     const int n = L.n;
-    const int vstride = bv ? nb : 1, vk = bv ? k : 0;
+    // value / diagonal addressing: shared, interleaved per realization, or transposed per realization
+    const int vstride = bv == 1 ? nb : 1;
+    const size_t vk = bv == 1 ? (size_t)k : bv == 2 ? (size_t)k * L.nslots : 0;
+    const size_t dk = bv == 1 ? (size_t)k : bv == 2 ? (size_t)k * L.n : 0;
     const double lmax = L.lmax, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho_old = 1.0 / sigma;
@@ -1079,14 +1082,14 @@ __device__ void tail_cheb(const TailLevelDev& L, int bv, int nb, int k, int degr
         const double c0 = (1.0 + rho1 * rho_old) / theta + 2.0 * rho1 / delta, c1 = 2.0 * rho1 / (delta * theta);
         for (int i = threadIdx.x; i < n; i += kTailThreads) {
             const double acc = tail_row_dot(L.slice_off, L.cols, L.vals_scaled, vstride, vk, i, r);
-            x[i] = L.dinv[(size_t)i * vstride + vk] * (c0 * r[i] - c1 * acc);
+            x[i] = L.dinv[(size_t)i * vstride + dk] * (c0 * r[i] - c1 * acc);
         }
         __syncthreads();
         return;
     }
     if (zero_guess) {
         for (int i = threadIdx.x; i < n; i += kTailThreads) {
-            const double v = L.dinv[(size_t)i * vstride + vk] * r[i] / theta;
+            const double v = L.dinv[(size_t)i * vstride + dk] * r[i] / theta;
             d[i] = v;
             x[i] = v;
         }
@@ -1107,7 +1110,7 @@ __device__ void tail_cheb(const TailLevelDev& L, int bv, int nb, int k, int degr
         for (int i = threadIdx.x; i < n; i += kTailThreads) {
             const double acc = tail_row_dot(L.slice_off, L.cols, L.vals, vstride, vk, i, x);
             const double dold = (a != 0.0) ? d[i] : 0.0;
-            d[i] = a * dold + b * L.dinv[(size_t)i * vstride + vk] * (r[i] - acc);
+            d[i] = a * dold + b * L.dinv[(size_t)i * vstride + dk] * (r[i] - acc);
         }
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += kTailThreads) x[i] += d[i];
@@ -1141,7 +1144,8 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(const TailParams*
             break;
         }
         tail_cheb(L, P.bv, nb, k, P.smooth_degree, P.smooth_ratio, true, r, x, d);
-        const int vstride = P.bv ? nb : 1, vk = P.bv ? k : 0;
+        const int vstride = P.bv == 1 ? nb : 1;
+        const size_t vk = P.bv == 1 ? (size_t)k : P.bv == 2 ? (size_t)k * L.nslots : 0;
         for (int i = threadIdx.x; i < L.n; i += kTailThreads)          // residual into d
             d[i] = r[i] - tail_row_dot(L.slice_off, L.cols, L.vals, vstride, vk, i, x);
         __syncthreads();
@@ -1479,6 +1483,22 @@ void refresh(hipStream_t st, int nb, int64_t nslots, const int* ptr, const int* 
 
 void diag_inv(hipStream_t st, int nb, int n, const int* diag_slot, const double* vals, double* dinv) {
     PMC_DISPATCH_NB(nb, { diag_inv_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, diag_slot, vals, dinv); });
+    check_launch();
+}
+
+__global__ __launch_bounds__(kBlock) void transpose_bv_kernel(size_t count, int nb, const double* __restrict__ in,
+                                                              double* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;   // coalesced reads; the writes of a small array stay in L2
+    if (e >= count * nb) return;
+    const size_t i = e / nb;
+    const int k = (int)(e % nb);
+    out[(size_t)k * count + i] = in[e];
+}
+
+void transpose_bv(hipStream_t st, int nb, size_t count, const double* in, double* out) {
+    if (count == 0) return;
+    const size_t total = count * nb;
+    transpose_bv_kernel<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, st>>>(count, nb, in, out);
     check_launch();
 }
 

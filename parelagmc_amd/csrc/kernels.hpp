@@ -106,11 +106,12 @@ void diag_inv(hipStream_t st, int nb, int n, const int* diag_slot, const double*
 namespace pmc {
 struct TailLevelDev {
     int n, nslices;
+    int nslots;                 // total SELL slots of the level (column stride of transposed per-realization values)
     const int* slice_off;
     const int* cols;
-    const double* vals;         // shared [nslots] or per-realization [nslots][nb]
+    const double* vals;         // shared [nslots], per-realization [nslots][nb] (bv 1) or transposed [nb][nslots] (bv 2)
     const double* vals_scaled;  // S D^-1 on the same pattern, may be null
-    const double* dinv;         // [n] or [n][nb]
+    const double* dinv;         // [n], [n][nb] (bv 1) or [nb][n] (bv 2)
     int p_nslices, pt_nslices;  // transfers to / from the next coarser level (unused on the last tail level)
     const int *p_off, *p_cols, *pt_off, *pt_cols;
     const double *p_vals, *pt_vals;
@@ -130,5 +131,8 @@ namespace k {
 // vectors of the first tail level.  dot_partial != nullptr: writes <r, xout> per column as ONE partial block.
 int mg_tail(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_doubles, const double* r, double* xout,
             double* dot_partial);
+// out[k][i] = in[i][k]: per-realization values of a small level re-laid column-major for the tail kernel, whose
+// workgroup k then streams only its own realization's values
+void transpose_bv(hipStream_t st, int nb, size_t count, const double* in, double* out);
 }  // namespace k
 }  // namespace pmc

@@ -81,6 +81,24 @@ void MgLevel::ensure(int nb) {
     res.ensure(need);
 }
 
+void Multigrid::enable_bv_tail(int max_rows) {
+    for (MgLevel& m : L) {
+        if (!m.bv || m.n > max_rows) continue;
+        m.vals_t.alloc((size_t)m.S.nslots * kMaxBatch);
+        m.scaled_t.alloc((size_t)m.S.nslots * kMaxBatch);
+        m.dinv_t.alloc((size_t)m.n * kMaxBatch);
+    }
+}
+
+void Multigrid::refresh_bv_tail(hipStream_t st, int nb) {
+    for (MgLevel& m : L) {
+        if (!m.vals_t.p) continue;
+        k::transpose_bv(st, nb, (size_t)m.S.nslots, m.vals_bv.p, m.vals_t.p);
+        k::transpose_bv(st, nb, (size_t)m.S.nslots, m.vals_scaled.p, m.scaled_t.p);
+        k::transpose_bv(st, nb, (size_t)m.n, m.dinv.p, m.dinv_t.p);
+    }
+}
+
 void Multigrid::build_tails(hipStream_t st) {
     const int nl = (int)L.size();
     tail.clear();
@@ -89,9 +107,10 @@ void Multigrid::build_tails(hipStream_t st) {
     for (int l0 = 0; l0 < nl; ++l0) {
         // per-realization values are interleaved [slot][nb]: one workgroup per column would pull 16x the bytes it uses
         // through its L1 (measured: slower than the separate kernels), so the tail is for shared-value hierarchies
-        if (L[l0].bv) continue;
+        // ... unless the levels carry transposed copies (enable_bv_tail): bv = 2
+        if (L[l0].bv && !L[l0].vals_t.p) continue;
         TailParams tp{};
-        tp.bv = L[l0].bv ? 1 : 0;
+        tp.bv = L[l0].bv ? 2 : 0;
         tp.smooth_degree = smooth_degree;
         tp.smooth_ratio = smooth_ratio;
         size_t off = 0;
@@ -100,14 +119,16 @@ void Multigrid::build_tails(hipStream_t st) {
         for (int l = l0; l < nl; ++l) {
             if (cnt == 8) { ok = false; break; }
             const MgLevel& m = L[l];
+            if (m.bv != L[l0].bv || (m.bv && !m.vals_t.p)) { ok = false; break; }
             TailLevelDev& d = tp.lev[cnt++];
             d.n = m.n;
             d.nslices = m.S.nslices;
+            d.nslots = (int)m.S.nslots;
             d.slice_off = m.S.slice_off.p;
             d.cols = m.S.cols.p;
-            d.vals = m.bv ? m.vals_bv.p : m.S.vals.p;
-            d.vals_scaled = m.vals_scaled.p;
-            d.dinv = m.dinv.p;
+            d.vals = m.bv ? m.vals_t.p : m.S.vals.p;
+            d.vals_scaled = m.bv ? m.scaled_t.p : m.vals_scaled.p;
+            d.dinv = m.bv ? m.dinv_t.p : m.dinv.p;
             d.lmax = m.lmax;
             d.lds_off = (int)off;
             off += 3 * (size_t)m.n;

@@ -45,6 +45,9 @@ struct MgLevel {
     DevBuf<double> dinv;         // shared: n ; batched: n*kMaxBatch
     DevBuf<double> vals_bv;      // batched values (Darcy): nslots*kMaxBatch
     DevBuf<double> vals_scaled;  // S D^-1 on S's pattern (shared, or nslots*kMaxBatch when bv): one-pass pre-smoothing
+    // small per-realization levels: column-major copies [nb][...] for the LDS tail kernel (allocated by
+    // Multigrid::enable_bv_tail, refreshed by refresh_bv_tail after the level's values changed)
+    DevBuf<double> vals_t, scaled_t, dinv_t;
     bool bv = false;
     double lmax = 2.0;
     // Coarsest-level treatment: `is_last` levels end the recursion with a Chebyshev solve of degree
@@ -78,6 +81,10 @@ struct Multigrid {
     std::vector<size_t> tail_lds;
     bool use_tail = true;
     void build_tails(hipStream_t st);
+    // per-realization hierarchies: give every level of at most max_rows rows transposed value copies so that
+    // build_tails can include them; refresh_bv_tail(nb) re-fills the copies (call after every numeric refresh)
+    void enable_bv_tail(int max_rows = 8192);
+    void refresh_bv_tail(hipStream_t st, int nb);
     // hash of the work-buffer pointers a V-cycle from level l0 touches (for GraphHint::sig)
     uint64_t signature(int l0) const;
     // x = V(r) starting at level l0 with zero initial guess; result written to xout (n(l0)*nb).
