@@ -5,6 +5,7 @@
 // only refreshes values on fixed patterns (K12-K14 of SURVEY.md 2.3).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <numeric>
 
@@ -202,6 +203,56 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         PMC_REQUIRE(has_diag_all, "darcy M_pattern must store the diagonal");
         sell_build(d.M, Mp, false, true, st);
         d.slot_src.upload(d.M.h_src, st);
+        {
+            // element-grouped layout: expand the contribution lists per row and group them by element
+            std::vector<std::vector<std::pair<int, std::vector<std::pair<int, double>>>>> rows(Mp.nrows);
+            bool ok = true;
+            int gw = 1;
+            for (int i = 0; i < Mp.nrows && ok; ++i) {
+                auto& groups = rows[i];
+                if (L.ess_mask[i]) {
+                    groups.push_back({L.n_p, {{i, 1.0}}});       // identity row: constant-one coefficient row
+                    continue;
+                }
+                for (int p = Mp.rowptr[i]; p < Mp.rowptr[i + 1]; ++p) {
+                    const int j = Mp.colind[p];
+                    for (int t = L.c_ptr[p]; t < L.c_ptr[p + 1]; ++t) {
+                        const int e = L.c_elem[t];
+                        size_t gi = 0;
+                        while (gi < groups.size() && groups[gi].first != e) ++gi;
+                        if (gi == groups.size()) groups.push_back({e, {}});
+                        groups[gi].second.push_back({j, L.ess_mask[j] ? 0.0 : L.c_val[t]});
+                    }
+                }
+                if (groups.size() > 2) ok = false;
+                for (auto& gr : groups) gw = std::max(gw, (int)gr.second.size());
+            }
+            if (ok && gw <= 16) {
+                HostCsr Meg;
+                Meg.nrows = Meg.ncols = Mp.nrows;
+                Meg.rowptr.resize(Mp.nrows + 1);
+                Meg.colind.assign((size_t)Mp.nrows * 2 * gw, 0);
+                Meg.vals.assign((size_t)Mp.nrows * 2 * gw, 0.0);
+                std::vector<int> e12((size_t)Mp.nrows * 2, L.n_p);
+                for (int i = 0; i < Mp.nrows; ++i) {
+                    Meg.rowptr[i] = i * 2 * gw;
+                    for (int q = 0; q < 2 * gw; ++q) Meg.colind[(size_t)i * 2 * gw + q] = i;   // padding: own (cached) entry, weight 0
+                    for (size_t gi = 0; gi < rows[i].size(); ++gi) {
+                        e12[2 * i + gi] = rows[i][gi].first;
+                        for (size_t q = 0; q < rows[i][gi].second.size(); ++q) {
+                            Meg.colind[(size_t)i * 2 * gw + gi * gw + q] = rows[i][gi].second[q].first;
+                            Meg.vals[(size_t)i * 2 * gw + gi * gw + q] = rows[i][gi].second[q].second;
+                        }
+                    }
+                }
+                Meg.rowptr[Mp.nrows] = Mp.nrows * 2 * gw;
+                sell_build(d.Meg, Meg, true, false, st);
+                d.eg_e12.upload(e12, st);
+                d.eg_gw = gw;
+                d.has_eg = true;
+                PMC_HIP(hipStreamSynchronize(st));
+            }
+        }
         if (o.cheb_ratio_M > 1.0) {
             d.ratio_M = o.cheb_ratio_M;
         } else {
@@ -391,12 +442,19 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
     }
 }
 
+bool Darcy::use_eg(const DarcyLevel& d) const {
+    static const bool off = getenv("PMC_DARCY_NO_EG") != nullptr;   // tuning / A-B switch
+    return d.has_eg && opts.cheb_degree_M == 2 && !off;
+}
+
 void Darcy::ensure(int level, int nb) {
     DarcyLevel& d = lv[level];
     const size_t n = (size_t)d.n_u + d.n_p;
-    d.coef.ensure((size_t)d.n_p * nb);
-    d.mvals.ensure((size_t)d.M.nslots * nb);
-    d.mvals_scaled.ensure((size_t)d.M.nslots * nb);
+    d.coef.ensure((size_t)(d.n_p + 1) * nb);     // + the constant-one row of the element-grouped layout
+    if (!use_eg(d)) {
+        d.mvals.ensure((size_t)d.M.nslots * nb);
+        d.mvals_scaled.ensure((size_t)d.M.nslots * nb);
+    }
     sol_compact.ensure((size_t)std::max(d.n_obs, 1) * nb);
     d.diagM.ensure((size_t)d.n_u * nb);
     d.l1invM.ensure((size_t)d.n_u * nb);
@@ -482,14 +540,16 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     const int n_u = d.n_u, n_p = d.n_p, n = n_u + n_p;
     ensure(level, nb);
     // K12/K13: M(k), elimination, rhs_bc
+    const bool eg = use_eg(d);
     k::darcy_coef(st, nb, n_p, k_d, k_divides, d.coef.p);
+    if (eg) k::fill(st, (size_t)nb, d.coef.p + (size_t)n_p * nb, 1.0);
     SellView Mpat = view(d.M);
     k::darcy_assemble(st, nb, Mpat, d.slot_src.p, d.c_ptr.p, d.c_elem.p, d.c_val.p, d.coef.p, d.ess.p, d.ess_data.p,
-                      d.rhs_u0.p, d.mvals.p, d.diagM.p, d.l1invM.p, d.rhs_bc.p);
+                      d.rhs_u0.p, eg ? nullptr : d.mvals.p, d.diagM.p, d.l1invM.p, d.rhs_bc.p);
     k::broadcast(st, nb, n_p, d.rhs_p.p, d.rhs_bc.p + (size_t)n_u * nb);
     // K14: Schur complement values on the level hierarchy
     DarcyChain* chain = (level < (int)chains.size()) ? chains[level].get() : nullptr;
-    k::scale_cols_bv(st, nb, d.M.nslots, d.M.cols.p, d.mvals.p, d.l1invM.p, d.mvals_scaled.p);
+    if (!eg) k::scale_cols_bv(st, nb, d.M.nslots, d.M.cols.p, d.mvals.p, d.l1invM.p, d.mvals_scaled.p);
     if (chain) {
         gwork.ensure(kMaxBatch);
         for (size_t j = 0; j < chain->cl.size(); ++j) {
@@ -520,12 +580,15 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     // operator [M(k) Bt; B 0] and block-diagonal preconditioner
     const SellView Mv = view_bv(d.M, d.mvals.p);
     const SellView Bv = view(d.B), Btv = view(d.Bt);
+    const EgView Mg{d.n_u, d.Meg.nslices, d.eg_gw, d.Meg.cols.p, d.Meg.vals.p, d.eg_e12.p};
+    const double* coefp = d.coef.p;
     LinOp A;
     A.n = n;
     A.apply = [=](hipStream_t s, int nb_, const double* x, double* y, double* partial) {
         // u-rows: M(k) x_u + B^T x_p in one pass; p-rows: B x_u; <x, Ax> fused into both
         const double* xp = x + (size_t)n_u * nb_;
-        const int nu_blk = k::pair_spmm(s, nb_, Mv, x, Btv, xp, y, partial, x);
+        const int nu_blk = eg ? k::eg_pair_spmm(s, nb_, Mg, coefp, x, Btv, xp, y, partial, x)
+                              : k::pair_spmm(s, nb_, Mv, x, Btv, xp, y, partial, x);
         const int np_blk = k::spmm(s, nb_, Bv, x, y + (size_t)n_u * nb_, false,
                                    partial ? partial + (size_t)nu_blk * nb_ : nullptr, xp);
         return nu_blk + np_blk;
@@ -541,8 +604,14 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
         double* start = (flips % 2 == 0) ? z : cxp;
         double* other = (flips % 2 == 0) ? cxp : z;
         int nblk_u = 0;
-        double* res = cheb_apply(s, nb_, Mv, l1, true, cpM, r, start, other, cdp, true, dot_partial, &nblk_u);
-        if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
+        if (eg) {
+            double c0, c1;
+            cheb2_coefficients(cpM.lmax, cpM.ratio, &c0, &c1);
+            nblk_u = k::eg_poly2(s, nb_, Mg, coefp, l1, r, z, c0, c1, dot_partial);
+        } else {
+            double* res = cheb_apply(s, nb_, Mv, l1, true, cpM, r, start, other, cdp, true, dot_partial, &nblk_u);
+            if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
+        }
         const int nblk_s = mgp->vcycle(s, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_,
                                        dot_partial ? dot_partial + (size_t)nblk_u * nb_ : nullptr);
         return nblk_u + nblk_s;

@@ -60,6 +60,12 @@ struct DarcyLevel {
     Sell M;                          // pattern only; values are per-realization
     DevBuf<int> slot_src, c_ptr, c_elem;
     DevBuf<double> c_val;
+    // element-grouped form of M(k) (EgView): shared element-matrix entries + two coefficient rows per dof; when present
+    // (every dof belongs to at most two elements) the solve never materialises per-realization values of M
+    Sell Meg;
+    DevBuf<int> eg_e12;
+    int eg_gw = 0;
+    bool has_eg = false;
     Sell B, Bt;                      // shared +-1 values (essential columns/rows removed)
     DevBuf<unsigned char> ess;
     DevBuf<double> ess_data, rhs_u0, rhs_p, obs;
@@ -109,6 +115,7 @@ struct Darcy {
     DevBuf<double> gwork;
     MinresWork work;
     DevBuf<double> sol, sol_compact, cx, cd, stage_k, stage_sol, qpartial, qout, gtmp, gout;
+    bool use_eg(const DarcyLevel& d) const;
     void set_observations(int level, const pmc_csr* Gobs);
     void compute_G(int level, int nbatch, const double* k, double* G, double* C, double* Q, int memspace, pmc_stats* stats);
 

@@ -110,18 +110,21 @@ __device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], doubl
 // per wavefront), then the wavefront sweeps the slice in T steps of G rows: lane (g, t) takes row
 // rs*G+g and the 16 B column pair t, fetching that row's value / column index with a cross-lane
 // shuffle, so each x gather and each y store is one contiguous NB*8-byte segment per row.
-template <int NB, bool BV>
-__device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_off, const int* __restrict__ cols,
-                                                 const double* __restrict__ vals, const double* __restrict__ x,
-                                                 int slice, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
+// sell_row_range works on `width` slice columns starting at slot `off`.  CS: every gathered x[col] is multiplied by a
+// second gathered per-realization vector cs[col] (column scaling A D^-1 without stored scaled values).  ZERO: acc is
+// cleared first, otherwise accumulated into.
+template <int NB, bool BV, bool CS, bool ZERO>
+__device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
+                                               const double* __restrict__ x, const double* __restrict__ cs, int off,
+                                               int width, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
-    const int off = slice_off[slice];
-    const int width = (slice_off[slice + 1] - off) >> 6;
     const int g = lane / T, t = lane % T;
+    if constexpr (ZERO) {
 #pragma unroll
-    for (int rs = 0; rs < T; ++rs)
+        for (int rs = 0; rs < T; ++rs)
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
+            for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
+    }
     int slot = off + lane;
 
     if constexpr (T == 1) {
@@ -140,10 +143,11 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
                 else aa[u] = ok ? vals[at] : 0.0;
             }
             __builtin_amdgcn_sched_barrier(0);
-            double xv[JU][C], av[JU][C];
+            double xv[JU][C], av[JU][C], sv[JU][C];
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
                 load_c<C>(x + (size_t)cc[u] * NB, xv[u]);
+                if constexpr (CS) load_c<C>(cs + (size_t)cc[u] * NB, sv[u]);
                 if constexpr (BV) load_c<C>(vals + (size_t)(j + u < width ? slot + u * kWave : slot) * NB, av[u]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -151,6 +155,7 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
             for (int u = 0; u < JU; ++u)
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
+                    if constexpr (CS) xv[u][c] *= sv[u][c];
                     if constexpr (BV) acc[0][c] = fma(aa[u] * av[u][c], xv[u][c], acc[0][c]);
                     else acc[0][c] = fma(aa[u], xv[u][c], acc[0][c]);
                 }
@@ -185,10 +190,12 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
         }
         double xv[T][C];
         double av[T][C];
+        double sv[T][C];
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise re-serialises load -> wait -> fma
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             load_c<C>(x + (size_t)cc[rs] * NB + t * C, xv[rs]);
+            if constexpr (CS) load_c<C>(cs + (size_t)cc[rs] * NB + t * C, sv[rs]);
             if constexpr (BV) load_c<C>(vals + (size_t)(slot - lane + rs * G + g) * NB + t * C, av[rs]);
         }
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
@@ -196,6 +203,7 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
         for (int rs = 0; rs < T; ++rs) {
 #pragma unroll
             for (int c = 0; c < C; ++c) {
+                if constexpr (CS) xv[rs][c] *= sv[rs][c];
                 if constexpr (BV) acc[rs][c] = fma(av[rs][c], xv[rs][c], acc[rs][c]);
                 else acc[rs][c] = fma(aa[rs], xv[rs][c], acc[rs][c]);
             }
@@ -203,6 +211,15 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
         cj = cn;
         vj = vn;
     }
+}
+
+template <int NB, bool BV>
+__device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_off, const int* __restrict__ cols,
+                                                 const double* __restrict__ vals, const double* __restrict__ x,
+                                                 int slice, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
+    const int off = slice_off[slice];
+    const int width = (slice_off[slice + 1] - off) >> 6;
+    sell_row_range<NB, BV, false, true>(cols, vals, x, nullptr, off, width, lane, acc);
 }
 
 // XCD-aware slice assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (block b runs
@@ -434,6 +451,110 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
 #pragma unroll
                 for (int c = 0; c < C; ++c) p[c] = fma(w[c], acc[rs][c], p[c]);
             }
+        }
+    }
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+}
+
+// Element-grouped per-realization mass matrix (EgView): acc = c1 * (group 1 row sums) + c2 * (group 2 row sums).
+template <int NB, bool CS>
+__device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, const double* __restrict__ w,
+                                               const int* __restrict__ e12, const double* __restrict__ coef, int gw,
+                                               const double* __restrict__ x, const double* __restrict__ cs, int nrows,
+                                               int slice, int lane, double (&y)[Lay<NB>::T][Lay<NB>::C]) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int g = lane / T, t = lane % T;
+    const int off = slice * 2 * gw * kWave;
+    double a[T][C];
+    sell_row_range<NB, false, CS, true>(cols, w, x, cs, off, gw, lane, a);
+#pragma unroll
+    for (int rs = 0; rs < T; ++rs) {
+        const int row = min(slice * kWave + rs * G + g, nrows - 1);
+        double c1[C];
+        load_c<C>(coef + (size_t)e12[2 * row] * NB + t * C, c1);
+#pragma unroll
+        for (int c = 0; c < C; ++c) y[rs][c] = c1[c] * a[rs][c];
+    }
+    sell_row_range<NB, false, CS, true>(cols, w, x, cs, off + gw * kWave, gw, lane, a);
+#pragma unroll
+    for (int rs = 0; rs < T; ++rs) {
+        const int row = min(slice * kWave + rs * G + g, nrows - 1);
+        double c2[C];
+        load_c<C>(coef + (size_t)e12[2 * row + 1] * NB + t * C, c2);
+#pragma unroll
+        for (int c = 0; c < C; ++c) y[rs][c] = fma(c2[c], a[rs][c], y[rs][c]);
+    }
+}
+
+template <int NB, bool DOT>
+__global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
+    int nrows, int nslices, int gw, const int* __restrict__ cols1, const double* __restrict__ w1,
+    const int* __restrict__ e12, const double* __restrict__ coef, const int* __restrict__ off2,
+    const int* __restrict__ cols2, const double* __restrict__ vals2, const double* __restrict__ x1,
+    const double* __restrict__ x2, double* __restrict__ y, const double* __restrict__ dot_with,
+    double* __restrict__ partial) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = lane / T, t = lane % T;
+    double p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = 0.0;
+    int slice_end;
+    for (int slice = first_slice(nslices, &slice_end); slice < slice_end; slice += kBlock / kWave) {
+        double acc[T][C];
+        eg_row_product<NB, false>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, acc);
+        {
+            const int o2 = off2[slice];
+            sell_row_range<NB, false, false, false>(cols2, vals2, x2, nullptr, o2, (off2[slice + 1] - o2) >> 6, lane, acc);
+        }
+#pragma unroll
+        for (int rs = 0; rs < T; ++rs) {
+            const int row = slice * kWave + rs * G + g;
+            if (row >= nrows) continue;
+            const size_t at = (size_t)row * NB + t * C;
+            store_c<C>(y + at, acc[rs]);
+            if constexpr (DOT) {
+                double wv[C];
+                load_c<C>(dot_with + at, wv);
+#pragma unroll
+                for (int c = 0; c < C; ++c) p[c] = fma(wv[c], acc[rs][c], p[c]);
+            }
+        }
+    }
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+}
+
+template <int NB, bool DOT>
+__global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices, int gw, const int* __restrict__ cols,
+                                                          const double* __restrict__ w, const int* __restrict__ e12,
+                                                          const double* __restrict__ coef,
+                                                          const double* __restrict__ dinv, const double* __restrict__ r,
+                                                          double* __restrict__ xout, double c0, double c1,
+                                                          double* __restrict__ partial) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = lane / T, t = lane % T;
+    double p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = 0.0;
+    int slice_end;
+    for (int slice = first_slice(nslices, &slice_end); slice < slice_end; slice += kBlock / kWave) {
+        double acc[T][C];
+        eg_row_product<NB, true>(cols, w, e12, coef, gw, r, dinv, nrows, slice, lane, acc);
+#pragma unroll
+        for (int rs = 0; rs < T; ++rs) {
+            const int row = slice * kWave + rs * G + g;
+            if (row >= nrows) continue;
+            const size_t at = (size_t)row * NB + t * C;
+            double rv[C], di[C], xv[C];
+            load_c<C>(r + at, rv);
+            load_c<C>(dinv + at, di);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                xv[c] = di[c] * (c0 * rv[c] - c1 * acc[rs][c]);
+                if constexpr (DOT) p[c] = fma(rv[c], xv[c], p[c]);
+            }
+            store_c<C>(xout + at, xv);
         }
     }
     if constexpr (DOT) reduce_cols_store<NB>(p, partial);
@@ -912,7 +1033,7 @@ __global__ __launch_bounds__(kBlock) void darcy_assemble_kernel(
                 if (c == row) dg[k] = v[k];
             }
         }
-        store_row<NB>(mvals + (size_t)slot * NB, v);
+        if (mvals) store_row<NB>(mvals + (size_t)slot * NB, v);
     }
     if (!live) return;
     double rb[NB];
@@ -1303,6 +1424,36 @@ int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool d
             else
                 sell_poly2_kernel<NB, false, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x);
         }
+    });
+    check_launch();
+    return dot_partial ? (int)g.x : 0;
+}
+
+int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, const double* x1, const SellView& A2,
+                 const double* x2, double* y, double* dot_partial, const double* dot_with) {
+    if (M.nrows == 0) return 0;
+    if (A2.bv || A2.nrows != M.nrows || A2.nslices != M.nslices)
+        throw Error(PMC_ERR_INTERNAL, "eg_pair_spmm: second operator must share the rows and carry shared values");
+    const dim3 g = grid_bounded(grid_slices(M.nslices), dot_partial != nullptr);
+    PMC_DISPATCH_NB(nb, {
+        if (dot_partial)
+            eg_pair_spmm_kernel<NB, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial);
+        else
+            eg_pair_spmm_kernel<NB, false><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr);
+    });
+    check_launch();
+    return dot_partial ? (int)g.x : 0;
+}
+
+int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, double* xout,
+             double c0, double c1, double* dot_partial) {
+    if (M.nrows == 0) return 0;
+    const dim3 g = grid_bounded(grid_slices(M.nslices), dot_partial != nullptr);
+    PMC_DISPATCH_NB(nb, {
+        if (dot_partial)
+            eg_poly2_kernel<NB, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial);
+        else
+            eg_poly2_kernel<NB, false><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;

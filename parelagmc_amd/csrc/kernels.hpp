@@ -21,6 +21,18 @@ inline SellView view_bv(const Sell& S, const double* vals) {
     return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, vals, true, S.sched.p};
 }
 
+// Element-grouped SELL view of a per-realization mass matrix M(k) = sum_e c(k_e) M_e: every row stores its entries in
+// two groups of `gw` slice columns, one per element the row's dof belongs to; the values of a group are the SHARED
+// element-matrix entries w, and the realization enters only through the two per-row coefficients coef[e12[row]][k].
+// A row product is  c1 * sum_g1 w x  +  c2 * sum_g2 w x : the matrix costs 12 B per stored entry for the whole batch
+// instead of 8 B per entry per realization.
+struct EgView {
+    int nrows = 0, nslices = 0, gw = 0;
+    const int* cols = nullptr;     // [nslices][2 gw][64]
+    const double* w = nullptr;     // same layout
+    const int* e12 = nullptr;      // [nrows][2] coefficient rows (n_elem = constant-one row for eliminated dofs)
+};
+
 // capacity (in blocks) of a partial-sum buffer for (fused) dots over nrows rows: allocate dot_capacity*kMaxBatch doubles
 int dot_capacity(int nrows);
 
@@ -92,6 +104,15 @@ void darcy_coef(hipStream_t st, int nb, int n, const double* kfield, bool k_divi
 void darcy_assemble(hipStream_t st, int nb, const SellView& Mp, const int* slot_src, const int* c_ptr, const int* c_elem,
                     const double* c_val, const double* coef, const unsigned char* ess, const double* ess_data,
                     const double* rhs0, double* mvals, double* diag, double* l1inv, double* rhs_bc);
+// y = M(k) x1 + A2 x2 over the same rows with M(k) element-grouped (the u-rows [M(k) | B^T] of the Darcy operator);
+// dot_partial != nullptr: partials of <dot_with, y>.  Returns the partial-block count.
+int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, const double* x1, const SellView& A2,
+                 const double* x2, double* y, double* dot_partial, const double* dot_with);
+// one-pass degree-2 Chebyshev polynomial of D^-1 M(k) from a zero guess (see sell_poly2_kernel) on the element-grouped
+// matrix: xout = dinv (c0 r - c1 M(k) (dinv r)); dot_partial != nullptr: partials of <r, xout>
+int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, double* xout,
+             double c0, double c1, double* dot_partial);
+
 // per-realization Gershgorin scaling of dinv (batched values): afterwards spec(diag(dinv) S) lies in (0, 1] for every
 // realization; gwork = kMaxBatch doubles of scratch
 void gersh_scale_bv(hipStream_t st, int nb, const SellView& S, double* dinv, double* gwork);

@@ -19,6 +19,14 @@ struct ChebParams {
     // degree-2 kernel for zero initial guesses
     const double* scaled_vals = nullptr;
 };
+// coefficients of the one-pass degree-2 Chebyshev polynomial on [lmax/ratio, lmax]: x2 = dinv (c0 r - c1 A dinv r)
+inline void cheb2_coefficients(double lmax, double ratio, double* c0, double* c1) {
+    const double lmin = lmax / ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    const double rho_old = 1.0 / sigma, rho1 = 1.0 / (2.0 * sigma - rho_old);
+    *c0 = (1.0 + rho1 * rho_old) / theta + 2.0 * rho1 / delta;
+    *c1 = 2.0 * rho1 / (delta * theta);
+}
 // degree 2 with column-scaled values runs as one polynomial pass (on r from a zero guess, on the residual otherwise)
 inline bool cheb_fused(const ChebParams& cp, bool /*zero_guess*/) { return cp.degree == 2 && cp.scaled_vals; }
 // Runs `degree` steps.  xa holds the initial guess (ignored when zero_guess); the iterate ping-pongs
