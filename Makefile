@@ -6,7 +6,8 @@ OBJDIR := build/obj
 SRCS := $(CSRC)/kernels.hip $(CSRC)/sparse.hip $(CSRC)/solver.hip $(CSRC)/sampler.hip $(CSRC)/darcy.hip $(CSRC)/capi.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.hpp) include/pmc.h
-CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+EXTRA ?=
+CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function $(EXTRA)
 LIB := parelagmc_amd/lib/libpmc.so
 
 all: $(LIB)

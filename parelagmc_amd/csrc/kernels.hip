@@ -51,6 +51,36 @@ __device__ __forceinline__ void store_c(double* __restrict__ p, const double (&v
     else *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]);
 }
 
+// Streaming accesses (matrix values / indices read once, result rows written once): non-temporal, so that they do not
+// displace the gathered x rows - the only data with reuse - from the XCD's L2.
+template <int C>
+__device__ __forceinline__ void store_c_stream(double* __restrict__ p, const double (&v)[C]) {
+#ifdef PMC_STREAM_HINTS
+    if constexpr (C == 1) {
+        __builtin_nontemporal_store(v[0], p);
+    } else {
+        __builtin_nontemporal_store(v[0], p);
+        __builtin_nontemporal_store(v[1], p + 1);
+    }
+#else
+    store_c<C>(p, v);
+#endif
+}
+__device__ __forceinline__ int load_stream(const int* __restrict__ p) {
+#ifdef PMC_STREAM_HINTS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ double load_stream(const double* __restrict__ p) {
+#ifdef PMC_STREAM_HINTS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 template <int NB>
 __device__ __forceinline__ void load_row(const double* __restrict__ p, double (&v)[NB]) {
     if constexpr (NB == 1) {
@@ -166,8 +196,8 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
     int cj = 0;
     double vj = 0.0;
     if (width > 0) {
-        cj = cols[slot];
-        if constexpr (!BV) vj = vals[slot];
+        cj = load_stream(cols + slot);
+        if constexpr (!BV) vj = load_stream(vals + slot);
     }
     for (int j = 0; j < width; ++j, slot += kWave) {
         // software pipeline: the next slice column's (value, index) pair is requested before this
@@ -175,8 +205,8 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         int cn = cj;
         double vn = vj;
         if (j + 1 < width) {
-            cn = cols[slot + kWave];
-            if constexpr (!BV) vn = vals[slot + kWave];
+            cn = load_stream(cols + slot + kWave);
+            if constexpr (!BV) vn = load_stream(vals + slot + kWave);
         }
         // phase 1: all cross-lane fetches, phase 2: all gathers (independent registers, so the T loads of a
         // slice column are in flight together), phase 3: FMAs
@@ -281,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
 #pragma unroll
                     for (int c = 0; c < C; ++c) acc[rs][c] = rv[c] - acc[rs][c];
                 }
-                store_c<C>(y + at, acc[rs]);
+                store_c_stream<C>(y + at, acc[rs]);
                 if constexpr (DOT) {
                     double w[C];
                     load_c<C>(dot_with + at, w);
