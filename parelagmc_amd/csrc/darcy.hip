@@ -4,7 +4,9 @@
 // src/DarcySolver.hpp:34); here all symbolic work is done once at create time and a realization
 // only refreshes values on fixed patterns (K12-K14 of SURVEY.md 2.3).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <numeric>
@@ -88,6 +90,17 @@ HostCsr drop_columns(const HostCsr& B, const unsigned char* mask) {
     return o;
 }
 
+struct SetupClock {   // PMC_VERBOSE=1: setup phase timings on stderr
+    const bool on = getenv("PMC_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what, int level) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pmc] darcy setup L%d %-28s %8.2f s\n", level, what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+
 std::vector<int> diag_slots(const Sell& S, const HostCsr& pat) {
     std::vector<int> ds(pat.nrows, -1);
     std::vector<int> n2s = nnz_to_slot(S, pat.nnz());
@@ -102,6 +115,8 @@ std::vector<int> diag_slots(const Sell& S, const HostCsr& pat) {
 std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, const pmc_solver_opts& o, hipStream_t st) {
     std::vector<AmgLevelHost> lvh = sa_hierarchy(K1, std::vector<double>(), /*passes=*/2, /*theta=*/0.25,
                                                  /*min_size=*/256, /*max_levels=*/14);
+    SetupClock clk;
+    clk.lap("  sa_hierarchy", (int)lvh.size());
     std::unique_ptr<DarcyChain> ch(new DarcyChain());
     Multigrid& mg = ch->mg;
     mg.smooth_degree = o.mg_smooth_degree;
@@ -149,8 +164,13 @@ std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, 
                     for (int b = P.rowptr[e2]; b < P.rowptr[e2 + 1]; ++b)
                         tr.push_back({P.colind[a], P.colind[b], n2s[p], P.vals[a] * P.vals[b]});
             }
+        const size_t ntr = tr.size();
         Symbolic next = build_symbolic(P.ncols, tr);
         PMC_HIP(hipStreamSynchronize(st));
+        if (clk.on)
+            fprintf(stderr, "[pmc]   chain level %d: n %d nnz %lld, P nnz %lld, %zu triples -> coarse n %d nnz %lld\n", j, m.n,
+                    (long long)pat.nnz(), (long long)P.nnz(), ntr, P.ncols, (long long)next.pat.nnz());
+        clk.lap("  chain level symbolic", j);
         sym = std::move(next);
     }
     for (int j = 0; j < nl; ++j) {
@@ -164,8 +184,10 @@ std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, 
 
 }  // namespace
 
+
 Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kdiv, const pmc_solver_opts& o)
     : ctx(c), nlevels(nlevels_), n_mc(n_mc_), k_divides(kdiv), opts(o) {
+    SetupClock clk;
     PMC_REQUIRE(nlevels >= 1 && n_mc >= 1 && n_mc <= nlevels, "darcy: need 1 <= n_mc_levels <= nlevels");
     PMC_REQUIRE(in != nullptr, "darcy: levels is NULL");
     ctx.activate();
@@ -203,6 +225,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         PMC_REQUIRE(has_diag_all, "darcy M_pattern must store the diagonal");
         sell_build(d.M, Mp, false, true, st);
         d.slot_src.upload(d.M.h_src, st);
+        clk.lap("checks + M pattern", l);
         {
             // element-grouped layout: expand the contribution lists per row and group them by element
             std::vector<std::vector<std::pair<int, std::vector<std::pair<int, double>>>>> rows(Mp.nrows);
@@ -253,6 +276,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
                 PMC_HIP(hipStreamSynchronize(st));
             }
         }
+        clk.lap("element-grouped M", l);
         if (o.cheb_ratio_M > 1.0) {
             d.ratio_M = o.cheb_ratio_M;
         } else {
@@ -279,6 +303,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         d.c_ptr.upload(L.c_ptr, nnzM + 1, st);
         d.c_elem.upload(L.c_elem, ncontrib, st);
         d.c_val.upload(L.c_val, ncontrib, st);
+        clk.lap("M-block interval (Lanczos)", l);
         d.ess.upload(L.ess_mask, L.n_u, st);
         d.ess_data.upload(L.ess_data, L.n_u, st);
         d.rhs_u0.upload(L.rhs, L.n_u, st);
@@ -323,6 +348,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
             }
         }
         schur[l] = build_symbolic(L.n_p, tr);
+        clk.lap("uploads + symbolic Schur", l);
         if (l < n_mc && o.mg_coarsening != 0) {
             // algebraic hierarchy of this MC level, prolongators from the k == 1 operator (c(1) = 1 either way)
             std::vector<double> dM1(L.n_u, 1.0);
@@ -339,6 +365,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
                 if ((int)chains.size() < n_mc) chains.resize(n_mc);
                 chains[l] = build_chain(schur[l], K1, o, st);
             }
+            clk.lap("algebraic chain", l);
         }
         if (l + 1 < nlevels) {
             Pl[l] = csr_from_c(L.P, true, "darcy P");
@@ -347,6 +374,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         PMC_HIP(hipStreamSynchronize(st));
     }
 
+    clk.lap("levels done", -1);
     // Level patterns: S_l pattern = own pattern U Galerkin image of level l-1's pattern.
     std::vector<HostCsr> pattern(nlevels);
     pattern[0] = schur[0].pat;
@@ -432,6 +460,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         lv[l + 1].g_w.upload(w, st);
         PMC_HIP(hipStreamSynchronize(st));
     }
+    clk.lap("geometric Galerkin lists", -1);
     mg.enable_bv_tail();
     mg.build_tails(st);
     for (int l = 0; l < nlevels; ++l) {   // host mirrors no longer needed

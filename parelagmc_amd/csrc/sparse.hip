@@ -368,8 +368,12 @@ std::vector<AmgLevelHost> sa_hierarchy(const HostCsr& K0, const std::vector<doub
         }
         const int n = L.S.nrows;
         if (n <= min_size || lvl + 1 >= max_levels) { out.push_back(std::move(L)); break; }
+        // aggregates of 2^passes rows on the finest level (follows the strong direction of stretched cells), one more
+        // matching pass below it: once the coupling is isotropic a smoothed prolongator over aggregates of 4 widens the
+        // stencil faster than the level shrinks (measured 7 -> 14 -> 33 -> 82 -> 123 entries per row; with aggregates
+        // of 8 it stays at ~30) and the per-realization Galerkin lists of the Darcy hierarchy grow with stencil x |P|^2
         std::vector<int> agg;
-        const int nc = aggregate_rows(K, passes, theta, agg);
+        const int nc = aggregate_rows(K, lvl == 0 ? passes : passes + 1, theta, agg);
         if (nc * 10 > n * 9 || nc < 1) { out.push_back(std::move(L)); break; }      // coarsening stalled
         // strength-filtered operator (weak off-diagonals lumped onto the diagonal), damped-Jacobi smoothing of P_tent
         const HostCsr& S = L.S;

@@ -79,12 +79,10 @@ def intersection_gt(orig: Mesh, embed: Mesh, method: str = "auto") -> sp.csr_mat
     """method: 'box' (axis-aligned boxes, interval products), 'clip' (general), 'auto' (box when both meshes qualify)."""
     if method not in ("auto", "box", "clip"):
         raise ValueError("method must be auto, box or clip")
-    if method in ("auto", "box"):
-        try:
-            return box_intersection_gt(orig, embed)
-        except ValueError:
-            if method == "box":
-                raise
+    if method == "box":
+        return box_intersection_gt(orig, embed)
+    # the C++ assembler has its own fast path for pairs of axis-aligned boxes and a bucket-grid candidate search, so it
+    # also is the scalable route for large box meshes (box_intersection_gt enumerates every overlap along one axis)
     return clipped_intersection_gt(orig, embed)
 
 

@@ -160,6 +160,7 @@ struct MeshSimplices {
     std::vector<P3> pts;                          // nelem * per_elem * (dim+1)
     std::vector<std::array<double, 6>> bbox;      // per element: lo xyz, hi xyz
     std::vector<double> measure;                  // per element
+    std::vector<char> is_box;                     // element is an axis-aligned box (= its bounding box)
 };
 
 double simplex_measure(int dim, const P3* s) {
@@ -198,6 +199,17 @@ MeshSimplices split(const pmc_mesh_view& m) {
             bb[3] = std::max(bb[3], p.x); bb[4] = std::max(bb[4], p.y); bb[5] = std::max(bb[5], p.z);
         }
         s.bbox[e] = bb;
+        // axis-aligned box: every vertex sits on a corner of the bounding box (quadrilaterals / hexahedra only)
+        bool box = (m.dim == 2 && npe == 4) || (m.dim == 3 && npe == 8);
+        for (int k = 0; k < npe && box; ++k) {
+            const P3 p = vert(ev[k]);
+            const double c[3] = {p.x, p.y, p.z};
+            for (int a = 0; a < m.dim && box; ++a) {
+                const double tol = 1e-12 * std::max(bb[3 + a] - bb[a], 1e-300);
+                box = std::fabs(c[a] - bb[a]) <= tol || std::fabs(c[a] - bb[3 + a]) <= tol;
+            }
+        }
+        s.is_box.push_back(box ? 1 : 0);
         for (int t = 0; t < ns; ++t) {
             P3* dst = &s.pts[((size_t)e * ns + t) * np];
             for (int k = 0; k < np; ++k) {
@@ -292,6 +304,12 @@ extern "C" int pmc_mortar_assemble(const pmc_mesh_view* a, const pmc_mesh_view* 
                 const double sc = std::min(scale, std::pow(std::max(B.measure[j], 1e-300), 1.0 / dim));
                 const double eps = 1e-13 * sc;       // "on the plane" distance
                 double v = 0.0;
+                if (A.is_box[i] && B.is_box[j]) {
+                    // two axis-aligned boxes: exact product of the interval overlaps, no clipping
+                    const auto& bb = B.bbox[j];
+                    v = 1.0;
+                    for (int k = 0; k < dim; ++k) v *= std::max(0.0, std::min(ab[3 + k], bb[3 + k]) - std::max(ab[k], bb[k]));
+                } else
                 for (int s = 0; s < A.per_elem; ++s)
                     for (int t = 0; t < B.per_elem; ++t) {
                         const P3* sa = &A.pts[((size_t)i * A.per_elem + s) * np];

@@ -55,14 +55,24 @@ def main():
             Sc = (0.5 * lv.P.T @ Sc @ lv.P).tocsr()
         geo.append(level_tuple(Sc, None))
         variants["geometric"] = geo
-        for mode in ("plain(k=1)", "SA(k=1)", "SA(k)"):
+        for mode in ("SA(k=1)", "SA-p233(k=1)", "SA-p234(k=1)", "SA-p244(k=1)", "SA-adapt(k=1)"):
             lvls = []
             Sc, Sref = S, (S if mode == "SA(k)" else S1)
             while True:
                 if Sc.shape[0] <= 200 or len(lvls) >= 12:
                     lvls.append(level_tuple(Sc, None)); break
-                agg, nc = aggregate(Sref, 2)
-                if mode.startswith("plain"):
+                npass = 2
+                if mode.startswith("SA-p"):
+                    seq = [int(c) for c in mode[4:7]]
+                    npass = seq[min(len(lvls), 2)]
+                if mode.startswith("SA-adapt"):
+                    rowlen = Sref.nnz / Sref.shape[0]
+                    npass = 2 if rowlen <= 10 else 3 if rowlen <= 20 else 4
+                agg, nc = aggregate(Sref, npass)
+                nsa = 1 if mode.startswith("SA1") else 2 if mode.startswith("SA2") else 99
+                if mode.startswith("plain") or len(lvls) >= nsa:
+                    if len(lvls) >= nsa:
+                        agg, nc = aggregate(Sref, 3)
                     P = sp.csr_matrix((np.ones(len(agg)), (np.arange(len(agg)), agg)), shape=(len(agg), nc))
                 else:
                     P = sa_prolongator(Sref, agg, nc)
@@ -73,6 +83,7 @@ def main():
                 lvls.append(level_tuple(Sc, P))
                 Sc = (P.T @ Sc @ P).tocsr()
                 Sref = (P.T @ Sref @ P).tocsr()
+                print(f"    {mode} level {len(lvls)}: n {Sc.shape[0]} nnz/row {Sc.nnz / Sc.shape[0]:.1f}")
             variants[mode] = lvls
         for name, lv in variants.items():
             mg = MG(lv)
