@@ -88,8 +88,8 @@ HostCsr csr_block2x2(const HostCsr& M, const HostCsr& Bt, const HostCsr& B, cons
 
 // algebraic coarsening helpers (setup): piecewise-constant aggregation
 HostCsr csr_galerkin_agg(const HostCsr& A, const std::vector<int>& agg, int nc);
-int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg);
-int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg);
+int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg, bool allow_weak = false);
+int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg, bool allow_weak = false);
 HostCsr prolongator_from_agg(const std::vector<int>& agg, int nc);
 
 HostCsr csr_spgemm(const HostCsr& A, const HostCsr& B);

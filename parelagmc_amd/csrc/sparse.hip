@@ -1,6 +1,8 @@
 // Host-side sparse helpers (setup only, outside every timed region): CSR copies, transpose,
 // block assembly and the CSR -> SELL-64 re-layout done once when a handle is created.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 
 #include "common.hpp"
@@ -212,7 +214,7 @@ HostCsr csr_galerkin_agg(const HostCsr& A, const std::vector<int>& agg, int nc) 
 // One pass of pairwise matching along the strongest negative coupling (Notay-style): every unmatched row joins its
 // strongest unmatched neighbour j with -a_ij >= theta * max_k(-a_ik), otherwise it stays alone.  Returns the number of
 // aggregates; agg[i] = aggregate of row i.  On anisotropic operators this coarsens along the strong direction only.
-int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg) {
+int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg, bool allow_weak) {
     const int n = A.nrows;
     agg.assign(n, -1);
     // visit rows by increasing number of strong neighbours... plain index order keeps the mesh ordering's locality
@@ -222,14 +224,18 @@ int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg) {
         double smax = 0.0;
         for (int p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p)
             if (A.colind[p] != i) smax = std::max(smax, -A.vals[p]);
-        int best = -1;
-        double bval = 0.0;
+        int best = -1, weak = -1;
+        double bval = 0.0, wval = 0.0;
         for (int p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) {
             const int j = A.colind[p];
             if (j == i || agg[j] >= 0) continue;
             const double s = -A.vals[p];
             if (s >= theta * smax && s > bval) { bval = s; best = j; }
+            if (s > wval) { wval = s; weak = j; }
         }
+        // isotropic / coarse operators: rather pair with the strongest FREE neighbour than stay a singleton (dense
+        // smoothed-aggregation stencils leave few strong neighbours unmatched and the coarsening would stall)
+        if (best < 0 && allow_weak) best = weak;
         agg[i] = nc;
         if (best >= 0) agg[best] = nc;
         ++nc;
@@ -239,15 +245,15 @@ int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg) {
 
 // `passes` rounds of pairwise matching (aggregates of up to 2^passes rows).  K = the coupling part of the operator that
 // steers the matching; returns agg and the number of aggregates.
-int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg) {
+int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg, bool allow_weak) {
     std::vector<int> cur;
-    int nc = pairwise_match(K, theta, cur);
+    int nc = pairwise_match(K, theta, cur, allow_weak);
     agg = cur;
     HostCsr Kc = K;
     for (int pass = 1; pass < passes; ++pass) {
         Kc = csr_galerkin_agg(Kc, cur, nc);
         std::vector<int> nxt;
-        const int nc2 = pairwise_match(Kc, theta, nxt);
+        const int nc2 = pairwise_match(Kc, theta, nxt, allow_weak);
         if (nc2 == nc) break;
         for (int& a : agg) a = nxt[a];
         cur = nxt;
@@ -341,6 +347,7 @@ std::vector<AmgLevelHost> sa_hierarchy(const HostCsr& K0, const std::vector<doub
                                        int min_size, int max_levels) {
     std::vector<AmgLevelHost> out;
     HostCsr K = K0;
+    bool iso0 = false;
     HostCsr Wm;           // mass part as a general matrix on coarse levels (diagonal on level 0)
     bool w_is_diag = true;
     std::vector<double> w = w0;
@@ -373,7 +380,14 @@ std::vector<AmgLevelHost> sa_hierarchy(const HostCsr& K0, const std::vector<doub
         // stencil faster than the level shrinks (measured 7 -> 14 -> 33 -> 82 -> 123 entries per row; with aggregates
         // of 8 it stays at ~30) and the per-realization Galerkin lists of the Darcy hierarchy grow with stencil x |P|^2
         std::vector<int> agg;
-        const int nc = aggregate_rows(K, lvl == 0 ? passes : passes + 1, theta, agg);
+        // isotropic coupling on the finest level as well (median strongest/weakest ratio <= 10): aggregates of 8 from
+        // the start, 16 below
+        const int extra = (lvl == 0 ? 0 : 1) + (lvl == 0 && csr_anisotropy(K) <= 10.0 ? 1 : 0) + (lvl > 0 && iso0 ? 1 : 0);
+        if (lvl == 0) iso0 = csr_anisotropy(K) <= 10.0;
+        const int nc = aggregate_rows(K, passes + extra, theta, agg, iso0);
+        if (getenv("PMC_VERBOSE"))
+            fprintf(stderr, "[pmc]   SA level %d: n %d, %.1f entries/row, aggregates of 2^%d -> %d rows\n", lvl, n,
+                    (double)L.S.nnz() / n, passes + extra, nc);
         if (nc * 10 > n * 9 || nc < 1) { out.push_back(std::move(L)); break; }      // coarsening stalled
         // strength-filtered operator (weak off-diagonals lumped onto the diagonal), damped-Jacobi smoothing of P_tent
         const HostCsr& S = L.S;
