@@ -382,9 +382,14 @@ std::vector<AmgLevelHost> sa_hierarchy(const HostCsr& K0, const std::vector<doub
         std::vector<int> agg;
         // isotropic coupling on the finest level as well (median strongest/weakest ratio <= 10): aggregates of 8 from
         // the start, 16 below
-        const int extra = (lvl == 0 ? 0 : 1) + (lvl == 0 && csr_anisotropy(K) <= 10.0 ? 1 : 0) + (lvl > 0 && iso0 ? 1 : 0);
+        int extra = (lvl == 0 ? 0 : 1) + (lvl == 0 && csr_anisotropy(K) <= 10.0 ? 1 : 0) + (lvl > 0 && iso0 ? 1 : 0);
         if (lvl == 0) iso0 = csr_anisotropy(K) <= 10.0;
-        const int nc = aggregate_rows(K, passes + extra, theta, agg, iso0);
+        bool weak = iso0;
+        if (iso0) {   // tuning overrides (isotropic problems only)
+            if (const char* e = getenv(lvl == 0 ? "PMC_SA_ISO_PASSES0" : "PMC_SA_ISO_PASSES1")) extra = atoi(e) - passes;
+            if (const char* e = getenv("PMC_SA_ISO_WEAK")) weak = atoi(e) != 0;
+        }
+        const int nc = aggregate_rows(K, passes + extra, theta, agg, weak);
         if (getenv("PMC_VERBOSE"))
             fprintf(stderr, "[pmc]   SA level %d: n %d, %.1f entries/row, aggregates of 2^%d -> %d rows\n", lvl, n,
                     (double)L.S.nnz() / n, passes + extra, nc);

@@ -729,3 +729,35 @@ def test_l2_projection_sampler_on_nonmatching_tet_pair(gpu_ctx, seeded_rng):
         ref = np.stack([so.eval(lvl, 0, x, projection=("l2",) + ops[lvl])[0] for x in xi])
         assert rel(s, ref) < 1e-9
     smp.close()
+
+
+def test_single_level_operators_without_a_caller_hierarchy(gpu_ctx, seeded_rng):
+    """operators handed over as plain CSR with NO level hierarchy (what an adapter to an unstructured
+    ParELAG / MFEM discretisation has at hand).  With mg_coarsening = 1 the library builds the Schur-complement hierarchy
+    itself; results equal the oracle's and MINRES needs fewer iterations than with the single-level fallback (the gap
+    widens with the mesh: 32^3 at the default tolerance 33 / 43 against 53 / 81 iterations for sampler / Darcy)."""
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem
+    h = build_hierarchy(box_mesh([20, 20, 20], [2.0, 2.0, 2.0], "hex"), 0)       # one level only
+    sp = build_sampler_problem(h, corlen=0.5, lognormal=True)                      # long correlation: S is far from diagonal
+    dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    assert len(sp.levels) == 1 and len(dp.levels) == 1
+    so, do = SamplerOracle(sp), DarcyOracle(dp)
+    xi = seeded_rng.standard_normal((2, sp.levels[0].n_s))
+    ref = np.stack([so.eval(0, 0, x)[0] for x in xi])
+    its = {}
+    for mode in (0, 1):
+        o = capi.solver_opts(mg_coarsening=mode, **TIGHT)
+        smp = capi.PDESampler(gpu_ctx, sp, o)
+        ds = capi.DarcySolver(gpu_ctx, dp, o)
+        s, st = smp.Eval(0, xi, return_stats=True)
+        Q, _, st2 = ds.SolveFwd(0, ref, return_stats=True)
+        assert rel(np.log(s), np.log(ref)) < 1e-8 and all(t[1] == 1 for t in st + st2)
+        for b in range(2):
+            assert abs(Q[b] - do.solve_fwd(0, ref[b])[0]) < 1e-8 * abs(Q[b])
+        its[mode] = (max(t[0] for t in st), max(t[0] for t in st2))
+        ds.close()
+        smp.close()
+    assert its[1][0] < its[0][0] and its[1][1] < its[0][1], its
