@@ -182,6 +182,11 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         loop_ms, loop_launches = smp.operator_time()
+        # the same measurement with lane 0 alone on the GPU (outside the timed region): the kernel's in-solver duration
+        # without other lanes' kernels sharing the bandwidth
+        for j in range(3):
+            one_batch(0, (args.warmup + args.steps + 1) * world * ns + j)
+        solo_ms, solo_launches = smp.operator_time()
         smp.set_operator_timing(False)
     # the one exchange of a sample farm: SUM all-reduce of the accumulators (here: field statistics)
     acc = np.array([float(np.sum(iters)), float(len(iters)), dt])
@@ -229,14 +234,17 @@ def main():
                          "bytes_per_launch": k_bytes, "avg_kernel_ms": k_ms,
                          "spmv_nb1": {"achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "bytes_per_launch": k1_bytes,
                                       "avg_kernel_ms": k1_ms, "frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / peak},
-                         # the same operator with its fused <u, Au>, every launch of lane 0 inside the timed region
-                         # (HIP events on that lane's stream); with streams > 1 other lanes' kernels share the GPU
-                         # during these launches, so this is a lower bound on what the kernel itself sustains
+                         # the same operator with its fused <u, Au> inside the MINRES loop (HIP events on the lane's
+                         # stream around every launch): in_loop = lane 0 alone on the GPU right after the timed region,
+                         # in_loop_timed_region = lane 0's launches during the timed region, where the other lanes'
+                         # kernels share the GPU with them
                          "in_loop": {"kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, true, 1>",
-                                     "launches": loop_launches, "concurrent_streams": ns,
-                                     "avg_kernel_ms": loop_ms / max(loop_launches, 1),
-                                     "achieved": k_bytes / (loop_ms / max(loop_launches, 1) * 1e-3) / 1e9,
-                                     "frac": k_bytes / (loop_ms / max(loop_launches, 1) * 1e-3) / 1e9 / peak}},
+                                     "launches": solo_launches, "concurrent_streams": 1,
+                                     "avg_kernel_ms": solo_ms / max(solo_launches, 1),
+                                     "achieved": k_bytes / (solo_ms / max(solo_launches, 1) * 1e-3) / 1e9,
+                                     "frac": k_bytes / (solo_ms / max(solo_launches, 1) * 1e-3) / 1e9 / peak},
+                         "in_loop_timed_region": {"launches": loop_launches, "concurrent_streams": ns,
+                                                  "avg_kernel_ms": loop_ms / max(loop_launches, 1)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, args.seed)

@@ -55,7 +55,7 @@ __device__ __forceinline__ void store_c(double* __restrict__ p, const double (&v
 // displace the gathered x rows - the only data with reuse - from the XCD's L2.
 template <int C>
 __device__ __forceinline__ void store_c_stream(double* __restrict__ p, const double (&v)[C]) {
-#ifdef PMC_STREAM_HINTS
+#if defined(PMC_STREAM_HINTS) || defined(PMC_STREAM_STORES)
     if constexpr (C == 1) {
         __builtin_nontemporal_store(v[0], p);
     } else {
@@ -67,14 +67,14 @@ __device__ __forceinline__ void store_c_stream(double* __restrict__ p, const dou
 #endif
 }
 __device__ __forceinline__ int load_stream(const int* __restrict__ p) {
-#ifdef PMC_STREAM_HINTS
+#if defined(PMC_STREAM_HINTS) || defined(PMC_STREAM_LOADS)
     return __builtin_nontemporal_load(p);
 #else
     return *p;
 #endif
 }
 __device__ __forceinline__ double load_stream(const double* __restrict__ p) {
-#ifdef PMC_STREAM_HINTS
+#if defined(PMC_STREAM_HINTS) || defined(PMC_STREAM_LOADS)
     return __builtin_nontemporal_load(p);
 #else
     return *p;
