@@ -761,3 +761,36 @@ def test_single_level_operators_without_a_caller_hierarchy(gpu_ctx, seeded_rng):
         ds.close()
         smp.close()
     assert its[1][0] < its[0][0] and its[1][1] < its[0][1], its
+
+
+def test_sample_statistics_match_the_exact_covariance(gpu_ctx, hex_hierarchy):
+    """The acceptance statistics of the reference's PDESamplerTest (examples/PDESamplerTest.cpp:205-209,262-274: sample
+    mean and marginal variance of Gaussian / log-normal draws) on its default problem (4^3 hex on [0,2]^3 refined, corlen
+    0.1), with the ON-DEVICE generator: N = 4096 realizations of level 1 (8^3 elements) from Sample() + Eval(), against
+    the exact moments of the discrete field, var_i = sum_j G_ij^2 for the linear map xi -> s of the oracle."""
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy, corlen=0.1)
+    so = SamplerOracle(sp)
+    n = sp.levels[1].n_s
+    G = np.stack([so.eval(1, 1, e)[0] for e in np.eye(n)], axis=1)          # s = G xi
+    var = (G ** 2).sum(axis=1)
+    smp = capi.PDESampler(gpu_ctx, sp)
+    N = 4096
+    acc1, acc2, accl = np.zeros(n), np.zeros(n), np.zeros(n)
+    for first in range(0, N, 512):
+        s = smp.Eval(1, smp.Sample(1, first_id=first, nbatch=512))
+        acc1 += s.sum(axis=0)
+        acc2 += (s ** 2).sum(axis=0)
+        accl += np.exp(s).sum(axis=0)
+    mean, m2, mexp = acc1 / N, acc2 / N, accl / N
+    # E[s] = 0: standardised means are N(0,1); Var[s] = var: relative error of a chi^2_N estimate is sqrt(2/N) = 2.2 %
+    z = mean / np.sqrt(var / N)
+    assert np.abs(z).max() < 5.0 and abs(z.mean()) < 0.5
+    ratio = (m2 - mean ** 2) / var
+    assert np.abs(ratio - 1.0).max() < 0.15 and abs(ratio.mean() - 1.0) < 0.02
+    # log-normal mean exp(sigma^2 / 2) (examples/PDESamplerTest.cpp:207)
+    lratio = mexp / np.exp(0.5 * var)
+    assert abs(lratio.mean() - 1.0) < 0.05
+    smp.close()
