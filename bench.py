@@ -62,7 +62,7 @@ def cpu_baseline(problem, seed, nsamples_per_core=12):
                       f"mean {float(np.mean(np.abs(iters))):.1f} iterations, {dt:.1f} s wall"}
 
 
-def mlmc_config3(seed, lanes=4):
+def mlmc_config3(seed, lanes=4, opts=None):
     """Secondary figure (BASELINE config 3): MLMC_Manager::InitRun with the SPDE sampler + Darcy QoI on cube_hex
     64^3 / 32^3 / 16^3, fixed sample counts, `lanes` concurrent streams.  Reported under "extra", never as `value`."""
     from parelagmc_amd import capi, host_api
@@ -71,8 +71,8 @@ def mlmc_config3(seed, lanes=4):
     sp = build_sampler_problem(h, corlen=0.1, lognormal=True, n_mc_levels=3)
     dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], n_mc_levels=3)
     ctxs = [capi.Context(0, seed=seed) for _ in range(lanes)]
-    sm = [capi.PDESampler(c, sp) for c in ctxs]
-    dr = [capi.DarcySolver(c, dp) for c in ctxs]
+    sm = [capi.PDESampler(c, sp, opts) for c in ctxs]
+    dr = [capi.DarcySolver(c, dp, opts) for c in ctxs]
     mgr = host_api.MLMCManager(3, sampler=sm[0], solver=dr[0], wall_time=True, batch=16)
     for i in range(1, lanes):
         mgr.add_lane(sm[i], dr[i])

@@ -2,6 +2,7 @@
 #include "parelagmc.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -345,17 +346,104 @@ void MLMC_Manager::run_level(int ilevel, int nsamples) {
     pending_[(size_t)nlevels * NVAR + ilevel] += now_s() - t0;
 }
 
+void MLMC_Manager::run_round_overlapped(const std::vector<int>& ns_init) {
+    struct Task { int level, first, m; };
+    std::vector<Task> tasks;
+    std::vector<std::vector<double>> yv(nlevels), qv(nlevels), qcv(nlevels), cv(nlevels);
+    for (int ilevel = 0; ilevel < nlevels; ++ilevel) {          // finest (longest) tasks first
+        const int ns = ns_init[ilevel];
+        if (ns < 0) throw std::invalid_argument("InitRun: negative sample count");
+        yv[ilevel].assign(ns, 0.0); qv[ilevel].assign(ns, 0.0); qcv[ilevel].assign(ns, 0.0); cv[ilevel].assign(ns, 0.0);
+        const int nblocks = (ns + batch_ - 1) / batch_;
+        for (int blk = rank_; blk < nblocks; blk += nranks_)
+            tasks.push_back({ilevel, blk * batch_, std::min(batch_, ns - blk * batch_)});
+    }
+    const int nlanes = (int)lanes_.size();
+    std::vector<std::vector<double>> lane_seconds(nlanes, std::vector<double>(nlevels, 0.0));
+    std::vector<std::string> lane_err(nlanes);
+    std::atomic<size_t> next{0};
+    auto work = [&](int lane) {
+        try {
+            Lane& L = *lanes_[lane];
+            std::vector<double> q(batch_), c(batch_), qc(batch_), cc(batch_);
+            for (;;) {
+                const size_t ti = next.fetch_add(1);
+                if (ti >= tasks.size()) break;
+                const Task t = tasks[ti];
+                const int ilevel = t.level;
+                const double t0 = now_s();
+                L.sampler->Sample(ilevel, L.xi, (uint64_t)level_nsamples[ilevel] + (uint64_t)t.first, t.m);
+                if (ilevel == nlevels - 1) {
+                    L.sampler->Eval(ilevel, L.xi, L.sparam);
+                    L.solver->SolveFwd(ilevel, L.sparam, q.data(), c.data());
+                    for (int b = 0; b < t.m; ++b) { qc[b] = 0.0; cc[b] = 0.0; }
+                } else {
+                    L.sampler->Eval(ilevel + 1, L.xi, L.sparam, L.init_s, false);
+                    L.solver->SolveFwd(ilevel + 1, L.sparam, qc.data(), cc.data());
+                    L.sampler->Eval(ilevel, L.xi, L.sparam, L.init_s, true);
+                    L.solver->SolveFwd(ilevel, L.sparam, q.data(), c.data());
+                }
+                for (int b = 0; b < t.m; ++b) {
+                    yv[ilevel][t.first + b] = (ilevel == nlevels - 1) ? q[b] : q[b] - qc[b];
+                    qv[ilevel][t.first + b] = q[b];
+                    qcv[ilevel][t.first + b] = qc[b];
+                    cv[ilevel][t.first + b] = c[b] + cc[b];
+                }
+                lane_seconds[lane][ilevel] += now_s() - t0;
+            }
+        } catch (const std::exception& e) {
+            lane_err[lane] = e.what();
+            next.store(tasks.size());
+        }
+    };
+    std::vector<std::thread> th;
+    for (int l = 0; l < nlanes; ++l) th.emplace_back(work, l);
+    for (auto& t : th) t.join();
+    for (const auto& e : lane_err)
+        if (!e.empty()) throw std::runtime_error(e);
+    // accumulate in realization order (the order a single lane would produce), coarsest level first as in :110-173
+    for (int ilevel = nlevels - 1; ilevel >= 0; --ilevel) {
+        double* psum = pending_.data() + (size_t)ilevel * NVAR;
+        const int ns = ns_init[ilevel];
+        const int nblocks = (ns + batch_ - 1) / batch_;
+        for (int blk = rank_; blk < nblocks; blk += nranks_)
+            for (int i = blk * batch_; i < std::min(ns, (blk + 1) * batch_); ++i) {
+                const double y = yv[ilevel][i], q = qv[ilevel][i];
+                psum[Y3] += y * y * y;
+                psum[Y4] += y * y * y * y;
+                psum[Y2] += y * y;
+                psum[Y] += y;
+                psum[ABSY] += std::fabs(y);
+                psum[Q2] += q * q;
+                psum[Q] += q;
+                psum[ABSQ] += std::fabs(q);
+                psum[C] += cv[ilevel][i];
+                if (logger.is_open())
+                    logger << std::setw(14) << ilevel << ' ' << std::setw(24) << y << ' ' << std::setw(24) << q << ' '
+                           << std::setw(24) << qcv[ilevel][i] << ' ' << std::setw(14) << cv[ilevel][i] << "\n";
+            }
+        // cost model: lane-seconds spent on the level / lanes = the wall time the level would take on its own
+        double sec = 0.0;
+        for (int l = 0; l < nlanes; ++l) sec += lane_seconds[l][ilevel];
+        pending_[(size_t)nlevels * NVAR + ilevel] += sec / nlanes;
+    }
+}
+
 void MLMC_Manager::InitRun(std::vector<int>& level_nsamples_init) {
     if ((int)level_nsamples_init.size() != nlevels) throw std::invalid_argument("InitRun: wrong number of levels");
     if (logger.is_open() && *std::max_element(level_nsamples.begin(), level_nsamples.end()) == 0)
         logger << "%" << std::setw(13) << "level " << std::setw(14) << "Y(xi) " << std::setw(14) << "Q(xi)"
                << std::setw(14) << "Q_c(xi)" << std::setw(14) << "c \n";
     pending_.assign((size_t)nlevels * (NVAR + 1), 0.0);
-    // coarsest level first, then the level pairs from coarse to fine (:110-173)
-    for (int ilevel = nlevels - 1; ilevel >= 0; --ilevel) {
-        const int ns = level_nsamples_init[ilevel];
-        if (ns < 0) throw std::invalid_argument("InitRun: negative sample count");
-        if (ns > 0) run_level(ilevel, ns);
+    if (lanes_.size() > 1) {
+        run_round_overlapped(level_nsamples_init);
+    } else {
+        // coarsest level first, then the level pairs from coarse to fine (:110-173)
+        for (int ilevel = nlevels - 1; ilevel >= 0; --ilevel) {
+            const int ns = level_nsamples_init[ilevel];
+            if (ns < 0) throw std::invalid_argument("InitRun: negative sample count");
+            if (ns > 0) run_level(ilevel, ns);
+        }
     }
     if (nranks_ > 1) reduce_(pending_.data(), (int)pending_.size());
     for (size_t i = 0; i < (size_t)nlevels * NVAR; ++i) sums[i] += pending_[i];

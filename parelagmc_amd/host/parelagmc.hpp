@@ -209,6 +209,9 @@ class MLMC_Manager {
   private:
     void computeNSamplesMSE();
     void run_level(int ilevel, int nsamples);
+    // several lanes: all levels of one InitRun round go through one task queue (finest level first), so the
+    // launch-latency-bound batches of the coarse levels overlap the bandwidth-bound batches of the fine ones
+    void run_round_overlapped(const std::vector<int>& level_nsamples_init);
     double& S(int l, int v) { return sums[(size_t)l * NVAR + v]; }
 
     pmc_ctx* ctx_;
