@@ -632,18 +632,19 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
         const int flips = cheb_flips(cpM, true);
         double* start = (flips % 2 == 0) ? z : cxp;
         double* other = (flips % 2 == 0) ? cxp : z;
+        // S-block first, M-block last (its output is the larger part of what the operator reads next)
+        const int nblk_s = mgp->vcycle(s, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_, dot_partial);
+        double* dpu = dot_partial ? dot_partial + (size_t)nblk_s * nb_ : nullptr;
         int nblk_u = 0;
         if (eg) {
             double c0, c1;
             cheb2_coefficients(cpM.lmax, cpM.ratio, &c0, &c1);
-            nblk_u = k::eg_poly2(s, nb_, Mg, coefp, l1, r, z, c0, c1, dot_partial);
+            nblk_u = k::eg_poly2(s, nb_, Mg, coefp, l1, r, z, c0, c1, dpu);
         } else {
-            double* res = cheb_apply(s, nb_, Mv, l1, true, cpM, r, start, other, cdp, true, dot_partial, &nblk_u);
+            double* res = cheb_apply(s, nb_, Mv, l1, true, cpM, r, start, other, cdp, true, dpu, &nblk_u);
             if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
         }
-        const int nblk_s = mgp->vcycle(s, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_,
-                                       dot_partial ? dot_partial + (size_t)nblk_u * nb_ : nullptr);
-        return nblk_u + nblk_s;
+        return nblk_s + nblk_u;
     };
     // SolveFwd only needs Q = <obs, sol>: unless the solution itself is requested, MINRES maintains just the rows in
     // the support of obs (compact w / x vectors)

@@ -324,12 +324,14 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
         const int flips = cheb_flips(cpM, true);
         double* start = (flips % 2 == 0) ? z : cxp;
         double* other = (flips % 2 == 0) ? cxp : z;
+        // S-block first, M-block last: the u-block of z (two thirds of the vector the operator reads next) is then the
+        // most recently written data when K5 starts
+        const int nblk_s = mgp->vcycle(s, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_, dot_partial);
         int nblk_u = 0;
-        double* res = cheb_apply(s, nb_, Mv, dinvM, false, cpM, r, start, other, cdp, true, dot_partial, &nblk_u);
+        double* res = cheb_apply(s, nb_, Mv, dinvM, false, cpM, r, start, other, cdp, true,
+                                 dot_partial ? dot_partial + (size_t)nblk_s * nb_ : nullptr, &nblk_u);
         if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
-        const int nblk_s = mgp->vcycle(s, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_,
-                                       dot_partial ? dot_partial + (size_t)nblk_u * nb_ : nullptr);
-        return nblk_u + nblk_s;   // <r, z> = u-block partials followed by s-block partials
+        return nblk_s + nblk_u;   // <r, z> = s-block partials followed by u-block partials
     };
     // only the s-block of the solution is ever read (PDESampler.cpp:526): update only those rows
     GraphHint hint;
