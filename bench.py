@@ -228,7 +228,7 @@ def main():
                                    f"MINRES 300/1e-6/1e-12, {ns} x {nb} realizations per step",
                        "mean_minres_iterations": acc[0] / max(acc[1], 1.0), "batch": nb, "streams": ns,
                        "parallelism": f"sample-farm x{world}"},
-            "roofline": {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, false, 1> (block operator K5)",
+            "roofline": {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, false, 2> (block operator K5)",
                          "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": peak, "unit": "GB/s",
                          "frac": k_bytes / (k_ms * 1e-3) / 1e9 / peak, "traffic": traffic,
                          "bytes_per_launch": k_bytes, "avg_kernel_ms": k_ms,

@@ -273,7 +273,8 @@ __device__ __forceinline__ int first_slice(int nslices, int* slice_end) {
 
 // MODE 0: y = Ax   1: y += Ax   2: y = r - Ax ; DOT: partial sums of <dot_with, result>.
 // Wavefronts stride over the slices (grid may be smaller than the slice count: bounded partial-sum count).
-// TAG only names the instantiation: 1 = the block saddle-point operator (K5), so that profiles show the
+// TAG only names the instantiation: 1 = the block saddle-point operator (K5) inside the solver, 2 = the same operator
+// launched by pmc_sampler_apply_operator (the isolated roofline measurement), so that profiles show the
 // hot operator's launches on their own row; 0 = every other matrix (transfers, residuals, ...).
 template <int NB, bool BV, int MODE, bool DOT, int TAG>
 __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
@@ -1396,6 +1397,7 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
     const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (A.tag == 1) spmm_launch<NB, 1>(st, g, A, x, y, accumulate, dot_partial, dot_with);
+        else if (A.tag == 2) spmm_launch<NB, 2>(st, g, A, x, y, accumulate, dot_partial, dot_with);
         else spmm_launch<NB, 0>(st, g, A, x, y, accumulate, dot_partial, dot_with);
     });
     check_launch();

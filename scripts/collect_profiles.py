@@ -51,7 +51,7 @@ def mean(d, key):
 
 out = {}
 for nb in (16, 1):
-    key = f"sell_spmm_kernel<{nb}, false, 0, false, 1>"
+    key = f"sell_spmm_kernel<{nb}, false, 0, false, 2>"
     fr, n = mean(fetch, key)
     wr, _ = mean(write, key)
     out[f"r5_nb{nb}"] = {"kernel": f"pmc::{key} on A", "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB_raw": wr,
