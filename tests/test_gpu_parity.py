@@ -794,3 +794,33 @@ def test_sample_statistics_match_the_exact_covariance(gpu_ctx, hex_hierarchy):
     lratio = mexp / np.exp(0.5 * var)
     assert abs(lratio.mean() - 1.0) < 0.05
     smp.close()
+
+
+def test_unstructured_triangles_2d_sampler_and_darcy(gpu_ctx, seeded_rng):
+    """2D, unstructured, simplicial: the reference's meshes/square.mesh (328 triangles, 4 boundary attributes) refined
+    once.  d = 2 changes the SPDE exponent (nu = 1, g = 50.13, src/Utilities.hpp:188-200) and the RT0 element (3 faces);
+    k == 1 with unit pressure drop across the unit square gives Q = 1 exactly on every level."""
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem, build_hierarchy, build_sampler_problem, mesh_from_json
+    h = build_hierarchy(mesh_from_json(golden_path("meshes", "square.json")), 1)
+    sp = build_sampler_problem(h, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(h, [1, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1])
+    assert abs(sp.matern_g - 50.13256549262001) < 1e-9
+    so, do = SamplerOracle(sp), DarcyOracle(dp)
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT))
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    xi = seeded_rng.standard_normal((3, sp.levels[0].n_s))
+    for lvl in range(2):
+        s = smp.Eval(lvl, xi, xi_level=0)
+        ref = np.stack([so.eval(lvl, 0, x)[0] for x in xi])
+        assert rel(np.log(s), np.log(ref)) < 1e-8
+        Q1, _ = ds.SolveFwd(lvl, np.ones((1, dp.levels[lvl].n_p)))
+        assert abs(Q1[0] - 1.0) < 1e-9
+        Q, C, sol = ds.SolveFwd(lvl, ref, want_solution=True)
+        for b in range(3):
+            Qr, Cr, sr = do.solve_fwd(lvl, ref[b], return_solution=True)
+            assert abs(Q[b] - Qr) < 1e-8 * abs(Qr) and C[b] == Cr and rel(sol[b], sr) < 1e-7
+    ds.close()
+    smp.close()
