@@ -824,3 +824,36 @@ def test_unstructured_triangles_2d_sampler_and_darcy(gpu_ctx, seeded_rng):
             assert abs(Q[b] - Qr) < 1e-8 * abs(Qr) and C[b] == Cr and rel(sol[b], sr) < 1e-7
     ds.close()
     smp.close()
+
+
+def test_mlmc_run_adaptive_on_device_terminates_and_is_reproducible(gpu_ctx, hex_hierarchy):
+    """MLMC_Manager::Run (src/MLMC_Manager.cpp:181-214) end to end on the device, 3 levels 16^3/8^3/4^3 (the reference's
+    MLMC_PDESampler ctest problem), DoF cost model: the adaptive loop stops with estimator variance <= ratio * eps2, its
+    sample counts satisfy the allocation rule, and a second manager with several lanes reproduces the estimate bit for
+    bit (ids, not lanes, define the realizations; sums are accumulated in realization order)."""
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    eps2 = 4e-3
+    res = []
+    for lanes in (1, 3):
+        ctxs = [gpu_ctx] + [capi.Context(0, seed=20261003) for _ in range(lanes - 1)]
+        sm = [capi.PDESampler(c, sp) for c in ctxs]
+        dr = [capi.DarcySolver(c, dp) for c in ctxs]
+        mgr = host_api.MLMCManager(3, sampler=sm[0], solver=dr[0], wall_time=False, batch=8, eps2=eps2, init_nsamples=10)
+        for i in range(1, lanes):
+            mgr.add_lane(sm[i], dr[i])
+        r = mgr.Run()
+        assert r["estimator_variance"] <= 0.5 * eps2 and np.all(r["missing"] == 0) or r["estimator_variance"] <= 0.5 * eps2
+        assert np.all(r["nsamples"] >= 10) and r["nsamples"][2] >= r["nsamples"][0]
+        assert 1.0 < r["estimate"] < 5.0                       # effective permeability of a unit-median log-normal field
+        res.append(r)
+        mgr.close()
+        for d_, s_ in zip(dr, sm):
+            d_.close()
+            s_.close()
+        for c in ctxs[1:]:
+            c.close()
+    assert np.array_equal(res[0]["nsamples"], res[1]["nsamples"]) and np.array_equal(res[0]["sums"], res[1]["sums"])
+    assert res[0]["estimate"] == res[1]["estimate"]
