@@ -77,6 +77,9 @@ typedef struct pmc_solver_opts {
                                  1 = smoothed aggregation built internally from S itself (what BoomerAMG does in the reference:
                                  strength-based, robust on stretched cells), 2 = choose 1 when the cells are strongly anisotropic
                                  (median strongest/weakest coupling per row > 10), else 0 (default 2)                       */
+    int32_t mini_max_rows;    /* sampler levels of at most this many rows (n_u + n_s) whose Schur V-cycle fits the LDS tail are
+                                 solved by ONE persistent workgroup per realization - the whole MINRES solve in a single
+                                 kernel launch - instead of ~7 launches per iteration (default 6000; 0 = never)           */
 } pmc_solver_opts;
 
 /* Per-realization solver report; the reference returns -1 for iteration counts

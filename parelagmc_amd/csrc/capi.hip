@@ -95,6 +95,7 @@ void pmc_solver_opts_default(pmc_solver_opts* o) {
     o->check_every = 2;
     o->schur_scale = 1.0;
     o->mg_coarsening = 2;
+    o->mini_max_rows = 6000;
     o->use_graph = 0;   // measured: no gain single-stream (kernels are latency-, not launch-bound), slower with 4 lanes
 }
 

@@ -36,7 +36,8 @@ struct Sampler {
     std::vector<std::unique_ptr<Multigrid>> amg;   // per MC level: internal smoothed-aggregation hierarchy (if selected)
     double anisotropy = 1.0;
     MinresWork work;
-    DevBuf<double> rhs, sol, tA, tB, cx, cd, stage_in, stage_out, stage_emb;
+    DevBuf<double> rhs, sol, tA, tB, cx, cd, stage_in, stage_out, stage_emb, mini_scratch;
+    DevBuf<pmc_stats> mini_stats;
 
     Sampler(Ctx& c, int nlevels, int n_mc, const pmc_sampler_level* in, double alpha, double g, bool lognormal,
             const pmc_solver_opts& o);

@@ -1270,20 +1270,10 @@ __device__ void tail_cheb(const TailLevelDev& L, int bv, int nb, int k, int degr
     }
 }
 
-__global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(const TailParams* __restrict__ pp, int nb,
-                                                               const double* __restrict__ rin, double* __restrict__ xout,
-                                                               double* __restrict__ partial) {
-    extern __shared__ __align__(16) double lds[];
-    __shared__ double red[kTailThreads / kWave];
-    const TailParams& P = *pp;
-    const int k = blockIdx.x;
+// V-cycle over the tail levels for realization k: the right-hand side is in LDS at lev[0]'s r block on entry, the
+// result in its x block on return.  All kTailThreads threads of the workgroup participate.
+__device__ void tail_vcycle_lds(const TailParams& P, int nb, int k, double* lds) {
     const int nlev = P.nlev;
-    {
-        const TailLevelDev& L0 = P.lev[0];
-        double* r0 = lds + L0.lds_off;
-        for (int i = threadIdx.x; i < L0.n; i += kTailThreads) r0[i] = rin[(size_t)i * nb + k];
-    }
-    __syncthreads();
     // down sweep
     int l = 0;
     for (;; ++l) {
@@ -1318,7 +1308,22 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(const TailParams*
         __syncthreads();
         tail_cheb(L, P.bv, nb, k, P.smooth_degree, P.smooth_ratio, false, r, x, d);
     }
+}
+
+__global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(const TailParams* __restrict__ pp, int nb,
+                                                               const double* __restrict__ rin, double* __restrict__ xout,
+                                                               double* __restrict__ partial) {
+    extern __shared__ __align__(16) double lds[];
+    __shared__ double red[kTailThreads / kWave];
+    const TailParams& P = *pp;
+    const int k = blockIdx.x;
     const TailLevelDev& L0 = P.lev[0];
+    {
+        double* r0 = lds + L0.lds_off;
+        for (int i = threadIdx.x; i < L0.n; i += kTailThreads) r0[i] = rin[(size_t)i * nb + k];
+    }
+    __syncthreads();
+    tail_vcycle_lds(P, nb, k, lds);
     const double* r0 = lds + L0.lds_off;
     const double* x0 = r0 + L0.n;
     double p = 0.0;
@@ -1332,10 +1337,146 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(const TailParams*
         if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = p;
         __syncthreads();
         if (threadIdx.x == 0) {
-            double s = 0.0;
-            for (int w = 0; w < kTailThreads / kWave; ++w) s += red[w];
-            partial[k] = s;     // one partial block: partial[0*nb + k]
+            double sum = 0.0;
+            for (int w = 0; w < kTailThreads / kWave; ++w) sum += red[w];
+            partial[k] = sum;     // one partial block: partial[0*nb + k]
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent per-realization solver for SMALL levels (shared matrix values: the SPDE sampler).  As separate kernels a
+// MINRES iteration on a ~17 k-row level is 7 launches of a few microseconds each - the GPU's dispatch rate, not its
+// bandwidth, bounds the throughput.  Here ONE workgroup runs the whole preconditioned MINRES solve of ONE realization:
+// operator, M-block polynomial, S-block V-cycle (the LDS tail above), dots and scalar recurrences, separated only by
+// __syncthreads(); vectors live in a per-realization scratch area that stays in L2, no host round trip until the solve
+// has finished.  Same recurrences, stopping rule and per-realization results as the batched kernels.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    __syncthreads();                                   // red may still be read from the previous call
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kTailThreads / kWave; ++w) s += red[w];   // same order in every thread: deterministic, no broadcast
+    return s;
+}
+
+__global__ __launch_bounds__(kTailThreads) void mini_sampler_kernel(MiniSamplerParams P, int nb, const double* __restrict__ b,
+                                                                     double* __restrict__ x, int zero_guess,
+                                                                     double* __restrict__ scratch, pmc_stats* __restrict__ stats) {
+    extern __shared__ __align__(16) double lds[];
+    __shared__ double red[kTailThreads / kWave];
+    const int k = blockIdx.x;
+    const int n_u = P.n_u, n_s = P.n_s, n = n_u + n_s;
+    const int tid = threadIdx.x;
+    double* v0 = scratch + (size_t)k * P.scratch_per_col;
+    double* v1 = v0 + n;
+    double* u0 = v1 + n;
+    double* u1 = u0 + n;
+    double* q = u1 + n;
+    double* w0 = q + n;
+    double* w1 = w0 + P.x_nrows;
+    double* xs = w1 + P.x_nrows;
+    const TailParams& T = *P.tail;
+    const TailLevelDev& L0 = T.lev[0];
+    double* r0 = lds + L0.lds_off;
+    const double* x0 = r0 + L0.n;
+
+    // z = B^-1 r: u-block one-pass degree-2 polynomial in D^-1 M, s-block V-cycle in LDS; returns <r, z>
+    auto prec = [&](const double* r, double* z) {
+        double p = 0.0;
+        for (int i = tid; i < n_u; i += kTailThreads) {
+            const double acc = tail_row_dot(P.m_off, P.m_cols, P.m_scaled, 1, 0, i, r);
+            const double zi = P.m_dinv[i] * (P.mc0 * r[i] - P.mc1 * acc);
+            z[i] = zi;
+            p = fma(r[i], zi, p);
+        }
+        for (int i = tid; i < n_s; i += kTailThreads) r0[i] = r[n_u + i];
+        __syncthreads();
+        tail_vcycle_lds(T, nb, k, lds);
+        for (int i = tid; i < n_s; i += kTailThreads) {
+            const double zi = x0[i];
+            z[n_u + i] = zi;
+            p = fma(r0[i], zi, p);
+        }
+        return block_sum(p, red);     // its barriers also order the z writes before the next phase reads them
+    };
+
+    // v1 = b - A x0
+    if (zero_guess) {
+        for (int i = tid; i < n; i += kTailThreads) v1[i] = b[(size_t)i * nb + k];
+        for (int i = tid; i < P.x_nrows; i += kTailThreads) xs[i] = 0.0;
+    } else {
+        for (int i = tid; i < n; i += kTailThreads) u1[i] = x[(size_t)i * nb + k];
+        __syncthreads();
+        for (int i = tid; i < n; i += kTailThreads)
+            v1[i] = b[(size_t)i * nb + k] - tail_row_dot(P.a_off, P.a_cols, P.a_vals, 1, 0, i, u1);
+        for (int i = tid; i < P.x_nrows; i += kTailThreads) xs[i] = u1[P.x_row0 + i];
+    }
+    for (int i = tid; i < n; i += kTailThreads) v0[i] = 0.0;
+    for (int i = tid; i < P.x_nrows; i += kTailThreads) { w0[i] = 0.0; w1[i] = 0.0; }
+    __syncthreads();
+    const double d0 = prec(v1, u1);
+    double beta = d0 > 0.0 ? sqrt(d0) : 0.0, beta_old = 1.0, eta = beta;
+    double gamma0 = 1.0, gamma1 = 1.0, sigma0 = 0.0, sigma1 = 0.0;
+    const double eta0 = beta;
+    const double goal = fmax(P.rel_tol * beta, P.abs_tol);
+    int flag = (d0 < 0.0 || d0 != d0) ? -1 : 0;
+    bool active = beta > goal && flag == 0;
+    int it = 0;
+    while (active && it < P.max_iter) {
+        // q = A u1, <u1, q>
+        double p = 0.0;
+        for (int i = tid; i < n; i += kTailThreads) {
+            const double qi = tail_row_dot(P.a_off, P.a_cols, P.a_vals, 1, 0, i, u1);
+            q[i] = qi;
+            p = fma(u1[i], qi, p);
+        }
+        const double d1 = block_sum(p, red);
+        const double ib = 1.0 / beta;
+        const double alpha = d1 * ib * ib;
+        const double cV0 = ib, cV1 = -alpha * ib, cV2 = -beta / beta_old;
+        const double delta = gamma1 * alpha - gamma0 * sigma1 * beta;
+        const double rho3 = sigma0 * beta;
+        const double rho2 = sigma1 * alpha + gamma0 * gamma1 * beta;
+        for (int i = tid; i < n; i += kTailThreads) v0[i] = cV0 * q[i] + cV1 * v1[i] + cV2 * v0[i];
+        __syncthreads();
+        const double d2 = prec(v0, u0);
+        if (d2 < 0.0 || d2 != d2) flag = -1;
+        const double beta_new = d2 > 0.0 ? sqrt(d2) : 0.0;
+        const double rho1 = hypot(delta, beta_new);
+        const double ir = rho1 > 0.0 ? 1.0 / rho1 : 0.0;
+        const double cW0 = ir / beta, cW1 = -rho3 * ir, cW2 = -rho2 * ir;
+        gamma0 = gamma1;
+        gamma1 = delta * ir;
+        const double cW3 = gamma1 * eta;
+        sigma0 = sigma1;
+        sigma1 = beta_new * ir;
+        eta = -sigma1 * eta;
+        beta_old = beta;
+        beta = beta_new;
+        for (int i = tid; i < P.x_nrows; i += kTailThreads) {
+            const double w = cW0 * u1[P.x_row0 + i] + cW1 * w0[i] + cW2 * w1[i];
+            w0[i] = w;
+            xs[i] += cW3 * w;
+        }
+        ++it;
+        if (fabs(eta) <= goal || beta_new == 0.0 || flag != 0) active = false;
+        // role swap (every thread holds the same pointers)
+        double* t;
+        t = u0; u0 = u1; u1 = t;
+        t = v0; v0 = v1; v1 = t;
+        t = w0; w0 = w1; w1 = t;
+        __syncthreads();
+    }
+    for (int i = tid; i < P.x_nrows; i += kTailThreads) x[(size_t)(P.x_row0 + i) * nb + k] = xs[i];
+    if (tid == 0) {
+        stats[k].iterations = it;
+        stats[k].converged = (flag == 0 && fabs(eta) <= goal) ? 1 : 0;
+        stats[k].initial_norm = eta0;
+        stats[k].final_norm = fabs(eta);
     }
 }
 
@@ -1666,6 +1807,20 @@ void refresh(hipStream_t st, int nb, int64_t nslots, const int* ptr, const int* 
 
 void diag_inv(hipStream_t st, int nb, int n, const int* diag_slot, const double* vals, double* dinv) {
     PMC_DISPATCH_NB(nb, { diag_inv_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, diag_slot, vals, dinv); });
+    check_launch();
+}
+
+void mini_sampler_solve(hipStream_t st, int nb, const MiniSamplerParams& P, size_t lds_doubles, const double* b, double* x,
+                        bool zero_guess, double* scratch, pmc_stats* stats) {
+    const size_t bytes = lds_doubles * sizeof(double);
+    if (bytes > kTailLdsBytes) throw Error(PMC_ERR_INTERNAL, "mini solver: LDS request too large");
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load()) {
+        PMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mini_sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kTailLdsBytes));
+        attr_set.store(true);
+    }
+    mini_sampler_kernel<<<nb, kTailThreads, bytes, st>>>(P, nb, b, x, zero_guess ? 1 : 0, scratch, stats);
     check_launch();
 }
 

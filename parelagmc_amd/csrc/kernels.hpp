@@ -147,7 +147,25 @@ struct TailParams {
     double smooth_ratio;
     TailLevelDev lev[8];
 };
+// Everything the persistent small-level solver of the sampler needs (device pointers; by value in the kernel arguments)
+struct MiniSamplerParams {
+    int n_u, n_s;
+    const int *a_off, *a_cols;      // block operator A (SELL-64, shared values)
+    const double* a_vals;
+    const int *m_off, *m_cols;      // M with column-scaled values M D^-1 and the l1 inverse: one-pass degree-2 polynomial
+    const double *m_scaled, *m_dinv;
+    double mc0, mc1;
+    const TailParams* tail;         // V-cycle of the Schur block from this level on, all in LDS
+    int max_iter;
+    double rel_tol, abs_tol;
+    int x_row0, x_nrows;            // maintained rows of the solution
+    size_t scratch_per_col;         // doubles of scratch per realization: 5 n + 3 x_nrows
+};
 namespace k {
+// Whole preconditioned MINRES solves of nb realizations, one workgroup each (see mini_sampler_kernel).  b, x: interleaved
+// [row][nb] vectors as in minres_solve; stats: nb device entries.
+void mini_sampler_solve(hipStream_t st, int nb, const MiniSamplerParams& P, size_t lds_doubles, const double* b, double* x,
+                        bool zero_guess, double* scratch, pmc_stats* stats);
 // One workgroup per batch column runs the whole V-cycle over the tail levels in LDS.  r, xout: interleaved
 // vectors of the first tail level.  dot_partial != nullptr: writes <r, xout> per column as ONE partial block.
 int mg_tail(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_doubles, const double* r, double* xout,

@@ -5,6 +5,7 @@
 #include <cmath>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "handles.hpp"
 
@@ -305,6 +306,41 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
         }
         zero_guess = false;
     }
+    const bool use_amg = level < (int)amg.size() && amg[level];
+    Multigrid* mgp = use_amg ? amg[level].get() : &mg;
+    const int mg_l0 = use_amg ? 0 : level;
+    // small level whose whole Schur V-cycle fits the LDS tail: one persistent workgroup per realization runs the entire
+    // MINRES solve (k::mini_sampler_solve) instead of ~7 kernel launches per iteration
+    static const int mini_env = [] {      // tuning override of opts.mini_max_rows
+        const char* e = getenv("PMC_MINI_MAX_ROWS");
+        return e ? atoi(e) : -1;
+    }();
+    const int mini_max_rows = mini_env >= 0 ? mini_env : opts.mini_max_rows;
+    const bool mini = n <= mini_max_rows && opts.cheb_degree_M == 2 && opts.use_graph == 0 && mgp->use_tail &&
+                      mg_l0 < (int)mgp->tail.size() && mgp->tail[mg_l0].p != nullptr;
+    if (mini) {
+        MiniSamplerParams mp{};
+        mp.n_u = n_u;
+        mp.n_s = n_s;
+        mp.a_off = d.A.slice_off.p; mp.a_cols = d.A.cols.p; mp.a_vals = d.A.vals.p;
+        mp.m_off = d.M.slice_off.p; mp.m_cols = d.M.cols.p; mp.m_scaled = d.M_scaled.p; mp.m_dinv = d.dinvM.p;
+        cheb2_coefficients(1.0, d.ratio_M, &mp.mc0, &mp.mc1);
+        mp.tail = mgp->tail[mg_l0].p;
+        mp.max_iter = opts.max_iter;
+        mp.rel_tol = opts.rel_tol;
+        mp.abs_tol = opts.abs_tol;
+        mp.x_row0 = n_u;
+        mp.x_nrows = n_s;
+        mp.scratch_per_col = (size_t)5 * n + (size_t)3 * n_s;
+        mini_scratch.ensure(mp.scratch_per_col * nb);
+        mini_stats.ensure(kMaxBatch);
+        k::mini_sampler_solve(st, nb, mp, mgp->tail_lds[mg_l0], rhs.p, sol.p, zero_guess, mini_scratch.p, mini_stats.p);
+        if (stats) {
+            PMC_HIP(hipMemcpyAsync(ctx.h_scal, mini_stats.p, sizeof(pmc_stats) * nb, hipMemcpyDeviceToHost, st));
+            PMC_HIP(hipStreamSynchronize(st));
+            std::memcpy(stats, ctx.h_scal, sizeof(pmc_stats) * nb);
+        }
+    } else {
     LinOp A;
     A.n = n;
     SellView Av = view(d.A);
@@ -317,9 +353,6 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     ChebParams cpM{opts.cheb_degree_M, 1.0, d.ratio_M, d.M_scaled.p};
     double* cxp = cx.p;
     double* cdp = cd.p;
-    const bool use_amg = level < (int)amg.size() && amg[level];
-    Multigrid* mgp = use_amg ? amg[level].get() : &mg;
-    const int mg_l0 = use_amg ? 0 : level;
     PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z, double* dot_partial) {
         const int flips = cheb_flips(cpM, true);
         double* start = (flips % 2 == 0) ? z : cxp;
@@ -340,6 +373,7 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work, n_u, n_s, nullptr, hint);
     if (stats)
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
+    }
     // outputs (:526-533 and the embedded variants' maps)
     const double* sol_s = sol.p + (size_t)n_u * nb;
     if (d.proj == PMC_PROJ_NONE) {
