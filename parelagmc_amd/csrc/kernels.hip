@@ -18,7 +18,10 @@
 
 namespace pmc {
 
-static constexpr int kBlock = 256;
+#ifndef PMC_KBLOCK
+#define PMC_KBLOCK 256
+#endif
+static constexpr int kBlock = PMC_KBLOCK;   // workgroup size of the streaming / SpMM kernels (tuning builds may override)
 static constexpr int kWave = 64;
 
 int dot_capacity(int nrows) {
