@@ -787,7 +787,7 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
     lds[threadIdx.x] = s;
     __syncthreads();
     double t = 0.0;
-    if (threadIdx.x < nb)
+    if ((int)threadIdx.x < nb)
         for (int g = 0; g < nq; ++g) t += lds[g * nb + threadIdx.x];
     return t;   // valid for threadIdx.x < nb
 }
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(kBlock) void gersh_scale_kernel(int nrows, const un
 __global__ __launch_bounds__(kScalBlock) void reduce_final_kernel(const double* __restrict__ partial, int nblocks, int nb,
                                                               double* __restrict__ out) {
     const double s = reduce_partials(partial, nblocks, nb);
-    if (threadIdx.x < nb) out[threadIdx.x] = s;
+    if ((int)threadIdx.x < nb) out[threadIdx.x] = s;
 }
 
 // out[i*NB+k] = a[i] (broadcast a shared vector into an interleaved batch)
