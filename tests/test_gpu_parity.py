@@ -881,3 +881,36 @@ def test_persistent_small_level_solver_equals_the_batched_kernels(gpu_ctx, hex_h
     assert [t[0] for t in sa] == [t[0] for t in sb] and rel(np.log(a), np.log(b)) < 1e-10
     mini.close()
     ref.close()
+
+
+def test_full_size_config3_darcy_properties(gpu_ctx):
+    """BASELINE config 3 at full size (cube_hex 64^3 / 32^3 / 16^3: 1 060 864 / 134 144 / 17 152 DoF), size-independent
+    properties instead of a direct solve: (i) the reference's known answer Q = 2 for k == 1 holds on every level
+    (examples/CMakeLists.txt:62-66 states it for 16^3 / 8^3 / 4^3), (ii) the effective permeability is homogeneous of degree
+    one, Q(c k) = c Q(k), for a rough log-normal field, (iii) a batch equals its single evaluations, (iv) with the
+    sampler: one MLMC level pair evaluated as MLMC_Manager does gives a small coarse/fine difference."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem
+    h = build_hierarchy(box_mesh([4, 4, 4], [2.0, 2.0, 2.0], "hex"), 4)
+    dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], n_mc_levels=3)
+    assert [L.ndofs for L in dp.levels[:3]] == [1060864, 134144, 17152]
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(rel_tol=1e-10, abs_tol=1e-30))
+    for lvl in range(3):
+        Q, C = ds.SolveFwd(lvl, np.ones((1, dp.levels[lvl].n_p)))
+        assert abs(Q[0] - 2.0) < 1e-8 and C[0] == dp.levels[lvl].ndofs
+    k = np.exp(np.random.default_rng(3).standard_normal((3, dp.levels[0].n_p)))
+    Q, _, st = ds.SolveFwd(0, k, return_stats=True)
+    Q3, _ = ds.SolveFwd(0, 3.0 * k[:1])
+    Q1, _ = ds.SolveFwd(0, k[1:2])
+    assert all(t[1] == 1 for t in st)
+    assert abs(Q3[0] - 3.0 * Q[0]) < 1e-7 * Q3[0] and abs(Q1[0] - Q[1]) < 1e-8 * Q[1]
+    sp = build_sampler_problem(h, corlen=0.1, lognormal=True, n_mc_levels=3)
+    smp = capi.PDESampler(gpu_ctx, sp)
+    xi = smp.Sample(0, first_id=0, nbatch=2)
+    sc, ec = smp.Eval(1, xi, xi_level=0, want_embed=True)
+    sf = smp.Eval(0, xi, xi_level=0, init_s=ec, init_level=1, use_init=True)
+    qf, _ = ds.SolveFwd(0, sf)
+    qc, _ = ds.SolveFwd(1, sc)
+    assert np.all(np.abs(qf - qc) < 0.25 * np.abs(qf)) and np.all(qf > 0.5) and np.all(qf < 6.0)
+    smp.close()
+    ds.close()
