@@ -604,7 +604,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
             k::diag_inv(st, nb, c.n, dc.s_diag_slot.p, c.vals_bv.p, c.dinv.p);
             k::scale_cols_bv(st, nb, c.S.nslots, c.S.cols.p, c.vals_bv.p, c.dinv.p, c.vals_scaled.p);
         }
-        mg.refresh_bv_tail(st, nb);
+        mg.refresh_bv_tail(st, nb, level);
     }
     // operator [M(k) Bt; B 0] and block-diagonal preconditioner
     const SellView Mv = view_bv(d.M, d.mvals.p);

@@ -90,8 +90,9 @@ void Multigrid::enable_bv_tail(int max_rows) {
     }
 }
 
-void Multigrid::refresh_bv_tail(hipStream_t st, int nb) {
-    for (MgLevel& m : L) {
+void Multigrid::refresh_bv_tail(hipStream_t st, int nb, int first_level) {
+    for (size_t l = (size_t)first_level; l < L.size(); ++l) {   // levels finer than the one being solved hold stale values
+        MgLevel& m = L[l];
         if (!m.vals_t.p) continue;
         k::transpose_bv(st, nb, (size_t)m.S.nslots, m.vals_bv.p, m.vals_t.p);
         k::transpose_bv(st, nb, (size_t)m.S.nslots, m.vals_scaled.p, m.scaled_t.p);

@@ -92,7 +92,7 @@ struct Multigrid {
     // per-realization hierarchies: give every level of at most max_rows rows transposed value copies so that
     // build_tails can include them; refresh_bv_tail(nb) re-fills the copies (call after every numeric refresh)
     void enable_bv_tail(int max_rows = 8192);
-    void refresh_bv_tail(hipStream_t st, int nb);
+    void refresh_bv_tail(hipStream_t st, int nb, int first_level = 0);
     // hash of the work-buffer pointers a V-cycle from level l0 touches (for GraphHint::sig)
     uint64_t signature(int l0) const;
     // x = V(r) starting at level l0 with zero initial guess; result written to xout (n(l0)*nb).
