@@ -166,3 +166,25 @@ def test_c_port_of_reference_solver_matches_direct_solve(hex_hierarchy, seeded_r
         assert np.linalg.norm(s - ref) <= 1e-9 * np.linalg.norm(ref) and (it > 0).all()
         s, it = cp.eval(lvl, 0, xi, nthreads=2)                     # reference tolerances 300 / 1e-6 / 1e-12
         assert np.linalg.norm(s - ref) <= 1e-5 * np.linalg.norm(ref) and (it > 0).all() and (it <= 300).all()
+
+
+def test_oracle_statistically_matches_reference_goldens_on_coarse_levels():
+    """The reference's DarcyRandomInputTest golden (examples/CMakeLists.txt:91-95: 10-sample means of the effective
+    permeability, 2.103 on the 8^3 and 1.998 on the 4^3 level, L2ProjectionPDESampler on the enlarged box) is a sample of the
+    distribution the ORACLE must reproduce: means over N realizations (numpy generator) within three standard errors of the
+    10-sample estimate.  (The 16^3 level and the MLMC golden are checked on the GPU path, tests/test_gpu_parity.py.)"""
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd.fe import (box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem,
+                                  l2_projection_hierarchy)
+    ho = build_hierarchy(box_mesh([4, 4, 4], [2.0, 2.0, 2.0], "hex"), 1)
+    he = build_hierarchy(box_mesh([6, 6, 6], [3.0, 3.0, 3.0], "hex", origin=[-0.5, -0.5, -0.5]), 1)
+    sp = build_sampler_problem(he, corlen=0.1, lognormal=True)
+    ops = l2_projection_hierarchy(ho, he)
+    dp = build_darcy_problem(ho, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    so, do = SamplerOracle(sp), DarcyOracle(dp)
+    rng = np.random.default_rng(20261003)
+    for lvl, gold, n in ((0, 2.103, 160), (1, 1.998, 400)):
+        q = np.array([do.solve_fwd(lvl, so.eval(lvl, lvl, rng.standard_normal(sp.levels[lvl].n_s),
+                                                 projection=("l2",) + ops[lvl])[0])[0] for _ in range(n)])
+        assert abs(q.mean() - gold) < 3.0 * q.std() * np.sqrt(1.0 / 10 + 1.0 / n), (lvl, q.mean(), q.std())
