@@ -54,6 +54,26 @@ __device__ __forceinline__ void store_c(double* __restrict__ p, const double (&v
     else *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]);
 }
 
+// Vector streams without reuse inside the iteration (MINRES w / x updates): optional non-temporal variants
+template <int C>
+__device__ __forceinline__ void load_c_nt(const double* __restrict__ p, double (&v)[C]) {
+#ifdef PMC_NT_VECTORS
+    v[0] = __builtin_nontemporal_load(p);
+    if constexpr (C == 2) v[1] = __builtin_nontemporal_load(p + 1);
+#else
+    load_c<C>(p, v);
+#endif
+}
+template <int C>
+__device__ __forceinline__ void store_c_nt(double* __restrict__ p, const double (&v)[C]) {
+#ifdef PMC_NT_VECTORS
+    __builtin_nontemporal_store(v[0], p);
+    if constexpr (C == 2) __builtin_nontemporal_store(v[1], p + 1);
+#else
+    store_c<C>(p, v);
+#endif
+}
+
 // Streaming accesses (matrix values / indices read once, result rows written once): non-temporal, so that they do not
 // displace the gathered x rows - the only data with reuse - from the XCD's L2.
 template <int C>
@@ -725,16 +745,16 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const d
     const int k0 = (int)(e % NB);
     double uv[C], w0v[C], w1v[C], xv[C];
     load_c<C>(u + e, uv);
-    load_c<C>(w0 + e, w0v);
-    load_c<C>(w1 + e, w1v);
-    load_c<C>(x + e, xv);
+    load_c_nt<C>(w0 + e, w0v);
+    load_c_nt<C>(w1 + e, w1v);
+    load_c_nt<C>(x + e, xv);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         w0v[c] = c0[k0 + c] * uv[c] + c1[k0 + c] * w0v[c] + c2[k0 + c] * w1v[c];
         xv[c] += c3[k0 + c] * w0v[c];
     }
-    store_c<C>(w0 + e, w0v);
-    store_c<C>(x + e, xv);
+    store_c_nt<C>(w0 + e, w0v);
+    store_c_nt<C>(x + e, xv);
 }
 
 // partial sums of <w, x[:,k]> with a shared (non-batched) weight vector w   (K15 QoI)
