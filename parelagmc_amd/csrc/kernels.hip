@@ -1837,11 +1837,13 @@ void mini_sampler_solve(hipStream_t st, int nb, const MiniSamplerParams& P, size
                         bool zero_guess, double* scratch, pmc_stats* stats) {
     const size_t bytes = lds_doubles * sizeof(double);
     if (bytes > kTailLdsBytes) throw Error(PMC_ERR_INTERNAL, "mini solver: LDS request too large");
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load()) {
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev = 0;
+    PMC_HIP(hipGetDevice(&dev));
+    if (!(attr_mask.load() & (1ull << (dev & 63)))) {
         PMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mini_sampler_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kTailLdsBytes));
-        attr_set.store(true);
+        attr_mask.fetch_or(1ull << (dev & 63));
     }
     mini_sampler_kernel<<<nb, kTailThreads, bytes, st>>>(P, nb, b, x, zero_guess ? 1 : 0, scratch, stats);
     check_launch();
@@ -1867,12 +1869,14 @@ int mg_tail(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_dou
             double* dot_partial) {
     const size_t bytes = lds_doubles * sizeof(double);
     if (bytes > kTailLdsBytes) throw Error(PMC_ERR_INTERNAL, "mg_tail: LDS request too large");
-    // one process drives one GPU; the attribute only has to be raised once (idempotent if two lanes race)
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load()) {
+    // the dynamic-LDS limit is a per-device function attribute: raise it once per device (idempotent if two lanes race)
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev = 0;
+    PMC_HIP(hipGetDevice(&dev));
+    if (!(attr_mask.load() & (1ull << (dev & 63)))) {
         PMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mg_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kTailLdsBytes));
-        attr_set.store(true);
+        attr_mask.fetch_or(1ull << (dev & 63));
     }
     mg_tail_kernel<<<nb, kTailThreads, bytes, st>>>(dev_params, nb, r, xout, dot_partial);
     check_launch();
