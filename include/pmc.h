@@ -86,7 +86,7 @@ typedef struct pmc_solver_opts {
  * (src/PDESampler.hpp:142-145, src/DarcySolver.hpp:104-107) and is silent on non-convergence. */
 typedef struct pmc_stats {
     int32_t iterations;
-    int32_t converged;
+    int32_t converged;   /* 1 converged, 0 iteration cap reached, -1 breakdown (non-finite data / indefinite preconditioner) */
     double initial_norm; /* preconditioned residual norm before the first iteration */
     double final_norm;   /* |eta| at exit */
 } pmc_stats;

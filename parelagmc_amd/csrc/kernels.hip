@@ -1497,7 +1497,7 @@ __global__ __launch_bounds__(kTailThreads) void mini_sampler_kernel(MiniSamplerP
     for (int i = tid; i < P.x_nrows; i += kTailThreads) x[(size_t)(P.x_row0 + i) * nb + k] = xs[i];
     if (tid == 0) {
         stats[k].iterations = it;
-        stats[k].converged = (flag == 0 && fabs(eta) <= goal) ? 1 : 0;
+        stats[k].converged = flag != 0 ? -1 : (fabs(eta) <= goal ? 1 : 0);   // -1: indefinite preconditioner / NaN
         stats[k].initial_norm = eta0;
         stats[k].final_norm = fabs(eta);
     }

@@ -958,3 +958,35 @@ def test_statistical_agreement_with_the_reference_goldens(gpu_ctx, hex_hierarchy
     for lvl, gold in enumerate((2.391, 2.103, 1.998)):
         assert abs(mean[lvl] - gold) < 3.0 * std[lvl] * np.sqrt(1.0 / 10 + 1.0 / N)
     ds.close()
+
+
+def test_non_convergence_and_bad_input_are_reported_not_hidden(gpu_ctx, hex_hierarchy_small):
+    """The reference is silent on solver failure (GetNumIters() returns -1, src/PDESampler.hpp:142-145).  Here pmc_stats says
+    so: an iteration cap that is too small gives converged = 0 with iterations = max_iter for every realization (batched
+    kernels and the persistent small-level kernel alike), a non-finite right-hand side gives converged = -1 without running
+    away, and per-realization freezing keeps the healthy members of a batch exact."""
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    xi = np.random.default_rng(1).standard_normal((5, sp.levels[0].n_s))
+    for mini in (0, 100000):
+        smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(max_iter=4, mini_max_rows=mini))
+        s, st = smp.Eval(0, xi, return_stats=True)
+        assert all(t[0] == 4 and t[1] == 0 for t in st) and np.all(np.isfinite(s))
+        smp.close()
+        smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(rel_tol=1e-12, abs_tol=1e-30, mini_max_rows=mini))
+        bad = xi.copy()
+        bad[2, 7] = np.nan
+        s, st = smp.Eval(0, bad, return_stats=True)
+        assert st[2][1] == -1 and st[2][0] <= 300       # breakdown is flagged, the loop stops
+        good = [0, 1, 3, 4]
+        assert all(st[b][1] == 1 for b in good)
+        ref = np.stack([SamplerOracle(sp).eval(0, 0, xi[b])[0] for b in good])
+        assert rel(s[good], ref) < 1e-9
+        smp.close()
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(max_iter=3))
+    Q, C, st = ds.SolveFwd(0, np.exp(xi), return_stats=True)
+    assert all(t[0] == 3 and t[1] == 0 for t in st) and np.all(np.isfinite(Q))
+    ds.close()
