@@ -96,3 +96,26 @@ def test_disjoint_meshes_and_errors():
         mortar_gt(a.verts, a.elems, c.verts, c.elems)
     with pytest.raises(capi.PmcError):
         mortar_gt(a.verts, a.elems[:, :2], a.verts, a.elems)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_symmetry_and_affine_covariance(seed):
+    """G(a, b)^T = G(b, a); under one affine map x -> T x + t applied to both meshes every intersection measure scales by
+    |det T| (clipping works on sheared / rotated / reflected simplices, not only on the meshes' own axes)."""
+    from parelagmc_amd.fe import refine_uniform
+    from parelagmc_amd.host_api import mortar_gt
+    rng = np.random.default_rng(seed)
+    for a, b in ((refine_uniform(_mesh("cube_tet"))[0], _mesh("cube_tet_enlarge")), (_mesh("square"), _mesh("square_enlarge"))):
+        sub = rng.choice(a.ne, size=min(a.ne, 40), replace=False)
+        ea = a.elems[np.sort(sub)]
+        G, _, _ = mortar_gt(a.verts, ea, b.verts, b.elems)
+        Gt, _, _ = mortar_gt(b.verts, b.elems, a.verts, ea)
+        assert abs(G - Gt.T).max() < 1e-13
+        d = a.dim
+        T = rng.standard_normal((d, d)) + 2.0 * np.eye(d)
+        if seed == 2:
+            T[:, 0] *= -1.0                                  # reflection: orientation of every simplex flips
+        t = rng.standard_normal(d)
+        G2, ma2, _ = mortar_gt(a.verts @ T.T + t, ea, b.verts @ T.T + t, b.elems)
+        det = abs(np.linalg.det(T))
+        assert abs(G2 - det * G).max() < 1e-11 * det and (G2 != 0).nnz == (G != 0).nnz
