@@ -23,6 +23,10 @@ namespace pmc {
 #endif
 static constexpr int kBlock = PMC_KBLOCK;   // workgroup size of the streaming / SpMM kernels (tuning builds may override)
 static constexpr int kWave = 64;
+#ifndef PMC_K5_TWO_COLUMNS
+#define PMC_K5_TWO_COLUMNS 0
+#endif
+static constexpr bool kK5TwoColumns = PMC_K5_TWO_COLUMNS != 0;   // tuning build: K5 steps two slice columns at a time (see sell_row_range); measured slower, off
 
 int dot_capacity(int nrows) {
     // upper bound on the partial blocks any (fused) dot over nrows rows writes, for every batch width
@@ -166,7 +170,7 @@ __device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], doubl
 // sell_row_range works on `width` slice columns starting at slot `off`.  CS: every gathered x[col] is multiplied by a
 // second gathered per-realization vector cs[col] (column scaling A D^-1 without stored scaled values).  ZERO: acc is
 // cleared first, otherwise accumulated into.
-template <int NB, bool BV, bool CS, bool ZERO>
+template <int NB, bool BV, bool CS, bool ZERO, int JC = 1>
 __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
                                                const double* __restrict__ x, const double* __restrict__ cs, int off,
                                                int width, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
@@ -216,6 +220,68 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         return;
     }
 
+    if constexpr (JC == 2) {
+        // TWO slice columns per step: 2 T gathers in flight per wavefront.  The extra registers halve the resident
+        // workgroups per CU - on purpose: fewer slices in flight shrink the set of x rows the XCD's L2 has to keep alive
+        // (measured with an occupancy-limited launch: FETCH_SIZE 182 -> 156 MB) and the doubled memory-level parallelism per
+        // wave was meant to keep the latency hidden.  Measured: FETCH_SIZE 182 -> 168 MB but 41 -> 48 us (3 instead of 4
+        // waves per SIMD cost more than the 16 gathers in flight return), so the build default is the one-column loop.
+        // Shared values, no column scaling (the block operator K5).
+        static_assert(!BV && !CS, "two-column stepping is written for shared values without column scaling");
+        int ca = 0, cb = 0;
+        double va = 0.0, vb = 0.0;
+        if (width > 0) {
+            ca = load_stream(cols + slot);
+            va = load_stream(vals + slot);
+            cb = ca;
+            if (width > 1) {
+                cb = load_stream(cols + slot + kWave);
+                vb = load_stream(vals + slot + kWave);
+            }
+        }
+        for (int j = 0; j < width; j += 2, slot += 2 * kWave) {
+            int na = ca, nb_ = cb;
+            double wa = 0.0, wb = 0.0;
+            if (j + 2 < width) {
+                na = load_stream(cols + slot + 2 * kWave);
+                wa = load_stream(vals + slot + 2 * kWave);
+                nb_ = na;
+                if (j + 3 < width) {
+                    nb_ = load_stream(cols + slot + 3 * kWave);
+                    wb = load_stream(vals + slot + 3 * kWave);
+                }
+            }
+            int cc0[T], cc1[T];
+            double aa0[T], aa1[T];
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs) {
+                const int src = rs * G + g;
+                cc0[rs] = __shfl(ca, src, kWave);
+                aa0[rs] = __shfl(va, src, kWave);
+                cc1[rs] = __shfl(cb, src, kWave);
+                aa1[rs] = __shfl(vb, src, kWave);
+            }
+            double x0[T][C], x1[T][C];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs) {
+                load_c<C>(x + (size_t)cc0[rs] * NB + t * C, x0[rs]);
+                load_c<C>(x + (size_t)cc1[rs] * NB + t * C, x1[rs]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    acc[rs][c] = fma(aa0[rs], x0[rs][c], acc[rs][c]);
+                    acc[rs][c] = fma(aa1[rs], x1[rs][c], acc[rs][c]);
+                }
+            }
+            ca = na; va = wa;
+            cb = nb_; vb = wb;
+        }
+        return;
+    }
     int cj = 0;
     double vj = 0.0;
     if (width > 0) {
@@ -318,7 +384,12 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
     for (int si = first_slice(nslices, &slice_end); si < slice_end; si += kBlock / kWave) {
         const int slice = sched ? sched[si] : si;   // optional processing order (locality), see Sell::sched
         double acc[T][C];
-        sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
+        if constexpr (TAG != 0 && !BV && T > 1 && kK5TwoColumns) {
+            const int off = slice_off[slice];
+            sell_row_range<NB, false, false, true, 2>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, acc);
+        } else {
+            sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
+        }
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
@@ -1550,8 +1621,14 @@ static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double*
             sell_spmm_kernel<NB, false, 0, true, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
         else if (accumulate)
             sell_spmm_kernel<NB, false, 1, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
-        else
-            sell_spmm_kernel<NB, false, 0, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+        else {
+            // tuning probe: unused dynamic LDS limits the workgroups per CU (occupancy experiment on the isolated launches)
+            static const size_t probe_lds = [] {
+                const char* e = getenv("PMC_K5_LDS");
+                return e ? (size_t)atol(e) : (size_t)0;
+            }();
+            sell_spmm_kernel<NB, false, 0, false, TAG><<<g, kBlock, TAG == 2 ? probe_lds : 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+        }
     }
 }
 
