@@ -88,6 +88,9 @@ int pmc_mlmc_reset(pmc_mlmc* m);                             /* zero sums and co
 int pmc_mlmc_replay_log(pmc_mlmc* m, const char* path, int64_t* nread);
 int pmc_mlmc_init_run(pmc_mlmc* m, const int32_t* nsamples); /* MLMC_Manager::InitRun  */
 int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* out);
+/* the table MLMC_Manager::ShowMe prints after every InitRun (src/MLMC_Manager.cpp:216-297), same labels / widths /
+ * precision, into buf (NUL-terminated, truncated to cap); *needed (may be NULL) receives the full size incl. the NUL */
+int pmc_mlmc_show_me(pmc_mlmc* m, char* buf, size_t cap, size_t* needed);
 const char* pmc_host_last_error(void);
 
 /* BayesianInverseProblem::ComputeLikelihood / ComputeLikelihoodAndQ / ComputeR (src/BayesianInverseProblem.cpp:188-218)

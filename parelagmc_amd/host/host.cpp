@@ -429,6 +429,54 @@ void MLMC_Manager::run_round_overlapped(const std::vector<int>& ns_init) {
     }
 }
 
+void MLMC_Manager::ShowMe(std::ostream& os) const {
+    const int total_width = 79, name_width = 40;
+    const std::streamsize old_prec = os.precision(8);
+    auto scalar = [&](const char* name, double v, const char* end = "\n") {
+        os << std::setw(name_width + 2) << std::left << name << std::setw(18) << std::left << v << end;
+    };
+    auto row = [&](const char* name, const std::vector<double>& v) {
+        os << std::setw(name_width + 2) << std::left << name << std::setw(2) << std::left;
+        for (size_t i = 0; i < v.size(); ++i) os << (i ? " " : "") << v[i];
+        os << '\n';
+    };
+    double est = 0.0;
+    for (double y : eY) est += y;
+    std::vector<double> ns(level_nsamples.begin(), level_nsamples.end()), snnz(nlevels), pnnz(nlevels);
+    for (int i = 0; i < nlevels; ++i) {
+        snnz[i] = (double)sampler.GetNNZ(i);
+        pnnz[i] = (double)pSolver.GetNNZ(i);
+    }
+    os << std::string(total_width, '=') << '\n' << "MLMC Manager Errors: " << '\n' << std::string(total_width, '-') << '\n';
+    scalar("Estimate", est);
+    scalar("Target MSE", eps2);
+    scalar("Actual MSE", actualMSE);
+    scalar("ML Estimator Variance", ml_estimator_variance);
+    scalar("Estimator Bias", expected_discretization_error2);
+    scalar("Alpha", alpha);
+    scalar("AlphaAbs", alphaABS);
+    scalar("Beta", beta);
+    scalar("Gamma", gamma, "\n\n");
+    row("DOFS in Forward Problem", M);
+    row("C_l ", eC);
+    os << '\n';
+    row("NumSamples ", ns);
+    os << '\n';
+    row("E[Y_l] ", eY);
+    row("E[|Y_l|] ", eABSY);
+    row("Var[Y_l] ", varY);
+    row("E[Q_l] ", eQ);
+    row("E[|Q_l|] ", eABSQ);
+    row("Var[Q_l] ", varQ);
+    row("V[Y_l]*C_l ", VC);
+    row("Consistency ", consistency);
+    row("Kurtosis", kurtosis);
+    row("NNZ-Sampler", snnz);
+    row("NNZ-ForwardSolve", pnnz);
+    os << std::string(total_width, '=') << '\n';
+    os.precision(old_prec);
+}
+
 void MLMC_Manager::InitRun(std::vector<int>& level_nsamples_init) {
     if ((int)level_nsamples_init.size() != nlevels) throw std::invalid_argument("InitRun: wrong number of levels");
     if (logger.is_open() && *std::max_element(level_nsamples.begin(), level_nsamples.end()) == 0)
@@ -560,43 +608,6 @@ void MLMC_Manager::computeNSamplesMSE() {
         level_nsamples_missing[i] = (cm > 0.0 && std::isfinite(cm)) ? (int64_t)std::min(cm, 2.0e9) : 0;
         VC[i] = varY[i] * cost[i];
     }
-}
-
-void MLMC_Manager::ShowMe(std::ostream& os) const {
-    auto row = [&](const char* name, const std::vector<double>& v) {
-        os << std::setw(42) << std::left << name;
-        for (double x : v) os << x << " ";
-        os << "\n";
-    };
-    os.precision(8);
-    os << std::string(79, '=') << "\nMLMC Manager Errors: \n" << std::string(79, '-') << "\n"
-       << std::setw(42) << std::left << "Estimate";
-    double est = 0;
-    for (double x : eY) est += x;
-    os << est << "\n"
-       << std::setw(42) << "Target MSE" << eps2 << "\n"
-       << std::setw(42) << "Actual MSE" << actualMSE << "\n"
-       << std::setw(42) << "ML Estimator Variance" << ml_estimator_variance << "\n"
-       << std::setw(42) << "Estimator Bias" << expected_discretization_error2 << "\n"
-       << std::setw(42) << "Alpha" << alpha << "\n"
-       << std::setw(42) << "AlphaAbs" << alphaABS << "\n"
-       << std::setw(42) << "Beta" << beta << "\n"
-       << std::setw(42) << "Gamma" << gamma << "\n\n";
-    row("DOFS in Forward Problem", M);
-    row("C_l ", eC);
-    os << std::setw(42) << std::left << "NumSamples ";
-    for (auto x : level_nsamples) os << x << " ";
-    os << "\n";
-    row("E[Y_l] ", eY);
-    row("E[|Y_l|] ", eABSY);
-    row("Var[Y_l] ", varY);
-    row("E[Q_l] ", eQ);
-    row("E[|Q_l|] ", eABSQ);
-    row("Var[Q_l] ", varQ);
-    row("V[Y_l]*C_l ", VC);
-    row("Consistency ", consistency);
-    row("Kurtosis", kurtosis);
-    os << std::string(79, '=') << std::endl;
 }
 
 
@@ -1014,6 +1025,20 @@ int pmc_mlmc_init_run(pmc_mlmc* m, const int32_t* nsamples) {
         if (!m || !nsamples) throw std::invalid_argument("pmc_mlmc_init_run: NULL argument");
         std::vector<int> v(nsamples, nsamples + m->mgr->nlevels);
         m->mgr->InitRun(v);
+    });
+}
+int pmc_mlmc_show_me(pmc_mlmc* m, char* buf, size_t cap, size_t* needed) {
+    return hguard([&] {
+        if (!m) throw std::invalid_argument("manager is NULL");
+        std::ostringstream ss;
+        m->mgr->ShowMe(ss);
+        const std::string t = ss.str();
+        if (needed) *needed = t.size() + 1;
+        if (buf && cap) {
+            const size_t k = std::min(cap - 1, t.size());
+            std::memcpy(buf, t.data(), k);
+            buf[k] = '\0';
+        }
     });
 }
 int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* r) {

@@ -20,6 +20,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <ostream>
 #include <vector>
 
 #include "../../include/pmc.h"

@@ -60,6 +60,7 @@ HOST_SYMBOLS = {
     "pmc_mlmc_replay_log": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
     "pmc_mlmc_init_run": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
     "pmc_mlmc_result_get": (C.c_int, [_VP, C.POINTER(pmc_mlmc_result)]),
+    "pmc_mlmc_show_me": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "pmc_bayes_likelihood": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_int, _DPTR, C.c_int, C.c_double, _DPTR, _DPTR, _DPTR,
                                        _DPTR]),
     "pmc_ratio_create": (C.c_int, [_VP, _VP, _VP, C.c_int, _DPTR, C.c_int, C.c_double, C.POINTER(pmc_mlmc_params),
@@ -415,6 +416,14 @@ class MLMCManager:
     def Run(self):
         _hcheck(self.lib.pmc_mlmc_run(self.h))
         return self.result()
+
+    def ShowMe(self) -> str:
+        """MLMC_Manager::ShowMe table as text (same labels and layout as the reference prints)."""
+        need = C.c_size_t(0)
+        _hcheck(self.lib.pmc_mlmc_show_me(self.h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        _hcheck(self.lib.pmc_mlmc_show_me(self.h, buf, need.value, None))
+        return buf.value.decode("utf-8", "replace")
 
     def Reset(self):
         _hcheck(self.lib.pmc_mlmc_reset(self.h))

@@ -299,3 +299,24 @@ def test_ratio_manager_run_converges():
     r = mgr.Run()
     assert r["estimator_variance"] <= 0.5 * 5e-4 and np.isfinite(r["ratio_estimate"])
     mgr.close()
+
+
+def test_show_me_prints_the_reference_table():
+    """MLMC_Manager::ShowMe (src/MLMC_Manager.cpp:216-297): labels, widths and precision of the reference's table, so that
+    its ctest regex on the estimate line ("Estimate" padded to 42 columns, examples/CMakeLists.txt:80) keeps matching."""
+    import re
+    pl = SyntheticPlugin(3)
+    mgr = host_api.MLMCManager(3, callbacks=pl.callbacks(), wall_time=False, batch=4)
+    r = mgr.InitRun([6, 9, 14])
+    txt = mgr.ShowMe()
+    lines = txt.splitlines()
+    assert lines[0] == "=" * 79 and lines[1].startswith("MLMC Manager Errors:") and lines[2] == "-" * 79 and lines[-1] == "=" * 79
+    m = re.search(r"^Estimate {34}(\S+)", txt, re.M)
+    assert m and float(m.group(1)) == pytest.approx(r["estimate"], rel=1e-7)
+    for label in ("Target MSE", "Actual MSE", "ML Estimator Variance", "Estimator Bias", "Alpha", "AlphaAbs", "Beta", "Gamma",
+                  "DOFS in Forward Problem", "C_l ", "NumSamples ", "E[Y_l] ", "E[|Y_l|] ", "Var[Y_l] ", "E[Q_l] ", "E[|Q_l|] ",
+                  "Var[Q_l] ", "V[Y_l]*C_l ", "Consistency ", "Kurtosis", "NNZ-Sampler", "NNZ-ForwardSolve"):
+        assert any(ln.startswith(label.ljust(42)) for ln in lines), label
+    ns_line = next(ln for ln in lines if ln.startswith("NumSamples"))
+    assert ns_line.split()[1:] == ["6", "9", "14"]
+    mgr.close()
