@@ -32,3 +32,14 @@ $(HOSTLIB): $(HOSTSRC) parelagmc_amd/host/parelagmc.hpp include/pmc.h include/pm
 	g++ -O2 -std=c++17 -fPIC -shared -Wall -pthread -Iinclude -o $@ $(HOSTSRC) -Lparelagmc_amd/lib -lpmc -Wl,-rpath,'$$ORIGIN'
 
 all: $(HOSTLIB)
+
+# kernel laboratory (tuning only): links the library's objects with a main(); kept next to the library so that it travels
+# to the GPU box (build/ does not)
+LABBIN := parelagmc_amd/lib/k5_lab
+$(OBJDIR)/k5_lab.o: scripts/lab/k5_lab.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+$(LABBIN): $(OBJDIR)/k5_lab.o $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -o $@ $(OBJDIR)/k5_lab.o $(OBJS) -ldl
+lab: $(LABBIN)
+.PHONY: lab

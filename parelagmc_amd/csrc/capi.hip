@@ -1,6 +1,7 @@
 // extern "C" surface of libpmc.so (see include/pmc.h).  No exception leaves this file.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -111,9 +112,15 @@ int pmc_ctx_create(int device_id, pmc_ctx** out) {
         std::unique_ptr<pmc_ctx> c(new pmc_ctx());
         c->device = device_id;
         PMC_HIP(hipSetDevice(device_id));
+        // two streams per handle (see Lanes).  Both at default priority: giving the second one a lower priority (measured)
+        // leaves one lane unchanged and costs 19 % with four lanes per GPU.
         PMC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        PMC_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         PMC_HIP(hipEventCreate(&c->ev0));
         PMC_HIP(hipEventCreate(&c->ev1));
+        PMC_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        PMC_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        PMC_HIP(hipEventCreateWithFlags(&c->ev_poll, hipEventDisableTiming));
         PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_flag), sizeof(int) * 16, hipHostMallocDefault));
         PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(double) * 4096, hipHostMallocDefault));
         *out = c.release();
@@ -128,10 +135,14 @@ void pmc_ctx_destroy(pmc_ctx* c) {
         c->nccl = nullptr;
     }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_poll})
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

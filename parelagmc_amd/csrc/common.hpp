@@ -122,6 +122,7 @@ struct Sell {
     // kinds of rows gather are fetched once while they are still in the XCD's L2.
     DevBuf<int> sched;
     std::vector<int> h_slice_off, h_cols, h_src;  // host mirrors (h_src: slot -> csr nnz or -1)
+    std::vector<int> h_sched;                     // host mirror of sched (empty = natural order)
     // algorithmic bytes of one SpMV with this matrix: 12 nnz + 12 nrows + 8 ncols
     double spmv_bytes() const { return 12.0 * nnz + 12.0 * nrows + 8.0 * ncols; }
 };
@@ -132,10 +133,34 @@ std::vector<double> sell_scaled_values(const Sell& S, const HostCsr& A, const st
 void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st);
 
 // ---- context ------------------------------------------------------------------------------
+// The two HIP streams one solve runs on.  Independent kernel chains (the two diagonal blocks of the preconditioner) are
+// issued on `main` and `aux` between fork() and join(): events only, no host synchronisation, capturable in a hipGraph.
+// split == false: aux == main and fork / join do nothing (small levels, where the extra event calls cost more than the
+// overlap returns).
+struct Lanes {
+    hipStream_t main = nullptr, aux = nullptr;
+    hipEvent_t ef = nullptr, ej = nullptr;
+    bool split = false;
+    void fork() const {
+        if (!split) return;
+        PMC_HIP(hipEventRecord(ef, main));
+        PMC_HIP(hipStreamWaitEvent(aux, ef, 0));
+    }
+    void join() const {
+        if (!split) return;
+        PMC_HIP(hipEventRecord(ej, aux));
+        PMC_HIP(hipStreamWaitEvent(main, ej, 0));
+    }
+    hipStream_t side() const { return split ? aux : main; }
+};
+
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // second stream of the same handle (see Lanes)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_poll = nullptr;
+    Lanes lanes(bool split) const { return Lanes{stream, split ? stream2 : stream, ev_fork, ev_join, split}; }
     uint64_t seed = 0;
     int nparts = 1, mypart = 0;
     void* nccl = nullptr;          // ncclComm_t

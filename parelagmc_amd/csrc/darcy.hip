@@ -613,14 +613,15 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     const double* coefp = d.coef.p;
     LinOp A;
     A.n = n;
-    A.apply = [=](hipStream_t s, int nb_, const double* x, double* y, double* partial) {
-        // u-rows: M(k) x_u + B^T x_p in one pass; p-rows: B x_u; <x, Ax> fused into both
+    A.apply = [=](const Lanes& L, int nb_, const double* x, double* y, double* partial, double* partial2) {
+        // u-rows: M(k) x_u + B^T x_p in one pass; p-rows: B x_u (beside it on the second stream); <x, Ax> fused into both
         const double* xp = x + (size_t)n_u * nb_;
-        const int nu_blk = eg ? k::eg_pair_spmm(s, nb_, Mg, coefp, x, Btv, xp, y, partial, x)
-                              : k::pair_spmm(s, nb_, Mv, x, Btv, xp, y, partial, x);
-        const int np_blk = k::spmm(s, nb_, Bv, x, y + (size_t)n_u * nb_, false,
-                                   partial ? partial + (size_t)nu_blk * nb_ : nullptr, xp);
-        return nu_blk + np_blk;
+        L.fork();
+        const int nu_blk = eg ? k::eg_pair_spmm(L.main, nb_, Mg, coefp, x, Btv, xp, y, partial, x)
+                              : k::pair_spmm(L.main, nb_, Mv, x, Btv, xp, y, partial, x);
+        const int np_blk = k::spmm(L.side(), nb_, Bv, x, y + (size_t)n_u * nb_, false, partial2, xp);
+        L.join();
+        return k::DotParts{partial, nu_blk, partial2, np_blk};
     };
     ChebParams cpM{opts.cheb_degree_M, 1.0, d.ratio_M, d.mvals_scaled.p};
     const double* l1 = d.l1invM.p;
@@ -628,23 +629,27 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     double* cdp = cd.p;
     Multigrid* mgp = chain ? &chain->mg : &mg;
     const int mg_l0 = chain ? 0 : level;
-    PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z, double* dot_partial) {
+    PrecFn prec = [=](const Lanes& L, int nb_, const double* r, double* z, double* dot_partial, double* dot_partial2) {
         const int flips = cheb_flips(cpM, true);
         double* start = (flips % 2 == 0) ? z : cxp;
         double* other = (flips % 2 == 0) ? cxp : z;
-        // S-block first, M-block last (its output is the larger part of what the operator reads next)
-        const int nblk_s = mgp->vcycle(s, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_, dot_partial);
-        double* dpu = dot_partial ? dot_partial + (size_t)nblk_s * nb_ : nullptr;
+        // independent diagonal blocks: V-cycle of the S-block on the main stream, the M-block polynomial on the second
+        // stream beside the V-cycle's coarse levels (see the sampler's preconditioner)
         int nblk_u = 0;
-        if (eg) {
-            double c0, c1;
-            cheb2_coefficients(cpM.lmax, cpM.ratio, &c0, &c1);
-            nblk_u = k::eg_poly2(s, nb_, Mg, coefp, l1, r, z, c0, c1, dpu);
-        } else {
-            double* res = cheb_apply(s, nb_, Mv, l1, true, cpM, r, start, other, cdp, true, dpu, &nblk_u);
-            if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
-        }
-        return nblk_s + nblk_u;
+        auto m_block = [&]() {
+            L.fork();
+            if (eg) {
+                double c0, c1;
+                cheb2_coefficients(cpM.lmax, cpM.ratio, &c0, &c1);
+                nblk_u = k::eg_poly2(L.side(), nb_, Mg, coefp, l1, r, z, c0, c1, dot_partial2);
+            } else {
+                double* res = cheb_apply(L.side(), nb_, Mv, l1, true, cpM, r, start, other, cdp, true, dot_partial2, &nblk_u);
+                if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
+            }
+        };
+        const int nblk_s = mgp->vcycle(L.main, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_, dot_partial, m_block);
+        L.join();
+        return k::DotParts{dot_partial, nblk_s, dot_partial2, nblk_u};
     };
     // SolveFwd only needs Q = <obs, sol>: unless the solution itself is requested, MINRES maintains just the rows in
     // the support of obs (compact w / x vectors)

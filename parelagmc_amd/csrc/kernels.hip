@@ -861,7 +861,10 @@ __global__ void fill_kernel(size_t n, double* __restrict__ x, double v) {
 // Column sums of the per-block partials: thread t reads column t % nb of blocks t / nb, t / nb + 256/nb, ...
 // (coalesced), then thread k adds the 256/nb group sums of its column in a fixed order (deterministic).
 static constexpr int kScalBlock = 1024;
-__device__ __forceinline__ double reduce_partials(const double* __restrict__ partial, int nblocks, int nb) {
+// Two segments (partial: nblocks blocks, partial2: nblocks2 blocks) are summed as one concatenated list: kernels that
+// run side by side on two streams each write their own segment.
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ partial, int nblocks, int nb,
+                                                  const double* __restrict__ partial2 = nullptr, int nblocks2 = 0) {
     __shared__ double lds[kScalBlock];
     const int k = threadIdx.x % nb, q = threadIdx.x / nb, nq = kScalBlock / nb;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains keep the loads in flight
@@ -873,6 +876,11 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
         s3 += partial[(size_t)(b + 3 * nq) * nb + k];
     }
     for (; b < nblocks; b += nq) s0 += partial[(size_t)b * nb + k];
+    for (b = q; b + 1 * nq < nblocks2; b += 2 * nq) {
+        s1 += partial2[(size_t)b * nb + k];
+        s2 += partial2[(size_t)(b + nq) * nb + k];
+    }
+    for (; b < nblocks2; b += nq) s3 += partial2[(size_t)b * nb + k];
     const double s = (s0 + s1) + (s2 + s3);
     __syncthreads();
     lds[threadIdx.x] = s;
@@ -894,8 +902,9 @@ __device__ __forceinline__ void count_active(k::MinresState* st, int nb, bool bu
 }
 
 __global__ __launch_bounds__(kScalBlock) void minres_init_kernel(k::MinresState* st, const double* __restrict__ partial,
-                                                             int nblocks, int nb, double rel_tol, double abs_tol) {
-    const double d = reduce_partials(partial, nblocks, nb);
+                                                             int nblocks, int nb, double rel_tol, double abs_tol,
+                                                             const double* __restrict__ partial2, int nblocks2) {
+    const double d = reduce_partials(partial, nblocks, nb, partial2, nblocks2);
     const int k = threadIdx.x;
     if (k < nb) {
         const double beta = d > 0.0 ? sqrt(d) : 0.0;
@@ -915,8 +924,9 @@ __global__ __launch_bounds__(kScalBlock) void minres_init_kernel(k::MinresState*
 
 // after q = A u1 and d1 = <u1, q>
 __global__ __launch_bounds__(kScalBlock) void minres_scal1_kernel(k::MinresState* st, const double* __restrict__ partial,
-                                                              int nblocks, int nb) {
-    const double d1 = reduce_partials(partial, nblocks, nb);
+                                                              int nblocks, int nb, const double* __restrict__ partial2,
+                                                              int nblocks2) {
+    const double d1 = reduce_partials(partial, nblocks, nb, partial2, nblocks2);
     const int k = threadIdx.x;
     if (k >= nb) return;
     if (st->active[k]) {
@@ -937,8 +947,9 @@ __global__ __launch_bounds__(kScalBlock) void minres_scal1_kernel(k::MinresState
 
 // after z_new = prec(v_new) and d2 = <v_new, z_new>
 __global__ __launch_bounds__(kScalBlock) void minres_scal2_kernel(k::MinresState* st, const double* __restrict__ partial,
-                                                              int nblocks, int nb) {
-    const double d2 = reduce_partials(partial, nblocks, nb);
+                                                              int nblocks, int nb, const double* __restrict__ partial2,
+                                                              int nblocks2) {
+    const double d2 = reduce_partials(partial, nblocks, nb, partial2, nblocks2);
     const int k = threadIdx.x;
     if (k < nb) {
         if (st->active[k]) {
@@ -1830,17 +1841,16 @@ void copy(hipStream_t st, size_t n, const double* src, double* dst) {
     if (n && src != dst) PMC_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, st));
 }
 
-void minres_init(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks, double rel_tol,
-                 double abs_tol) {
-    minres_init_kernel<<<1, kScalBlock, 0, st>>>(s, partial, nblocks, nb, rel_tol, abs_tol);
+void minres_init(hipStream_t st, int nb, MinresState* s, const DotParts& d, double rel_tol, double abs_tol) {
+    minres_init_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, rel_tol, abs_tol, d.p2, d.n2);
     check_launch();
 }
-void minres_scal1(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks) {
-    minres_scal1_kernel<<<1, kScalBlock, 0, st>>>(s, partial, nblocks, nb);
+void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d) {
+    minres_scal1_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, d.p2, d.n2);
     check_launch();
 }
-void minres_scal2(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks) {
-    minres_scal2_kernel<<<1, kScalBlock, 0, st>>>(s, partial, nblocks, nb);
+void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d) {
+    minres_scal2_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, d.p2, d.n2);
     check_launch();
 }
 

@@ -86,10 +86,18 @@ void minres_wx(hipStream_t st, int nb, int n, const double* c0, const double* u,
 void fill(hipStream_t st, size_t n, double* x, double v);
 void copy(hipStream_t st, size_t n, const double* src, double* dst);
 
-void minres_init(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks, double rel_tol,
-                 double abs_tol);
-void minres_scal1(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks);
-void minres_scal2(hipStream_t st, int nb, MinresState* s, const double* partial, int nblocks);
+// per-block partial sums of one dot product, in up to two segments (n blocks of nb doubles each): kernels that run side
+// by side on two streams write a segment each
+struct DotParts {
+    const double* p1 = nullptr;
+    int n1 = 0;
+    const double* p2 = nullptr;
+    int n2 = 0;
+    int total() const { return n1 + n2; }
+};
+void minres_init(hipStream_t st, int nb, MinresState* s, const DotParts& d, double rel_tol, double abs_tol);
+void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d);
+void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d);
 
 void normal_fill(hipStream_t st, int n, int nbatch, uint64_t seed, uint64_t first_id, uint32_t stream, double mean,
                  double sigma, double* out);

@@ -201,6 +201,16 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
         PMC_HIP(hipStreamSynchronize(st));
     }
     mg.build_tails(st);
+    if (getenv("PMC_VERBOSE")) {
+        for (int l = 0; l < nlevels; ++l) {
+            const MgLevel& m = mg.L[l];
+            fprintf(stderr, "[pmc] sampler level %d: n_u %d n_s %d ratio_M %.2f | S: lmax %.3f last %d (degree %d, ratio %.1f) "
+                            "tail %s (%zu doubles) injection %d\n",
+                    l, lv[l].n_u, lv[l].n_s, lv[l].ratio_M, m.lmax, (int)m.is_last, m.last_degree, m.last_ratio,
+                    (l < (int)mg.tail.size() && mg.tail[l].p) ? "yes" : "no", l < (int)mg.tail_lds.size() ? mg.tail_lds[l] : 0,
+                    (int)m.has_sp);
+        }
+    }
 }
 
 void Sampler::set_projection(int level, int kind, const pmc_csr* Gt, const int32_t* idx, const double* inv_w,
@@ -345,26 +355,30 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     A.n = n;
     SellView Av = view(d.A);
     Av.tag = 1;
-    A.apply = [Av](hipStream_t s, int nb_, const double* x, double* y, double* partial) {
-        return k::spmm(s, nb_, Av, x, y, false, partial, x);
+    A.apply = [Av](const Lanes& L, int nb_, const double* x, double* y, double* partial, double*) {
+        return k::DotParts{partial, k::spmm(L.main, nb_, Av, x, y, false, partial, x)};
     };
     const SellView Mv = view(d.M);
     const double* dinvM = d.dinvM.p;
     ChebParams cpM{opts.cheb_degree_M, 1.0, d.ratio_M, d.M_scaled.p};
     double* cxp = cx.p;
     double* cdp = cd.p;
-    PrecFn prec = [=](hipStream_t s, int nb_, const double* r, double* z, double* dot_partial) {
+    PrecFn prec = [=](const Lanes& L, int nb_, const double* r, double* z, double* dot_partial, double* dot_partial2) {
         const int flips = cheb_flips(cpM, true);
         double* start = (flips % 2 == 0) ? z : cxp;
         double* other = (flips % 2 == 0) ? cxp : z;
-        // S-block first, M-block last: the u-block of z (two thirds of the vector the operator reads next) is then the
-        // most recently written data when K5 starts
-        const int nblk_s = mgp->vcycle(s, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_, dot_partial);
+        // The two diagonal blocks are independent.  The V-cycle of the S-block runs on the main stream; once its
+        // bandwidth-bound finest-level kernels are enqueued, the one-pass polynomial of the M-block starts on the second
+        // stream and fills the chip while the V-cycle's coarse levels (short kernels, a few workgroups each) run.
         int nblk_u = 0;
-        double* res = cheb_apply(s, nb_, Mv, dinvM, false, cpM, r, start, other, cdp, true,
-                                 dot_partial ? dot_partial + (size_t)nblk_s * nb_ : nullptr, &nblk_u);
-        if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
-        return nblk_s + nblk_u;   // <r, z> = s-block partials followed by u-block partials
+        auto m_block = [&]() {
+            L.fork();
+            double* res = cheb_apply(L.side(), nb_, Mv, dinvM, false, cpM, r, start, other, cdp, true, dot_partial2, &nblk_u);
+            if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
+        };
+        const int nblk_s = mgp->vcycle(L.main, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_, dot_partial, m_block);
+        L.join();
+        return k::DotParts{dot_partial, nblk_s, dot_partial2, nblk_u};   // <r, z> = s-block partials + u-block partials
     };
     // only the s-block of the solution is ever read (PDESampler.cpp:526): update only those rows
     GraphHint hint;

@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 
 namespace pmc {
@@ -150,9 +151,11 @@ void Multigrid::build_tails(hipStream_t st) {
 }
 
 double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, double* dot_partial,
-                         int* dot_blocks) {
+                         int* dot_blocks, const std::function<void()>* side) {
     MgLevel& lv = L[l];
     lv.ensure(nb);
+    const bool ends_here = (use_tail && l < (int)tail.size() && tail[l].p) || l == (int)L.size() - 1 || lv.is_last;
+    if (side && *side && ends_here) (*side)();   // beside the bottom of the V: the least parallel kernels of the cycle
     if (use_tail && l < (int)tail.size() && tail[l].p) {
         double* out = target ? target : lv.xa.p;
         const int nblk = k::mg_tail(st, nb, tail[l].p, tail_lds[l], r, out, dot_partial);
@@ -183,7 +186,7 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     MgLevel& lc = L[l + 1];
     lc.ensure(nb);
     k::spmm(st, nb, view(lv.Pt), lv.res.p, lc.r.p, false, nullptr, nullptr);
-    double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr);
+    double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, side);
     if (lv.has_sp && !lv.bv && cheb_fused(cp, false)) {
         // r - S (x + P xc) = res - (S P) xc, in place; then x <- x + P xc + p2(that residual) in one pass
         k::residual(st, nb, view(lv.SP), lv.res.p, xc, lv.res.p);
@@ -196,9 +199,10 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, x, oth, lv.d.p, false, dot_partial, dot_blocks);
 }
 
-int Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial) {
+int Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial,
+                      const std::function<void()>& side) {
     int nblk = 0;
-    double* res = cycle(st, nb, l0, l0, r, xout, dot_partial, &nblk);
+    double* res = cycle(st, nb, l0, l0, r, xout, dot_partial, &nblk, side ? &side : nullptr);
     if (res != xout) throw Error(PMC_ERR_INTERNAL, "V-cycle result landed in the wrong buffer");
     return nblk;
 }
@@ -224,7 +228,9 @@ void MinresWork::ensure(int n, int nb) {
     const size_t need = (size_t)n * nb;
     v0.ensure(need); v1.ensure(need); u0.ensure(need); u1.ensure(need);
     w0.ensure(need); w1.ensure(need); q.ensure(need);
-    partial.ensure((size_t)dot_capacity(n) * kMaxBatch);
+    // two segments each (see k::DotParts): [0, cap) and [cap, 2 cap)
+    partial.ensure((size_t)2 * dot_capacity(n) * kMaxBatch);
+    partial_op.ensure((size_t)2 * dot_capacity(n) * kMaxBatch);
     if (!state.p) state.alloc(1);
 }
 
@@ -242,12 +248,22 @@ static void axpby(hipStream_t st, size_t n, double a, const double* x, double b,
     PMC_HIP(hipGetLastError());
 }
 
+// Rows x batch width from which a solve uses both streams of its handle (PMC_SPLIT_MIN overrides; 0 = never split)
+static size_t split_threshold() {
+    static const size_t v = [] {
+        const char* e = getenv("PMC_SPLIT_MIN");
+        return e ? (size_t)atoll(e) : (size_t)1500000;
+    }();
+    return v;
+}
+
 MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, const double* b, double* x,
                           bool zero_guess, const pmc_solver_opts& o, MinresWork& w, int x_row0, int x_nrows,
                           const int* x_rows, GraphHint hint) {
     hipStream_t st = ctx.stream;
     const int n = A.n;
     const size_t len = (size_t)n * nb;
+    const Lanes L = ctx.lanes(split_threshold() > 0 && len >= split_threshold());
     w.ensure(n, nb);
     k::MinresState* S = w.state.p;
     double* v0 = w.v0.p; double* v1 = w.v1.p; double* u0 = w.u0.p; double* u1 = w.u1.p;
@@ -259,15 +275,16 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         k::fill(st, x_rows ? (size_t)x_nrows * nb : len, x, 0.0);
         k::copy(st, len, b, v1);
     } else {
-        A.apply(st, nb, x, v1, nullptr);
+        A.apply(L, nb, x, v1, nullptr, nullptr);
         axpby(st, len, 1.0, b, -1.0, v1);
     }
     if (x_row0 < 0 || x_nrows < 0 || (!x_rows && x_row0 + x_nrows > n))
         throw Error(PMC_ERR_INTERNAL, "minres: bad solution row range");
     const size_t xoff = (size_t)x_row0 * nb;
-    int nblocks = prec(st, nb, v1, u1, w.partial.p);
-    if (nblocks == 0) nblocks = k::dot(st, nb, n, v1, u1, w.partial.p);
-    k::minres_init(st, nb, S, w.partial.p, nblocks, o.rel_tol, o.abs_tol);
+    const size_t seg2 = (size_t)dot_capacity(n) * kMaxBatch;
+    k::DotParts dp = prec(L, nb, v1, u1, w.partial.p, w.partial.p + seg2);
+    if (dp.total() == 0) dp = k::DotParts{w.partial.p, k::dot(st, nb, n, v1, u1, w.partial.p)};
+    k::minres_init(st, nb, S, dp, o.rel_tol, o.abs_tol);
     k::fill(st, len, v0, 0.0);
     k::fill(st, len, w0, 0.0);
     k::fill(st, len, w1, 0.0);
@@ -290,10 +307,13 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
 
     MinresResult out;
     const int every = o.check_every > 0 ? o.check_every : 1;
-    // one MINRES iteration with explicit roles of the ping-pong vectors
     size_t ev_used = 0;
     const bool timing = w.time_operator && !(hint.key != 0 && o.use_graph != 0);
-    auto iteration = [&](double* u0_, double* u1_, double* v0_, double* v1_, double* w0_, double* w1_) {
+    // q = A u, d1 = <u, A u>.  The product for iteration i+1 is issued right after the preconditioner of iteration i has
+    // written u (both blocks of u are then the most recently written data on the chip), before the scalar recurrences
+    // and the w / x update of iteration i, which do not depend on it.
+    k::DotParts dp_op;
+    auto apply_op = [&](const double* u) {
         if (timing) {
             while (w.ev.size() < ev_used + 2) {
                 hipEvent_t e;
@@ -302,26 +322,40 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             }
             PMC_HIP(hipEventRecord(w.ev[ev_used], st));
         }
-        int nblk = A.apply(st, nb, u1_, q, w.partial.p);
+        dp_op = A.apply(L, nb, u, q, w.partial_op.p, w.partial_op.p + seg2);
         if (timing) {
             PMC_HIP(hipEventRecord(w.ev[ev_used + 1], st));
             ev_used += 2;
         }
-        k::minres_scal1(st, nb, S, w.partial.p, nblk);
+    };
+    // one MINRES iteration with explicit roles of the ping-pong vectors; on entry q = A u1_ and its dot are in place
+    auto iteration = [&](double* u0_, double* u1_, double* v0_, double* v1_, double* w0_, double* w1_, bool last) {
+        k::minres_scal1(st, nb, S, dp_op);
         k::lincomb3(st, nb, n, cV0, q, cV1, v1_, cV2, v0_);
-        nblk = prec(st, nb, v0_, u0_, w.partial.p);
-        if (nblk == 0) nblk = k::dot(st, nb, n, v0_, u0_, w.partial.p);
-        k::minres_scal2(st, nb, S, w.partial.p, nblk);
+        k::DotParts d2 = prec(L, nb, v0_, u0_, w.partial.p, w.partial.p + seg2);
+        if (d2.total() == 0) d2 = k::DotParts{w.partial.p, k::dot(st, nb, n, v0_, u0_, w.partial.p)};
+        if (!last) apply_op(u0_);
+        k::minres_scal2(st, nb, S, d2);
         if (x_rows) k::minres_wx_idx(st, nb, x_nrows, x_rows, cW0, u1_, cW1, w0_, cW2, w1_, cW3, x);
         else k::minres_wx(st, nb, x_nrows, cW0, u1_ + xoff, cW1, w0_, cW2, w1_, cW3, x + xoff);
     };
     // two iterations return every vector to its original role
     auto pair = [&]() {
-        iteration(u0, u1, v0, v1, w0, w1);
-        iteration(u1, u0, v1, v0, w1, w0);
+        iteration(u0, u1, v0, v1, w0, w1, false);
+        iteration(u1, u0, v1, v0, w1, w0, false);
     };
     int it = 0;
     int n_active = poll();
+    // Convergence polls drain the stream; iteration counts of one configuration barely move between batches, so the polls
+    // start a few iterations before the count the previous solve of this configuration needed.  Converged columns are
+    // frozen on the device (zero update coefficients), so iterating past convergence never changes a result.
+    const uint64_t hint_key = hint.key ? hash_mix(hint.key, zero_guess ? 1 : 2) : 0;
+    int first_poll = 0;
+    if (hint_key) {
+        auto f = w.iter_hint.find(hint_key);
+        if (f != w.iter_hint.end()) first_poll = std::max(0, f->second - 4);
+    }
+    if (n_active > 0 && o.max_iter > 0) apply_op(u1);
     const bool graphs = hint.key != 0 && o.use_graph != 0 && every == 2;
     if (graphs) {
         // hipGraph path: the first pair runs eagerly (it also performs every lazy allocation), later pairs replay one
@@ -337,9 +371,11 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             sig = hash_mix(sig, (uint64_t)n);
             for (const void* p : {(const void*)b, (const void*)x, (const void*)v0, (const void*)v1, (const void*)u0,
                                   (const void*)u1, (const void*)w0, (const void*)w1, (const void*)q,
-                                  (const void*)w.partial.p, (const void*)S, (const void*)x_rows})
+                                  (const void*)w.partial.p, (const void*)w.partial_op.p, (const void*)S,
+                                  (const void*)x_rows})
                 sig = hash_ptr(sig, p);
             sig = hash_mix(sig, ((uint64_t)x_row0 << 32) ^ (uint64_t)x_nrows);
+            sig = hash_mix(sig, L.split ? 7 : 3);
             MinresWork::GraphEntry& ge = w.graphs[hint.key];
             if (ge.exec && ge.sig != sig) {
                 PMC_HIP(hipGraphExecDestroy(ge.exec));
@@ -363,22 +399,22 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             while (n_active > 0 && it + 2 <= o.max_iter) {
                 PMC_HIP(hipGraphLaunch(ge.exec, st));
                 it += 2;
-                n_active = poll();
+                if (it >= first_poll) n_active = poll();
             }
         }
         if (n_active > 0 && it < o.max_iter) {   // odd max_iter: one last eager iteration
-            iteration(u0, u1, v0, v1, w0, w1);
+            iteration(u0, u1, v0, v1, w0, w1, true);
             ++it;
             n_active = poll();
         }
     } else {
         while (n_active > 0 && it < o.max_iter) {
             ++it;
-            iteration(u0, u1, v0, v1, w0, w1);
+            iteration(u0, u1, v0, v1, w0, w1, it == o.max_iter);
             std::swap(u0, u1);
             std::swap(v0, v1);
             std::swap(w0, w1);
-            if (it % every == 0 || it == o.max_iter) n_active = poll();
+            if ((it % every == 0 && it >= first_poll) || it == o.max_iter) n_active = poll();
         }
     }
     out.iterations = it;
@@ -393,14 +429,17 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     }
     k::MinresState hs;
     std::memcpy(&hs, ctx.h_scal, sizeof(hs));
+    int max_it = 0;
     for (int kcol = 0; kcol < nb; ++kcol) {
         pmc_stats& s = out.col[kcol];
         s.iterations = hs.iters[kcol];
+        max_it = std::max(max_it, s.iterations);
         s.initial_norm = hs.eta0[kcol];
         s.final_norm = std::fabs(hs.eta[kcol]);
         s.converged = (hs.flag[kcol] == 0 && hs.active[kcol] == 0 && s.final_norm <= hs.goal[kcol]) ? 1 : 0;
         if (hs.flag[kcol] != 0) s.converged = -1;   // indefinite preconditioner / NaN
     }
+    if (hint_key) w.iter_hint[hint_key] = max_it;
     return out;
 }
 

@@ -97,23 +97,35 @@ struct Multigrid {
     uint64_t signature(int l0) const;
     // x = V(r) starting at level l0 with zero initial guess; result written to xout (n(l0)*nb).
     // dot_partial != nullptr: also per-block partials of <r, xout>; returns their count.
-    int vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial = nullptr);
+    // side (optional) is called exactly once, just before the kernels of the bottom level of the V are enqueued (the LDS
+    // tail: one workgroup per realization): work issued from it on another stream then runs beside the least parallel
+    // part of the cycle instead of competing with the bandwidth-bound fine levels or stretching the short kernels of
+    // the intermediate ones (measured: a 9 us level-1 residual takes 37 us next to the M-block polynomial).
+    int vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial = nullptr,
+               const std::function<void()>& side = nullptr);
 
   private:
     double* cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, double* dot_partial,
-                  int* dot_blocks);
+                  int* dot_blocks, const std::function<void()>* side);
 };
 
 // Abstract pieces MINRES needs.
 struct LinOp {
     int n = 0;
     // y = A x ; when dot_partial != nullptr also per-block partials of <x, A x>; returns the number of
-    // partial blocks written (0 when dot_partial == nullptr)
-    std::function<int(hipStream_t, int nb, const double* x, double* y, double* dot_partial)> apply;
+    // partial blocks written (none when dot_partial == nullptr); two row blocks on two streams may use a segment each
+    // (independent row blocks may run between L.fork() and L.join(); ordered on L.main again on return)
+    std::function<k::DotParts(const Lanes& L, int nb, const double* x, double* y, double* dot_partial,
+                              double* dot_partial2)> apply;
 };
 // z = B^-1 r.  When dot_partial != nullptr the preconditioner may fuse <r, z> into its last kernels and
 // return the number of partial blocks it wrote (0 = not computed, the solver then runs a separate dot).
-using PrecFn = std::function<int(hipStream_t, int nb, const double* r, double* z, double* dot_partial)>;
+// The preconditioner receives both streams of the solve: independent blocks may run between L.fork() and L.join(); on
+// return everything must be ordered on L.main again.
+// dot_partial / dot_partial2 (each dot_capacity(n) blocks) receive the fused <r, z>: return where the partials are
+// (total() == 0: not computed, the solver then runs a separate dot).
+using PrecFn = std::function<k::DotParts(const Lanes& L, int nb, const double* r, double* z, double* dot_partial,
+                                         double* dot_partial2)>;
 
 // Caller-side identity of one solver configuration for hipGraph reuse: `key` names the configuration (handle, level,
 // batch width, ...), `sig` hashes every device pointer the caller's operator / preconditioner closures use, so a
@@ -129,6 +141,8 @@ inline uint64_t hash_ptr(uint64_t h, const void* p) { return hash_mix(h, (uint64
 
 struct MinresWork {
     DevBuf<double> v0, v1, u0, u1, w0, w1, q, partial;
+    DevBuf<double> partial_op;               // partials of the operator's fused <u, Au> (the preconditioner's live in `partial`)
+    std::map<uint64_t, int> iter_hint;       // per solver configuration: iterations its previous solve needed
     DevBuf<k::MinresState> state;
     struct GraphEntry {
         uint64_t sig = 0;

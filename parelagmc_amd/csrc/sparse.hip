@@ -173,6 +173,7 @@ void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st) {
     for (int i = 0; i < S.nslices; ++i) order[i] = key[i].second;
     S.sched.upload(order, st);
     PMC_HIP(hipStreamSynchronize(st));
+    S.h_sched = order;
 }
 
 }  // namespace pmc
