@@ -170,10 +170,13 @@ __device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], doubl
 // sell_row_range works on `width` slice columns starting at slot `off`.  CS: every gathered x[col] is multiplied by a
 // second gathered per-realization vector cs[col] (column scaling A D^-1 without stored scaled values).  ZERO: acc is
 // cleared first, otherwise accumulated into.
+// x0 != nullptr: the x values gathered for slice column 0 are also returned in x0[rs][c] (for a matrix stored
+// diagonal-first these are the wavefront's own rows of x: the fused <x, Ax> needs no second read of x).
 template <int NB, bool BV, bool CS, bool ZERO, int JC = 1>
 __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
                                                const double* __restrict__ x, const double* __restrict__ cs, int off,
-                                               int width, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
+                                               int width, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C],
+                                               double (*x0)[Lay<NB>::C] = nullptr) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int g = lane / T, t = lane % T;
     if constexpr (ZERO) {
@@ -208,6 +211,10 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
                 if constexpr (BV) load_c<C>(vals + (size_t)(j + u < width ? slot + u * kWave : slot) * NB, av[u]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (x0 && j == 0) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) x0[0][c] = xv[0][c];
+            }
 #pragma unroll
             for (int u = 0; u < JU; ++u)
 #pragma unroll
@@ -318,6 +325,12 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
             if constexpr (BV) load_c<C>(vals + (size_t)(slot - lane + rs * G + g) * NB + t * C, av[rs]);
         }
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
+        if (x0 && j == 0) {
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+                for (int c = 0; c < C; ++c) x0[rs][c] = xv[rs][c];
+        }
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
 #pragma unroll
@@ -384,9 +397,14 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
     for (int si = first_slice(nslices, &slice_end); si < slice_end; si += kBlock / kWave) {
         const int slice = sched ? sched[si] : si;   // optional processing order (locality), see Sell::sched
         double acc[T][C];
+        [[maybe_unused]] double xd[T][C];
         if constexpr (TAG != 0 && !BV && T > 1 && kK5TwoColumns) {
             const int off = slice_off[slice];
             sell_row_range<NB, false, false, true, 2>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, acc);
+        } else if (DOT && !BV && dot_with == nullptr) {
+            // diagonal-first matrix: column 0 gathers the wavefront's own rows of x
+            const int off = slice_off[slice];
+            sell_row_range<NB, false, false, true>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, acc, xd);
         } else {
             sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
         }
@@ -409,7 +427,12 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                 store_c_stream<C>(y + at, acc[rs]);
                 if constexpr (DOT) {
                     double w[C];
-                    load_c<C>(dot_with + at, w);
+                    if (dot_with) {
+                        load_c<C>(dot_with + at, w);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) w[c] = xd[rs][c];
+                    }
 #pragma unroll
                     for (int c = 0; c < C; ++c) p[c] = fma(w[c], acc[rs][c], p[c]);
                 }
@@ -867,20 +890,31 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
                                                   const double* __restrict__ partial2 = nullptr, int nblocks2 = 0) {
     __shared__ double lds[kScalBlock];
     const int k = threadIdx.x % nb, q = threadIdx.x / nb, nq = kScalBlock / nb;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains keep the loads in flight
+    // eight independent chains keep the loads in flight (the partials of a 2 000-block launch are 36 values per thread)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
     int b = q;
-    for (; b + 3 * nq < nblocks; b += 4 * nq) {
+    for (; b + 7 * nq < nblocks; b += 8 * nq) {
         s0 += partial[(size_t)b * nb + k];
         s1 += partial[(size_t)(b + nq) * nb + k];
         s2 += partial[(size_t)(b + 2 * nq) * nb + k];
         s3 += partial[(size_t)(b + 3 * nq) * nb + k];
+        s4 += partial[(size_t)(b + 4 * nq) * nb + k];
+        s5 += partial[(size_t)(b + 5 * nq) * nb + k];
+        s6 += partial[(size_t)(b + 6 * nq) * nb + k];
+        s7 += partial[(size_t)(b + 7 * nq) * nb + k];
     }
     for (; b < nblocks; b += nq) s0 += partial[(size_t)b * nb + k];
-    for (b = q; b + 1 * nq < nblocks2; b += 2 * nq) {
-        s1 += partial2[(size_t)b * nb + k];
-        s2 += partial2[(size_t)(b + nq) * nb + k];
+    for (b = q; b + 3 * nq < nblocks2; b += 4 * nq) {
+        s4 += partial2[(size_t)b * nb + k];
+        s5 += partial2[(size_t)(b + nq) * nb + k];
+        s6 += partial2[(size_t)(b + 2 * nq) * nb + k];
+        s7 += partial2[(size_t)(b + 3 * nq) * nb + k];
     }
-    for (; b < nblocks2; b += nq) s3 += partial2[(size_t)b * nb + k];
+    for (; b < nblocks2; b += nq) s1 += partial2[(size_t)b * nb + k];
+    s0 += s4;
+    s1 += s5;
+    s2 += s6;
+    s3 += s7;
     const double s = (s0 + s1) + (s2 + s3);
     __syncthreads();
     lds[threadIdx.x] = s;
@@ -1320,6 +1354,86 @@ __device__ __forceinline__ double tail_row_dot(const int* __restrict__ off, cons
     return acc;
 }
 
+// Many-step Chebyshev solve on the LAST tail level with the thread's matrix rows held in registers.  In tail_cheb every
+// step re-reads the (index, value) pairs of its rows from L2 - two dependent round trips per step, ~3 us, while the
+// arithmetic of a step on a few thousand rows takes a fraction of that; a degree-14 solve costs ~80 us that way.  Here a
+// thread loads the pairs of its R rows (at most W entries each) once and all steps run on registers + LDS.
+// Same recurrences and summation order as tail_cheb: bit-identical results.  Returns false (nothing done) when the
+// level does not fit R rows per thread x W entries per row.
+template <int R, int W>
+__device__ bool tail_cheb_cached(const TailLevelDev& L, int bv, int nb, int k, int degree, double ratio, const double* r,
+                                 double* x, double* d) {
+    const int n = L.n;
+    if (n > R * kTailThreads) return false;
+    const int vstride = bv == 1 ? nb : 1;
+    const size_t vk = bv == 1 ? (size_t)k : bv == 2 ? (size_t)k * L.nslots : 0;
+    const size_t dk = bv == 1 ? (size_t)k : bv == 2 ? (size_t)k * L.n : 0;
+    // widths are uniform per slice; reject the level if any slice is wider than W (uniform decision: every thread scans
+    // the same few slice offsets)
+    for (int s = 0; s < L.nslices; ++s)
+        if (((L.slice_off[s + 1] - L.slice_off[s]) >> 6) > W) return false;
+    int c[R][W];
+    double v[R][W], di[R], rr[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int i = threadIdx.x + q * kTailThreads;
+        const bool live = i < n;
+        const int row = live ? i : 0;
+        const int slice = row >> 6, lane = row & 63;
+        const int o = L.slice_off[slice];
+        const int width = (L.slice_off[slice + 1] - o) >> 6;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const bool ok = live && j < width;
+            const int at = o + (ok ? j : 0) * kWave + lane;
+            c[q][j] = L.cols[at];
+            const double val = L.vals[(size_t)at * vstride + vk];
+            v[q][j] = ok ? val : 0.0;
+        }
+        di[q] = L.dinv[(size_t)row * vstride + dk];
+        rr[q] = live ? r[row] : 0.0;
+    }
+    const double lmax = L.lmax, lmin = lmax / ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho_old = 1.0 / sigma;
+    // step 0 from a zero guess: d = x = dinv r / theta
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int i = threadIdx.x + q * kTailThreads;
+        if (i < n) {
+            const double t = di[q] * rr[q] / theta;
+            d[i] = t;
+            x[i] = t;
+        }
+    }
+    __syncthreads();
+    for (int step = 1; step < degree; ++step) {
+        const double rho = 1.0 / (2.0 * sigma - rho_old);
+        const double a = rho * rho_old, b = 2.0 * rho / delta;
+        rho_old = rho;
+        double dn[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int i = threadIdx.x + q * kTailThreads;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc = fma(v[q][j], x[c[q][j]], acc);
+            dn[q] = i < n ? a * d[i] + b * di[q] * (rr[q] - acc) : 0.0;
+        }
+        __syncthreads();       // every gather of x is done before anyone updates it
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int i = threadIdx.x + q * kTailThreads;
+            if (i < n) {
+                d[i] = dn[q];
+                x[i] += dn[q];
+            }
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
 // Chebyshev iteration on one tail level, in place: x (zero or given) -> x.  All threads participate.
 // (A variant that cached each thread's matrix rows in registers across the steps spilled to scratch under
 // hipcc 7.2 and was not faster; the matrix is re-read from L2 every step.)
@@ -1387,7 +1501,10 @@ __device__ void tail_vcycle_lds(const TailParams& P, int nb, int k, double* lds)
         double* x = r + L.n;
         double* d = x + L.n;
         if (l == nlev - 1) {     // host guarantees last_degree > 0 on the final tail level
-            tail_cheb(L, P.bv, nb, k, L.last_degree, L.last_ratio, true, r, x, d);
+            // rows in registers: 3 rows x 5 entries (tets: 4 neighbours + diagonal) or 2 rows x 7 (hexahedra) per thread
+            if (!(L.last_degree > 2 && (tail_cheb_cached<3, 5>(L, P.bv, nb, k, L.last_degree, L.last_ratio, r, x, d) ||
+                                        tail_cheb_cached<2, 7>(L, P.bv, nb, k, L.last_degree, L.last_ratio, r, x, d))))
+                tail_cheb(L, P.bv, nb, k, L.last_degree, L.last_ratio, true, r, x, d);
             break;
         }
         tail_cheb(L, P.bv, nb, k, P.smooth_degree, P.smooth_ratio, true, r, x, d);
@@ -1646,6 +1763,7 @@ static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double*
 int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate, double* dot_partial,
          const double* dot_with) {
     if (A.nrows == 0) return 0;
+    if (dot_partial && !dot_with && A.bv) throw Error(PMC_ERR_INTERNAL, "spmm: the gathered-diagonal dot needs shared values");
     const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (A.tag == 1) spmm_launch<NB, 1>(st, g, A, x, y, accumulate, dot_partial, dot_with);

@@ -104,8 +104,19 @@ HostCsr csr_block2x2(const HostCsr& M, const HostCsr& Bt, const HostCsr& B, cons
     return A;
 }
 
-void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st) {
+void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st, bool diag_first) {
     PMC_REQUIRE(A.nrows == 0 || A.ncols > 0, "SELL: matrix with rows but no columns");
+    // position of the diagonal entry in every row (diag_first only when every row has one)
+    std::vector<int> dpos;
+    if (diag_first) {
+        dpos.assign(A.nrows, -1);
+        for (int r = 0; r < A.nrows && diag_first; ++r) {
+            for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p)
+                if (A.colind[p] == r) { dpos[r] = p - A.rowptr[r]; break; }
+            if (dpos[r] < 0) diag_first = false;
+        }
+    }
+    S.diag_first = diag_first && A.nrows > 0;
     S.nrows = A.nrows;
     S.ncols = A.ncols;
     S.nnz = A.nnz();
@@ -132,12 +143,15 @@ void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipS
             const int r = s * 64 + lane;
             const int pad_col = r < A.ncols ? r : 0;   // padding gathers a nearby (cached) entry, times 0
             const int b = r < A.nrows ? A.rowptr[r] : 0, e = r < A.nrows ? A.rowptr[r + 1] : 0;
+            const int dp = (S.diag_first && r < A.nrows) ? dpos[r] : 0;
             for (int j = 0; j < w; ++j) {
                 const int slot = off + j * 64 + lane;
                 if (b + j < e) {
-                    S.h_cols[slot] = A.colind[b + j];
-                    if (upload_vals) hv[slot] = A.vals[b + j];
-                    if (keep_src) S.h_src[slot] = b + j;
+                    // diagonal first, the other entries keep their order: j = 0 -> dp, 1..dp -> j-1, beyond -> j
+                    const int src = b + (S.diag_first ? (j == 0 ? dp : (j <= dp ? j - 1 : j)) : j);
+                    S.h_cols[slot] = A.colind[src];
+                    if (upload_vals) hv[slot] = A.vals[src];
+                    if (keep_src) S.h_src[slot] = src;
                 } else {
                     S.h_cols[slot] = pad_col;
                 }

@@ -20,6 +20,55 @@ __global__ void lab_stream_kernel(size_t n, const double2* __restrict__ a, doubl
     }
 }
 
+// probe: the gather kernel's structure (one wave per slice, 8 lanes per row, shuffled (value, index) pairs, 16 FMAs per
+// slice column) with every x row loaded ONCE per row instead of once per entry: what the kernel would cost if the
+// per-entry gathers through the vector L1 were free.  Only meaningful with LAB_COLS=1 (every entry refers to its own row).
+__global__ __launch_bounds__(256) void lab_oneload_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+                                                          const int* __restrict__ sched, const int* __restrict__ cols,
+                                                          const double* __restrict__ vals, const double* __restrict__ x,
+                                                          double* __restrict__ y, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane / 8, t = lane % 8;
+    const int si = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (si >= nslices) return;
+    const int slice = sched ? sched[si] : si;
+    const int off = slice_off[slice];
+    const int width = (slice_off[slice + 1] - off) >> 6;
+    double acc[8][2], xr[8][2];
+    for (int rs = 0; rs < 8; ++rs) {
+        const int row = min(slice * 64 + rs * 8 + g, nrows - 1);
+        const double2 v = *reinterpret_cast<const double2*>(x + (size_t)row * 16 + t * 2);
+        xr[rs][0] = v.x; xr[rs][1] = v.y;
+        acc[rs][0] = acc[rs][1] = 0.0;
+    }
+    int slot = off + lane;
+    int cj = cols[slot];
+    double vj = vals[slot];
+    for (int j = 0; j < width; ++j, slot += 64) {
+        int cn = cj;
+        double vn = vj;
+        if (j + 1 < width) { cn = cols[slot + 64]; vn = vals[slot + 64]; }
+#pragma unroll
+        for (int rs = 0; rs < 8; ++rs) {
+            const int src = rs * 8 + g;
+            const int cc = __shfl(cj, src, 64);
+            const double aa = __shfl(vj, src, 64);
+            double x0 = xr[rs][0], x1 = xr[rs][1];
+            if (mode == 1) {   // keep the address arithmetic of a gather alive without the load
+                x0 += (double)(cc & 1) * 1e-300;
+            }
+            acc[rs][0] = fma(aa, x0, acc[rs][0]);
+            acc[rs][1] = fma(aa, x1, acc[rs][1]);
+        }
+        cj = cn;
+        vj = vn;
+    }
+    for (int rs = 0; rs < 8; ++rs) {
+        const int row = slice * 64 + rs * 8 + g;
+        if (row < nrows) *reinterpret_cast<double2*>(y + (size_t)row * 16 + t * 2) = make_double2(acc[rs][0], acc[rs][1]);
+    }
+}
+
 template <class T>
 static std::vector<T> rd(FILE* f, size_t n) {
     std::vector<T> v(n);
@@ -47,6 +96,19 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n_s; ++i) maw[i] = -al[0] * w[i];
     HostCsr Bt = csr_transpose(B);
     HostCsr A = csr_block2x2(M, Bt, B, maw.data());
+    if (const char* e = getenv("LAB_COLS")) {
+        // access-pattern probes: 1 = every entry gathers its own row (sequential, full reuse), 2 = columns shifted by a
+        // constant (same locality, no structure change), 3 = random columns (no locality at all)
+        const int mode = atoi(e);
+        uint64_t r = 1234567;
+        for (int i = 0; i < A.nrows; ++i)
+            for (int p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) {
+                if (mode == 1) A.colind[p] = i;
+                else if (mode == 2) A.colind[p] = (A.colind[p] + 4096) % A.ncols;
+                else if (mode == 3) { r ^= r << 13; r ^= r >> 7; r ^= r << 17; A.colind[p] = (int)(r % (uint64_t)A.ncols); }
+            }
+        printf("LAB_COLS=%d\n", mode);
+    }
     const int n = n_u + n_s;
     hipStream_t st;
     PMC_HIP(hipStreamCreate(&st));
@@ -109,6 +171,15 @@ int main(int argc, char** argv) {
                 timeit("flat copy, same bytes", fl_, [&] { lab_stream_kernel<<<4096, 256, 0, st>>>(n1, (const double2*)ca.p, (double2*)cb.p); });
                 timeit("flat copy, 288 MB (reported as 206)", fl_, [&] { lab_stream_kernel<<<4096, 256, 0, st>>>(n2, (const double2*)ca.p, (double2*)cb.p); });
             }
+        }
+        if (nb == 16) {
+            DevBuf<int> dcols;
+            dcols.upload(S.h_cols.empty() ? std::vector<int>(S.nslots, 0) : S.h_cols, st);
+            for (int fl_ = 0; fl_ < 2; ++fl_)
+                timeit("probe: one x load per row", fl_, [&] {
+                    lab_oneload_kernel<<<(S.nslices + 3) / 4, 256, 0, st>>>(S.nrows, S.nslices, S.slice_off.p, S.sched.p, S.cols.p,
+                                                                          S.vals.p, x.p, y1.p, 1);
+                });
         }
         for (int fl_ = 0; fl_ < 2; ++fl_) {
             timeit("gather (round 1 kernel)", fl_, [&] { k::spmm(st, nb, V, x.p, y0.p, false, nullptr, nullptr); });
