@@ -1,6 +1,7 @@
 // extern "C" surface of libpmc.so (see include/pmc.h).  No exception leaves this file.
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -13,6 +14,18 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string& m) { g_last_error = m; }
 
 void Ctx::activate() const { PMC_HIP(hipSetDevice(device)); }
+
+static std::atomic<int> g_live_ctx[64];
+int Ctx::contexts_on_device(int device) { return g_live_ctx[device & 63].load(); }
+
+Lanes Ctx::lanes(bool split) {
+    if (split && !stream2) {
+        PMC_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        PMC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        PMC_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    return Lanes{stream, split ? stream2 : stream, ev_fork, ev_join, split};
+}
 
 template <class F>
 static int guarded(F&& f) {
@@ -112,23 +125,19 @@ int pmc_ctx_create(int device_id, pmc_ctx** out) {
         std::unique_ptr<pmc_ctx> c(new pmc_ctx());
         c->device = device_id;
         PMC_HIP(hipSetDevice(device_id));
-        // two streams per handle (see Lanes).  Both at default priority: giving the second one a lower priority (measured)
-        // leaves one lane unchanged and costs 19 % with four lanes per GPU.
         PMC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        PMC_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         PMC_HIP(hipEventCreate(&c->ev0));
         PMC_HIP(hipEventCreate(&c->ev1));
-        PMC_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        PMC_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        PMC_HIP(hipEventCreateWithFlags(&c->ev_poll, hipEventDisableTiming));
         PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_flag), sizeof(int) * 16, hipHostMallocDefault));
         PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(double) * 4096, hipHostMallocDefault));
+        g_live_ctx[device_id & 63].fetch_add(1);
         *out = c.release();
     });
 }
 
 void pmc_ctx_destroy(pmc_ctx* c) {
     if (!c) return;
+    g_live_ctx[c->device & 63].fetch_sub(1);
     (void)hipSetDevice(c->device);
     if (c->nccl) {
         try { rccl().CommDestroy(c->nccl); } catch (...) {}
@@ -140,7 +149,7 @@ void pmc_ctx_destroy(pmc_ctx* c) {
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_poll})
+    for (hipEvent_t e : {c->ev_fork, c->ev_join})
         if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -161,8 +161,12 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // second stream of the same handle (see Lanes)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_poll = nullptr;
-    Lanes lanes(bool split) const { return Lanes{stream, split ? stream2 : stream, ev_fork, ev_join, split}; }
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // split: spread a solve over two streams.  The second stream is created on first use, and only a handle that is the
+    // only one on its device ever asks for it (contexts_on_device): every additional HIP stream changes how the runtime
+    // maps streams to hardware queues, which cost multi-lane runs up to 30 % when each lane carried an idle second stream.
+    Lanes lanes(bool split);
+    static int contexts_on_device(int device);
     uint64_t seed = 0;
     int nparts = 1, mypart = 0;
     void* nccl = nullptr;          // ncclComm_t

@@ -258,25 +258,16 @@ static size_t split_threshold() {
     return v;
 }
 
-// Solves in flight per device.  A handle that has the GPU to itself spreads a solve over its two streams; when other
-// handles (manager lanes, bench streams) are solving on the same GPU their kernels already fill the gaps, and the extra
-// stream only adds event traffic (measured at config 2: one lane 826 -> 930 samples/s with the split, four lanes
-// 1328 -> 1273).
-static std::atomic<int> g_solves_in_flight[64];
-struct SolveTicket {
-    int dev, others;
-    explicit SolveTicket(int d) : dev(d & 63), others(g_solves_in_flight[d & 63].fetch_add(1)) {}
-    ~SolveTicket() { g_solves_in_flight[dev].fetch_sub(1); }
-};
-
 MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, const double* b, double* x,
                           bool zero_guess, const pmc_solver_opts& o, MinresWork& w, int x_row0, int x_nrows,
                           const int* x_rows, GraphHint hint) {
     hipStream_t st = ctx.stream;
     const int n = A.n;
     const size_t len = (size_t)n * nb;
-    const SolveTicket ticket(ctx.device);
-    const Lanes L = ctx.lanes(split_threshold() > 0 && len >= split_threshold() && ticket.others == 0);
+    // A handle that has the GPU to itself spreads a solve over two streams; when other handles (manager lanes, bench
+    // streams) share the GPU their kernels already fill the gaps and the second stream only adds event traffic
+    // (measured at config 2: one lane 826 -> 930 samples/s with the split, four lanes 1328 -> 1273).
+    const Lanes L = ctx.lanes(split_threshold() > 0 && len >= split_threshold() && Ctx::contexts_on_device(ctx.device) == 1);
     w.ensure(n, nb);
     k::MinresState* S = w.state.p;
     double* v0 = w.v0.p; double* v1 = w.v1.p; double* u0 = w.u0.p; double* u1 = w.u1.p;
