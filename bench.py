@@ -128,9 +128,10 @@ class SamplerFarm:
         return sm.Eval(0, xi_d, xi_level=0, s_out=s_d, return_stats=True)[1]
 
     def step(self, i):
-        """`streams` batches of nb realizations in flight at once; batch ids block-cyclic over ranks"""
+        """`streams` batches of nb realizations in flight at once.  Batch ids are LOCAL to the rank: the generator is split
+        over the ranks (pmc_rng_seed nparts / mypart = NormalDistributionSampler::Split), so no two ranks share a realization"""
         res = [None] * self.ns
-        base = (i * self.world + self.rank) * self.ns
+        base = i * self.ns
 
         def work(lane):
             res[lane] = self.one_batch(lane, base + lane)
@@ -333,7 +334,7 @@ def main():
     out = None
     if rank == 0:
         sbytes = solver_bytes_per_iteration(problem, nb)
-        next_batch = (args.warmup + args.steps + 1) * world * ns
+        next_batch = (args.warmup + args.steps + 1) * ns
         out = {
             "metric": "MC samples/sec (SPDE field + Darcy QoI) at stated DoF; SpMV HBM GB/s vs roofline",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

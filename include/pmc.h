@@ -80,6 +80,10 @@ typedef struct pmc_solver_opts {
     int32_t mini_max_rows;    /* sampler levels of at most this many rows (n_u + n_s) whose Schur V-cycle fits the LDS tail are
                                  solved by ONE persistent workgroup per realization - the whole MINRES solve in a single
                                  kernel launch - instead of ~7 launches per iteration (default 6000; 0 = never)           */
+    int32_t two_streams;      /* the two diagonal blocks of the preconditioner on two HIP streams of the handle: 0 = automatic
+                                 (default: only when the handle is the only one on its device and the level has at least
+                                 ~1.5 M rows x realizations; with several handles per GPU their kernels already fill the
+                                 gaps), 1 = always, 2 = never.  Results do not depend on it.                                 */
 } pmc_solver_opts;
 
 /* Per-realization solver report; the reference returns -1 for iteration counts
@@ -141,8 +145,11 @@ int pmc_memcpy_h2d(pmc_ctx* ctx, void* dst, const void* src, size_t bytes);
 int pmc_memcpy_d2h(pmc_ctx* ctx, void* dst, const void* src, size_t bytes);
 
 /* ---- NormalDistributionSampler (src/NormalDistributionSampler.cpp:17-37) ---------------- */
-/* Seed the counter-based generator; (nparts, mypart) mirror Split(): sample ids handed to
- * pmc_*_sample are global, each part simply owns the ids congruent to mypart mod nparts. */
+/* Seed the counter-based generator.  (nparts, mypart) restate NormalDistributionSampler::Split
+ * (src/NormalDistributionSampler.cpp:21-24, a leap-frog of the stream): part `mypart` owns the generator's
+ * realizations mypart, mypart + nparts, ...; the ids handed to pmc_*_sample / pmc_normal_fill are LOCAL to the part
+ * (local id i = generator realization i * nparts + mypart), so parts with the same seed and different mypart never
+ * share a realization, and the union over the parts is exactly the unsplit stream.  (1, 0) = no split. */
 int pmc_rng_seed(pmc_ctx* ctx, uint64_t seed, int nparts, int mypart);
 /* out[b*n + i] = mean + sqrt(sigma2) * Phi^-1(u),  b < nbatch, realization id first_id+b */
 int pmc_normal_fill(pmc_ctx* ctx, double mean, double sigma2, uint64_t first_sample_id, uint32_t stream,

@@ -34,7 +34,8 @@ class pmc_solver_opts(C.Structure):
                 ("cheb_degree_M", C.c_int32), ("cheb_ratio_M", C.c_double),
                 ("mg_smooth_degree", C.c_int32), ("mg_smooth_ratio", C.c_double),
                 ("mg_coarse_degree", C.c_int32), ("mg_coarse_ratio", C.c_double), ("check_every", C.c_int32),
-                ("use_graph", C.c_int32), ("schur_scale", C.c_double), ("mg_coarsening", C.c_int32), ("mini_max_rows", C.c_int32)]
+                ("use_graph", C.c_int32), ("schur_scale", C.c_double), ("mg_coarsening", C.c_int32), ("mini_max_rows", C.c_int32),
+                ("two_streams", C.c_int32)]
 
 
 class pmc_stats(C.Structure):

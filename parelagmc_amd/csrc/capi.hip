@@ -110,6 +110,7 @@ void pmc_solver_opts_default(pmc_solver_opts* o) {
     o->schur_scale = 1.0;
     o->mg_coarsening = 2;
     o->mini_max_rows = 6000;
+    o->two_streams = 0;
     o->use_graph = 0;   // measured: no gain single-stream (kernels are latency-, not launch-bound), slower with 4 lanes
 }
 
@@ -239,10 +240,10 @@ int pmc_normal_fill(pmc_ctx* c, double mean, double sigma2, uint64_t first_id, u
         c->activate();
         const double sigma = std::sqrt(sigma2);   // NormalDistributionSampler ctor, cpp:17-19
         if (memspace == PMC_MEM_DEVICE) {
-            k::normal_fill(c->stream, n, nbatch, c->seed, first_id, stream, mean, sigma, out);
+            k::normal_fill(c->stream, n, nbatch, c->seed, c->stream_id(first_id), stream, mean, sigma, out, (uint64_t)c->nparts);
         } else {
             DevBuf<double> tmp((size_t)n * nbatch);
-            k::normal_fill(c->stream, n, nbatch, c->seed, first_id, stream, mean, sigma, tmp.p);
+            k::normal_fill(c->stream, n, nbatch, c->seed, c->stream_id(first_id), stream, mean, sigma, tmp.p, (uint64_t)c->nparts);
             PMC_HIP(hipMemcpyAsync(out, tmp.p, sizeof(double) * n * nbatch, hipMemcpyDeviceToHost, c->stream));
             PMC_HIP(hipStreamSynchronize(c->stream));
         }

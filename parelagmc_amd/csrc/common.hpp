@@ -168,7 +168,10 @@ struct Ctx {
     Lanes lanes(bool split);
     static int contexts_on_device(int device);
     uint64_t seed = 0;
+    // NormalDistributionSampler::Split: part `mypart` of `nparts` owns the realizations mypart, mypart + nparts, ...;
+    // realization id i of this handle is the generator's realization i * nparts + mypart (see stream_id)
     int nparts = 1, mypart = 0;
+    uint64_t stream_id(uint64_t local_id) const { return local_id * (uint64_t)nparts + (uint64_t)mypart; }
     void* nccl = nullptr;          // ncclComm_t
     int nranks = 1, rank = 0;
     DevBuf<double> comm_buf;

@@ -1077,14 +1077,16 @@ __device__ double inv_normal_cdf(double p) {
 #pragma clang fp contract(fast)
 
 // out[b*n + i], sample-major.  One thread per (pair of elements, realization).
+// Realization b of the launch is the generator's realization first_id + b * id_stride (id_stride = nparts of a split
+// generator: part p owns the ids p, p + nparts, ...).
 __global__ __launch_bounds__(kBlock) void normal_fill_kernel(int n, int nbatch, uint64_t seed, uint64_t first_id,
-                                                             uint32_t stream, double mean, double sigma,
+                                                             uint64_t id_stride, uint32_t stream, double mean, double sigma,
                                                              double* __restrict__ out) {
     const int npair = (n + 1) >> 1;
     const int j = blockIdx.x * kBlock + threadIdx.x;
     const int b = blockIdx.y;
     if (j >= npair || b >= nbatch) return;
-    const uint64_t sid = first_id + (uint64_t)b;
+    const uint64_t sid = first_id + (uint64_t)b * id_stride;
     uint32_t c[4] = {(uint32_t)j, (uint32_t)sid, (uint32_t)(sid >> 32), stream};
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -1973,11 +1975,11 @@ void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d) {
 }
 
 void normal_fill(hipStream_t st, int n, int nbatch, uint64_t seed, uint64_t first_id, uint32_t stream, double mean,
-                 double sigma, double* out) {
+                 double sigma, double* out, uint64_t id_stride) {
     if (n == 0 || nbatch == 0) return;
     const int npair = (n + 1) / 2;
     dim3 g((unsigned)((npair + kBlock - 1) / kBlock), (unsigned)nbatch);
-    normal_fill_kernel<<<g, kBlock, 0, st>>>(n, nbatch, seed, first_id, stream, mean, sigma, out);
+    normal_fill_kernel<<<g, kBlock, 0, st>>>(n, nbatch, seed, first_id, id_stride, stream, mean, sigma, out);
     check_launch();
 }
 

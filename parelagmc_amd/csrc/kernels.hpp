@@ -99,8 +99,9 @@ void minres_init(hipStream_t st, int nb, MinresState* s, const DotParts& d, doub
 void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d);
 void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d);
 
+// realization b of the batch = generator realization first_id + b * id_stride
 void normal_fill(hipStream_t st, int n, int nbatch, uint64_t seed, uint64_t first_id, uint32_t stream, double mean,
-                 double sigma, double* out);
+                 double sigma, double* out, uint64_t id_stride = 1);
 // out[i*nb+k] = scale * in[k*n+i] * (w ? w[i] : 1)
 void interleave(hipStream_t st, int nb, int n, const double* in, const double* w, double scale, double* out);
 // out[k*m+i] = post(rowscale[i] * in[(idx?idx[i]:i)*nb + k])

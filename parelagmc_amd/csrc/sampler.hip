@@ -249,6 +249,8 @@ void Sampler::ensure(int level, int nb) {
         smax = std::max(smax, (size_t)lv[l].n_s);
     }
     for (int l = level; l < nlevels; ++l) smax = std::max(smax, (size_t)lv[l].n_s);
+    // L2-projected samplers return fields on the ORIGINAL mesh, which may have more elements than the enlarged one
+    for (int l = 0; l < n_mc; ++l) smax = std::max(smax, (size_t)lv[l].out_size);
     rhs.ensure(nmax * nb);
     sol.ensure(nmax * nb);
     tA.ensure(smax * nb);
@@ -267,10 +269,10 @@ void Sampler::sample(int level, uint64_t first_id, int nbatch, double* xi, int m
     hipStream_t st = ctx.stream;
     const int n = lv[level].n_s;
     if (memspace == PMC_MEM_DEVICE) {
-        k::normal_fill(st, n, nbatch, ctx.seed, first_id, (uint32_t)level, 0.0, 1.0, xi);
+        k::normal_fill(st, n, nbatch, ctx.seed, ctx.stream_id(first_id), (uint32_t)level, 0.0, 1.0, xi, (uint64_t)ctx.nparts);
     } else {
         DevBuf<double> tmp((size_t)n * nbatch);
-        k::normal_fill(st, n, nbatch, ctx.seed, first_id, (uint32_t)level, 0.0, 1.0, tmp.p);
+        k::normal_fill(st, n, nbatch, ctx.seed, ctx.stream_id(first_id), (uint32_t)level, 0.0, 1.0, tmp.p, (uint64_t)ctx.nparts);
         PMC_HIP(hipMemcpyAsync(xi, tmp.p, sizeof(double) * n * nbatch, hipMemcpyDeviceToHost, st));
         PMC_HIP(hipStreamSynchronize(st));
     }
@@ -476,6 +478,15 @@ void Sampler::eval(int level, int xi_level, int nbatch, const double* xi, double
     hipStream_t st = ctx.stream;
     const int n_xi = lv[xi_level].n_s, n_out = lv[level].out_size, n_s = lv[level].n_s;
     const int n_init = use_init ? lv[init_level].n_s : 0;
+    // embed_s_out may alias init_s (the managers pass one buffer for both).  With several chunks and a coarser
+    // init_level a chunk's embed rows (n_s each) would overwrite init rows (n_init < n_s each) of later chunks before
+    // they are read: keep a private copy of init_s for the whole call then.
+    DevBuf<double> init_copy;
+    if (use_init && memspace == PMC_MEM_DEVICE && emb_out == init_s && nbatch > 16 && n_init != n_s) {
+        init_copy.alloc((size_t)n_init * nbatch);
+        PMC_HIP(hipMemcpyAsync(init_copy.p, init_s, sizeof(double) * n_init * nbatch, hipMemcpyDeviceToDevice, st));
+        init_s = init_copy.p;
+    }
     int done = 0;
     while (done < nbatch) {
         int nb = 16;
@@ -502,6 +513,7 @@ void Sampler::eval(int level, int xi_level, int nbatch, const double* xi, double
         }
         done += nb;
     }
+    if (init_copy.p) PMC_HIP(hipStreamSynchronize(st));   // the private copy is released on return
 }
 
 }  // namespace pmc

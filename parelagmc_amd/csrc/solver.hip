@@ -267,7 +267,9 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     // A handle that has the GPU to itself spreads a solve over two streams; when other handles (manager lanes, bench
     // streams) share the GPU their kernels already fill the gaps and the second stream only adds event traffic
     // (measured at config 2: one lane 826 -> 930 samples/s with the split, four lanes 1328 -> 1273).
-    const Lanes L = ctx.lanes(split_threshold() > 0 && len >= split_threshold() && Ctx::contexts_on_device(ctx.device) == 1);
+    const bool split = o.two_streams == 1 || (o.two_streams == 0 && split_threshold() > 0 && len >= split_threshold() &&
+                                              Ctx::contexts_on_device(ctx.device) == 1);
+    const Lanes L = ctx.lanes(split);
     w.ensure(n, nb);
     k::MinresState* S = w.state.p;
     double* v0 = w.v0.p; double* v1 = w.v1.p; double* u0 = w.u0.p; double* u1 = w.u1.p;

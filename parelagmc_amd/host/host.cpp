@@ -251,10 +251,16 @@ MLMC_Manager::MLMC_Manager(pmc_ctx* ctx, int memspace, int nlevels_, PhysicalMLS
     M.resize(nlevels);
     for (int i = 0; i < nlevels; ++i) M[i] = pSolver.GetGlobalNumberOfDofs(i);
     if (p.log_file && p.log_file[0]) {
-        logger.open(p.log_file);
-        logger.precision(17);    // the per-sample log doubles as a checkpoint (ReplayLog), so it must round-trip
+        log_path_ = p.log_file;   // opened by the first InitRun, once the rank (SetFarm) is known
     }
     Reset();
+}
+
+// In a farm every rank logs the realizations of its own shard; the reference logs on pid 0 only
+// (src/MLMC_Manager.cpp:106-108), which sees every sample there.  Rank r > 0 writes "<log>.rank<r>" so that ranks
+// sharing a file system never clobber each other's shard; rank 0 keeps the plain name.
+static std::string shard_name(const std::string& base, int rank) {
+    return rank == 0 ? base : base + ".rank" + std::to_string(rank);
 }
 
 void MLMC_Manager::SetFarm(int nranks, int rank, std::function<void(double*, int)> reduce) {
@@ -263,6 +269,7 @@ void MLMC_Manager::SetFarm(int nranks, int rank, std::function<void(double*, int
     nranks_ = nranks;
     rank_ = rank;
     reduce_ = std::move(reduce);
+    if (logger.is_open()) logger.close();   // re-opened under this rank's shard name by the next InitRun
 }
 
 void MLMC_Manager::Reset() {
@@ -479,6 +486,11 @@ void MLMC_Manager::ShowMe(std::ostream& os) const {
 
 void MLMC_Manager::InitRun(std::vector<int>& level_nsamples_init) {
     if ((int)level_nsamples_init.size() != nlevels) throw std::invalid_argument("InitRun: wrong number of levels");
+    if (!log_path_.empty() && !logger.is_open()) {
+        // a log that has just been replayed into this manager is continued, not truncated
+        logger.open(shard_name(log_path_, rank_), append_log_ ? std::ios::app : std::ios::trunc);
+        logger.precision(17);    // the per-sample log doubles as a checkpoint (ReplayLog), so it must round-trip
+    }
     if (logger.is_open() && *std::max_element(level_nsamples.begin(), level_nsamples.end()) == 0)
         logger << "%" << std::setw(13) << "level " << std::setw(14) << "Y(xi) " << std::setw(14) << "Q(xi)"
                << std::setw(14) << "Q_c(xi)" << std::setw(14) << "c \n";
@@ -507,10 +519,15 @@ void MLMC_Manager::InitRun(std::vector<int>& level_nsamples_init) {
 // MLMC.dat, src/MLMC_Manager.cpp:106-108,133-135,170-172: level, Y, Q, Q_c, cost).  The reference never reads its log
 // back; this is the resume path SURVEY.md 5 asks for.  Returns the number of realizations read.
 int64_t MLMC_Manager::ReplayLog(const std::string& path) {
-    std::ifstream in(path);
-    if (!in) throw std::runtime_error("ReplayLog: cannot open " + path);
-    std::string line;
+    // a farm's log is sharded by rank (shard_name): every rank replays ALL shards, so the rebuilt sums and counters
+    // are the global ones on every rank, exactly as after the all-reduce of a live run
     int64_t nread = 0;
+    if (path == log_path_) append_log_ = true;
+    for (int r = 0; r < nranks_; ++r) {
+    std::ifstream in(shard_name(path, r));
+    if (!in) throw std::runtime_error("ReplayLog: cannot open " + shard_name(path, r) +
+                                      (nranks_ > 1 ? " (a farm of " + std::to_string(nranks_) + " ranks needs every rank's shard)" : ""));
+    std::string line;
     while (std::getline(in, line)) {
         if (line.empty() || line[0] == '%') continue;
         std::istringstream ss(line);
@@ -529,6 +546,7 @@ int64_t MLMC_Manager::ReplayLog(const std::string& path) {
         S(lvl, C) += c;
         level_nsamples[lvl] += 1;
         ++nread;
+    }
     }
     bool all = true;
     for (int l = 0; l < nlevels; ++l) all = all && level_nsamples[l] > 1;

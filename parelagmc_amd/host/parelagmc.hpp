@@ -234,6 +234,8 @@ class MLMC_Manager {
     };
     std::vector<std::unique_ptr<Lane>> lanes_;
     std::ofstream logger;
+    std::string log_path_;
+    bool append_log_ = false;
 };
 
 /// What the ratio managers call (the reference's BayesianInverseProblem seen from ML_BayesRatio_Manager):

@@ -1,0 +1,128 @@
+"""GPU tests added in round 2: Split semantics of the generator, buffers of L2-projected samplers whose original mesh is
+finer than the enlarged one, aliasing of the warm-start / embedded-field buffers over several chunks, and the two-stream
+solver schedule against the one-stream one.  Run with -m gpu on an MI355X; everything goes through the C ABI."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+def test_split_partitions_the_stream_like_the_reference(hex_hierarchy_small):
+    """NormalDistributionSampler::Split(nparts, mypart) (src/NormalDistributionSampler.cpp:21-24) leap-frogs ONE stream:
+    the parts never share a variate and together they reproduce the unsplit stream.  Here: part p's local realization i is
+    the generator's realization i * nparts + p, for pmc_normal_fill and for PDESampler::Sample alike."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    from oracle.rng_oracle import normal_fill
+    seed = 424242
+    whole = capi.Context(0, seed=seed)
+    ref = whole.normal_fill(257, nbatch=6, first_id=0, stream=3)
+    assert np.max(np.abs(ref - np.stack([normal_fill(257, seed, b, 3) for b in range(6)]))) < 1e-14
+    sp_ = build_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    parts = []
+    for p in range(2):
+        c = capi.Context(0, seed=seed)
+        c.seed(seed, nparts=2, mypart=p)
+        x = c.normal_fill(257, nbatch=3, first_id=0, stream=3)
+        assert np.array_equal(x, ref[p::2])                      # local ids 0,1,2 -> global p, p+2, p+4
+        assert np.array_equal(c.normal_fill(257, nbatch=1, first_id=2, stream=3)[0], ref[4 + p])
+        smp = capi.PDESampler(c, sp_)
+        parts.append(smp.Sample(0, first_id=0, nbatch=3))
+        smp.close()
+        c.close()
+    smp = capi.PDESampler(whole, sp_)
+    xi = smp.Sample(0, first_id=0, nbatch=6)
+    assert np.array_equal(parts[0], xi[0::2]) and np.array_equal(parts[1], xi[1::2])
+    assert not np.array_equal(parts[0], parts[1])
+    smp.close()
+    whole.close()
+
+
+def test_l2_projection_onto_a_finer_original_mesh(gpu_ctx, seeded_rng):
+    """L2ProjectionPDESampler::Eval returns one value per ORIGINAL element (src/L2ProjectionPDESampler.cpp:603-611,735); the
+    original mesh may have more elements than the enlarged sampler mesh.  Here the original mesh is the once-refined
+    sampler mesh (8 children per element): Gt[i, j] = |child_i| for parent j, s_o = diag(|e_o|)^-1 Gt s."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import box_mesh, build_hierarchy, build_sampler_problem
+    from oracle.sampler_oracle import SamplerOracle
+    h = build_hierarchy(box_mesh([3, 3, 3], [1.5, 1.5, 1.5], "hex"), 2)          # levels 12^3 / 6^3 / 3^3
+    fine_vol = h.spaces[0].vol
+    # sampler on the two coarser levels only; original mesh = the finest one
+    import dataclasses
+    hs = dataclasses.replace(h, spaces=h.spaces[1:], P=h.P[1:])
+    prob = build_sampler_problem(hs, corlen=0.2, lognormal=True)
+    so = SamplerOracle(prob)
+    P01 = h.P[0].tocsr()                                     # fine (1728) x sampler level 0 (216)
+    Gt0 = sp.diags(fine_vol) @ P01
+    Gt1 = Gt0 @ h.P[1].tocsr()                               # RAP with the identity on the original side (:512-513)
+    l2 = [(Gt0.tocsr(), 1.0 / fine_vol), (Gt1.tocsr(), 1.0 / fine_vol)]
+    smp = capi.PDESampler(gpu_ctx, prob, capi.solver_opts(rel_tol=1e-12, abs_tol=1e-30, max_iter=400), projection="l2", l2_ops=l2)
+    xi = seeded_rng.standard_normal((19, prob.levels[0].n_s))          # 19 -> chunks of 16 + 2 + 1
+    for lvl in range(2):
+        assert smp.SampleSize(lvl) == fine_vol.size > smp.xi_size(lvl)
+        s = smp.Eval(lvl, xi, xi_level=0)
+        Gt, iw = l2[lvl]
+        ref = np.stack([so.eval(lvl, 0, x, projection=("l2", Gt, iw))[0] for x in xi])
+        assert s.shape == (19, fine_vol.size) and rel(s, ref) < 1e-9
+        d_xi = gpu_ctx.array(xi)
+        d_s = gpu_ctx.empty(19 * fine_vol.size)
+        smp.Eval(lvl, d_xi, xi_level=0, s_out=d_s)
+        assert np.array_equal(d_s.download().reshape(19, -1), s)          # device-pointer path, same result
+    smp.close()
+
+
+def test_warm_start_buffer_may_alias_the_embedded_output_over_chunks(gpu_ctx, hex_hierarchy, seeded_rng):
+    """pmc.h lets embed_s_out alias init_s (MLMC_Manager threads one buffer through, src/MLMC_Manager.cpp:150-156).  With
+    more than one chunk of 16 realizations and a coarser init level the first chunk's embedded rows would overwrite later
+    chunks' initial guesses: results must equal the non-aliased call."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    sp_ = build_sampler_problem(hex_hierarchy, corlen=0.1)
+    smp = capi.PDESampler(gpu_ctx, sp_)
+    nb, n0, n1 = 37, sp_.levels[0].n_s, sp_.levels[1].n_s
+    xi = gpu_ctx.array(seeded_rng.standard_normal((nb, n0)))
+    s1, emb1 = gpu_ctx.empty(nb * n1), gpu_ctx.empty(nb * n0)
+    smp.Eval(1, xi, xi_level=0, s_out=s1, embed_out=emb1)                 # coarse fields, n1 per realization
+    coarse = emb1.download()[: nb * n1].copy()
+    ref_s, ref_e = gpu_ctx.empty(nb * n0), gpu_ctx.empty(nb * n0)
+    init = gpu_ctx.array(coarse)
+    _, _, st_ref = smp.Eval(0, xi, xi_level=0, init_s=init, init_level=1, use_init=True, s_out=ref_s, embed_out=ref_e,
+                            return_stats=True)
+    buf = gpu_ctx.empty(nb * n0)                                           # one buffer: init on entry, embedded field on exit
+    buf.upload(np.concatenate([coarse, np.zeros(nb * (n0 - n1))]))
+    out = gpu_ctx.empty(nb * n0)
+    _, _, st = smp.Eval(0, xi, xi_level=0, init_s=buf, init_level=1, use_init=True, s_out=out, embed_out=buf, return_stats=True)
+    assert np.array_equal(out.download(), ref_s.download()) and np.array_equal(buf.download(), ref_e.download())
+    assert [t[0] for t in st] == [t[0] for t in st_ref] and all(t[1] == 1 for t in st)
+    smp.close()
+
+
+def test_two_stream_schedule_equals_the_one_stream_schedule(gpu_ctx, hex_hierarchy, seeded_rng):
+    """opts.two_streams: the two diagonal blocks of the preconditioner (and the two row blocks of the Darcy operator) on two
+    streams of the handle, or everything on one.  Same kernels, same reduction order: bit-identical fields, QoIs and
+    iteration counts, for the sampler and for Darcy."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp_ = build_sampler_problem(hex_hierarchy, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    xi = seeded_rng.standard_normal((16, sp_.levels[0].n_s))
+    res = []
+    for mode in (1, 2):
+        o = capi.solver_opts(two_streams=mode, mini_max_rows=0)
+        smp, ds = capi.PDESampler(gpu_ctx, sp_, o), capi.DarcySolver(gpu_ctx, dp, o)
+        out = []
+        for lvl in range(3):
+            s, st = smp.Eval(lvl, xi, xi_level=0, return_stats=True)
+            Q, _ = ds.SolveFwd(lvl, s)
+            out.append((s, [t[:2] for t in st], Q))
+        res.append(out)
+        ds.close()
+        smp.close()
+    for (s1, st1, q1), (s2, st2, q2) in zip(*res):
+        assert np.array_equal(s1, s2) and st1 == st2 and np.array_equal(q1, q2)
+        assert all(t[1] == 1 for t in st1)

@@ -1,5 +1,7 @@
 """Host logic of the MLMC / MC managers (libpmc_host.so) against the plain-Python restatement
 of MLMC_Manager (oracle/mlmc_oracle.py).  Plugins are Python callbacks: no GPU involved."""
+import os
+
 import numpy as np
 import pytest
 
@@ -198,6 +200,48 @@ def test_log_replay_resumes_a_run(tmp_path):
     assert np.allclose(b.InitRun([2, 3, 4])["sums"], a2.InitRun([2, 3, 4])["sums"], rtol=1e-13)
     b.close()
     a2.close()
+    # resuming INTO the same log continues it: a second resume still sees every realization
+    c = host_api.MLMCManager(3, callbacks=SyntheticPlugin(3).callbacks(), wall_time=False, batch=4, log_file=log)
+    assert c.ReplayLog(log) == 29
+    c.InitRun([2, 3, 4])
+    c.close()
+    d = host_api.MLMCManager(3, callbacks=SyntheticPlugin(3).callbacks(), wall_time=False, batch=4)
+    assert d.ReplayLog(log) == 29 + 9
+    d.close()
+
+
+def test_farm_logs_are_sharded_by_rank_and_replayed_together(tmp_path):
+    """Every farm rank logs its own shard (rank r > 0 -> "<log>.rank<r>"); ReplayLog of a farm manager reads all shards, so
+    the rebuilt sums / counters are the global ones and resumed sample ids do not overlap earlier ones.  (The reference
+    logs on pid 0 only, src/MLMC_Manager.cpp:106-108.)"""
+    log = str(tmp_path / "MLMC.dat")
+    parts = []
+    for rank in range(2):
+        m = host_api.MLMCManager(3, callbacks=SyntheticPlugin(3).callbacks(), wall_time=False, batch=4, log_file=log)
+        m.set_farm(2, rank, lambda buf: None)        # no exchange: each rank keeps its partial sums
+        parts.append(m.InitRun([6, 9, 14])["sums"].copy())
+        m.close()
+    assert os.path.exists(log) and os.path.exists(log + ".rank1")
+    n0 = len([ln for ln in open(log) if not ln.startswith("%")])
+    n1 = len([ln for ln in open(log + ".rank1") if not ln.startswith("%")])
+    assert n0 + n1 == 29 and 0 < n1 < 29
+    serial = host_api.MLMCManager(3, callbacks=SyntheticPlugin(3).callbacks(), wall_time=False, batch=4)
+    ref = serial.InitRun([6, 9, 14])
+    assert np.allclose(parts[0] + parts[1], ref["sums"], rtol=1e-13, atol=1e-14)
+    b = host_api.MLMCManager(3, callbacks=SyntheticPlugin(3).callbacks(), wall_time=False, batch=4)
+    b.set_farm(2, 0, lambda buf: None)
+    assert b.ReplayLog(log) == 29
+    rb = b.result()
+    assert np.allclose(rb["sums"], ref["sums"], rtol=1e-13, atol=1e-14) and list(rb["nsamples"]) == [6, 9, 14]
+    b.close()
+    # a missing shard is an error, not a silent partial resume
+    os.remove(log + ".rank1")
+    c = host_api.MLMCManager(3, callbacks=SyntheticPlugin(3).callbacks(), wall_time=False, batch=4)
+    c.set_farm(2, 0, lambda buf: None)
+    with pytest.raises(Exception):
+        c.ReplayLog(log)
+    c.close()
+    serial.close()
 
 
 # ---------------------------------------------------------------------------------- ratio estimator (Bayesian)
