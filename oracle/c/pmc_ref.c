@@ -214,3 +214,224 @@ int pmc_ref_max_threads(void) {
     return 1;
 #endif
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Darcy leg of the per-realization work, as the reference performs it for EVERY sample
+ * (/root/reference/src/DarcySolver.cpp:472-520 assemble, :562-649 BuildForwardSolver + solve):
+ *   1. M(k) = sum_e c(k_e) M_e  (ComputeMassOperator(uform, k), :479)
+ *   2. EliminateRowCol on the essential u-dofs, right-hand side fix-up (:487-498)
+ *   3. REBUILD the solver: block operator [M(k) B^T; B 0], block-diagonal preconditioner with
+ *      3 x symmetric GS on M(k) and a V-cycle on S(k) = B diag(M(k))^-1 B^T - the Schur complement and every
+ *      coarse operator of its hierarchy are re-assembled numerically (the reference's BoomerAMG setup, which also
+ *      builds the coarse grids, costs more than this Galerkin refresh on the caller's nested levels)
+ *   4. MINRES, Q = <obs, sol> (src/Utilities.cpp:411-420)
+ * B and B^T arrive with the essential columns / rows already removed and the k-independent part of the right-hand side
+ * fix-up applied (setup, done once by the caller).
+ */
+typedef struct {
+    int n_u, n_p;
+    csr_t Mpat;            /* pattern of M (values ignored) */
+    const int* c_ptr;      /* per stored nonzero: contributions c_ptr[p]..c_ptr[p+1] */
+    const int* c_elem;
+    const double* c_val;
+    csr_t B, Bt;           /* essential columns / rows removed */
+    const unsigned char* ess;
+    const double* ess_data;
+    const double* rhs;     /* n_u + n_p, before the M(k)-dependent fix-up */
+    const double* obs;     /* n_u + n_p */
+    csr_t Spat;            /* pattern of S on this level (values ignored) */
+    const int* parent;     /* p-dof of the next coarser level owning each p-dof (injection prolongator); NULL on the last */
+    csr_t P, Pt;
+} dlevel_t;
+
+typedef struct {
+    int nlev;              /* levels of the V-cycle from the solved level on */
+    csr_t M;               /* M(k) after elimination (own values) */
+    const dlevel_t* L;     /* solved level */
+    level_t* mg;           /* per V-cycle level: S with own values, P, Pt (the sampler's level_t reused; n_u/M/B unused) */
+    mgwork_t* mw;
+} dsys_t;
+
+static void darcy_apply_A(const dsys_t* s, const double* x, double* y) {
+    const int nu = s->L->n_u;
+    spmv(&s->M, x, y);
+    spmv_add(&s->L->Bt, x + nu, y, 1.0);
+    spmv(&s->L->B, x, y + nu);
+}
+static void darcy_apply_prec(const dsys_t* s, const double* r, double* z) {
+    const int nu = s->L->n_u;
+    memset(z, 0, sizeof(double) * nu);
+    for (int it = 0; it < 3; ++it) sym_gs(&s->M, r, z);
+    vcycle(s->nlev, s->mg, s->mw, 0, r + nu, z + nu);
+}
+
+/* MINRES as in minres() above, on the Darcy system */
+static int darcy_minres(const dsys_t* s, const double* b, double* x, int max_iter, double rel_tol, double abs_tol,
+                        double* work) {
+    const int n = s->L->n_u + s->L->n_p;
+    double *v0 = work, *v1 = work + n, *u1 = work + 2 * n, *q = work + 3 * n, *w0 = work + 4 * n, *w1 = work + 5 * n;
+    memset(x, 0, sizeof(double) * n);
+    memset(v0, 0, sizeof(double) * n);
+    memset(w0, 0, sizeof(double) * n);
+    memset(w1, 0, sizeof(double) * n);
+    memcpy(v1, b, sizeof(double) * n);
+    darcy_apply_prec(s, v1, u1);
+    double beta = sqrt(fmax(dot(n, v1, u1), 0.0));
+    double eta = beta, gamma0 = 1.0, gamma1 = 1.0, sigma0 = 0.0, sigma1 = 0.0;
+    const double goal = fmax(rel_tol * eta, abs_tol);
+    if (eta <= goal) return 0;
+    for (int it = 1; it <= max_iter; ++it) {
+        const double ib = 1.0 / beta;
+        for (int i = 0; i < n; ++i) { v1[i] *= ib; u1[i] *= ib; }
+        darcy_apply_A(s, u1, q);
+        const double alpha = dot(n, u1, q);
+        for (int i = 0; i < n; ++i) v0[i] = q[i] - alpha * v1[i] - beta * v0[i];
+        const double delta = gamma1 * alpha - gamma0 * sigma1 * beta;
+        const double rho3 = sigma0 * beta;
+        const double rho2 = sigma1 * alpha + gamma0 * gamma1 * beta;
+        darcy_apply_prec(s, v0, q);
+        const double beta_new = sqrt(fmax(dot(n, v0, q), 0.0));
+        const double rho1 = hypot(delta, beta_new);
+        for (int i = 0; i < n; ++i) w0[i] = (u1[i] - rho3 * w0[i] - rho2 * w1[i]) / rho1;
+        gamma0 = gamma1;
+        gamma1 = delta / rho1;
+        const double step = gamma1 * eta;
+        for (int i = 0; i < n; ++i) x[i] += step * w0[i];
+        sigma0 = sigma1;
+        sigma1 = beta_new / rho1;
+        eta = -sigma1 * eta;
+        double* t;
+        memcpy(u1, q, sizeof(double) * n);
+        t = v0; v0 = v1; v1 = t;
+        t = w0; w0 = w1; w1 = t;
+        beta = beta_new;
+        if (fabs(eta) <= goal) return it;
+        if (beta == 0.0) return it;
+    }
+    return -max_iter;
+}
+
+static int find_col(const csr_t* A, int row, int col) {
+    for (int p = A->rp[row]; p < A->rp[row + 1]; ++p)
+        if (A->ci[p] == col) return p;
+    return -1;
+}
+
+/* Solves the Darcy system of `level` for nsamples coefficient fields k (n_p each, sample-major) and returns
+ * Q[i] = <obs, sol_i>; sol (optional) receives the solutions.  nlevels dlevel_t entries, finest first. */
+int pmc_ref_darcy_batch(int nlevels, const dlevel_t* lv, int level, int k_divides, int nsamples, const double* kf, double* Q,
+                        double* sol, int max_iter, double rel_tol, double abs_tol, int nthreads, int* iters) {
+    if (nlevels < 1 || level < 0 || level >= nlevels || nsamples < 0) return -1;
+    const dlevel_t* L = &lv[level];
+    const int nu = L->n_u, np = L->n_p, n = nu + np;
+    const int nlev = nlevels - level;
+    int fail = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        double* work = (double*)malloc(sizeof(double) * 6 * (size_t)n);
+        double* rhs = (double*)malloc(sizeof(double) * (size_t)n);
+        double* x = (double*)malloc(sizeof(double) * (size_t)n);
+        double* coef = (double*)malloc(sizeof(double) * (size_t)np);
+        double* mval = (double*)malloc(sizeof(double) * (size_t)L->Mpat.rp[nu]);
+        double* dinv = (double*)malloc(sizeof(double) * (size_t)nu);
+        level_t* mg = (level_t*)calloc((size_t)nlev, sizeof(level_t));
+        mgwork_t* mw = (mgwork_t*)calloc((size_t)nlev, sizeof(mgwork_t));
+        double** sval = (double**)calloc((size_t)nlev, sizeof(double*));
+        int ok = work && rhs && x && coef && mval && dinv && mg && mw && sval;
+        for (int l = 0; ok && l < nlev; ++l) {
+            const dlevel_t* D = &lv[level + l];
+            const size_t m = (size_t)D->n_p;
+            sval[l] = (double*)malloc(sizeof(double) * (size_t)D->Spat.rp[D->n_p]);
+            mw[l].r = (double*)malloc(sizeof(double) * m);
+            mw[l].x = (double*)malloc(sizeof(double) * m);
+            mw[l].t = (double*)malloc(sizeof(double) * m);
+            ok = sval[l] && mw[l].r && mw[l].x && mw[l].t;
+            if (!ok) break;
+            mg[l].n_u = 0;
+            mg[l].n_s = D->n_p;
+            mg[l].S = D->Spat;
+            mg[l].S.v = sval[l];
+            mg[l].P = D->P;
+            mg[l].Pt = D->Pt;
+        }
+        if (!ok) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+            dsys_t sys;
+            sys.nlev = nlev;
+            sys.M = L->Mpat;
+            sys.M.v = mval;
+            sys.L = L;
+            sys.mg = mg;
+            sys.mw = mw;
+#pragma omp for schedule(dynamic, 1)
+            for (int i = 0; i < nsamples; ++i) {
+                const double* k = kf + (size_t)i * np;
+                for (int e = 0; e < np; ++e) coef[e] = k_divides ? 1.0 / k[e] : k[e];
+                /* 1. M(k) */
+                const int nnzM = L->Mpat.rp[nu];
+                for (int p = 0; p < nnzM; ++p) {
+                    double v = 0.0;
+                    for (int t = L->c_ptr[p]; t < L->c_ptr[p + 1]; ++t) v += coef[L->c_elem[t]] * L->c_val[t];
+                    mval[p] = v;
+                }
+                /* 2. EliminateRowCol(ess_dofs, ess_data, rhs) */
+                memcpy(rhs, L->rhs, sizeof(double) * n);
+                for (int r = 0; r < nu; ++r) {
+                    const int re = L->ess[r];
+                    for (int p = L->Mpat.rp[r]; p < L->Mpat.rp[r + 1]; ++p) {
+                        const int c = L->Mpat.ci[p];
+                        if (re || L->ess[c]) {
+                            if (!re) rhs[r] -= mval[p] * L->ess_data[c];
+                            mval[p] = (c == r) ? 1.0 : 0.0;
+                        }
+                    }
+                    if (re) rhs[r] = L->ess_data[r];
+                }
+                /* 3. rebuild the preconditioner: S(k) = B diag(M(k))^-1 B^T and its Galerkin coarse operators */
+                for (int r = 0; r < nu; ++r) {
+                    const int p = find_col(&L->Mpat, r, r);
+                    dinv[r] = 1.0 / mval[p];
+                }
+                {
+                    const csr_t* S = &mg[0].S;
+                    memset(sval[0], 0, sizeof(double) * (size_t)S->rp[np]);
+                    for (int e = 0; e < np; ++e)
+                        for (int p = L->B.rp[e]; p < L->B.rp[e + 1]; ++p) {
+                            const int f = L->B.ci[p];
+                            const double w = L->B.v[p] * dinv[f];
+                            for (int q2 = L->Bt.rp[f]; q2 < L->Bt.rp[f + 1]; ++q2)
+                                sval[0][find_col(S, e, L->Bt.ci[q2])] += w * L->Bt.v[q2];
+                        }
+                }
+                for (int l = 0; l + 1 < nlev; ++l) {
+                    const dlevel_t* D = &lv[level + l];
+                    const csr_t* Sf = &mg[l].S;
+                    const csr_t* Sc = &mg[l + 1].S;
+                    memset(sval[l + 1], 0, sizeof(double) * (size_t)Sc->rp[Sc->nrows]);
+                    for (int r = 0; r < Sf->nrows; ++r) {
+                        const int I = D->parent[r];
+                        for (int p = Sf->rp[r]; p < Sf->rp[r + 1]; ++p)
+                            sval[l + 1][find_col(Sc, I, D->parent[Sf->ci[p]])] += 0.5 * sval[l][p];
+                    }
+                }
+                /* 4. solve, Q */
+                const int it = darcy_minres(&sys, rhs, x, max_iter, rel_tol, abs_tol, work);
+                if (iters) iters[i] = it;
+                Q[i] = dot(n, L->obs, x);
+                if (sol) memcpy(sol + (size_t)i * n, x, sizeof(double) * n);
+            }
+        }
+        if (mw)
+            for (int l = 0; l < nlev; ++l) { free(mw[l].r); free(mw[l].x); free(mw[l].t); }
+        if (sval)
+            for (int l = 0; l < nlev; ++l) free(sval[l]);
+        free(sval); free(mw); free(mg); free(dinv); free(mval); free(coef); free(x); free(rhs); free(work);
+    }
+    return fail ? -2 : 0;
+}

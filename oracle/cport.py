@@ -97,3 +97,83 @@ class CPort:
         sol, iters = self.solve(level, self.rhs(level, xi_level, xi), **kw)
         s = sol[:, self.p.levels[level].n_u:]
         return (np.exp(s) if self.p.lognormal else s), iters
+
+
+class _dlevel(C.Structure):
+    _fields_ = [("n_u", C.c_int), ("n_p", C.c_int), ("Mpat", _csr), ("c_ptr", C.POINTER(C.c_int)),
+                ("c_elem", C.POINTER(C.c_int)), ("c_val", C.POINTER(C.c_double)), ("B", _csr), ("Bt", _csr),
+                ("ess", C.POINTER(C.c_ubyte)), ("ess_data", C.POINTER(C.c_double)), ("rhs", C.POINTER(C.c_double)),
+                ("obs", C.POINTER(C.c_double)), ("Spat", _csr), ("parent", C.POINTER(C.c_int)), ("P", _csr), ("Pt", _csr)]
+
+
+class DarcyCPort:
+    """ctypes driver of pmc_ref_darcy_batch: the reference's per-sample Darcy work (assemble M(k), eliminate, REBUILD the
+    preconditioner incl. the Schur hierarchy, MINRES, Q) restated in C; see oracle/c/pmc_ref.c for the line references."""
+
+    def __init__(self, problem):
+        self.lib = C.CDLL(build())
+        self.lib.pmc_ref_darcy_batch.restype = C.c_int
+        self.p = problem
+        self._keep = []
+        nl = len(problem.levels)
+        self.levels = (_dlevel * nl)()
+        spat = []
+        for i, L in enumerate(problem.levels):
+            keep = sp.diags((~L.ess_mask.astype(bool)).astype(np.float64))
+            B = (L.B @ keep).tocsr()
+            B.eliminate_zeros()
+            B.sort_indices()
+            if i == 0:
+                S = (abs(B) @ abs(B).T).tocsr()
+            else:                                   # Galerkin pattern of the finer level
+                Pf = problem.levels[i - 1].P.tocsr()
+                S = (Pf.T @ spat[i - 1] @ Pf).tocsr()
+            S = (S + sp.identity(L.n_p)).tocsr()
+            S.sort_indices()
+            S.data[:] = 1.0
+            spat.append(S)
+        helper = CPort.__new__(CPort)
+        helper._keep = self._keep
+        for i, L in enumerate(problem.levels):
+            keepm = (~L.ess_mask.astype(bool)).astype(np.float64)
+            B = (L.B @ sp.diags(keepm)).tocsr()
+            B.eliminate_zeros()
+            B.sort_indices()
+            Bt = B.T.tocsr()
+            rhs = L.rhs.copy()
+            rhs[L.n_u:] -= L.B @ (L.ess_data * L.ess_mask)          # k-independent part of the elimination
+            P = L.P.tocsr() if L.P is not None else sp.csr_matrix((0, 0))
+            parent = self._i32(P.indices) if L.P is not None else C.POINTER(C.c_int)()
+            if L.P is not None:
+                assert np.all(np.diff(P.indptr) == 1), "the C port handles injection-type prolongators"
+            pat = L.M_pattern.tocsr()
+            self.levels[i] = _dlevel(L.n_u, L.n_p, helper._csr(pat), self._i32(L.c_ptr), self._i32(L.c_elem),
+                                     helper._f64(L.c_val), helper._csr(B), helper._csr(Bt), self._u8(L.ess_mask),
+                                     helper._f64(L.ess_data), helper._f64(rhs), helper._f64(L.obs), helper._csr(spat[i]),
+                                     parent, helper._csr(P), helper._csr(P.T.tocsr()))
+
+    def _i32(self, a):
+        a = np.ascontiguousarray(a, np.int32)
+        self._keep.append(a)
+        return a.ctypes.data_as(C.POINTER(C.c_int))
+
+    def _u8(self, a):
+        a = np.ascontiguousarray(a, np.uint8)
+        self._keep.append(a)
+        return a.ctypes.data_as(C.POINTER(C.c_ubyte))
+
+    def solve(self, level, k, max_iter=300, rel_tol=1e-6, abs_tol=1e-12, nthreads=0, return_solution=False):
+        k = np.ascontiguousarray(np.atleast_2d(k), np.float64)
+        ns = k.shape[0]
+        L = self.p.levels[level]
+        Q = np.empty(ns)
+        iters = np.zeros(ns, np.int32)
+        sol = np.empty((ns, L.n_u + L.n_p)) if return_solution else None
+        rc = self.lib.pmc_ref_darcy_batch(len(self.p.levels), self.levels, level, 1 if self.p.k_divides else 0, ns,
+                                          k.ctypes.data_as(C.POINTER(C.c_double)), Q.ctypes.data_as(C.POINTER(C.c_double)),
+                                          sol.ctypes.data_as(C.POINTER(C.c_double)) if return_solution else None, max_iter,
+                                          C.c_double(rel_tol), C.c_double(abs_tol), nthreads,
+                                          iters.ctypes.data_as(C.POINTER(C.c_int)))
+        if rc != 0:
+            raise RuntimeError(f"pmc_ref_darcy_batch failed ({rc})")
+        return (Q, iters, sol) if return_solution else (Q, iters)
