@@ -156,18 +156,41 @@ class DarcyProblem:
     k_divides: bool = True
 
 
+def elements_near_points(mesh: Mesh, points, eps: float) -> np.ndarray:
+    """(npoints, nelem) bool: element e is marked for point j when the point lies in the element's bounding box enlarged
+    by eps, lower bounds inclusive and upper bounds exclusive - ChangeMeshAttributes of the reference
+    (/root/reference/src/MeshUtilities.cpp:268-334), which labels the elements a local pressure average is taken over."""
+    pts = np.atleast_2d(np.asarray(points, dtype=np.float64))
+    xv = mesh.verts[mesh.elems]                      # (nelem, nverts, dim)
+    lo, hi = xv.min(axis=1) - eps, xv.max(axis=1) + eps
+    return np.stack([np.all((lo <= x[None, :]) & (x[None, :] < hi), axis=1) for x in pts])
+
+
 def build_darcy_problem(h: Hierarchy, ess_attr, obs_attr, inflow_attr, n_mc_levels=None,
-                        p_inflow=-1.0, qoi="eff_perm", k_divides=True) -> DarcyProblem:
+                        p_inflow=-1.0, qoi="eff_perm", k_divides=True, qoi_point=(0.5, 0.5, 0.5),
+                        qoi_eps=0.1) -> DarcyProblem:
     """Default test problem of the reference drivers (examples/DarcyTest.cpp:186-215,
     example_helpers/CreateDarcyParameterList.hpp:32-36): u.n = 0 on `ess_attr`, boundary
     pressure coefficient `p_inflow` on `inflow_attr`, QoI = boundary flux through `obs_attr`.
     Volume forcing f = 0 and q = 0, so rhs / obs live on boundary faces only and their
     restriction with P^T (DarcySolver.cpp:313-314,411-412) equals direct evaluation on each
-    (nested) level."""
+    (nested) level.  qoi: "eff_perm" (boundary flux through obs_attr, default), "p_int" (integral of the pressure,
+    DarcySolver.cpp:267-295) or "local_avg_p" (integral of the pressure over the fine elements around qoi_point,
+    BuildPWObservationFunctional_p, DarcySolver.cpp:321-358; defaults of examples/MLMC.cpp:105-109), the three the
+    reference's drivers select (examples/MLMC.cpp:228-236)."""
     ess_attr = np.asarray(ess_attr, dtype=bool)
     obs_attr = np.asarray(obs_attr, dtype=bool)
     inflow_attr = np.asarray(inflow_attr, dtype=bool)
     levels = []
+    obs_p = None
+    if qoi == "local_avg_p":
+        # fine-level indicator weighted by the element volumes (DomainLFIntegrator of a restricted unit coefficient),
+        # restricted to the coarser levels with P^T (:353-354)
+        s0 = h.spaces[0]
+        mark = elements_near_points(s0.mesh, np.asarray(qoi_point, dtype=np.float64)[None, :s0.mesh.dim], qoi_eps)[0]
+        obs_p = [np.where(mark, s0.vol, 0.0)]
+        for P in h.P:
+            obs_p.append(P.T @ obs_p[-1])
     for i, s in enumerate(h.spaces):
         fattr = s.faces.face_bdr_attr
         isb = fattr > 0
@@ -185,6 +208,8 @@ def build_darcy_problem(h: Hierarchy, ess_attr, obs_attr, inflow_attr, n_mc_leve
             obs[:n_u][obs_f] = 1.0
         elif qoi == "p_int":
             obs[n_u:] = s.vol
+        elif qoi == "local_avg_p":
+            obs[n_u:] = obs_p[i]
         else:
             raise ValueError(qoi)
         pat, c_ptr, c_elem, c_val = mass_contributions(s.emass)

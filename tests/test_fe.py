@@ -164,3 +164,41 @@ def test_glvis_output_round_trip(tmp_path):
             assert compute_max_error(c, 0.25) == max(c.max() - 0.25, 0.25 - c.min())
         vtk = open(str(tmp_path / f"{name}_field_L01.000000.vtk")).read()
         assert "UNSTRUCTURED_GRID" in vtk and f"CELL_DATA {h.spaces[0].n_s}" in vtk
+
+
+def test_local_average_pressure_qoi_functional(hex_hierarchy):
+    """"local_avg_p" (BuildPWObservationFunctional_p, src/DarcySolver.cpp:321-358): the QoI vector integrates the
+    pressure over the fine elements whose eps-enlarged bounding box contains the point (ChangeMeshAttributes,
+    src/MeshUtilities.cpp:268-334: lower bounds inclusive, upper exclusive) and is restricted with P^T to the coarser
+    levels.  Third QoI examples/MLMC.cpp:228-236 can select, next to eff_perm and p_int."""
+    from parelagmc_amd.fe import build_darcy_problem, elements_near_points
+    from oracle.darcy_oracle import DarcyOracle
+    h = hex_hierarchy
+    m0 = h.spaces[0].mesh
+    # a vertex of the 16^3 mesh with the default eps of the Bayesian problem (0.01): the 8 cells around it
+    mark = elements_near_points(m0, [[1.0, 1.0, 1.0]], 0.01)[0]
+    assert mark.sum() == 8
+    cen = m0.verts[m0.elems].mean(axis=1)
+    assert np.allclose(np.abs(cen[mark] - 1.0).max(), 0.0625)
+    # a point on an upper cell boundary belongs to the next cell only when eps == 0 (half-open boxes)
+    assert elements_near_points(m0, [[0.125, 0.06, 0.06]], 0.0)[0].sum() == 1
+    dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], qoi="local_avg_p",
+                             qoi_point=(0.5, 0.5, 0.5), qoi_eps=0.1)
+    vol = [s.vol for s in h.spaces]
+    mk = elements_near_points(m0, [[0.5, 0.5, 0.5]], 0.1)[0]
+    assert mk.sum() == 8                                # eps 0.1 < h = 0.125: the two cells per direction that touch 0.5
+    assert elements_near_points(m0, [[0.5, 0.5, 0.5]], 0.13)[0].sum() == 64
+    for lvl, L in enumerate(dp.levels):
+        assert np.all(L.obs[:L.n_u] == 0.0)
+        assert np.isclose(L.obs[L.n_u:].sum(), vol[0][mk].sum())          # P^T keeps the integral's weight
+        assert np.all(L.obs[L.n_u:] <= vol[lvl] + 1e-15)
+    # k == 1: the exact pressure is linear between the two open faces, p = 0 on the observation face (attribute 1,
+    # z = 0) and p = 1 on the inflow face; RT0/P0 reproduces cell means of a linear field exactly
+    do = DarcyOracle(dp)
+    for lvl in range(3):
+        Q, _, sol = do.solve_fwd(lvl, np.ones(dp.levels[lvl].n_p), return_solution=True)
+        L = dp.levels[lvl]
+        assert np.isclose(Q, L.obs[L.n_u:] @ sol[L.n_u:])
+    Q0 = do.solve_fwd(0, np.ones(dp.levels[0].n_p))[0]
+    pbar = Q0 / vol[0][mk].sum()
+    assert 0.0 < abs(pbar) < 1.0
