@@ -202,3 +202,84 @@ def test_local_average_pressure_qoi_functional(hex_hierarchy):
     Q0 = do.solve_fwd(0, np.ones(dp.levels[0].n_p))[0]
     pbar = Q0 / vol[0][mk].sum()
     assert 0.0 < abs(pbar) < 1.0
+
+
+def _flux_dofs(sp_, field):
+    """RT0 degrees of freedom (total flux through every face along its GLOBAL normal) of a field that is affine with a
+    constant normal component per planar face: field(x_f) . n |f|, computed from the geometry alone."""
+    m, ft = sp_.mesh, sp_.faces
+    X = m.verts
+    nf = ft.face_verts.shape[0]
+    xf = X[ft.face_verts].mean(axis=1)
+    owner = ft.face_elem[:, 0]
+    xe = X[m.elems].mean(axis=1)[owner]
+    if m.etype == "tet":
+        v = X[ft.face_verts]
+        a = 0.5 * np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    elif m.etype == "tri":
+        v = X[ft.face_verts]
+        t = v[:, 1] - v[:, 0]
+        a = np.stack([t[:, 1], -t[:, 0]], axis=1)
+    else:                                   # axis-aligned boxes: the face is degenerate along exactly one axis
+        v = X[ft.face_verts]
+        ext = v.max(axis=1) - v.min(axis=1)
+        ax = np.argmin(ext, axis=1)
+        area = np.prod(np.where(np.arange(m.dim)[None, :] == ax[:, None], 1.0, ext), axis=1)
+        a = np.zeros((nf, m.dim))
+        a[np.arange(nf), ax] = area
+    a *= np.sign(np.einsum("fd,fd->f", a, xf - xe))[:, None]            # outward from the owner
+    # sign of the owner's local face in B tells whether the global normal is the owner's outward one
+    s_owner = np.asarray(sp_.B[owner, np.arange(nf)]).ravel()
+    return s_owner * np.einsum("fd,fd->f", field(xf), a), xf, s_owner
+
+
+@pytest.mark.parametrize("name", ["cube_tet", "square", "hex_box", "quad_box"])
+def test_rt0_p0_patch_test_without_the_oracle(name):
+    """Operator-level check of parelagmc_amd/fe that involves neither the oracle nor a solve (the oracle and the product
+    share these builders): for the affine pressure p = a.x + b with unit permeability the mixed form
+    (u, v) - (p, div v) = -<p, v.n> holds EXACTLY in RT0/P0 for u = -a, p_h = cell means of p, so
+      * B u = 0 for constant fields and B u = d |e| for u = x                        (discrete divergence)
+      * u1^T M u2 = int u1.u2 for fields in RT0 (constants, u = x)                    (mass matrix)
+      * (M u* - B^T p_h)_f = 0 on interior faces and = -(n_f.n_out) p(x_f) on boundary faces  (the patch test)
+    on tetrahedra, unstructured triangles, and boxes with unequal edge lengths."""
+    from parelagmc_amd.fe import box_mesh, build_spaces, mass_matrix, mesh_from_json, refine_uniform
+    if name in ("cube_tet", "square"):
+        mesh = mesh_from_json(golden_path("meshes", name + ".json"))
+        if name == "cube_tet":
+            mesh = refine_uniform(refine_uniform(mesh)[0])[0]
+    elif name == "hex_box":
+        mesh = box_mesh([3, 4, 5], [1.0, 2.0, 1.5], "hex", origin=[-0.25, 0.5, 0.0])
+    else:
+        mesh = box_mesh([5, 3], [2.0, 0.7], "quad")
+    s = build_spaces(mesh)
+    d = mesh.dim
+    M = mass_matrix(s.emass)
+    rng = np.random.Generator(np.random.PCG64(11))
+    c1, c2, a = rng.standard_normal(d), rng.standard_normal(d), rng.standard_normal(d)
+    b = 0.37
+    u1, xf, s_owner = _flux_dofs(s, lambda x: np.broadcast_to(c1, x.shape))
+    u2 = _flux_dofs(s, lambda x: np.broadcast_to(c2, x.shape))[0]
+    ux = _flux_dofs(s, lambda x: x)[0]
+    scale = np.abs(u1).max()
+    assert np.abs(s.B @ u1).max() < 1e-12 * scale
+    assert np.allclose(s.B @ ux, d * s.vol, rtol=1e-12, atol=1e-14)
+    vol = s.vol.sum()
+    assert np.isclose(u1 @ (M @ u2), vol * (c1 @ c2), rtol=1e-11)
+    # int |x|^2 over the mesh by a degree-2 exact rule on the same cells (vertices + centroid weights for simplices /
+    # tensor Simpson for boxes reduce to: |e| (|centroid|^2 + second-moment term)); use the element second moments
+    X = mesh.verts[mesh.elems]
+    xc = X.mean(axis=1)
+    if mesh.etype in ("tet", "tri"):
+        nv = d + 1
+        second = ((X - xc[:, None, :]) ** 2).sum(axis=(1, 2)) / (nv * (nv + 1))      # (1/|K|) int |x - c|^2
+    else:
+        ext = X.max(axis=1) - X.min(axis=1)
+        second = (ext ** 2).sum(axis=1) / 12.0
+    exact = (s.vol * ((xc ** 2).sum(axis=1) + second)).sum()
+    assert np.isclose(ux @ (M @ ux), exact, rtol=1e-11)
+    ustar = _flux_dofs(s, lambda x: np.broadcast_to(-a, x.shape))[0]
+    pbar = xc @ a + b
+    r = M @ ustar - s.B.T @ pbar
+    bdr = s.faces.face_elem[:, 1] < 0
+    assert np.abs(r[~bdr]).max() < 1e-12 * max(1.0, np.abs(pbar).max())
+    assert np.allclose(r[bdr], -s_owner[bdr] * (xf[bdr] @ a + b), rtol=1e-11, atol=1e-13)
