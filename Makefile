@@ -43,3 +43,16 @@ $(LABBIN): $(OBJDIR)/k5_lab.o $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -o $@ $(OBJDIR)/k5_lab.o $(OBJS) -ldl
 lab: $(LABBIN)
 .PHONY: lab
+
+# Boundary tests compiled from C and C++ (tests/test_abi_binaries.py runs them): the C program sees include/pmc.h only,
+# the C++ one the MFEM adapter (against tests/c/mfem_shim.hpp) and the mirror classes of parelagmc.hpp
+ABIBIN := tests/c/bin
+# (the libraries are order-only prerequisites: on a box that received the built .so files but not build/obj, nothing is rebuilt)
+$(ABIBIN)/abi_smoke: tests/c/abi_smoke.c tests/c/prob_io.h include/pmc.h | $(LIB)
+	@mkdir -p $(ABIBIN)
+	gcc -std=c11 -O1 -Wall -Wextra -Werror -Iinclude -Itests/c -o $@ tests/c/abi_smoke.c -Lparelagmc_amd/lib -lpmc -lm -Wl,-rpath,'$$ORIGIN/../../../parelagmc_amd/lib'
+$(ABIBIN)/adapter_smoke: tests/c/adapter_smoke.cpp tests/c/prob_io.h tests/c/mfem_shim.hpp parelagmc_amd/host/mfem_adapter.hpp parelagmc_amd/host/parelagmc.hpp include/pmc.h include/pmc_host.h | $(HOSTLIB)
+	@mkdir -p $(ABIBIN)
+	g++ -std=c++17 -O1 -Wall -Wextra -Iinclude -Itests/c -o $@ tests/c/adapter_smoke.cpp -Lparelagmc_amd/lib -lpmc_host -lpmc -pthread -Wl,-rpath,'$$ORIGIN/../../../parelagmc_amd/lib'
+test-abi: $(ABIBIN)/abi_smoke $(ABIBIN)/adapter_smoke
+.PHONY: test-abi

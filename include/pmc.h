@@ -171,6 +171,9 @@ int pmc_sampler_num_levels(const pmc_sampler* s);
 int pmc_sampler_xi_size(const pmc_sampler* s, int level);     /* size Sample() fills            */
 int pmc_sampler_sample_size(const pmc_sampler* s, int level); /* SampleSize(): size of Eval's s */
 int64_t pmc_sampler_nnz(const pmc_sampler* s, int level);     /* GetNNZ()                       */
+/* GetTrueP(level) (src/MLSampler.hpp:85-87, src/PDESampler.hpp:153-156): the prolongator of the s-space from level+1 to
+ * level as handed over at create time; the pointers stay valid for the life of the handle.  Error on the last level. */
+int pmc_sampler_true_p(const pmc_sampler* s, int level, pmc_csr* out);
 /* Sample(level, xi): xi ~ N(0, 1) of pmc_sampler_xi_size(level) entries per realization */
 int pmc_sampler_sample(pmc_sampler* s, int level, uint64_t first_sample_id, int nbatch, double* xi,
                        int memspace);

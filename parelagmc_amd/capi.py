@@ -83,6 +83,7 @@ SYMBOLS = {
     "pmc_sampler_xi_size": (C.c_int, [_VP, C.c_int]),
     "pmc_sampler_sample_size": (C.c_int, [_VP, C.c_int]),
     "pmc_sampler_nnz": (C.c_int64, [_VP, C.c_int]),
+    "pmc_sampler_true_p": (C.c_int, [_VP, C.c_int, C.POINTER(pmc_csr)]),
     "pmc_sampler_sample": (C.c_int, [_VP, C.c_int, C.c_uint64, C.c_int, _DP, C.c_int]),
     "pmc_sampler_eval": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _DP, _DP, _DP, C.c_int, C.c_int, _DP, C.c_int,
                                    C.POINTER(pmc_stats)]),
@@ -354,6 +355,17 @@ class PDESampler:
 
     def GetNNZ(self, level):
         return self.ctx.lib.pmc_sampler_nnz(self.h, level)
+
+    def GetTrueP(self, level):
+        """MLSampler::GetTrueP: the s-space prolongator from level+1 to level as a scipy CSR matrix (a copy)."""
+        import scipy.sparse as sp
+        c = pmc_csr()
+        _check(self.ctx.lib.pmc_sampler_true_p(self.h, level, C.byref(c)))
+        nnz = c.rowptr[c.nrows]
+        rp = np.ctypeslib.as_array(c.rowptr, shape=(c.nrows + 1,)).copy()
+        ci = np.ctypeslib.as_array(c.colind, shape=(nnz,)).copy()
+        v = np.ctypeslib.as_array(c.vals, shape=(nnz,)).copy()
+        return sp.csr_matrix((v, ci, rp), shape=(c.nrows, c.ncols))
 
     def Sample(self, level, first_id=0, nbatch=1, out=None):
         n = self.xi_size(level)

@@ -288,6 +288,15 @@ int pmc_sampler_sample_size(const pmc_sampler* s, int level) {
     if (!s || level < 0 || level >= s->impl.nlevels) return PMC_ERR_INVALID;
     return s->impl.lv[level].out_size;
 }
+int pmc_sampler_true_p(const pmc_sampler* s, int level, pmc_csr* out) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr && out != nullptr, "pmc_sampler_true_p: NULL argument");
+        PMC_REQUIRE(level >= 0 && level + 1 < s->impl.nlevels, "pmc_sampler_true_p: level has no coarser level");
+        const HostCsr& P = s->impl.lv[level].P_host;
+        *out = pmc_csr{P.nrows, P.ncols, P.rowptr.data(), P.colind.data(), P.vals.data()};
+    });
+}
+
 int64_t pmc_sampler_nnz(const pmc_sampler* s, int level) {
     if (!s || level < 0 || level >= s->impl.nlevels) return PMC_ERR_INVALID;
     return s->impl.lv[level].nnz;

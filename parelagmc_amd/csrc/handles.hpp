@@ -23,6 +23,7 @@ struct SamplerLevel {
     Sell Gt;
     DevBuf<int> gather;
     DevBuf<double> inv_w;
+    HostCsr P_host;         // ComputeTrueP(sform) as handed over (MLSampler::GetTrueP); empty on the last level
 };
 
 struct Sampler {

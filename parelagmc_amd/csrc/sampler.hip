@@ -183,6 +183,7 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
             HostCsr P = csr_from_c(L.P, true, "sampler P");
             PMC_REQUIRE(P.nrows == L.n_s && P.ncols == in[l + 1].n_s, "sampler P: wrong shape");
             HostCsr Pt = csr_transpose(P);
+            d.P_host = P;
             sell_build(m.P, P, true, false, st);
             sell_build(m.Pt, Pt, true, false, st);
             // injection-type prolongator (P0 on nested meshes): coarse correction folded into the post-smoothing

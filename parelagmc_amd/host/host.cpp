@@ -123,6 +123,14 @@ void PDESampler::Eval(const int level, const Vector& xi, Vector& s, Vector& u, b
     }
     last_iters_ = st[0].iterations;
 }
+void PDESampler::BuildHierarchy() {
+    if (!h_ || pmc_sampler_num_levels(h_) < 1) throw std::runtime_error("PDESampler::BuildHierarchy: no device handle");
+}
+pmc_csr PDESampler::GetTrueP(int level) const {
+    pmc_csr P{};
+    check(pmc_sampler_true_p(h_, level, &P), "PDESampler::GetTrueP");
+    return P;
+}
 int PDESampler::SampleSize(int level) const { return pmc_sampler_sample_size(h_, level); }
 size_t PDESampler::GetNNZ(int level) const { return (size_t)pmc_sampler_nnz(h_, level); }
 
@@ -131,6 +139,16 @@ void DarcySolver::SolveFwd(int ilevel, Vector& k, double* Q, double* C) {
     check(pmc_darcy_solve_fwd(h_, ilevel, k.Batch(), k.GetData(), Q, C, nullptr, k.MemSpace(), nullptr),
           "DarcySolver::SolveFwd");
 }
+void DarcySolver::SolveFwd_RtnPressure(int ilevel, Vector& k, Vector& P, double* C, double* Q, bool compute_Q) {
+    const int np = pmc_darcy_num_pressure_dofs(h_, ilevel);
+    if (np < 0) throw std::out_of_range("DarcySolver::SolveFwd_RtnPressure: level");
+    if (P.MemSpace() != k.MemSpace()) throw std::invalid_argument("SolveFwd_RtnPressure: k and P must share a memory space");
+    P.SetSize(np, k.Batch());
+    check(pmc_darcy_solve_fwd_pressure(h_, ilevel, k.Batch(), k.GetData(), P.GetData(), C, Q, compute_Q ? 1 : 0, k.MemSpace(),
+                                       nullptr),
+          "DarcySolver::SolveFwd_RtnPressure");
+}
+int DarcySolver::GetSizeOfStochasticData(int l) const { return pmc_darcy_num_pressure_dofs(h_, l); }
 int DarcySolver::GetNumberOfDofs(int l) const { return pmc_darcy_num_dofs(h_, l); }
 int DarcySolver::GetGlobalNumberOfDofs(int l) const { return pmc_darcy_num_dofs(h_, l); }
 int DarcySolver::GetNNZ(int l) const { return (int)pmc_darcy_nnz(h_, l); }

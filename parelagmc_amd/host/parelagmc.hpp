@@ -65,6 +65,12 @@ class MLSampler {
     virtual void Eval(const int level, const Vector& xi, Vector& s, Vector& u, bool use_init) = 0;
     virtual int SampleSize(int level) const = 0;
     virtual size_t GetNNZ(int level) const = 0;
+    /// Build the hierarchy of the sampler (src/MLSampler.hpp:64-66).  The operators arrive assembled through the C ABI,
+    /// so for handle-backed samplers this only checks that the handle exists; plugins may do real work here.
+    virtual void BuildHierarchy() {}
+    /// Prolongator of the sample space from level+1 to level (src/MLSampler.hpp:85-87; a HypreParMatrix there, a CSR
+    /// view with host pointers owned by the sampler here).  Default: not available.
+    virtual pmc_csr GetTrueP(int /*level*/) const { throw std::runtime_error("GetTrueP: not provided by this sampler"); }
 };
 
 class PhysicalMLSolver {
@@ -72,6 +78,21 @@ class PhysicalMLSolver {
     virtual ~PhysicalMLSolver() = default;
     /// Solve and update quantity of interest Q, cost C (arrays of k.Batch() entries)
     virtual void SolveFwd(int ilevel, Vector& k_over_k_ref, double* Q, double* C) = 0;
+    /// The reference's signature (src/PhysicalMLSolver.hpp:33-39): one realization, Q and C by reference
+    void SolveFwd(int ilevel, Vector& k_over_k_ref, double& Q, double& C) {
+        if (k_over_k_ref.Batch() != 1) throw std::invalid_argument("SolveFwd(double&, double&): one realization expected");
+        SolveFwd(ilevel, k_over_k_ref, &Q, &C);
+    }
+    /// Solve and return the pressure block P (k.Batch() x pressure dofs), cost C and, when compute_Q, the QoI Q
+    /// (src/PhysicalMLSolver.hpp:41-47).  Arrays of k.Batch() entries.
+    virtual void SolveFwd_RtnPressure(int /*ilevel*/, Vector& /*k_over_k_ref*/, Vector& /*P*/, double* /*C*/, double* /*Q*/,
+                                      bool /*compute_Q*/) {
+        throw std::runtime_error("SolveFwd_RtnPressure: not provided by this solver");
+    }
+    void SolveFwd_RtnPressure(int ilevel, Vector& k_over_k_ref, Vector& P, double& C, double& Q, bool compute_Q) {
+        if (k_over_k_ref.Batch() != 1) throw std::invalid_argument("SolveFwd_RtnPressure(double&, double&): one realization expected");
+        SolveFwd_RtnPressure(ilevel, k_over_k_ref, P, &C, &Q, compute_Q);
+    }
     virtual int GetNumberOfDofs(int ilevel) const = 0;
     virtual int GetGlobalNumberOfDofs(int ilevel) const = 0;
     virtual int GetNNZ(int ilevel) const = 0;
@@ -105,6 +126,8 @@ class PDESampler : public MLSampler {
     void Eval(const int level, const Vector& xi, Vector& s, Vector& u, bool use_init) override;
     int SampleSize(int level) const override;
     size_t GetNNZ(int level) const override;
+    void BuildHierarchy() override;
+    pmc_csr GetTrueP(int level) const override;
     int GetNumIters() const { return last_iters_; }   // the reference returns -1 (PDESampler.hpp:142-145)
 
   private:
@@ -118,7 +141,11 @@ class PDESampler : public MLSampler {
 class DarcySolver : public PhysicalMLSolver {
   public:
     DarcySolver(pmc_ctx* ctx, pmc_darcy* handle) : ctx_(ctx), h_(handle) {}
+    using PhysicalMLSolver::SolveFwd;
+    using PhysicalMLSolver::SolveFwd_RtnPressure;
     void SolveFwd(int ilevel, Vector& k_over_k_ref, double* Q, double* C) override;
+    void SolveFwd_RtnPressure(int ilevel, Vector& k_over_k_ref, Vector& P, double* C, double* Q, bool compute_Q) override;
+    int GetSizeOfStochasticData(int ilevel) const;   // entries of k (src/DarcySolver.hpp:127-130)
     int GetNumberOfDofs(int ilevel) const override;
     int GetGlobalNumberOfDofs(int ilevel) const override;
     int GetNNZ(int ilevel) const override;

@@ -1,0 +1,112 @@
+/* Boundary test in plain C: everything a C caller needs comes from include/pmc.h alone.  Builds the sampler and the
+ * Darcy solver from the CSR arrays of a problem file (written by tests/test_abi_binaries.py together with the oracle's
+ * expected fields / QoIs), evaluates them through the C ABI on host buffers and on device buffers, and compares.
+ * Usage: abi_smoke problem.bin      exit code 0 and a final line "abi_smoke OK" on success. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pmc.h"
+#include "prob_io.h"
+
+#define CHECK(call)                                                                        \
+    do {                                                                                   \
+        int rc_ = (call);                                                                  \
+        if (rc_ != PMC_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, pmc_last_error()); return 1; } \
+    } while (0)
+
+static pmc_csr as_csr(const t_csr* a) {
+    pmc_csr c;
+    c.nrows = a->nrows; c.ncols = a->ncols; c.rowptr = a->rp; c.colind = a->ci; c.vals = a->v;
+    return c;
+}
+static double rel_err(const double* a, const double* b, size_t n) {
+    double d = 0.0, s = 0.0;
+    for (size_t i = 0; i < n; ++i) { d += (a[i] - b[i]) * (a[i] - b[i]); s += b[i] * b[i]; }
+    return sqrt(d / s);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: abi_smoke problem.bin\n"); return 2; }
+    t_problem p = t_load(argv[1]);
+    printf("pmc version %d\n", pmc_version());
+    pmc_ctx* ctx = NULL;
+    CHECK(pmc_ctx_create(0, &ctx));
+    pmc_solver_opts opts;
+    pmc_solver_opts_default(&opts);
+    opts.rel_tol = 1e-12;
+    opts.abs_tol = 1e-30;
+    opts.max_iter = 400;
+
+    /* ---- sampler */
+    pmc_sampler_level* sl = (pmc_sampler_level*)calloc((size_t)p.s_nlevels, sizeof(pmc_sampler_level));
+    for (int l = 0; l < p.s_nlevels; ++l) {
+        sl[l].n_u = p.sl[l].n_u; sl[l].n_s = p.sl[l].n_s;
+        sl[l].M = as_csr(&p.sl[l].M); sl[l].B = as_csr(&p.sl[l].B); sl[l].w_diag = p.sl[l].w;
+        if (p.sl[l].has_p) sl[l].P = as_csr(&p.sl[l].P);
+    }
+    pmc_sampler* smp = NULL;
+    CHECK(pmc_sampler_create(ctx, p.s_nlevels, p.s_nlevels, sl, p.alpha, p.g, p.lognormal, &opts, &smp));
+    if (pmc_sampler_num_levels(smp) != p.s_nlevels) { fprintf(stderr, "level count\n"); return 1; }
+    for (int l = 0; l < p.s_nlevels; ++l) {
+        const int ns = pmc_sampler_sample_size(smp, l);
+        if (ns != p.sl[l].n_s || pmc_sampler_xi_size(smp, l) != ns) { fprintf(stderr, "sizes on level %d\n", l); return 1; }
+        double* s = (double*)malloc(8 * (size_t)p.nbatch * ns);
+        pmc_stats* st = (pmc_stats*)calloc((size_t)p.nbatch, sizeof(pmc_stats));
+        CHECK(pmc_sampler_eval(smp, l, 0, p.nbatch, p.xi, s, NULL, -1, 0, NULL, PMC_MEM_HOST, st));
+        const double e = rel_err(s, p.s_expect[l], (size_t)p.nbatch * ns);
+        printf("sampler level %d: rel. error vs oracle %.2e, %d iterations, converged %d\n", l, e, st[0].iterations, st[0].converged);
+        if (!(e < 1e-9) || st[0].converged != 1) return 1;
+        /* the same through device buffers */
+        void *dxi = NULL, *ds = NULL;
+        CHECK(pmc_malloc(ctx, 8 * (size_t)p.nbatch * p.sl[0].n_s, &dxi));
+        CHECK(pmc_malloc(ctx, 8 * (size_t)p.nbatch * ns, &ds));
+        CHECK(pmc_memcpy_h2d(ctx, dxi, p.xi, 8 * (size_t)p.nbatch * p.sl[0].n_s));
+        CHECK(pmc_sampler_eval(smp, l, 0, p.nbatch, (const double*)dxi, (double*)ds, NULL, -1, 0, NULL, PMC_MEM_DEVICE, NULL));
+        double* s2 = (double*)malloc(8 * (size_t)p.nbatch * ns);
+        CHECK(pmc_memcpy_d2h(ctx, s2, ds, 8 * (size_t)p.nbatch * ns));
+        if (memcmp(s, s2, 8 * (size_t)p.nbatch * ns) != 0) { fprintf(stderr, "host and device paths differ\n"); return 1; }
+        CHECK(pmc_free(ctx, dxi));
+        CHECK(pmc_free(ctx, ds));
+        free(s); free(s2); free(st);
+    }
+    /* error paths return codes, never abort */
+    if (pmc_sampler_eval(smp, p.s_nlevels, 0, 1, p.xi, p.xi, NULL, -1, 0, NULL, PMC_MEM_HOST, NULL) == PMC_OK) {
+        fprintf(stderr, "out-of-range level accepted\n");
+        return 1;
+    }
+    pmc_csr P0;
+    if (p.s_nlevels > 1) {
+        CHECK(pmc_sampler_true_p(smp, 0, &P0));
+        if (P0.nrows != p.sl[0].n_s || P0.ncols != p.sl[1].n_s) { fprintf(stderr, "GetTrueP shape\n"); return 1; }
+    }
+
+    /* ---- Darcy */
+    pmc_darcy_level* dl = (pmc_darcy_level*)calloc((size_t)p.d_nlevels, sizeof(pmc_darcy_level));
+    for (int l = 0; l < p.d_nlevels; ++l) {
+        const t_dlevel* L = &p.dl[l];
+        dl[l].n_u = L->n_u; dl[l].n_p = L->n_p;
+        dl[l].M_pattern = as_csr(&L->M);
+        dl[l].c_ptr = L->c_ptr; dl[l].c_elem = L->c_elem; dl[l].c_val = L->c_val;
+        dl[l].B = as_csr(&L->B);
+        dl[l].rhs = L->rhs; dl[l].ess_mask = L->ess; dl[l].ess_data = L->ess_data; dl[l].obs = L->obs;
+        if (L->has_p) dl[l].P = as_csr(&L->P);
+    }
+    pmc_darcy* dar = NULL;
+    CHECK(pmc_darcy_create(ctx, p.d_nlevels, p.d_nlevels, dl, p.k_divides, &opts, &dar));
+    for (int l = 0; l < p.d_nlevels; ++l) {
+        double* Q = (double*)malloc(8 * (size_t)p.nbatch);
+        double* C = (double*)malloc(8 * (size_t)p.nbatch);
+        CHECK(pmc_darcy_solve_fwd(dar, l, p.nbatch, p.k[l], Q, C, NULL, PMC_MEM_HOST, NULL));
+        const double e = rel_err(Q, p.q_expect[l], (size_t)p.nbatch);
+        printf("darcy level %d: Q[0] = %.12g, rel. error vs oracle %.2e, C = %g\n", l, Q[0], e, C[0]);
+        if (!(e < 1e-8) || C[0] != (double)(p.dl[l].n_u + p.dl[l].n_p)) return 1;
+        free(Q); free(C);
+    }
+    pmc_darcy_destroy(dar);
+    pmc_sampler_destroy(smp);
+    pmc_ctx_destroy(ctx);
+    printf("abi_smoke OK\n");
+    return 0;
+}

@@ -1,0 +1,147 @@
+// Boundary test in C++: (1) the MFEM adapter (parelagmc_amd/host/mfem_adapter.hpp) compiled against a stand-in for the
+// MFEM containers, driven the way ParELAGMC's managers drive MLSampler / PhysicalMLSolver; (2) the mirror classes of
+// parelagmc.hpp (PDESampler, DarcySolver, MLMC_Manager with the reference's names) used directly from C++.
+// Usage: adapter_smoke problem.bin      exit code 0 and a final line "adapter_smoke OK" on success.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "mfem_shim.hpp"
+
+#include "../../parelagmc_amd/host/mfem_adapter.hpp"
+#include "../../parelagmc_amd/host/parelagmc.hpp"
+
+extern "C" {
+#include "prob_io.h"
+}
+
+using namespace parelagmc;
+
+static double rel_err(const double* a, const double* b, size_t n) {
+    double d = 0.0, s = 0.0;
+    for (size_t i = 0; i < n; ++i) { d += (a[i] - b[i]) * (a[i] - b[i]); s += b[i] * b[i]; }
+    return std::sqrt(d / s);
+}
+static mfem::SparseMatrix to_mfem(const t_csr& a) { return mfem::SparseMatrix(a.nrows, a.ncols, a.rp, a.ci, a.v); }
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: adapter_smoke problem.bin\n"); return 2; }
+    t_problem p = t_load(argv[1]);
+    try {
+        pmc_solver_opts opts;
+        pmc_solver_opts_default(&opts);
+        opts.rel_tol = 1e-12;
+        opts.abs_tol = 1e-30;
+        opts.max_iter = 400;
+        // ---- operators as MFEM objects, as a ParELAGMC class holds them
+        std::vector<mfem::SparseMatrix> M, B, P, dM, dB, dP;
+        std::vector<mfem::Vector> w, rhs, ess_data, obs, c_val;
+        std::vector<mfem::Array<int>> c_ptr, c_elem, ess_dofs;
+        for (int l = 0; l < p.s_nlevels; ++l) {
+            M.push_back(to_mfem(p.sl[l].M));
+            B.push_back(to_mfem(p.sl[l].B));
+            w.emplace_back(p.sl[l].w, p.sl[l].n_s);
+            P.push_back(p.sl[l].has_p ? to_mfem(p.sl[l].P) : mfem::SparseMatrix());
+        }
+        std::vector<mfem_adapter::SamplerLevelOps> sops(p.s_nlevels);
+        for (int l = 0; l < p.s_nlevels; ++l) sops[l] = {&M[l], &B[l], &w[l], p.sl[l].has_p ? &P[l] : nullptr};
+        mfem_adapter::DevicePDESampler sampler(0, sops, p.s_nlevels, p.alpha, p.g, p.lognormal != 0, &opts, 7);
+        sampler.BuildHierarchy();
+        // the managers' protocol (src/MLMC_Manager.cpp:144-156): coarse Eval first, then fine with the coarse field as
+        // initial guess, one buffer threaded through as `u`
+        const int n0 = p.sl[0].n_s;
+        for (int b = 0; b < p.nbatch; ++b) {
+            mfem::Vector xi(p.xi + (size_t)b * n0, n0), s, u;
+            for (int l = p.s_nlevels - 1; l >= 0; --l) {
+                sampler.Eval(l, xi, s, u, l < p.s_nlevels - 1);
+                const double e = rel_err(s.GetData(), p.s_expect[l] + (size_t)b * p.sl[l].n_s, (size_t)p.sl[l].n_s);
+                if (!(e < 1e-9) || s.Size() != sampler.SampleSize(l) || u.Size() != p.sl[l].n_s) {
+                    std::fprintf(stderr, "adapter sampler level %d sample %d: rel. error %.2e\n", l, b, e);
+                    return 1;
+                }
+            }
+            mfem::Vector s2;
+            sampler.Eval(0, xi, s2);
+            if (!(rel_err(s2.GetData(), s.GetData(), (size_t)n0) < 1e-9)) { std::fprintf(stderr, "Eval overloads disagree\n"); return 1; }
+        }
+        mfem::Vector xr;
+        sampler.Sample(0, xr);
+        if (xr.Size() != n0) { std::fprintf(stderr, "Sample size\n"); return 1; }
+        std::printf("adapter sampler: %d levels, %d realizations, last solve %d iterations\n", p.s_nlevels, p.nbatch,
+                    sampler.GetNumIters());
+        if (p.s_nlevels > 1 && sampler.GetTrueP(0).nrows != n0) { std::fprintf(stderr, "GetTrueP\n"); return 1; }
+
+        for (int l = 0; l < p.d_nlevels; ++l) {
+            const t_dlevel& L = p.dl[l];
+            dM.push_back(to_mfem(L.M));
+            dB.push_back(to_mfem(L.B));
+            dP.push_back(L.has_p ? to_mfem(L.P) : mfem::SparseMatrix());
+            rhs.emplace_back(L.rhs, L.n_u + L.n_p);
+            ess_data.emplace_back(L.ess_data, L.n_u);
+            obs.emplace_back(L.obs, L.n_u + L.n_p);
+            c_val.emplace_back(L.c_val, L.ncontrib);
+            c_ptr.emplace_back(L.c_ptr, L.M.nnz + 1);
+            c_elem.emplace_back(L.c_elem, L.ncontrib);
+            std::vector<int> marked;
+            for (int i = 0; i < L.n_u; ++i)
+                if (L.ess[i]) marked.push_back(i);
+            ess_dofs.emplace_back(marked.data(), (int)marked.size());
+        }
+        std::vector<mfem_adapter::DarcyLevelOps> dops(p.d_nlevels);
+        for (int l = 0; l < p.d_nlevels; ++l)
+            dops[l] = {&dM[l], &c_ptr[l], &c_elem[l], &c_val[l], &dB[l], &rhs[l], &ess_dofs[l], &ess_data[l], &obs[l],
+                       p.dl[l].has_p ? &dP[l] : nullptr};
+        mfem_adapter::DeviceDarcySolver darcy(sampler.context(), dops, p.d_nlevels, p.k_divides != 0, &opts);
+        for (int l = 0; l < p.d_nlevels; ++l)
+            for (int b = 0; b < p.nbatch; ++b) {
+                mfem::Vector k(p.k[l] + (size_t)b * p.dl[l].n_p, p.dl[l].n_p), pr;
+                double Q = 0, C = 0, Q2 = 0, C2 = 0;
+                darcy.SolveFwd(l, k, Q, C);
+                darcy.SolveFwd_RtnPressure(l, k, pr, C2, Q2, true);
+                const double e = std::fabs(Q - p.q_expect[l][b]) / std::fabs(p.q_expect[l][b]);
+                if (!(e < 1e-8) || C != darcy.GetGlobalNumberOfDofs(l) || pr.Size() != darcy.GetSizeOfStochasticData(l) ||
+                    !(std::fabs(Q2 - Q) <= 1e-9 * std::fabs(Q))) {
+                    std::fprintf(stderr, "adapter darcy level %d sample %d: Q %.12g, expected %.12g\n", l, b, Q, p.q_expect[l][b]);
+                    return 1;
+                }
+            }
+        std::printf("adapter darcy: %d levels ok\n", p.d_nlevels);
+
+        // ---- the mirror classes with the reference's names, straight from C++
+        PDESampler ps(sampler.context(), sampler.handle());
+        DarcySolver dsolve(sampler.context(), darcy.handle());
+        ps.BuildHierarchy();
+        if (p.s_nlevels > 1 && ps.GetTrueP(0).ncols != p.sl[1].n_s) { std::fprintf(stderr, "mirror GetTrueP\n"); return 1; }
+        {
+            Vector k(sampler.context(), PMC_MEM_HOST), pr(sampler.context(), PMC_MEM_HOST);
+            k.SetSize(p.dl[0].n_p, 1);
+            std::memcpy(k.GetData(), p.k[0], sizeof(double) * (size_t)p.dl[0].n_p);
+            double Q = 0, C = 0, Q2 = 0, C2 = 0;
+            dsolve.SolveFwd(0, k, Q, C);                        // the reference's double& signature
+            dsolve.SolveFwd_RtnPressure(0, k, pr, C2, Q2, true);
+            if (!(std::fabs(Q - p.q_expect[0][0]) <= 1e-8 * std::fabs(Q)) || pr.Size() != p.dl[0].n_p || !(std::fabs(Q2 - Q) <= 1e-9 * std::fabs(Q))) {
+                std::fprintf(stderr, "mirror DarcySolver\n");
+                return 1;
+            }
+        }
+        pmc_mlmc_params mp;
+        pmc_mlmc_params_default(&mp);
+        mp.wall_time = 0;
+        mp.batch = 4;
+        MLMC_Manager mgr(sampler.context(), PMC_MEM_DEVICE, p.s_nlevels, dsolve, ps, mp);
+        std::vector<int> ns((size_t)p.s_nlevels, 6);
+        mgr.InitRun(ns);
+        double est = 0.0;
+        for (double e : mgr.eY) est += e;
+        for (int l = 0; l < p.s_nlevels; ++l)
+            if (mgr.level_nsamples[l] != 6 || !(mgr.varY[l] >= 0.0)) { std::fprintf(stderr, "manager counters\n"); return 1; }
+        if (!std::isfinite(est) || !(est > 0.0)) { std::fprintf(stderr, "manager estimate %g\n", est); return 1; }
+        std::printf("MLMC_Manager::InitRun on device vectors: estimate %.6f\n", est);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "exception: %s\n", e.what());
+        return 1;
+    }
+    std::printf("adapter_smoke OK\n");
+    return 0;
+}
