@@ -199,15 +199,16 @@ def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters
 def mlmc_config3(seed, lanes=4, opts=None, farm=None):
     """Secondary figure (BASELINE config 3): MLMC_Manager::InitRun with the SPDE sampler + Darcy QoI on cube_hex
     64^3 / 32^3 / 16^3, fixed sample counts, `lanes` concurrent streams.  Reported under "extra", never as `value`.
-    farm = (world, rank, uid): the realizations of every level are sharded over the ranks and the accumulators are
-    all-reduced through the library's own RCCL communicator (MLMC_Manager::SetFarm with reduce == NULL)."""
+    farm = (world, rank, comm_ctx, device): the realizations of every level are sharded over the ranks and the accumulators
+    are all-reduced through the library's own RCCL communicator of comm_ctx (MLMC_Manager::SetFarm with reduce == NULL)."""
     from parelagmc_amd import capi, host_api
     from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem
     h = build_hierarchy(box_mesh([4, 4, 4], [2, 2, 2], "hex"), 4)
     sp = build_sampler_problem(h, corlen=0.1, lognormal=True, n_mc_levels=3)
     dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], n_mc_levels=3)
     dev = farm[3] if farm else 0
-    ctxs = [capi.Context(dev, seed=seed) for _ in range(lanes)]
+    # farm: the manager's primary context is the one that carries the RCCL communicator
+    ctxs = ([farm[2]] if farm else []) + [capi.Context(dev, seed=seed) for _ in range(lanes - (1 if farm else 0))]
     sm = [capi.PDESampler(c, sp, opts) for c in ctxs]
     dr = [capi.DarcySolver(c, dp, opts) for c in ctxs]
     mgr = host_api.MLMCManager(3, sampler=sm[0], solver=dr[0], wall_time=True, batch=16)
@@ -215,9 +216,8 @@ def mlmc_config3(seed, lanes=4, opts=None, farm=None):
         mgr.add_lane(sm[i], dr[i])
     world = 1
     if farm:
-        world, rank, uid, _ = farm
-        ctxs[0].comm_init(uid, world, rank)          # RCCL communicator of the manager's primary context
-        mgr.set_farm(world, rank, None)              # reduce == NULL -> pmc_allreduce_sum_f64
+        world, rank = farm[0], farm[1]
+        mgr.set_farm(world, rank, None)              # reduce == NULL -> pmc_allreduce_sum_f64 (RCCL) of ctxs[0]
     mgr.InitRun([16 * lanes * world] * 3)       # warm-up: allocations
     mgr.Reset()
     ns = [64 * world, 256 * world, 1024 * world]
@@ -368,16 +368,32 @@ def main():
                         m["cpu_baseline"] = {"error": repr(e)}
                 extra["mlmc_config3"] = m
             else:
-                # every rank takes part: sharded InitRun, accumulators summed by pmc_allreduce_sum_f64 (RCCL)
+                # every rank takes part: sharded InitRun, accumulators summed by pmc_allreduce_sum_f64 (RCCL).  The
+                # communicator is set up and tried FIRST, and the ranks agree (torch.distributed) on whether it works, so
+                # that no rank enters the farm alone
                 uid = [None]
+                c0 = capi.Context(dev, seed=args.seed)
                 if rank == 0:
-                    c0 = capi.Context(dev, seed=args.seed)
                     uid[0] = c0.comm_unique_id()
-                    c0.close()
                 dist.broadcast_object_list(uid, src=0)
-                m, _ = mlmc_config3(args.seed, farm=(world, rank, uid[0], dev))
-                if rank == 0:
-                    extra["mlmc_farm"] = m
+                ok, why = 1, ""
+                try:
+                    c0.comm_init(uid[0], world, rank)
+                    probe = c0.allreduce_sum(np.array([1.0, float(rank)]))
+                    ok = 1 if probe[0] == float(world) else 0
+                except Exception as e:   # noqa: BLE001
+                    ok, why = 0, repr(e)
+                flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    m, _ = mlmc_config3(args.seed, farm=(world, rank, c0, dev))
+                    m["ranks_in_rccl_communicator"] = world
+                    if rank == 0:
+                        extra["mlmc_farm"] = m
+                else:
+                    c0.close()
+                    if rank == 0:
+                        extra["mlmc_farm"] = {"error": "RCCL communicator of the library not available on every rank: " + why}
         except Exception as e:   # noqa: BLE001 - the secondary figure must never cost the headline line
             extra["mlmc_config3" if world == 1 else "mlmc_farm"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_r6 and args.refine != 6:
