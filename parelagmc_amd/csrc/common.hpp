@@ -121,18 +121,17 @@ struct Sell {
     // [u-rows; s-rows] it interleaves the u- and s-slices of the same mesh region, so the x entries both
     // kinds of rows gather are fetched once while they are still in the XCD's L2.
     DevBuf<int> sched;
-    bool diag_first = false;   // slice column 0 holds the diagonal entry of every row (see sell_build)
     std::vector<int> h_slice_off, h_cols, h_src;  // host mirrors (h_src: slot -> csr nnz or -1)
     std::vector<int> h_sched;                     // host mirror of sched (empty = natural order)
     // algorithmic bytes of one SpMV with this matrix: 12 nnz + 12 nrows + 8 ncols
     double spmv_bytes() const { return 12.0 * nnz + 12.0 * nrows + 8.0 * ncols; }
 };
-// diag_first: every row stores its diagonal entry in slice column 0 (only if all rows have one; S.diag_first tells)
-void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st, bool diag_first = false);
+void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st);
 // values of A*diag(colscale) laid out on the SELL pattern S was built with (S must keep its host mirrors)
 std::vector<double> sell_scaled_values(const Sell& S, const HostCsr& A, const std::vector<double>& colscale);
-// schedule that merges the slices of row block [0, n0) with those of [n0, nrows) by relative position
-void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st);
+// schedule that merges the slices of row block [0, n0) with those of [n0, nrows): every second-block slice right behind
+// the first-block slices its rows reference (A given) or by relative position (A == nullptr)
+void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st, const HostCsr* A = nullptr);
 
 // ---- context ------------------------------------------------------------------------------
 // The two HIP streams one solve runs on.  Independent kernel chains (the two diagonal blocks of the preconditioner) are

@@ -170,13 +170,10 @@ __device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], doubl
 // sell_row_range works on `width` slice columns starting at slot `off`.  CS: every gathered x[col] is multiplied by a
 // second gathered per-realization vector cs[col] (column scaling A D^-1 without stored scaled values).  ZERO: acc is
 // cleared first, otherwise accumulated into.
-// x0 != nullptr: the x values gathered for slice column 0 are also returned in x0[rs][c] (for a matrix stored
-// diagonal-first these are the wavefront's own rows of x: the fused <x, Ax> needs no second read of x).
 template <int NB, bool BV, bool CS, bool ZERO, int JC = 1>
 __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
                                                const double* __restrict__ x, const double* __restrict__ cs, int off,
-                                               int width, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C],
-                                               double (*x0)[Lay<NB>::C] = nullptr) {
+                                               int width, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int g = lane / T, t = lane % T;
     if constexpr (ZERO) {
@@ -211,10 +208,6 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
                 if constexpr (BV) load_c<C>(vals + (size_t)(j + u < width ? slot + u * kWave : slot) * NB, av[u]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (x0 && j == 0) {
-#pragma unroll
-                for (int c = 0; c < C; ++c) x0[0][c] = xv[0][c];
-            }
 #pragma unroll
             for (int u = 0; u < JU; ++u)
 #pragma unroll
@@ -320,17 +313,18 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise re-serialises load -> wait -> fma
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
+#ifdef PMC_OFF32
+            // uniform base + 32-bit byte offset per lane: one VGPR of address instead of two, no 64-bit address arithmetic
+            if constexpr (!BV && !CS) {
+                const unsigned off = ((unsigned)cc[rs] * (unsigned)(NB * 8)) + (unsigned)(t * C * 8);
+                load_c<C>(reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + off), xv[rs]);
+            } else
+#endif
             load_c<C>(x + (size_t)cc[rs] * NB + t * C, xv[rs]);
             if constexpr (CS) load_c<C>(cs + (size_t)cc[rs] * NB + t * C, sv[rs]);
             if constexpr (BV) load_c<C>(vals + (size_t)(slot - lane + rs * G + g) * NB + t * C, av[rs]);
         }
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
-        if (x0 && j == 0) {
-#pragma unroll
-            for (int rs = 0; rs < T; ++rs)
-#pragma unroll
-                for (int c = 0; c < C; ++c) x0[rs][c] = xv[rs][c];
-        }
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
 #pragma unroll
@@ -354,23 +348,27 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
     sell_row_range<NB, BV, false, true>(cols, vals, x, nullptr, off, width, lane, acc);
 }
 
-// XCD-aware slice assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (block b runs
-// on XCD b % 8), and each XCD has its own 4 MiB L2.  Every workgroup takes one CONTIGUOUS chunk of slices, and
-// the chunks of the workgroups of one XCD are contiguous too, so an XCD sweeps one eighth of the rows and
-// the x entries its gathers touch (mesh neighbours = nearby indices) stay in that XCD's L2 instead of being
-// fetched by all eight.  Placement only affects speed, never results.
-__device__ __forceinline__ int first_slice(int nslices, int* slice_end) {
-    const int nblk = gridDim.x;
-    int rb = blockIdx.x;
-    if (nblk >= 8) {
-        const int per = nblk / 8, rem = nblk % 8;          // XCD x owns per + (x < rem) blocks
-        const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-        rb = xcd * per + (xcd < rem ? xcd : rem) + idx;
-    }
-    const int chunk = (nslices + nblk - 1) / nblk;
-    const int begin = rb * chunk;
-    *slice_end = min(begin + chunk, nslices);
-    return begin + (int)(threadIdx.x / kWave);
+// XCD-aware slice assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (block b runs on XCD b % 8),
+// and each XCD has its own 4 MiB L2.  XCD x owns one CONTIGUOUS eighth of the slices (in processing order), so the x
+// entries its gathers touch (mesh neighbours = nearby indices) stay in that XCD's L2 instead of being fetched by all
+// eight.  Inside the eighth the slices are dealt CYCLICALLY over the XCD's workgroups (block i of the XCD takes the
+// slices 4 i .. 4 i + 3, then those one full round of workgroups further on, ...): whatever the grid size, the slices
+// in flight on an XCD at any time form one compact window of the rows.  (With one contiguous chunk per workgroup - the
+// round-1 layout - a bounded grid of 4096 workgroups at 4.7 M rows had concurrently running workgroups 19 slices apart:
+// the window of x rows in flight was 5x wider than the L2 and x was fetched 3 times, 2.87 GB per launch against
+// 1.65 GB algorithmic.)  Placement only affects speed, never results.
+struct SliceWalk {
+    int begin, end, stride;
+};
+__device__ __forceinline__ SliceWalk slice_walk(int nslices) {
+    constexpr int WPB = kBlock / kWave;                     // wavefronts = slices per workgroup and round
+    const int nblk = gridDim.x, wave = threadIdx.x / kWave;
+    if (nblk < 8) return SliceWalk{(int)blockIdx.x * WPB + wave, nslices, nblk * WPB};
+    const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    const int nb_x = nblk / 8 + (xcd < nblk % 8 ? 1 : 0);   // workgroups of this XCD
+    const int per = (nslices + 7) / 8;                      // slices of an XCD (the last one may get fewer)
+    const int lo = min(xcd * per, nslices), hi = min(lo + per, nslices);
+    return SliceWalk{lo + idx * WPB + wave, hi, nb_x * WPB};
 }
 
 // MODE 0: y = Ax   1: y += Ax   2: y = r - Ax ; DOT: partial sums of <dot_with, result>.
@@ -393,18 +391,13 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    int slice_end;
-    for (int si = first_slice(nslices, &slice_end); si < slice_end; si += kBlock / kWave) {
+    const SliceWalk sw = slice_walk(nslices);
+    for (int si = sw.begin; si < sw.end; si += sw.stride) {
         const int slice = sched ? sched[si] : si;   // optional processing order (locality), see Sell::sched
         double acc[T][C];
-        [[maybe_unused]] double xd[T][C];
         if constexpr (TAG != 0 && !BV && T > 1 && kK5TwoColumns) {
             const int off = slice_off[slice];
             sell_row_range<NB, false, false, true, 2>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, acc);
-        } else if (DOT && !BV && dot_with == nullptr) {
-            // diagonal-first matrix: column 0 gathers the wavefront's own rows of x
-            const int off = slice_off[slice];
-            sell_row_range<NB, false, false, true>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, acc, xd);
         } else {
             sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
         }
@@ -427,12 +420,7 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                 store_c_stream<C>(y + at, acc[rs]);
                 if constexpr (DOT) {
                     double w[C];
-                    if (dot_with) {
-                        load_c<C>(dot_with + at, w);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) w[c] = xd[rs][c];
-                    }
+                    load_c<C>(dot_with + at, w);
 #pragma unroll
                     for (int c = 0; c < C; ++c) p[c] = fma(w[c], acc[rs][c], p[c]);
                 }
@@ -459,8 +447,8 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    int slice_end;
-    for (int si = first_slice(nslices, &slice_end); si < slice_end; si += kBlock / kWave) {
+    const SliceWalk sw = slice_walk(nslices);
+    for (int si = sw.begin; si < sw.end; si += sw.stride) {
         const int slice = sched ? sched[si] : si;
         double acc[T][C];
         sell_row_product<NB, BV>(slice_off, cols, vals, xin, slice, lane, acc);
@@ -522,8 +510,8 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    int slice_end;
-    for (int si = first_slice(nslices, &slice_end); si < slice_end; si += kBlock / kWave) {
+    const SliceWalk sw = slice_walk(nslices);
+    for (int si = sw.begin; si < sw.end; si += sw.stride) {
         const int slice = sched ? sched[si] : si;
         double acc[T][C];
         sell_row_product<NB, BV>(slice_off, cols, vals_scaled, r, slice, lane, acc);
@@ -580,8 +568,8 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    int slice_end;
-    for (int slice = first_slice(nslices, &slice_end); slice < slice_end; slice += kBlock / kWave) {
+    const SliceWalk sw = slice_walk(nslices);
+    for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C], acc2[T][C];
         sell_row_product<NB, true>(off1, cols1, vals1, x1, slice, lane, acc);
         sell_row_product<NB, false>(off2, cols2, vals2, x2, slice, lane, acc2);
@@ -647,8 +635,8 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    int slice_end;
-    for (int slice = first_slice(nslices, &slice_end); slice < slice_end; slice += kBlock / kWave) {
+    const SliceWalk sw = slice_walk(nslices);
+    for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
         eg_row_product<NB, false>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, acc);
         {
@@ -685,8 +673,8 @@ __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
-    int slice_end;
-    for (int slice = first_slice(nslices, &slice_end); slice < slice_end; slice += kBlock / kWave) {
+    const SliceWalk sw = slice_walk(nslices);
+    for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
         eg_row_product<NB, true>(cols, w, e12, coef, gw, r, dinv, nrows, slice, lane, acc);
 #pragma unroll
@@ -1765,7 +1753,7 @@ static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double*
 int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate, double* dot_partial,
          const double* dot_with) {
     if (A.nrows == 0) return 0;
-    if (dot_partial && !dot_with && A.bv) throw Error(PMC_ERR_INTERNAL, "spmm: the gathered-diagonal dot needs shared values");
+    if (dot_partial && !dot_with) throw Error(PMC_ERR_INTERNAL, "spmm: fused dot without its second vector");
     const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (A.tag == 1) spmm_launch<NB, 1>(st, g, A, x, y, accumulate, dot_partial, dot_with);

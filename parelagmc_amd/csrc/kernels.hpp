@@ -15,10 +15,13 @@ struct SellView {
     bool bv = false;
     const int* sched = nullptr;   // optional slice processing order
     int tag = 0;                  // 1 = block saddle-point operator (own kernel instantiation / profile row)
+    int ncols_hint = 0;           // number of columns (rows of x): kernels with 32-bit gather offsets check it
 };
-inline SellView view(const Sell& S) { return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, S.vals.p, false, S.sched.p}; }
+inline SellView view(const Sell& S) {
+    return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, S.vals.p, false, S.sched.p, 0, S.ncols};
+}
 inline SellView view_bv(const Sell& S, const double* vals) {
-    return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, vals, true, S.sched.p};
+    return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, vals, true, S.sched.p, 0, S.ncols};
 }
 
 // Element-grouped SELL view of a per-realization mass matrix M(k) = sum_e c(k_e) M_e: every row stores its entries in

@@ -126,8 +126,8 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
         }
         HostCsr A = csr_block2x2(M, Bt, B, maw.data());
         d.nnz = A.nnz();
-        sell_build(d.A, A, true, false, st, /*diag_first=*/true);
-        sell_schedule_two_blocks(d.A, L.n_u, st);
+        sell_build(d.A, A, true, false, st);
+        sell_schedule_two_blocks(d.A, L.n_u, st, &A);
         sell_build(d.M, M, true, true, st);
         std::vector<double> dM = csr_diag(M);
         for (double v : dM) PMC_REQUIRE(v > 0.0, "sampler M must have a positive diagonal");
@@ -358,10 +358,8 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     A.n = n;
     SellView Av = view(d.A);
     Av.tag = 1;
-    // A is stored diagonal-first: the fused <x, Ax> takes x from the gathers (dot_with == nullptr)
-    const bool diag_first = d.A.diag_first;
-    A.apply = [Av, diag_first](const Lanes& L, int nb_, const double* x, double* y, double* partial, double*) {
-        return k::DotParts{partial, k::spmm(L.main, nb_, Av, x, y, false, partial, diag_first ? nullptr : x)};
+    A.apply = [Av](const Lanes& L, int nb_, const double* x, double* y, double* partial, double*) {
+        return k::DotParts{partial, k::spmm(L.main, nb_, Av, x, y, false, partial, x)};
     };
     const SellView Mv = view(d.M);
     const double* dinvM = d.dinvM.p;

@@ -104,19 +104,8 @@ HostCsr csr_block2x2(const HostCsr& M, const HostCsr& Bt, const HostCsr& B, cons
     return A;
 }
 
-void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st, bool diag_first) {
+void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st) {
     PMC_REQUIRE(A.nrows == 0 || A.ncols > 0, "SELL: matrix with rows but no columns");
-    // position of the diagonal entry in every row (diag_first only when every row has one)
-    std::vector<int> dpos;
-    if (diag_first) {
-        dpos.assign(A.nrows, -1);
-        for (int r = 0; r < A.nrows && diag_first; ++r) {
-            for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p)
-                if (A.colind[p] == r) { dpos[r] = p - A.rowptr[r]; break; }
-            if (dpos[r] < 0) diag_first = false;
-        }
-    }
-    S.diag_first = diag_first && A.nrows > 0;
     S.nrows = A.nrows;
     S.ncols = A.ncols;
     S.nnz = A.nnz();
@@ -143,15 +132,12 @@ void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipS
             const int r = s * 64 + lane;
             const int pad_col = r < A.ncols ? r : 0;   // padding gathers a nearby (cached) entry, times 0
             const int b = r < A.nrows ? A.rowptr[r] : 0, e = r < A.nrows ? A.rowptr[r + 1] : 0;
-            const int dp = (S.diag_first && r < A.nrows) ? dpos[r] : 0;
             for (int j = 0; j < w; ++j) {
                 const int slot = off + j * 64 + lane;
                 if (b + j < e) {
-                    // diagonal first, the other entries keep their order: j = 0 -> dp, 1..dp -> j-1, beyond -> j
-                    const int src = b + (S.diag_first ? (j == 0 ? dp : (j <= dp ? j - 1 : j)) : j);
-                    S.h_cols[slot] = A.colind[src];
-                    if (upload_vals) hv[slot] = A.vals[src];
-                    if (keep_src) S.h_src[slot] = src;
+                    S.h_cols[slot] = A.colind[b + j];
+                    if (upload_vals) hv[slot] = A.vals[b + j];
+                    if (keep_src) S.h_src[slot] = b + j;
                 } else {
                     S.h_cols[slot] = pad_col;
                 }
@@ -175,13 +161,28 @@ std::vector<double> sell_scaled_values(const Sell& S, const HostCsr& A, const st
     return v;
 }
 
-void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st) {
+void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st, const HostCsr* A) {
     // slices [0, s0) lie (mostly) in the first row block, [s0, nslices) in the second
     const int s0 = (n0 + 63) / 64, s1 = S.nslices - s0;
     if (s0 <= 0 || s1 <= 0) return;
     std::vector<std::pair<double, int>> key(S.nslices);
-    for (int k = 0; k < s0; ++k) key[k] = {(k + 0.5) / s0, k};
-    for (int j = 0; j < s1; ++j) key[s0 + j] = {(j + 0.5) / s1, s0 + j};
+    for (int k = 0; k < s0; ++k) key[k] = {k + 0.5, k};
+    for (int j = 0; j < s1; ++j) {
+        // default: by relative position; with the matrix at hand: right behind the first-block slices its rows actually
+        // reference (their mean), so that both kinds of rows of one mesh region gather the same x rows at the same time.
+        // (The proportional rule drifts: dofs per element vary over the mesh, and at 596 k rows the two blocks were up
+        // to 80 slices apart - median distance between two uses of an x row 65 slices, 15 with the matrix-based key.)
+        double pos = (j + 0.5) / s1 * s0;
+        if (A) {
+            double sum = 0.0;
+            int64_t cnt = 0;
+            for (int r = n0 + j * 64; r < std::min(A->nrows, n0 + (j + 1) * 64); ++r)
+                for (int p = A->rowptr[r]; p < A->rowptr[r + 1]; ++p)
+                    if (A->colind[p] < n0) { sum += A->colind[p] / 64.0; ++cnt; }
+            if (cnt) pos = sum / cnt + 0.5;
+        }
+        key[s0 + j] = {pos + 1e-6, s0 + j};
+    }
     std::stable_sort(key.begin(), key.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
     std::vector<int> order(S.nslices);
     for (int i = 0; i < S.nslices; ++i) order[i] = key[i].second;

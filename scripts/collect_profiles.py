@@ -1,5 +1,7 @@
 """Copies the rocprofv3 summaries produced by scripts/make_profiles.sh (gpurun_out/) into profiles/ and recomputes
-profiles/pmc_traffic.json (HBM bytes per K5 launch from FETCH_SIZE / WRITE_SIZE with the gfx950 correction)."""
+profiles/pmc_traffic.json: HBM bytes per launch of the block operator K5 from FETCH_SIZE / WRITE_SIZE, corrected as
+MI355X_MICROARCH.md (HBM section) prescribes for gfx950 (FETCH_SIZE counts half the bytes of wide coalesced reads; the
+factor is cross-checked in the same pass on the flat lincomb3 kernel, whose byte count is known exactly)."""
 import collections
 import csv
 import json
@@ -9,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def find(d, suffix):
@@ -20,11 +22,13 @@ def find(d, suffix):
     raise FileNotFoundError(f"{d}/*{suffix}")
 
 
-shutil.copy(find("prof_bench", "kernel_stats.csv"), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
-with open(os.path.join(G, "prof_bench.log")) as f:
-    lines = [ln for ln in f if ln.startswith("{")]
-with open(os.path.join(P, f"{tag}_bench_output.log"), "w") as f:
-    f.write("# python bench.py under rocprofv3 --kernel-trace --stats (scripts/make_profiles.sh)\n" + lines[-1])
+for src, dst, what in (("prof_bench", "bench", "python bench.py"),
+                       ("prof_s1", "bench_s1", "python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-mlmc --no-r6")):
+    shutil.copy(find(src, "kernel_stats.csv"), os.path.join(P, f"{tag}_{dst}_kernel_stats.csv"))
+    with open(os.path.join(G, f"{src}.log")) as f:
+        lines = [ln for ln in f if ln.startswith("{")]
+    with open(os.path.join(P, f"{tag}_{dst}_output.log"), "w") as f:
+        f.write(f"# {what} under rocprofv3 --kernel-trace --stats (scripts/make_profiles.sh)\n" + lines[-1])
 
 
 def per_kernel(path):
@@ -35,31 +39,34 @@ def per_kernel(path):
     return acc
 
 
-fetch, write = per_kernel(find("pmc_fetch", "counter_collection.csv")), per_kernel(find("pmc_write", "counter_collection.csv"))
-for name, src in (("fetch_size", "pmc_fetch"), ("write_size", "pmc_write")):
-    acc = per_kernel(find(src, "counter_collection.csv"))
-    with open(os.path.join(P, f"{tag}_pmc_{name}.csv"), "w") as f:
-        f.write("kernel,launches,mean_counter_value_KB\n")
-        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-            f.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.3f}\n")
-
-
 def mean(d, key):
     v = [x for k, vals in d.items() if key in k for x in vals]
-    return sum(v) / len(v), len(v)
+    return (sum(v) / len(v), len(v)) if v else (None, 0)
 
 
 out = {}
-for nb in (16, 1):
-    key = f"sell_spmm_kernel<{nb}, false, 0, false, 2>"
-    fr, n = mean(fetch, key)
-    wr, _ = mean(write, key)
-    out[f"r5_nb{nb}"] = {"kernel": f"pmc::{key} on A", "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB_raw": wr,
-                         "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
-lf, _ = mean(fetch, "lincomb3_kernel<16>")
-out["r5_nb16"]["correction"] = ("FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section); cross-check in the same pass on the flat "
-                                f"lincomb3_kernel<16>: raw {lf:.0f} KB for 223488 KB actually read")
-out["r5_nb16"]["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 "
-                             "--streams 1 --no-cpu-baseline --no-mlmc (two separate passes, scripts/make_profiles.sh)")
+for refine, nvec in ((5, 595968), (6, 4743168)):
+    fetch = per_kernel(find(f"pmc_fetch_r{refine}", "counter_collection.csv"))
+    write = per_kernel(find(f"pmc_write_r{refine}", "counter_collection.csv"))
+    for name, acc in (("fetch_size", fetch), ("write_size", write)):
+        with open(os.path.join(P, f"{tag}_pmc_{name}_r{refine}.csv"), "w") as f:
+            f.write("kernel,launches,mean_counter_value_KB\n")
+            for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+                f.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.3f}\n")
+    lf, _ = mean(fetch, "lincomb3_kernel<16>")
+    read_kb = 3 * nvec * 16 * 8 / 1024.0
+    for key, kern in ((f"r{refine}_nb16_inloop", "sell_spmm_kernel<16, false, 0, true, 1>"),
+                      (f"r{refine}_nb16", "sell_spmm_kernel<16, false, 0, false, 2>"),
+                      (f"r{refine}_nb1", "sell_spmm_kernel<1, false, 0, false, 2>")):
+        fr, n = mean(fetch, kern)
+        wr, _ = mean(write, kern)
+        if fr is None or wr is None:
+            continue
+        out[key] = {"kernel": f"pmc::{kern} on A", "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB_raw": wr,
+                    "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
+    out[f"r{refine}_correction"] = ("FETCH_SIZE x2 on gfx950; cross-check in the same pass on the flat lincomb3_kernel<16>: raw "
+                                    f"{lf:.0f} KB for {read_kb:.0f} KB actually read (ratio {read_kb / lf:.3f})")
+out["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py [--refine 6] --steps 2 --warmup 1 "
+                  "--streams 1 --no-cpu-baseline --no-mlmc (separate passes, scripts/make_profiles.sh)")
 json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -69,6 +69,28 @@ __global__ __launch_bounds__(256) void lab_oneload_kernel(int nrows, int nslices
     }
 }
 
+// a copy with four independent 16-byte loads in flight per thread (the plain grid-stride copy above has one)
+__global__ __launch_bounds__(256) void lab_stream4_kernel(size_t n, const double2* __restrict__ a, double2* __restrict__ b) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const double2 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
+        b[i] = v0; b[i + stride] = v1; b[i + 2 * stride] = v2; b[i + 3 * stride] = v3;
+    }
+    for (; i < n; i += stride) b[i] = a[i];
+}
+// read-only streaming (sum), to separate read from write bandwidth
+__global__ __launch_bounds__(256) void lab_read_kernel(size_t n, const double2* __restrict__ a, double* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double s = 0.0;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const double2 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
+        s += (v0.x + v1.x) + (v2.x + v3.x);
+    }
+    if (s == 1.2345e300) out[0] = s;
+}
+
 template <class T>
 static std::vector<T> rd(FILE* f, size_t n) {
     std::vector<T> v(n);
@@ -159,17 +181,23 @@ int main(int argc, char** argv) {
     try {
         Sell S;
         sell_build(S, A, true, false, st);
-        sell_schedule_two_blocks(S, n_u, st);
+        sell_schedule_two_blocks(S, n_u, st, getenv("LAB_OLD_SCHED") ? nullptr : &A);
         SellView V = view(S);
         V.tag = 2;
         {
             // reference: a flat copy that moves the same 206.5 MB (half read, half written), and one moving 288 MB
-            DevBuf<double> ca((size_t)18 << 20), cb((size_t)18 << 20);
+            const size_t n1 = (size_t)(bytes / 32.0), n2 = (size_t)(bytes * 1.4 / 32.0);   // double2 elements
+            DevBuf<double> ca(4 * n1 + 2 * n2 + 16), cb(2 * n2 + 16);
             PMC_HIP(hipMemset(ca.p, 0, ca.n * 8));
-            const size_t n1 = (size_t)(bytes / 32.0), n2 = (size_t)(288e6 / 32.0);
             for (int fl_ = 0; fl_ < 2; ++fl_) {
                 timeit("flat copy, same bytes", fl_, [&] { lab_stream_kernel<<<4096, 256, 0, st>>>(n1, (const double2*)ca.p, (double2*)cb.p); });
-                timeit("flat copy, 288 MB (reported as 206)", fl_, [&] { lab_stream_kernel<<<4096, 256, 0, st>>>(n2, (const double2*)ca.p, (double2*)cb.p); });
+                for (unsigned gsz : {2048u, 8192u, 32768u}) {
+                    char nm[64];
+                    snprintf(nm, sizeof nm, "copy x4 unrolled, grid %u", gsz);
+                    timeit(nm, fl_, [&] { lab_stream4_kernel<<<gsz, 256, 0, st>>>(n1, (const double2*)ca.p, (double2*)cb.p); });
+                }
+                timeit("read only, same bytes", fl_, [&] { lab_read_kernel<<<8192, 256, 0, st>>>(2 * n1, (const double2*)ca.p, cb.p); });
+                timeit("flat copy, 1.4 x the bytes", fl_, [&] { lab_stream_kernel<<<4096, 256, 0, st>>>(n2, (const double2*)ca.p, (double2*)cb.p); });
             }
         }
         if (nb == 16) {

@@ -1,17 +1,25 @@
 #!/bin/bash
 # Regenerates the judged artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
-#   1. rocprofv3 --kernel-trace --stats of the DEFAULT bench command  -> gpurun_out/prof_bench/
-#   2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) on a short single-stream bench -> gpurun_out/pmc_{fetch,write}/
-# scripts/collect_profiles.py then copies the summaries into profiles/ (tracked).
+#   1. rocprofv3 --kernel-trace --stats of the DEFAULT bench command               -> gpurun_out/prof_bench/
+#   2. the same for one lane per GPU (--streams 1): per-kernel time without overlap -> gpurun_out/prof_s1/
+#   3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) on short single-lane runs at r = 5 and at the HBM-bound r = 6
+#                                                                                   -> gpurun_out/pmc_{fetch,write}_r{5,6}/
+# scripts/collect_profiles.py then copies the summaries into profiles/ (tracked) and rebuilds profiles/pmc_traffic.json.
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 420 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o b --output-format csv -- python3 $R/bench.py > $R/gpurun_out/prof_bench.log 2>&1 || exit 1
-rm -f $R/gpurun_out/prof_bench/*kernel_trace.csv $R/gpurun_out/prof_bench/*/*kernel_trace.csv
-echo "bench profile done"
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-mlmc > $R/gpurun_out/pmc_fetch.log 2>&1 || exit 1
-rm -f $R/gpurun_out/pmc_fetch/*kernel_trace.csv $R/gpurun_out/pmc_fetch/*/*kernel_trace.csv
-echo "fetch pass done"
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-mlmc > $R/gpurun_out/pmc_write.log 2>&1 || exit 1
-rm -f $R/gpurun_out/pmc_write/*kernel_trace.csv $R/gpurun_out/pmc_write/*/*kernel_trace.csv
-echo "write pass done"
+run() {   # name, then the bench arguments
+  local name=$1; shift
+  timeout -k 10 500 rocprofv3 "${PROF[@]}" -d $R/gpurun_out/$name -o p --output-format csv -- python3 $R/bench.py "$@" > $R/gpurun_out/$name.log 2>&1 || return 1
+  rm -f $R/gpurun_out/$name/*kernel_trace.csv $R/gpurun_out/$name/*/*kernel_trace.csv
+  echo "$name done"
+}
+PROF=(--kernel-trace --stats)
+run prof_bench || exit 1
+run prof_s1 --streams 1 --steps 40 --no-cpu-baseline --no-mlmc --no-r6 || exit 1
+for c in FETCH_SIZE WRITE_SIZE; do
+  PROF=(--kernel-trace --pmc $c)
+  n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+  run pmc_${n}_r5 --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-mlmc --no-r6 || exit 1
+  run pmc_${n}_r6 --refine 6 --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-mlmc || exit 1
+done
