@@ -78,34 +78,29 @@ __device__ __forceinline__ void store_c_nt(double* __restrict__ p, const double 
 #endif
 }
 
-// Streaming accesses (matrix values / indices read once, result rows written once): non-temporal, so that they do not
-// displace the gathered x rows - the only data with reuse - from the XCD's L2.
-template <int C>
+// Streaming accesses (matrix values / indices read once, result rows written once) with NT = true are non-temporal, so
+// that they do not displace the gathered x rows - the only data with reuse - from the XCD's L2.  Worth it only when the
+// operands exceed the 256 MiB Infinity Cache, which non-temporal accesses bypass: measured on the block operator at
+// 4.7 M rows (1.65 GB per launch) 460-475 -> 435-448 us inside the solver loop; at 0.6 M rows (206 MB, cache-resident when
+// launched back to back) 43 -> 55 us, and no change inside the loop.  The launcher picks NT by operand size.
+template <bool NT, int C>
 __device__ __forceinline__ void store_c_stream(double* __restrict__ p, const double (&v)[C]) {
-#if defined(PMC_STREAM_HINTS) || defined(PMC_STREAM_STORES)
-    if constexpr (C == 1) {
+    if constexpr (NT) {
         __builtin_nontemporal_store(v[0], p);
+        if constexpr (C == 2) __builtin_nontemporal_store(v[1], p + 1);
     } else {
-        __builtin_nontemporal_store(v[0], p);
-        __builtin_nontemporal_store(v[1], p + 1);
+        store_c<C>(p, v);
     }
-#else
-    store_c<C>(p, v);
-#endif
 }
+template <bool NT>
 __device__ __forceinline__ int load_stream(const int* __restrict__ p) {
-#if defined(PMC_STREAM_HINTS) || defined(PMC_STREAM_LOADS)
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
+template <bool NT>
 __device__ __forceinline__ double load_stream(const double* __restrict__ p) {
-#if defined(PMC_STREAM_HINTS) || defined(PMC_STREAM_LOADS)
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
 
 template <int NB>
@@ -170,7 +165,7 @@ __device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], doubl
 // sell_row_range works on `width` slice columns starting at slot `off`.  CS: every gathered x[col] is multiplied by a
 // second gathered per-realization vector cs[col] (column scaling A D^-1 without stored scaled values).  ZERO: acc is
 // cleared first, otherwise accumulated into.
-template <int NB, bool BV, bool CS, bool ZERO, int JC = 1>
+template <int NB, bool BV, bool CS, bool ZERO, int JC = 1, bool NT = false>
 __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
                                                const double* __restrict__ x, const double* __restrict__ cs, int off,
                                                int width, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
@@ -231,24 +226,24 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         int ca = 0, cb = 0;
         double va = 0.0, vb = 0.0;
         if (width > 0) {
-            ca = load_stream(cols + slot);
-            va = load_stream(vals + slot);
+            ca = load_stream<NT>(cols + slot);
+            va = load_stream<NT>(vals + slot);
             cb = ca;
             if (width > 1) {
-                cb = load_stream(cols + slot + kWave);
-                vb = load_stream(vals + slot + kWave);
+                cb = load_stream<NT>(cols + slot + kWave);
+                vb = load_stream<NT>(vals + slot + kWave);
             }
         }
         for (int j = 0; j < width; j += 2, slot += 2 * kWave) {
             int na = ca, nb_ = cb;
             double wa = 0.0, wb = 0.0;
             if (j + 2 < width) {
-                na = load_stream(cols + slot + 2 * kWave);
-                wa = load_stream(vals + slot + 2 * kWave);
+                na = load_stream<NT>(cols + slot + 2 * kWave);
+                wa = load_stream<NT>(vals + slot + 2 * kWave);
                 nb_ = na;
                 if (j + 3 < width) {
-                    nb_ = load_stream(cols + slot + 3 * kWave);
-                    wb = load_stream(vals + slot + 3 * kWave);
+                    nb_ = load_stream<NT>(cols + slot + 3 * kWave);
+                    wb = load_stream<NT>(vals + slot + 3 * kWave);
                 }
             }
             int cc0[T], cc1[T];
@@ -285,8 +280,8 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
     int cj = 0;
     double vj = 0.0;
     if (width > 0) {
-        cj = load_stream(cols + slot);
-        if constexpr (!BV) vj = load_stream(vals + slot);
+        cj = load_stream<NT>(cols + slot);
+        if constexpr (!BV) vj = load_stream<NT>(vals + slot);
     }
     for (int j = 0; j < width; ++j, slot += kWave) {
         // software pipeline: the next slice column's (value, index) pair is requested before this
@@ -294,8 +289,8 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         int cn = cj;
         double vn = vj;
         if (j + 1 < width) {
-            cn = load_stream(cols + slot + kWave);
-            if constexpr (!BV) vn = load_stream(vals + slot + kWave);
+            cn = load_stream<NT>(cols + slot + kWave);
+            if constexpr (!BV) vn = load_stream<NT>(vals + slot + kWave);
         }
         // phase 1: all cross-lane fetches, phase 2: all gathers (independent registers, so the T loads of a
         // slice column are in flight together), phase 3: FMAs
@@ -376,7 +371,7 @@ __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
 // TAG only names the instantiation: 1 = the block saddle-point operator (K5) inside the solver, 2 = the same operator
 // launched by pmc_sampler_apply_operator (the isolated roofline measurement), so that profiles show the
 // hot operator's launches on their own row; 0 = every other matrix (transfers, residuals, ...).
-template <int NB, bool BV, int MODE, bool DOT, int TAG>
+template <int NB, bool BV, int MODE, bool DOT, int TAG, bool NT = false>
 __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
@@ -398,6 +393,9 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
         if constexpr (TAG != 0 && !BV && T > 1 && kK5TwoColumns) {
             const int off = slice_off[slice];
             sell_row_range<NB, false, false, true, 2>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, acc);
+        } else if constexpr (NT) {
+            const int off = slice_off[slice];
+            sell_row_range<NB, BV, false, true, 1, true>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, acc);
         } else {
             sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
         }
@@ -417,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
 #pragma unroll
                     for (int c = 0; c < C; ++c) acc[rs][c] = rv[c] - acc[rs][c];
                 }
-                store_c_stream<C>(y + at, acc[rs]);
+                store_c_stream<NT, C>(y + at, acc[rs]);
                 if constexpr (DOT) {
                     double w[C];
                     load_c<C>(dot_with + at, w);
@@ -1291,6 +1289,29 @@ __global__ __launch_bounds__(kBlock) void gersh_scale_kernel(int nrows, const un
     store_row<NB>(dinv + (size_t)row * NB, d);
 }
 
+// First stage of a two-stage reduction for launches with many partial blocks: block j of kCompressBlocks sums the input
+// blocks j, j + kCompressBlocks, ... (fixed order: deterministic) into out[j][k].
+static constexpr int kCompressBlocks = 256;
+__global__ __launch_bounds__(256) void compress_partials_kernel(const double* __restrict__ in, int nblocks, int nb,
+                                                                double* __restrict__ out) {
+    __shared__ double lds[256];
+    const int k = threadIdx.x % nb, q = threadIdx.x / nb, nq = 256 / nb;
+    double s0 = 0.0, s1 = 0.0;
+    int b = blockIdx.x + kCompressBlocks * q;
+    for (; b + kCompressBlocks * nq < nblocks; b += 2 * kCompressBlocks * nq) {
+        s0 += in[(size_t)b * nb + k];
+        s1 += in[(size_t)(b + kCompressBlocks * nq) * nb + k];
+    }
+    if (b < nblocks) s0 += in[(size_t)b * nb + k];
+    lds[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+        double t = 0.0;
+        for (int g = 0; g < nq; ++g) t += lds[g * nb + threadIdx.x];
+        out[(size_t)blockIdx.x * nb + threadIdx.x] = t;
+    }
+}
+
 // out[k] = sum_b partial[b*nb+k]   (single block)
 __global__ __launch_bounds__(kScalBlock) void reduce_final_kernel(const double* __restrict__ partial, int nblocks, int nb,
                                                               double* __restrict__ out) {
@@ -1724,6 +1745,12 @@ static unsigned dot_grid_bound() {
 }
 static inline dim3 grid_bounded(dim3 g, bool bounded) { return bounded ? dim3(std::min(g.x, dot_grid_bound())) : g; }
 
+// non-temporal matrix / result streams for the block operator once its operands no longer fit the Infinity Cache
+static inline bool nt_streams(const SellView& A, int nb) {
+    const double bytes = 12.0 * (double)A.nslices * 64.0 * 6.0 + 16.0 * nb * (double)A.nrows;   // ~6 entries per row
+    return bytes > 256.0 * 1024.0 * 1024.0;
+}
+
 template <int NB, int TAG>
 static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double* x, double* y, bool accumulate,
                         double* dot_partial, const double* dot_with) {
@@ -1734,6 +1761,13 @@ static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double*
             sell_spmm_kernel<NB, true, 1, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
         else
             sell_spmm_kernel<NB, true, 0, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+    } else if (TAG != 0 && nt_streams(A, NB)) {
+        if (dot_partial)
+            sell_spmm_kernel<NB, false, 0, true, TAG, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+        else if (accumulate)
+            sell_spmm_kernel<NB, false, 1, false, TAG, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+        else
+            sell_spmm_kernel<NB, false, 0, false, TAG, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
     } else {
         if (dot_partial)
             sell_spmm_kernel<NB, false, 0, true, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
@@ -1754,13 +1788,27 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
          const double* dot_with) {
     if (A.nrows == 0) return 0;
     if (dot_partial && !dot_with) throw Error(PMC_ERR_INTERNAL, "spmm: fused dot without its second vector");
-    const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
+    dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
+    // The block operator keeps one slice per wavefront also with a fused dot (a bounded grid of looping workgroups cost
+    // 22 us of 450 at 4.7 M rows); its partial blocks - more than the single-block consumers should read - are first
+    // compressed to kCompressBlocks.  They are written behind the compressed ones: dot_capacity() leaves the room.
+    const bool two_stage = dot_partial && A.tag != 0 && !A.bv && grid_slices(A.nslices).x > g.x;
+    double* kernel_partial = dot_partial;
+    if (two_stage) {
+        g = grid_slices(A.nslices);
+        kernel_partial = dot_partial + (size_t)kCompressBlocks * nb;
+    }
     PMC_DISPATCH_NB(nb, {
-        if (A.tag == 1) spmm_launch<NB, 1>(st, g, A, x, y, accumulate, dot_partial, dot_with);
-        else if (A.tag == 2) spmm_launch<NB, 2>(st, g, A, x, y, accumulate, dot_partial, dot_with);
-        else spmm_launch<NB, 0>(st, g, A, x, y, accumulate, dot_partial, dot_with);
+        if (A.tag == 1) spmm_launch<NB, 1>(st, g, A, x, y, accumulate, kernel_partial, dot_with);
+        else if (A.tag == 2) spmm_launch<NB, 2>(st, g, A, x, y, accumulate, kernel_partial, dot_with);
+        else spmm_launch<NB, 0>(st, g, A, x, y, accumulate, kernel_partial, dot_with);
     });
     check_launch();
+    if (two_stage) {
+        compress_partials_kernel<<<kCompressBlocks, 256, 0, st>>>(kernel_partial, (int)g.x, nb, dot_partial);
+        check_launch();
+        return kCompressBlocks;
+    }
     return dot_partial ? (int)g.x : 0;
 }
 
