@@ -93,6 +93,8 @@ int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>&
 HostCsr prolongator_from_agg(const std::vector<int>& agg, int nc);
 
 HostCsr csr_spgemm(const HostCsr& A, const HostCsr& B);
+// P(i, i / 8) == 1 is the only entry of row i, for every row, and P has 8 rows per column
+bool csr_is_oct_injection(const HostCsr& P);
 double csr_anisotropy(const HostCsr& K);
 // lambda_min(D^-1 M) estimate (host Lanczos) and the M-block Chebyshev ratio derived from it
 double lanczos_lambda_min_scaled(const HostCsr& M, const std::vector<double>& dinv, int steps);

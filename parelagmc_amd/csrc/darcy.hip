@@ -444,6 +444,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
             HostCsr Pt = csr_transpose(Pl[l]);
             sell_build(m.P, Pl[l], true, false, st);
             sell_build(m.Pt, Pt, true, false, st);
+            m.p_oct = csr_is_oct_injection(Pl[l]);
         }
         PMC_HIP(hipStreamSynchronize(st));
     }

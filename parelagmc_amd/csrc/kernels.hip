@@ -371,7 +371,12 @@ __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
 // TAG only names the instantiation: 1 = the block saddle-point operator (K5) inside the solver, 2 = the same operator
 // launched by pmc_sampler_apply_operator (the isolated roofline measurement), so that profiles show the
 // hot operator's launches on their own row; 0 = every other matrix (transfers, residuals, ...).
-template <int NB, bool BV, int MODE, bool DOT, int TAG, bool NT = false>
+// R8 (with MODE 2, no DOT): the rows of the result are also summed in groups of 8 consecutive rows into
+// partial[(row / 8) * NB + k] - the restriction P^T res of a prolongator whose parent i has exactly the children
+// 8 i .. 8 i + 7 with unit weights (uniformly refined tetrahedra / hexahedra): a slice holds 8 whole groups, the sum is
+// a fixed xor tree over the lanes of a row step, and the separate restriction kernel (13 us of dependent latency for a
+// few MB) disappears from the V-cycle.
+template <int NB, bool BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false>
 __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                                                            const double* __restrict__ r,
                                                            const double* __restrict__ dot_with,
                                                            double* __restrict__ partial) {
+    static_assert(!R8 || (MODE == 2 && !DOT), "fused restriction goes with the residual");
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
@@ -422,6 +428,22 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
 #pragma unroll
                     for (int c = 0; c < C; ++c) p[c] = fma(w[c], acc[rs][c], p[c]);
                 }
+            } else if constexpr (R8) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;     // rows past the end add nothing to their group
+            }
+            if constexpr (R8) {
+                // lanes (g, t): the 8 rows of a group differ in the low three bits of g = lane / T
+                double s[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    double v = acc[rs][c];
+                    v += __shfl_xor(v, T, kWave);
+                    v += __shfl_xor(v, 2 * T, kWave);
+                    v += __shfl_xor(v, 4 * T, kWave);
+                    s[c] = v;
+                }
+                if ((g & 7) == 0 && row < nrows) store_c<C>(partial + (size_t)(row >> 3) * NB + t * C, s);
             }
         }
     }
@@ -1810,6 +1832,20 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
         return kCompressBlocks;
     }
     return dot_partial ? (int)g.x : 0;
+}
+
+void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out,
+                        double* coarse) {
+    if (A.nrows == 0) return;
+    if (A.nrows % 8 != 0) throw Error(PMC_ERR_INTERNAL, "residual_restrict8: rows are not groups of 8");
+    const dim3 g = grid_slices(A.nslices);
+    PMC_DISPATCH_NB(nb, {
+        if (A.bv)
+            sell_spmm_kernel<NB, true, 2, false, 0, false, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse);
+        else
+            sell_spmm_kernel<NB, false, 2, false, 0, false, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse);
+    });
+    check_launch();
 }
 
 void residual(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out) {

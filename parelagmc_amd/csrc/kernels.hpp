@@ -56,6 +56,10 @@ struct MinresState {
 // writes per-block partial sums of <dot_with, A x>; returns the number of partial blocks written.
 int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate,
           double* dot_partial, const double* dot_with);
+// out = r - A x and coarse[i] = sum of out over the rows 8 i .. 8 i + 7 (restriction with the transpose of an
+// "8 consecutive children, unit weights" prolongator); A.nrows must be a multiple of 8
+void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out,
+                        double* coarse);
 // out = r - A x
 void residual(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out);
 // Chebyshev / Jacobi step:  d = a*d + b*dinv.*(r - A xin);  xout = xin + d   (xin != xout).

@@ -186,6 +186,7 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
             d.P_host = P;
             sell_build(m.P, P, true, false, st);
             sell_build(m.Pt, Pt, true, false, st);
+            m.p_oct = csr_is_oct_injection(P);
             // injection-type prolongator (P0 on nested meshes): coarse correction folded into the post-smoothing
             bool injection = true;
             std::vector<int> parent(P.nrows, 0);

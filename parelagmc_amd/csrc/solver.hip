@@ -183,10 +183,14 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     const ChebParams& cp = cp_smooth;
     double* x = cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true);
     double* oth = (x == start) ? other : start;
-    k::residual(st, nb, A, r, x, lv.res.p);
     MgLevel& lc = L[l + 1];
     lc.ensure(nb);
-    k::spmm(st, nb, view(lv.Pt), lv.res.p, lc.r.p, false, nullptr, nullptr);
+    if (lv.p_oct) {
+        k::residual_restrict8(st, nb, A, r, x, lv.res.p, lc.r.p);
+    } else {
+        k::residual(st, nb, A, r, x, lv.res.p);
+        k::spmm(st, nb, view(lv.Pt), lv.res.p, lc.r.p, false, nullptr, nullptr);
+    }
     double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, side);
     if (lv.has_sp && !lv.bv && cheb_fused(cp, false)) {
         // r - S (x + P xc) = res - (S P) xc, in place; then x <- x + P xc + p2(that residual) in one pass

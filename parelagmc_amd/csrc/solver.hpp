@@ -72,6 +72,9 @@ struct MgLevel {
     Sell SP;
     DevBuf<int> parent;
     bool has_sp = false;
+    // P has exactly the children 8 i .. 8 i + 7 of parent i with unit weights (uniform refinement with contiguous
+    // children): the restriction is fused into the residual kernel (k::residual_restrict8)
+    bool p_oct = false;
     DevBuf<double> r, xa, xb, d, res;
     void ensure(int nb);
     SellView sview() const { return bv ? view_bv(S, vals_bv.p) : view(S); }

@@ -104,6 +104,13 @@ HostCsr csr_block2x2(const HostCsr& M, const HostCsr& Bt, const HostCsr& B, cons
     return A;
 }
 
+bool csr_is_oct_injection(const HostCsr& P) {
+    if (P.nrows != 8 * P.ncols || P.nrows == 0) return false;
+    for (int i = 0; i < P.nrows; ++i)
+        if (P.rowptr[i + 1] - P.rowptr[i] != 1 || P.colind[P.rowptr[i]] != i / 8 || P.vals[P.rowptr[i]] != 1.0) return false;
+    return true;
+}
+
 void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st) {
     PMC_REQUIRE(A.nrows == 0 || A.ncols > 0, "SELL: matrix with rows but no columns");
     S.nrows = A.nrows;

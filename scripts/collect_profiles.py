@@ -15,11 +15,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def find(d, suffix):
-    for root, _, files in os.walk(os.path.join(G, d)):
-        for f in files:
-            if f.endswith(suffix):
-                return os.path.join(root, f)
-    raise FileNotFoundError(f"{d}/*{suffix}")
+    """newest match (gpurun merges new files next to those of earlier runs)"""
+    hits = [os.path.join(root, f) for root, _, files in os.walk(os.path.join(G, d)) for f in files if f.endswith(suffix)]
+    if not hits:
+        raise FileNotFoundError(f"{d}/*{suffix}")
+    return max(hits, key=os.path.getmtime)
 
 
 for src, dst, what in (("prof_bench", "bench", "python bench.py"),

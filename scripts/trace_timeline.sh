@@ -2,7 +2,7 @@
 # kernel timeline of a short single-lane bench run (development aid): keeps the kernel trace, trimmed to the timed steps
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace -d $R/gpurun_out/trace -o t --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --streams ${STREAMS:-1} --no-cpu-baseline --no-mlmc > $R/gpurun_out/trace.log 2>&1 || exit 1
+rocprofv3 --kernel-trace -d $R/gpurun_out/trace -o t --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --streams ${STREAMS:-1} --no-cpu-baseline --no-mlmc --no-r6 > $R/gpurun_out/trace.log 2>&1 || exit 1
 f=$(find $R/gpurun_out/trace -name '*kernel_trace.csv' | head -1)
 python3 - "$f" $R/gpurun_out/trace_tail.csv <<'PY'
 import csv, sys
