@@ -176,7 +176,8 @@ def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters
     _, k_ms, k_bytes = smp.Mult(0, x, repeat=50)
     x1 = ctx.array(np.random.default_rng(0).standard_normal(L.n_u + L.n_s))
     _, k1_ms, k1_bytes = smp.Mult(0, x1, repeat=50)
-    loop_ms = solo_ms / max(solo_launches, 1)
+    # (hipGraph replay, opts.use_graph, cannot be bracketed by events: fall back to the isolated launches then)
+    loop_ms = solo_ms / solo_launches if solo_launches > 0 else k_ms
     ach = k_bytes / (loop_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, true, 1> (block operator K5 as launched by the "
                                      "MINRES loop: fused <u, Au>, one lane alone on the GPU)",

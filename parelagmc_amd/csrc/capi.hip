@@ -112,6 +112,7 @@ void pmc_solver_opts_default(pmc_solver_opts* o) {
     o->mini_max_rows = 6000;
     o->two_streams = 0;
     o->use_graph = 0;   // measured: no gain single-stream (kernels are latency-, not launch-bound), slower with 4 lanes
+    if (const char* e = getenv("PMC_USE_GRAPH")) o->use_graph = atoi(e);   // tuning override of the default
 }
 
 int pmc_ctx_create(int device_id, pmc_ctx** out) {

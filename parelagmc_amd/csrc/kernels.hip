@@ -964,13 +964,8 @@ __global__ __launch_bounds__(kScalBlock) void minres_init_kernel(k::MinresState*
     count_active(st, nb, false);
 }
 
-// after q = A u1 and d1 = <u1, q>
-__global__ __launch_bounds__(kScalBlock) void minres_scal1_kernel(k::MinresState* st, const double* __restrict__ partial,
-                                                              int nblocks, int nb, const double* __restrict__ partial2,
-                                                              int nblocks2) {
-    const double d1 = reduce_partials(partial, nblocks, nb, partial2, nblocks2);
-    const int k = threadIdx.x;
-    if (k >= nb) return;
+// after q = A u1 and d1 = <u1, q>   (thread k < nb owns column k)
+__device__ __forceinline__ void scal1_body(k::MinresState* st, int k, double d1) {
     if (st->active[k]) {
         const double beta = st->beta[k];
         const double ib = 1.0 / beta;
@@ -986,36 +981,59 @@ __global__ __launch_bounds__(kScalBlock) void minres_scal1_kernel(k::MinresState
         st->cV[0][k] = st->cV[1][k] = st->cV[2][k] = 0.0;
     }
 }
-
 // after z_new = prec(v_new) and d2 = <v_new, z_new>
+__device__ __forceinline__ void scal2_body(k::MinresState* st, int k, double d2) {
+    if (st->active[k]) {
+        if (d2 < 0.0 || d2 != d2) st->flag[k] = -1;
+        const double beta_new = d2 > 0.0 ? sqrt(d2) : 0.0;
+        const double delta = st->delta[k];
+        const double rho1 = hypot(delta, beta_new);
+        const double ir = rho1 > 0.0 ? 1.0 / rho1 : 0.0;
+        st->cW[0][k] = ir / st->beta[k];
+        st->cW[1][k] = -st->rho3[k] * ir;
+        st->cW[2][k] = -st->rho2[k] * ir;
+        st->gamma0[k] = st->gamma1[k];
+        st->gamma1[k] = delta * ir;
+        st->cW[3][k] = st->gamma1[k] * st->eta[k];
+        st->sigma0[k] = st->sigma1[k];
+        st->sigma1[k] = beta_new * ir;
+        st->eta[k] = -st->sigma1[k] * st->eta[k];
+        st->beta_old[k] = st->beta[k];
+        st->beta[k] = beta_new;
+        st->iters[k] = st->it + 1;
+        if (fabs(st->eta[k]) <= st->goal[k] || beta_new == 0.0 || st->flag[k] != 0) st->active[k] = 0;
+    } else {
+        st->cW[0][k] = st->cW[1][k] = st->cW[2][k] = st->cW[3][k] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(kScalBlock) void minres_scal1_kernel(k::MinresState* st, const double* __restrict__ partial,
+                                                              int nblocks, int nb, const double* __restrict__ partial2,
+                                                              int nblocks2) {
+    const double d1 = reduce_partials(partial, nblocks, nb, partial2, nblocks2);
+    if ((int)threadIdx.x < nb) scal1_body(st, threadIdx.x, d1);
+}
+
 __global__ __launch_bounds__(kScalBlock) void minres_scal2_kernel(k::MinresState* st, const double* __restrict__ partial,
                                                               int nblocks, int nb, const double* __restrict__ partial2,
                                                               int nblocks2) {
     const double d2 = reduce_partials(partial, nblocks, nb, partial2, nblocks2);
-    const int k = threadIdx.x;
-    if (k < nb) {
-        if (st->active[k]) {
-            if (d2 < 0.0 || d2 != d2) st->flag[k] = -1;
-            const double beta_new = d2 > 0.0 ? sqrt(d2) : 0.0;
-            const double delta = st->delta[k];
-            const double rho1 = hypot(delta, beta_new);
-            const double ir = rho1 > 0.0 ? 1.0 / rho1 : 0.0;
-            st->cW[0][k] = ir / st->beta[k];
-            st->cW[1][k] = -st->rho3[k] * ir;
-            st->cW[2][k] = -st->rho2[k] * ir;
-            st->gamma0[k] = st->gamma1[k];
-            st->gamma1[k] = delta * ir;
-            st->cW[3][k] = st->gamma1[k] * st->eta[k];
-            st->sigma0[k] = st->sigma1[k];
-            st->sigma1[k] = beta_new * ir;
-            st->eta[k] = -st->sigma1[k] * st->eta[k];
-            st->beta_old[k] = st->beta[k];
-            st->beta[k] = beta_new;
-            st->iters[k] = st->it + 1;
-            if (fabs(st->eta[k]) <= st->goal[k] || beta_new == 0.0 || st->flag[k] != 0) st->active[k] = 0;
-        } else {
-            st->cW[0][k] = st->cW[1][k] = st->cW[2][k] = st->cW[3][k] = 0.0;
-        }
+    if ((int)threadIdx.x < nb) scal2_body(st, threadIdx.x, d2);
+    count_active(st, nb, true);
+}
+
+// Both scalar steps in one launch: the recurrences of iteration i (from <v_new, z_new>) and, with the operator product
+// of iteration i + 1 already done, the first half of iteration i + 1 (from <z_new, A z_new>).  One single-block launch
+// per iteration instead of two.
+__global__ __launch_bounds__(kScalBlock) void minres_scal21_kernel(k::MinresState* st, const double* __restrict__ pa,
+                                                               int na, const double* __restrict__ pa2, int na2,
+                                                               const double* __restrict__ pb, int nbk,
+                                                               const double* __restrict__ pb2, int nbk2, int nb) {
+    const double d2 = reduce_partials(pa, na, nb, pa2, na2);
+    const double d1 = reduce_partials(pb, nbk, nb, pb2, nbk2);
+    if ((int)threadIdx.x < nb) {
+        scal2_body(st, threadIdx.x, d2);
+        scal1_body(st, threadIdx.x, d1);          // same thread, same column: sees the state scal2 has just written
     }
     count_active(st, nb, true);
 }
@@ -2043,6 +2061,10 @@ void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d) {
 }
 void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d) {
     minres_scal2_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, d.p2, d.n2);
+    check_launch();
+}
+void minres_scal21(hipStream_t st, int nb, MinresState* s, const DotParts& d2, const DotParts& d1) {
+    minres_scal21_kernel<<<1, kScalBlock, 0, st>>>(s, d2.p1, d2.n1, d2.p2, d2.n2, d1.p1, d1.n1, d1.p2, d1.n2, nb);
     check_launch();
 }
 

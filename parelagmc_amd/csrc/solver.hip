@@ -339,13 +339,18 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         }
     };
     // one MINRES iteration with explicit roles of the ping-pong vectors; on entry q = A u1_ and its dot are in place
+    // (the first scalar step of an iteration - alpha and the Lanczos coefficients from <u, Au> - has already been done: by
+    // the prologue for the first iteration, by the fused scalar launch of the previous iteration otherwise)
     auto iteration = [&](double* u0_, double* u1_, double* v0_, double* v1_, double* w0_, double* w1_, bool last) {
-        k::minres_scal1(st, nb, S, dp_op);
         k::lincomb3(st, nb, n, cV0, q, cV1, v1_, cV2, v0_);
         k::DotParts d2 = prec(L, nb, v0_, u0_, w.partial.p, w.partial.p + seg2);
         if (d2.total() == 0) d2 = k::DotParts{w.partial.p, k::dot(st, nb, n, v0_, u0_, w.partial.p)};
-        if (!last) apply_op(u0_);
-        k::minres_scal2(st, nb, S, d2);
+        if (!last) {
+            apply_op(u0_);
+            k::minres_scal21(st, nb, S, d2, dp_op);
+        } else {
+            k::minres_scal2(st, nb, S, d2);
+        }
         if (x_rows) k::minres_wx_idx(st, nb, x_nrows, x_rows, cW0, u1_, cW1, w0_, cW2, w1_, cW3, x);
         else k::minres_wx(st, nb, x_nrows, cW0, u1_ + xoff, cW1, w0_, cW2, w1_, cW3, x + xoff);
     };
@@ -365,7 +370,10 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         auto f = w.iter_hint.find(hint_key);
         if (f != w.iter_hint.end()) first_poll = std::max(0, f->second - 4);
     }
-    if (n_active > 0 && o.max_iter > 0) apply_op(u1);
+    if (n_active > 0 && o.max_iter > 0) {
+        apply_op(u1);
+        k::minres_scal1(st, nb, S, dp_op);
+    }
     const bool graphs = hint.key != 0 && o.use_graph != 0 && every == 2;
     if (graphs) {
         // hipGraph path: the first pair runs eagerly (it also performs every lazy allocation), later pairs replay one
