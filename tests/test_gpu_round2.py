@@ -181,3 +181,77 @@ def test_two_rank_rccl_allreduce_of_the_accumulators(tmp_path):
     ref = np.arange(30, dtype=np.float64) * 3.0
     for o in outs:
         assert np.array_equal(np.load(o), ref)
+
+
+def test_full_size_config4_embedded_level_pairs(gpu_ctx):
+    """BASELINE config 4 at FULL size on one GPU: EmbeddedPDESampler on cube_tet_embed.mesh refined 4 times (831 488
+    tetrahedra, 2.5 M DoF on the finest of 3 Monte Carlo levels; 225 280 / 28 160 / 3 520 original elements), log-normal.
+    Size-independent properties: the level pairs the manager drives (coarse Eval, then fine Eval warm-started from the
+    coarse Gaussian field) converge on every level, s = exp(embedded field restricted to the original elements), a batch
+    equals its single evaluations, and the sample variance of the log-field has the magnitude the SPDE scaling gives."""
+    from conftest import golden_path
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hierarchy, build_sampler_problem, mesh_from_json
+    h = build_hierarchy(mesh_from_json(golden_path("meshes", "cube_tet_embed.json")), 4)
+    sp_ = build_sampler_problem(h, corlen=0.1, embedded=True, lognormal=True, n_mc_levels=3)
+    assert [L.n_u + L.n_s for L in sp_.levels[:3]] == [2502400, 313792, 39472]
+    assert [len(i) for i in sp_.orig_index] == [225280, 28160, 3520]
+    smp = capi.PDESampler(gpu_ctx, sp_, projection="gather")
+    nb = 4
+    for lvl in (2, 1, 0):
+        xi = smp.Sample(lvl, first_id=100 * lvl, nbatch=nb)
+        if lvl < 2:
+            _, ec, stc = smp.Eval(lvl + 1, xi, xi_level=lvl, want_embed=True, return_stats=True)
+            s, emb, st = smp.Eval(lvl, xi, xi_level=lvl, init_s=ec, init_level=lvl + 1, use_init=True, want_embed=True,
+                                  return_stats=True)
+            assert all(t[1] == 1 for t in stc)
+        else:
+            s, emb, st = smp.Eval(lvl, xi, want_embed=True, return_stats=True)
+        assert all(t[1] == 1 and 0 < t[0] <= 150 for t in st), st
+        assert s.shape == (nb, len(sp_.orig_index[lvl])) and emb.shape == (nb, sp_.levels[lvl].n_s)
+        assert np.allclose(s, np.exp(emb[:, sp_.orig_index[lvl]]), rtol=1e-12)
+        one = smp.Eval(lvl, xi[1:2], xi_level=lvl)
+        cold = smp.Eval(lvl, xi, xi_level=lvl)                 # no warm start: same solution within the solver tolerance
+        assert rel(one[0], cold[1]) < 1e-9
+        assert rel(np.log(cold), np.log(s)) < 1e-4
+        v = np.log(s).var()
+        assert 2.0 < v < 4.5, v                                 # Gamma(nu + d) scaling: 3.3 away from the boundary
+    smp.close()
+
+
+def test_full_size_config5_spe10_box_four_levels(gpu_ctx):
+    """BASELINE config 5 at FULL size on one GPU: SPE10-shaped box 1200 x 2200 x 170 (56 x 216 x 80 = 967 680 hexahedra, 3.9 M
+    Darcy DoF), L2ProjectionPDESampler on the box enlarged by one coarse cell per side (6.5 M DoF), correlation length 100,
+    FOUR levels, stretched cells (algebraic Schur hierarchies are selected automatically).  RNG-free known answer: with
+    k == 1 and the reference's boundary conditions (flow along y, spe10_3D_parameters.xml:45-49) the flux through the
+    observation face is k dp / L x area = 1200 * 170 / 2200 on every level; plus convergence on every level and one MLMC
+    round through the manager."""
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import (box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem,
+                                  l2_projection_hierarchy)
+    nx, ny, nz = 7, 27, 10
+    hx, hy, hz = 1200.0 / nx, 2200.0 / ny, 170.0 / nz
+    ho = build_hierarchy(box_mesh([nx, ny, nz], [1200.0, 2200.0, 170.0], "hex"), 3)
+    he = build_hierarchy(box_mesh([nx + 2, ny + 2, nz + 2], [1200.0 + 2 * hx, 2200.0 + 2 * hy, 170.0 + 2 * hz], "hex",
+                                  origin=[-hx, -hy, -hz]), 3)
+    sp_ = build_sampler_problem(he, corlen=100.0, lognormal=True)
+    dp = build_darcy_problem(ho, [1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0])
+    assert [L.ndofs for L in dp.levels] == [3904576, 492304, 62596, 8089]
+    smp = capi.PDESampler(gpu_ctx, sp_, projection="l2", l2_ops=l2_projection_hierarchy(ho, he))
+    ds = capi.DarcySolver(gpu_ctx, dp)
+    exact = 1200.0 * 170.0 / 2200.0
+    for lvl in range(4):
+        Q1, C1, st1 = ds.SolveFwd(lvl, np.ones((1, dp.levels[lvl].n_p)), return_stats=True)
+        assert abs(Q1[0] - exact) < 1e-4 * exact and st1[0][1] == 1 and C1[0] == dp.levels[lvl].ndofs
+        xi = smp.Sample(lvl, first_id=7, nbatch=2)
+        s, st = smp.Eval(lvl, xi, return_stats=True)
+        Q, _, st2 = ds.SolveFwd(lvl, s, return_stats=True)
+        assert all(t[1] == 1 for t in st) and all(t[1] == 1 and t[0] <= 200 for t in st2), (lvl, st, st2)
+        assert s.shape[1] == dp.levels[lvl].n_p and np.all(s > 0) and np.all(Q > 0)
+    mgr = host_api.MLMCManager(4, sampler=smp, solver=ds, wall_time=True, batch=16)
+    r = mgr.InitRun([4, 8, 16, 32])
+    assert list(r["nsamples"]) == [4, 8, 16, 32] and np.isfinite(r["estimate"]) and r["estimate"] > 0
+    assert np.all(np.asarray(r["varY"]) >= 0)
+    mgr.close()
+    ds.close()
+    smp.close()
