@@ -614,6 +614,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     const double* coefp = d.coef.p;
     LinOp A;
     A.n = n;
+    A.n0 = n_u;
     A.apply = [=](const Lanes& L, int nb_, const double* x, double* y, double* partial, double* partial2) {
         // u-rows: M(k) x_u + B^T x_p in one pass; p-rows: B x_u (beside it on the second stream); <x, Ax> fused into both
         const double* xp = x + (size_t)n_u * nb_;

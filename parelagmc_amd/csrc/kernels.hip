@@ -1038,6 +1038,41 @@ __global__ __launch_bounds__(kScalBlock) void minres_scal21_kernel(k::MinresStat
     count_active(st, nb, true);
 }
 
+// First stage for long partial lists (a fine-level iteration hands ~4 600 blocks x nb values to the single-block scalar
+// kernel, which then spends ~19 us on load latency alone): kStageBlocks workgroups sum contiguous chunks of the two dot
+// products' lists into stage[list][g][nb]; the scalar kernel adds the kStageBlocks chunk sums in index order.  Fixed chunking
+// and fixed order: deterministic.
+static constexpr int kStageBlocks = 64;
+__global__ __launch_bounds__(256) void stage_partials_kernel(const double* __restrict__ pa, int na,
+                                                             const double* __restrict__ pa2, int na2,
+                                                             const double* __restrict__ pb, int nbk,
+                                                             const double* __restrict__ pb2, int nbk2, int nb,
+                                                             double* __restrict__ stage) {
+    __shared__ double lds[2][256];
+    const int g = blockIdx.x, k = threadIdx.x % nb, q = threadIdx.x / nb, nq = 256 / nb;
+    auto chunk = [&](const double* __restrict__ p, int n) {
+        const int per = (n + kStageBlocks - 1) / kStageBlocks;
+        const int lo = min(n, g * per), hi = min(n, lo + per);
+        double a = 0.0, b = 0.0;
+        int i = lo + q;
+        for (; i + nq < hi; i += 2 * nq) {
+            a += p[(size_t)i * nb + k];
+            b += p[(size_t)(i + nq) * nb + k];
+        }
+        if (i < hi) a += p[(size_t)i * nb + k];
+        return a + b;
+    };
+    lds[0][threadIdx.x] = chunk(pa, na) + chunk(pa2, na2);
+    lds[1][threadIdx.x] = chunk(pb, nbk) + chunk(pb2, nbk2);
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * nb) {
+        const int list = threadIdx.x / nb, c = threadIdx.x % nb;
+        double t = 0.0;
+        for (int j = 0; j < nq; ++j) t += lds[list][j * nb + c];
+        stage[((size_t)list * kStageBlocks + g) * nb + c] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10 + AS241 inverse normal CDF (bit-level twin: oracle/rng_oracle.py)
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -2063,8 +2098,16 @@ void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d) {
     minres_scal2_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, d.p2, d.n2);
     check_launch();
 }
-void minres_scal21(hipStream_t st, int nb, MinresState* s, const DotParts& d2, const DotParts& d1) {
-    minres_scal21_kernel<<<1, kScalBlock, 0, st>>>(s, d2.p1, d2.n1, d2.p2, d2.n2, d1.p1, d1.n1, d1.p2, d1.n2, nb);
+size_t scal_stage_doubles() { return (size_t)2 * kStageBlocks * kMaxBatch; }
+void minres_scal21(hipStream_t st, int nb, MinresState* s, const DotParts& d2, const DotParts& d1, double* stage) {
+    if (stage && d2.total() + d1.total() >= 8 * kStageBlocks) {
+        stage_partials_kernel<<<kStageBlocks, 256, 0, st>>>(d2.p1, d2.n1, d2.p2, d2.n2, d1.p1, d1.n1, d1.p2, d1.n2, nb, stage);
+        check_launch();
+        minres_scal21_kernel<<<1, kScalBlock, 0, st>>>(s, stage, kStageBlocks, nullptr, 0,
+                                                        stage + (size_t)kStageBlocks * nb, kStageBlocks, nullptr, 0, nb);
+    } else {
+        minres_scal21_kernel<<<1, kScalBlock, 0, st>>>(s, d2.p1, d2.n1, d2.p2, d2.n2, d1.p1, d1.n1, d1.p2, d1.n2, nb);
+    }
     check_launch();
 }
 

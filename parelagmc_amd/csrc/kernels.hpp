@@ -106,7 +106,9 @@ void minres_init(hipStream_t st, int nb, MinresState* s, const DotParts& d, doub
 void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d);
 void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d);
 // scal2 of this iteration followed by scal1 of the next one (d1 = partials of the next operator product) in one launch
-void minres_scal21(hipStream_t st, int nb, MinresState* s, const DotParts& d2, const DotParts& d1);
+// stage (scal_stage_doubles() doubles, may be null): scratch of the multi-block first reduction stage for long lists
+void minres_scal21(hipStream_t st, int nb, MinresState* s, const DotParts& d2, const DotParts& d1, double* stage = nullptr);
+size_t scal_stage_doubles();
 
 // realization b of the batch = generator realization first_id + b * id_stride
 void normal_fill(hipStream_t st, int n, int nbatch, uint64_t seed, uint64_t first_id, uint32_t stream, double mean,

@@ -357,6 +357,7 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     } else {
     LinOp A;
     A.n = n;
+    A.n0 = n_u;
     SellView Av = view(d.A);
     Av.tag = 1;
     A.apply = [Av](const Lanes& L, int nb_, const double* x, double* y, double* partial, double*) {

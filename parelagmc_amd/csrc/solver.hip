@@ -237,6 +237,7 @@ void MinresWork::ensure(int n, int nb) {
     partial.ensure((size_t)2 * dot_capacity(n) * kMaxBatch);
     partial_op.ensure((size_t)2 * dot_capacity(n) * kMaxBatch);
     if (!state.p) state.alloc(1);
+    stage.ensure(k::scal_stage_doubles());
 }
 
 // y = a*x + b*y with host scalars, via lincomb on a tiny device constant block would need a copy;
@@ -258,6 +259,22 @@ static size_t split_threshold() {
     static const size_t v = [] {
         const char* e = getenv("PMC_SPLIT_MIN");
         return e ? (size_t)atoll(e) : (size_t)1500000;
+    }();
+    return v;
+}
+
+static bool stage_on() {
+    static const bool v = [] {
+        const char* e = getenv("PMC_SCAL_STAGE");
+        return !e || atoi(e) != 0;
+    }();
+    return v;
+}
+// PMC_LATE_WX=0 keeps the w / x update inside its own iteration also on two streams (A/B switch)
+static bool late_wx() {
+    static const bool v = [] {
+        const char* e = getenv("PMC_LATE_WX");
+        return !e || atoi(e) != 0;
     }();
     return v;
 }
@@ -317,6 +334,13 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
 
     MinresResult out;
     const int every = o.check_every > 0 ? o.check_every : 1;
+    const bool graphs = hint.key != 0 && o.use_graph != 0 && every == 2;
+    const bool late = L.split && !graphs && A.n0 > 0 && A.n0 < n && late_wx();
+    double* u2 = nullptr;
+    if (late) {
+        w.u2.ensure(len);
+        u2 = w.u2.p;
+    }
     size_t ev_used = 0;
     const bool timing = w.time_operator && !(hint.key != 0 && o.use_graph != 0);
     // q = A u, d1 = <u, A u>.  The product for iteration i+1 is issued right after the preconditioner of iteration i has
@@ -341,18 +365,41 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     // one MINRES iteration with explicit roles of the ping-pong vectors; on entry q = A u1_ and its dot are in place
     // (the first scalar step of an iteration - alpha and the Lanczos coefficients from <u, Au> - has already been done: by
     // the prologue for the first iteration, by the fused scalar launch of the previous iteration otherwise)
+    //
+    // Two-stream schedule (`late`): the w / x update of an iteration needs nothing but that iteration's scalars, and
+    // nothing needs it before the solve ends, so it is issued one iteration late on the second stream, behind the u-rows
+    // of the next Lanczos update and ahead of the M-block of the preconditioner; the first stream carries the s-rows of
+    // the update and the V-cycle, whose coarse levels leave most of the chip idle.  Same kernels, same arguments, same
+    // results; the preconditioned vector the update reads must survive one more iteration, hence three of them.
+    struct PendingWx { const double* u = nullptr; double *w0 = nullptr, *w1 = nullptr; } pend;
+    auto wx = [&](hipStream_t s, const double* u_, double* w0_, double* w1_) {
+        if (x_rows) k::minres_wx_idx(s, nb, x_nrows, x_rows, cW0, u_, cW1, w0_, cW2, w1_, cW3, x);
+        else k::minres_wx(s, nb, x_nrows, cW0, u_ + xoff, cW1, w0_, cW2, w1_, cW3, x + xoff);
+    };
+    auto flush_wx = [&](hipStream_t s) {
+        if (pend.u) wx(s, pend.u, pend.w0, pend.w1);
+        pend.u = nullptr;
+    };
     auto iteration = [&](double* u0_, double* u1_, double* v0_, double* v1_, double* w0_, double* w1_, bool last) {
-        k::lincomb3(st, nb, n, cV0, q, cV1, v1_, cV2, v0_);
-        k::DotParts d2 = prec(L, nb, v0_, u0_, w.partial.p, w.partial.p + seg2);
+        if (late) {
+            const size_t off = (size_t)A.n0 * nb;
+            L.fork();
+            k::lincomb3(L.aux, nb, A.n0, cV0, q, cV1, v1_, cV2, v0_);
+            flush_wx(L.aux);
+            k::lincomb3(st, nb, n - A.n0, cV0, q + off, cV1, v1_ + off, cV2, v0_ + off);
+        } else {
+            k::lincomb3(st, nb, n, cV0, q, cV1, v1_, cV2, v0_);
+        }
+        k::DotParts d2 = prec(L, nb, v0_, u0_, w.partial.p, w.partial.p + seg2);   // joins the second stream
         if (d2.total() == 0) d2 = k::DotParts{w.partial.p, k::dot(st, nb, n, v0_, u0_, w.partial.p)};
         if (!last) {
             apply_op(u0_);
-            k::minres_scal21(st, nb, S, d2, dp_op);
+            k::minres_scal21(st, nb, S, d2, dp_op, stage_on() ? w.stage.p : nullptr);
         } else {
             k::minres_scal2(st, nb, S, d2);
         }
-        if (x_rows) k::minres_wx_idx(st, nb, x_nrows, x_rows, cW0, u1_, cW1, w0_, cW2, w1_, cW3, x);
-        else k::minres_wx(st, nb, x_nrows, cW0, u1_ + xoff, cW1, w0_, cW2, w1_, cW3, x + xoff);
+        if (late && !last) pend = PendingWx{u1_, w0_, w1_};
+        else wx(st, u1_, w0_, w1_);
     };
     // two iterations return every vector to its original role
     auto pair = [&]() {
@@ -374,7 +421,6 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         apply_op(u1);
         k::minres_scal1(st, nb, S, dp_op);
     }
-    const bool graphs = hint.key != 0 && o.use_graph != 0 && every == 2;
     if (graphs) {
         // hipGraph path: the first pair runs eagerly (it also performs every lazy allocation), later pairs replay one
         // captured graph - ~70 kernel launches become a single hipGraphLaunch, which is what the launch-bound small
@@ -389,7 +435,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             sig = hash_mix(sig, (uint64_t)n);
             for (const void* p : {(const void*)b, (const void*)x, (const void*)v0, (const void*)v1, (const void*)u0,
                                   (const void*)u1, (const void*)w0, (const void*)w1, (const void*)q,
-                                  (const void*)w.partial.p, (const void*)w.partial_op.p, (const void*)S,
+                                  (const void*)w.partial.p, (const void*)w.partial_op.p, (const void*)S, (const void*)w.stage.p,
                                   (const void*)x_rows})
                 sig = hash_ptr(sig, p);
             sig = hash_mix(sig, ((uint64_t)x_row0 << 32) ^ (uint64_t)x_nrows);
@@ -429,11 +475,19 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         while (n_active > 0 && it < o.max_iter) {
             ++it;
             iteration(u0, u1, v0, v1, w0, w1, it == o.max_iter);
-            std::swap(u0, u1);
+            if (late) {                      // u1 (read by the pending update) stays untouched for one more iteration
+                double* t = u1;
+                u1 = u0;
+                u0 = u2;
+                u2 = t;
+            } else {
+                std::swap(u0, u1);
+            }
             std::swap(v0, v1);
             std::swap(w0, w1);
             if ((it % every == 0 && it >= first_poll) || it == o.max_iter) n_active = poll();
         }
+        flush_wx(st);
     }
     out.iterations = it;
     static_assert(sizeof(k::MinresState) <= 4096 * sizeof(double), "pinned scratch too small");

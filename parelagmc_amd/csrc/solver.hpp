@@ -115,6 +115,9 @@ struct Multigrid {
 // Abstract pieces MINRES needs.
 struct LinOp {
     int n = 0;
+    // rows [0, n0) and [n0, n) are the two diagonal blocks of the preconditioner (0: unknown); a solve that owns both
+    // streams then updates the two blocks of the Lanczos vector on the stream that preconditions them
+    int n0 = 0;
     // y = A x ; when dot_partial != nullptr also per-block partials of <x, A x>; returns the number of
     // partial blocks written (none when dot_partial == nullptr); two row blocks on two streams may use a segment each
     // (independent row blocks may run between L.fork() and L.join(); ordered on L.main again on return)
@@ -144,6 +147,8 @@ inline uint64_t hash_ptr(uint64_t h, const void* p) { return hash_mix(h, (uint64
 
 struct MinresWork {
     DevBuf<double> v0, v1, u0, u1, w0, w1, q, partial;
+    DevBuf<double> stage;                    // first-stage sums of the scalar kernel (k::minres_scal21)
+    DevBuf<double> u2;                       // third preconditioned vector: only when the w / x update runs one iteration late
     DevBuf<double> partial_op;               // partials of the operator's fused <u, Au> (the preconditioner's live in `partial`)
     std::map<uint64_t, int> iter_hint;       // per solver configuration: iterations its previous solve needed
     DevBuf<k::MinresState> state;
