@@ -308,13 +308,6 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise re-serialises load -> wait -> fma
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
-#ifdef PMC_OFF32
-            // uniform base + 32-bit byte offset per lane: one VGPR of address instead of two, no 64-bit address arithmetic
-            if constexpr (!BV && !CS) {
-                const unsigned off = ((unsigned)cc[rs] * (unsigned)(NB * 8)) + (unsigned)(t * C * 8);
-                load_c<C>(reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + off), xv[rs]);
-            } else
-#endif
             load_c<C>(x + (size_t)cc[rs] * NB + t * C, xv[rs]);
             if constexpr (CS) load_c<C>(cs + (size_t)cc[rs] * NB + t * C, sv[rs]);
             if constexpr (BV) load_c<C>(vals + (size_t)(slot - lane + rs * G + g) * NB + t * C, av[rs]);

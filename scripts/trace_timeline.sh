@@ -2,14 +2,14 @@
 # kernel timeline of a short single-lane bench run (development aid): keeps the kernel trace, trimmed to the timed steps
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace -d $R/gpurun_out/trace -o t --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --streams ${STREAMS:-1} --no-cpu-baseline --no-mlmc --no-r6 > $R/gpurun_out/trace.log 2>&1 || exit 1
+rocprofv3 --kernel-trace -d $R/gpurun_out/trace -o t --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --streams ${STREAMS:-1} --no-cpu-baseline --no-mlmc --no-r6 > $R/gpurun_out/trace.log 2>&1 || exit 1
 f=$(find $R/gpurun_out/trace -name '*kernel_trace.csv' | head -1)
 python3 - "$f" $R/gpurun_out/trace_tail.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # keep a window of ~6000 kernels out of the middle of the run
-mid = len(rows) // 2
+mid = len(rows) // 4
 sel = rows[mid:mid + 1500]
 t0 = int(sel[0]['Start_Timestamp'])
 with open(sys.argv[2], 'w') as o:
