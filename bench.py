@@ -93,8 +93,7 @@ def solver_bytes_per_iteration(problem, nb):
         nnzS = ((abs(B) @ abs(B).T) + sp.identity(ns_l)).nnz   # pattern of aW + B diag(M)^-1 B^T
         nc = L[lv + 1].n_s
         total += mat(nnzS, ns_l) + 8.0 * ns_l + V * 2 * ns_l           # pre-smoothing (one pass)
-        total += mat(nnzS, ns_l) + V * 3 * ns_l                        # residual
-        total += mat(ns_l, nc) + V * (ns_l + nc)                       # restriction
+        total += mat(nnzS, ns_l) + V * (3 * ns_l + nc)                 # residual with the restriction fused in (octree P)
         total += mat(nnzS, ns_l) + V * (2 * ns_l + nc)                 # res - (S P) xc   (S P has the pattern of S)
         total += mat(nnzS, ns_l) + 12.0 * ns_l + V * (4 * ns_l + nc)   # post-smoothing + coarse correction + dot
     return total
