@@ -116,6 +116,9 @@ struct Sell {
     int nrows = 0, ncols = 0, nslices = 0;
     int64_t nnz = 0;       // algorithmic (CSR) nonzeros
     int64_t nslots = 0;    // stored incl. padding
+    // built with every row's diagonal entry stored LAST (and padded with zero-weight copies of it): the last slice column
+    // of every row then gathers x[row] - see sell_row_range's xlast
+    bool diag_last = false;
     DevBuf<int> slice_off; // nslices+1
     DevBuf<int> cols;      // nslots
     DevBuf<double> vals;   // nslots (shared values) - empty for batched-value matrices
@@ -128,7 +131,8 @@ struct Sell {
     // algorithmic bytes of one SpMV with this matrix: 12 nnz + 12 nrows + 8 ncols
     double spmv_bytes() const { return 12.0 * nnz + 12.0 * nrows + 8.0 * ncols; }
 };
-void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st);
+// diag_last: request the diagonal-last order (granted when A is square and stores its whole diagonal)
+void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st, bool diag_last = false);
 // values of A*diag(colscale) laid out on the SELL pattern S was built with (S must keep its host mirrors)
 std::vector<double> sell_scaled_values(const Sell& S, const HostCsr& A, const std::vector<double>& colscale);
 // schedule that merges the slices of row block [0, n0) with those of [n0, nrows): every second-block slice right behind

@@ -165,10 +165,15 @@ __device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], doubl
 // sell_row_range works on `width` slice columns starting at slot `off`.  CS: every gathered x[col] is multiplied by a
 // second gathered per-realization vector cs[col] (column scaling A D^-1 without stored scaled values).  ZERO: acc is
 // cleared first, otherwise accumulated into.
+// xlast (optional): receives the x rows gathered by the LAST slice column.  A matrix built diagonal-last (Sell::diag_last:
+// every row ends with its diagonal entry and is padded with zero-weight copies of it) gathers x[row] there, so a fused
+// <x, Ax> needs no second read of x - which by the end of a slice has long left the L2 (measured at 0.6 M rows: 25 MB of
+// 280 MB per launch).
 template <int NB, bool BV, bool CS, bool ZERO, int JC = 1, bool NT = false>
 __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
                                                const double* __restrict__ x, const double* __restrict__ cs, int off,
-                                               int width, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
+                                               int width, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C],
+                                               double (*xlast)[Lay<NB>::C] = nullptr) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int g = lane / T, t = lane % T;
     if constexpr (ZERO) {
@@ -322,6 +327,12 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
                 else acc[rs][c] = fma(aa[rs], xv[rs][c], acc[rs][c]);
             }
         }
+        if (xlast && j + 1 == width) {
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+                for (int c = 0; c < C; ++c) xlast[rs][c] = xv[rs][c];
+        }
         cj = cn;
         vj = vn;
     }
@@ -369,7 +380,7 @@ __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
 // 8 i .. 8 i + 7 with unit weights (uniformly refined tetrahedra / hexahedra): a slice holds 8 whole groups, the sum is
 // a fixed xor tree over the lanes of a row step, and the separate restriction kernel (13 us of dependent latency for a
 // few MB) disappears from the V-cycle.
-template <int NB, bool BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false>
+template <int NB, bool BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false, bool DL = false>
 __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
@@ -379,6 +390,7 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                                                            const double* __restrict__ dot_with,
                                                            double* __restrict__ partial) {
     static_assert(!R8 || (MODE == 2 && !DOT), "fused restriction goes with the residual");
+    static_assert(!DL || (DOT && !BV && Lay<NB>::T > 1), "diagonal-last serves the fused <x, Ax> of shared-value operators");
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
@@ -389,7 +401,12 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
     for (int si = sw.begin; si < sw.end; si += sw.stride) {
         const int slice = sched ? sched[si] : si;   // optional processing order (locality), see Sell::sched
         double acc[T][C];
-        if constexpr (TAG != 0 && !BV && T > 1 && kK5TwoColumns) {
+        double xd[DL ? T : 1][C];
+        if constexpr (DL) {
+            const int off = slice_off[slice];
+            sell_row_range<NB, false, false, true, 1, NT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane,
+                                                         acc, xd);
+        } else if constexpr (TAG != 0 && !BV && T > 1 && kK5TwoColumns) {
             const int off = slice_off[slice];
             sell_row_range<NB, false, false, true, 2>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, acc);
         } else if constexpr (NT) {
@@ -415,7 +432,10 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                     for (int c = 0; c < C; ++c) acc[rs][c] = rv[c] - acc[rs][c];
                 }
                 store_c_stream<NT, C>(y + at, acc[rs]);
-                if constexpr (DOT) {
+                if constexpr (DL) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) p[c] = fma(xd[rs][c], acc[rs][c], p[c]);
+                } else if constexpr (DOT) {
                     double w[C];
                     load_c<C>(dot_with + at, w);
 #pragma unroll
@@ -1822,6 +1842,8 @@ static inline bool nt_streams(const SellView& A, int nb) {
 template <int NB, int TAG>
 static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double* x, double* y, bool accumulate,
                         double* dot_partial, const double* dot_with) {
+    // <x, Ax> with a diagonal-last matrix: x_i is what the row's last slice column gathers
+    const bool dl = TAG == 1 && Lay<NB>::T > 1 && A.diag_last && dot_with == x;
     if (A.bv) {
         if (dot_partial)
             sell_spmm_kernel<NB, true, 0, true, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
@@ -1830,14 +1852,18 @@ static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double*
         else
             sell_spmm_kernel<NB, true, 0, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
     } else if (TAG != 0 && nt_streams(A, NB)) {
-        if (dot_partial)
+        if (dot_partial && dl)
+            sell_spmm_kernel<NB, false, 0, true, TAG, true, false, (Lay<NB>::T > 1)><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+        else if (dot_partial)
             sell_spmm_kernel<NB, false, 0, true, TAG, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
         else if (accumulate)
             sell_spmm_kernel<NB, false, 1, false, TAG, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
         else
             sell_spmm_kernel<NB, false, 0, false, TAG, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
     } else {
-        if (dot_partial)
+        if (dot_partial && dl)
+            sell_spmm_kernel<NB, false, 0, true, TAG, false, false, (Lay<NB>::T > 1)><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+        else if (dot_partial)
             sell_spmm_kernel<NB, false, 0, true, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
         else if (accumulate)
             sell_spmm_kernel<NB, false, 1, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);

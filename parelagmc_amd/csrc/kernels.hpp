@@ -16,9 +16,10 @@ struct SellView {
     const int* sched = nullptr;   // optional slice processing order
     int tag = 0;                  // 1 = block saddle-point operator (own kernel instantiation / profile row)
     int ncols_hint = 0;           // number of columns (rows of x): kernels with 32-bit gather offsets check it
+    bool diag_last = false;       // see Sell::diag_last
 };
 inline SellView view(const Sell& S) {
-    return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, S.vals.p, false, S.sched.p, 0, S.ncols};
+    return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, S.vals.p, false, S.sched.p, 0, S.ncols, S.diag_last};
 }
 inline SellView view_bv(const Sell& S, const double* vals) {
     return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, vals, true, S.sched.p, 0, S.ncols};

@@ -11,6 +11,16 @@
 
 namespace pmc {
 
+// PMC_DIAG_LAST=0 builds the block operator in plain CSR order (A/B switch for the diagonal-last fused dot)
+static bool diag_last_on() {
+    static const bool v = [] {
+        const char* e = getenv("PMC_DIAG_LAST");
+        return !e || atoi(e) != 0;
+    }();
+    return v;
+}
+
+
 // S = diag_add + B diag(dM)^-1 B^T as host CSR (setup).  B has its essential columns removed.
 HostCsr schur_host(const HostCsr& B, const HostCsr& Bt, const std::vector<double>& dM, const double* diag_add) {
     HostCsr S;
@@ -126,7 +136,7 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
         }
         HostCsr A = csr_block2x2(M, Bt, B, maw.data());
         d.nnz = A.nnz();
-        sell_build(d.A, A, true, false, st);
+        sell_build(d.A, A, true, false, st, diag_last_on());
         sell_schedule_two_blocks(d.A, L.n_u, st, &A);
         sell_build(d.M, M, true, true, st);
         std::vector<double> dM = csr_diag(M);

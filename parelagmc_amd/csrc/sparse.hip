@@ -111,8 +111,21 @@ bool csr_is_oct_injection(const HostCsr& P) {
     return true;
 }
 
-void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st) {
+void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st, bool diag_last) {
     PMC_REQUIRE(A.nrows == 0 || A.ncols > 0, "SELL: matrix with rows but no columns");
+    // position of the diagonal entry of every row (diagonal-last order only when all rows have one)
+    std::vector<int> dpos;
+    if (diag_last && A.nrows == A.ncols) {
+        dpos.assign(A.nrows, -1);
+        for (int r = 0; r < A.nrows && diag_last; ++r) {
+            for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p)
+                if (A.colind[p] == r) dpos[r] = p;
+            if (dpos[r] < 0) diag_last = false;
+        }
+    } else {
+        diag_last = false;
+    }
+    S.diag_last = diag_last;
     S.nrows = A.nrows;
     S.ncols = A.ncols;
     S.nnz = A.nnz();
@@ -142,9 +155,11 @@ void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipS
             for (int j = 0; j < w; ++j) {
                 const int slot = off + j * 64 + lane;
                 if (b + j < e) {
-                    S.h_cols[slot] = A.colind[b + j];
-                    if (upload_vals) hv[slot] = A.vals[b + j];
-                    if (keep_src) S.h_src[slot] = b + j;
+                    int p = b + j;                     // CSR order, or: the diagonal entry moved behind the others
+                    if (diag_last) p = (p == e - 1) ? dpos[r] : (p >= dpos[r] ? p + 1 : p);
+                    S.h_cols[slot] = A.colind[p];
+                    if (upload_vals) hv[slot] = A.vals[p];
+                    if (keep_src) S.h_src[slot] = p;
                 } else {
                     S.h_cols[slot] = pad_col;
                 }
