@@ -62,7 +62,8 @@ typedef struct pmc_solver_opts {
     int32_t max_iter;
     double rel_tol;
     double abs_tol;
-    int32_t cheb_degree_M;    /* polynomial degree on the M block (default 2) */
+    int32_t cheb_degree_M;    /* polynomial degree on the M block; 0 (default) = automatic: 2, or 4 on sampler levels whose
+                                 measured Chebyshev interval exceeds 16 (badly shaped cells)                                */
     double cheb_ratio_M;      /* Chebyshev interval lambda_max/lambda_min of the l1-scaled M-block; <= 0 (default): measured at
                                  create time by a host Lanczos run on M (Darcy: on M(k == 1))                              */
     int32_t mg_smooth_degree; /* Chebyshev pre/post smoothing degree per level (default 2) */

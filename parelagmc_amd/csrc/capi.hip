@@ -100,7 +100,7 @@ void pmc_solver_opts_default(pmc_solver_opts* o) {
     o->abs_tol = 1e-12;
     // tuned on MI355X (scripts/sweep.py, cube_tet r=5): degree 2 on M needs no more MINRES iterations than
     // degree 3; smoothing interval [lmax/8, lmax]
-    o->cheb_degree_M = 2;
+    o->cheb_degree_M = 0;
     o->cheb_ratio_M = 0.0;
     o->mg_smooth_degree = 2;
     o->mg_smooth_ratio = 8.0;
@@ -260,7 +260,7 @@ int pmc_sampler_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_sampl
         pmc_solver_opts o;
         pmc_solver_opts_default(&o);
         if (opts) o = *opts;
-        PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 1 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
+        PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 0 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
                         (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
                     "solver options out of range");
         *out = new pmc_sampler(*c, nlevels, n_mc_levels, levels, alpha, matern_g, lognormal != 0, o);
@@ -351,7 +351,7 @@ int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_l
         pmc_solver_opts o;
         pmc_solver_opts_default(&o);
         if (opts) o = *opts;
-        PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 1 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
+        PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 0 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
                         (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
                     "solver options out of range");
         *out = new pmc_darcy(*c, nlevels, n_mc_levels, levels, k_divides != 0, o);

@@ -474,7 +474,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
 
 bool Darcy::use_eg(const DarcyLevel& d) const {
     static const bool off = getenv("PMC_DARCY_NO_EG") != nullptr;   // tuning / A-B switch
-    return d.has_eg && opts.cheb_degree_M == 2 && !off;
+    return d.has_eg && (opts.cheb_degree_M == 2 || opts.cheb_degree_M == 0) && !off;   // 0 (automatic) = 2 here: the element-grouped form is degree 2
 }
 
 void Darcy::ensure(int level, int nb) {
@@ -625,7 +625,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
         L.join();
         return k::DotParts{partial, nu_blk, partial2, np_blk};
     };
-    ChebParams cpM{opts.cheb_degree_M, 1.0, d.ratio_M, d.mvals_scaled.p};
+    ChebParams cpM{opts.cheb_degree_M > 0 ? opts.cheb_degree_M : 2, 1.0, d.ratio_M, d.mvals_scaled.p};
     const double* l1 = d.l1invM.p;
     double* cxp = cx.p;
     double* cdp = cd.p;
