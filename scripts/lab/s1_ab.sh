@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 python -m pytest tests/test_gpu_round2.py tests/test_gpu_parity.py -x -q -m gpu -k "two_stream or hipgraph or full_size_config2 or matches_direct" > gpurun_out/s1_test.log 2>&1 || { tail -30 gpurun_out/s1_test.log; exit 1; }
 tail -2 gpurun_out/s1_test.log
 for s in 1 4; do
-for v in 1 0 1 0; do
+for v in ${VALS:-1 0 1 0}; do
   env $VAR=$v python bench.py --streams $s --steps 60 --warmup 5 --no-cpu-baseline --no-mlmc --no-r6 > gpurun_out/s1_ab.json 2> gpurun_out/s1_ab.err
   python - <<PY
 import json
