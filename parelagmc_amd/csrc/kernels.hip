@@ -1833,10 +1833,17 @@ static unsigned dot_grid_bound() {
 }
 static inline dim3 grid_bounded(dim3 g, bool bounded) { return bounded ? dim3(std::min(g.x, dot_grid_bound())) : g; }
 
-// non-temporal matrix / result streams for the block operator once its operands no longer fit the Infinity Cache
-static inline bool nt_streams(const SellView& A, int nb) {
+// non-temporal matrix / result streams for the block operator once its operands no longer fit the Infinity Cache.  Inside
+// the MINRES loop (in_loop: the launch with the fused dot) they never are cache-resident from half that size on - the rest
+// of the iteration moves ~5 x the operator's bytes in between - and the hints pay earlier (0.6 M rows, 195 MB: one lane
+// 1057 -> 1063, four lanes 1417 -> 1434 samples/s); PMC_NT_MIN_MB overrides the in-loop threshold.
+static inline bool nt_streams(const SellView& A, int nb, bool in_loop) {
     const double bytes = 12.0 * (double)A.nslices * 64.0 * 6.0 + 16.0 * nb * (double)A.nrows;   // ~6 entries per row
-    return bytes > 256.0 * 1024.0 * 1024.0;
+    static const double loop_limit = [] {
+        const char* e = getenv("PMC_NT_MIN_MB");
+        return (e ? atof(e) : 128.0) * 1024.0 * 1024.0;
+    }();
+    return bytes > (in_loop ? loop_limit : 256.0 * 1024.0 * 1024.0);
 }
 
 template <int NB, int TAG>
@@ -1851,7 +1858,7 @@ static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double*
             sell_spmm_kernel<NB, true, 1, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
         else
             sell_spmm_kernel<NB, true, 0, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
-    } else if (TAG != 0 && nt_streams(A, NB)) {
+    } else if (TAG != 0 && nt_streams(A, NB, dot_partial != nullptr)) {
         if (dot_partial && dl)
             sell_spmm_kernel<NB, false, 0, true, TAG, true, false, (Lay<NB>::T > 1)><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
         else if (dot_partial)
