@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
 // 3 + 5 vector passes of cheb_first + cheb_step.  DOT: partials of <r, x2>.
 // From a NONZERO guess x0 the same polynomial acts on the residual: x2 = x0 + p2(r - A x0); then r is that residual,
 // xadd = x0 (may alias xout: no gathers on it) and the dot is taken with dot_with (the right-hand side).
-template <int NB, bool BV, bool DOT>
+template <int NB, bool BV, bool DOT, bool NT = false>
 __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                             const int* __restrict__ sched,
                                                             const int* __restrict__ cols,
@@ -547,7 +547,13 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
     for (int si = sw.begin; si < sw.end; si += sw.stride) {
         const int slice = sched ? sched[si] : si;
         double acc[T][C];
-        sell_row_product<NB, BV>(slice_off, cols, vals_scaled, r, slice, lane, acc);
+        if constexpr (NT) {
+            const int off = slice_off[slice];
+            sell_row_range<NB, BV, false, true, 1, true>(cols, vals_scaled, r, nullptr, off, (slice_off[slice + 1] - off) >> 6,
+                                                        lane, acc);
+        } else {
+            sell_row_product<NB, BV>(slice_off, cols, vals_scaled, r, slice, lane, acc);
+        }
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
 #pragma unroll
                 for (int c = 0; c < C; ++c) p[c] = fma(rv[c], xv[c], p[c]);
             }
-            store_c<C>(xout + at, xv);
+            store_c_stream<NT, C>(xout + at, xv);
         }
     }
     if constexpr (DOT) reduce_cols_store<NB>(p, partial);
@@ -1846,6 +1852,19 @@ static inline bool nt_streams(const SellView& A, int nb, bool in_loop) {
     return bytes > (in_loop ? loop_limit : 256.0 * 1024.0 * 1024.0);
 }
 
+// The same hints for the one-pass polynomial kernels (smoothers) of large levels: their matrix and result streams no longer
+// displace the gathered rows from L2 (0.6 M rows: one lane 1048 -> 1081 samples/s, four lanes 1367 -> 1380).  Not for the
+// residual kernels: their result is read again two launches later (one lane 1103 -> 1084 with the hints).
+// PMC_NT_POLY_MB: threshold in MiB of operands, 0 = never.
+static inline bool nt_poly(const SellView& A, int nb) {
+    static const double limit = [] {
+        const char* e = getenv("PMC_NT_POLY_MB");
+        return (e ? atof(e) : 32.0) * 1024.0 * 1024.0;
+    }();
+    const double bytes = 12.0 * (double)A.nslices * 64.0 * 6.0 + 16.0 * nb * (double)A.nrows;
+    return limit > 0.0 && bytes > limit;
+}
+
 template <int NB, int TAG>
 static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double* x, double* y, bool accumulate,
                         double* dot_partial, const double* dot_with) {
@@ -1973,6 +1992,11 @@ int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool d
                 sell_poly2_kernel<NB, true, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
             else
                 sell_poly2_kernel<NB, true, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x);
+        } else if (nt_poly(As, NB)) {
+            if (dot_partial)
+                sell_poly2_kernel<NB, false, true, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
+            else
+                sell_poly2_kernel<NB, false, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x);
         } else {
             if (dot_partial)
                 sell_poly2_kernel<NB, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
