@@ -58,24 +58,27 @@ __device__ __forceinline__ void store_c(double* __restrict__ p, const double (&v
     else *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]);
 }
 
-// Vector streams without reuse inside the iteration (MINRES w / x updates): optional non-temporal variants
-template <int C>
+// Vector streams without reuse inside the iteration (MINRES w / x updates of large levels): non-temporal variants, so that a
+// flat kernel running beside a gather kernel (second stream, other lanes) does not sweep that kernel's rows out of L2.
+// Measured at 0.6 M rows x 16: one lane 1096 -> 1112, four lanes 1446 -> 1454 samples/s; small levels keep the cached
+// accesses (their vectors live in the caches from one iteration to the next).
+template <bool NT, int C>
 __device__ __forceinline__ void load_c_nt(const double* __restrict__ p, double (&v)[C]) {
-#ifdef PMC_NT_VECTORS
-    v[0] = __builtin_nontemporal_load(p);
-    if constexpr (C == 2) v[1] = __builtin_nontemporal_load(p + 1);
-#else
-    load_c<C>(p, v);
-#endif
+    if constexpr (NT) {
+        v[0] = __builtin_nontemporal_load(p);
+        if constexpr (C == 2) v[1] = __builtin_nontemporal_load(p + 1);
+    } else {
+        load_c<C>(p, v);
+    }
 }
-template <int C>
+template <bool NT, int C>
 __device__ __forceinline__ void store_c_nt(double* __restrict__ p, const double (&v)[C]) {
-#ifdef PMC_NT_VECTORS
-    __builtin_nontemporal_store(v[0], p);
-    if constexpr (C == 2) __builtin_nontemporal_store(v[1], p + 1);
-#else
-    store_c<C>(p, v);
-#endif
+    if constexpr (NT) {
+        __builtin_nontemporal_store(v[0], p);
+        if constexpr (C == 2) __builtin_nontemporal_store(v[1], p + 1);
+    } else {
+        store_c<C>(p, v);
+    }
 }
 
 // Streaming accesses (matrix values / indices read once, result rows written once) with NT = true are non-temporal, so
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(size_t nflat, const double*
     reduce_cols_store<NB>(p, partial);
 }
 
-template <int NB>
+template <int NB, bool NT = false>
 __global__ __launch_bounds__(kBlock) void lincomb3_kernel(size_t nflat, const double* __restrict__ c0,
                                                           const double* __restrict__ a, const double* __restrict__ c1,
                                                           const double* __restrict__ b, const double* __restrict__ c2,
@@ -845,15 +848,15 @@ __global__ __launch_bounds__(kBlock) void lincomb3_kernel(size_t nflat, const do
     const size_t e = i * C;
     const int k0 = (int)(e % NB);
     double av[C], bv[C], yv[C];
-    load_c<C>(a + e, av);
-    load_c<C>(b + e, bv);
-    load_c<C>(y + e, yv);
+    load_c_nt<NT, C>(a + e, av);   // the three inputs are read once; the result is gathered by the next kernels
+    load_c_nt<NT, C>(b + e, bv);
+    load_c_nt<NT, C>(y + e, yv);
 #pragma unroll
     for (int c = 0; c < C; ++c) yv[c] = c0[k0 + c] * av[c] + c1[k0 + c] * bv[c] + c2[k0 + c] * yv[c];
     store_c<C>(y + e, yv);
 }
 
-template <int NB>
+template <int NB, bool NT>
 __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const double* __restrict__ c0,
                                                            const double* __restrict__ u, const double* __restrict__ c1,
                                                            double* __restrict__ w0, const double* __restrict__ c2,
@@ -865,17 +868,17 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const d
     const size_t e = i * C;
     const int k0 = (int)(e % NB);
     double uv[C], w0v[C], w1v[C], xv[C];
-    load_c<C>(u + e, uv);
-    load_c_nt<C>(w0 + e, w0v);
-    load_c_nt<C>(w1 + e, w1v);
-    load_c_nt<C>(x + e, xv);
+    load_c_nt<NT, C>(u + e, uv);
+    load_c_nt<NT, C>(w0 + e, w0v);
+    load_c_nt<NT, C>(w1 + e, w1v);
+    load_c_nt<NT, C>(x + e, xv);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         w0v[c] = c0[k0 + c] * uv[c] + c1[k0 + c] * w0v[c] + c2[k0 + c] * w1v[c];
         xv[c] += c3[k0 + c] * w0v[c];
     }
-    store_c_nt<C>(w0 + e, w0v);
-    store_c_nt<C>(x + e, xv);
+    store_c_nt<NT, C>(w0 + e, w0v);
+    store_c_nt<NT, C>(x + e, xv);
 }
 
 // partial sums of <w, x[:,k]> with a shared (non-batched) weight vector w   (K15 QoI)
@@ -1824,6 +1827,14 @@ static inline dim3 grid_slices(int nslices) { return dim3((unsigned)((nslices + 
 static inline size_t flat_count(int n, int nb) { return (size_t)n * nb / (nb >= 2 ? 2 : 1); }
 static inline dim3 grid_flat(int n, int nb) { return dim3((unsigned)((flat_count(n, nb) + kBlock - 1) / kBlock)); }
 static inline void check_launch() { PMC_HIP(hipGetLastError()); }
+// flat vector kernels stream non-temporally once one vector exceeds PMC_NT_FLAT_MB MiB (default 8; 0 = never)
+static inline bool nt_flat(size_t doubles) {
+    static const double limit = [] {
+        const char* e = getenv("PMC_NT_FLAT_MB");
+        return (e ? atof(e) : 8.0) * 1024.0 * 1024.0;
+    }();
+    return limit > 0.0 && (double)doubles * 8.0 > limit;
+}
 
 namespace k {
 
@@ -2111,13 +2122,23 @@ void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, do
 
 void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b,
               const double* c2, double* y) {
-    PMC_DISPATCH_NB(nb, { lincomb3_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y); });
+    // non-temporal loads on large levels (one lane 1104 -> 1129, four lanes 1400 -> 1412 samples/s); PMC_NT_LINCOMB=0: off
+    static const bool nt_on = [] { const char* e = getenv("PMC_NT_LINCOMB"); return !e || atoi(e) != 0; }();
+    const bool nt = nt_on && nt_flat((size_t)n * nb);
+    PMC_DISPATCH_NB(nb, {
+        if (nt) lincomb3_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y);
+        else lincomb3_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y);
+    });
     check_launch();
 }
 
 void minres_wx(hipStream_t st, int nb, int n, const double* c0, const double* u, const double* c1, double* w0,
                const double* c2, const double* w1, const double* c3, double* x) {
-    PMC_DISPATCH_NB(nb, { minres_wx_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x); });
+    const bool nt = nt_flat((size_t)n * nb);
+    PMC_DISPATCH_NB(nb, {
+        if (nt) minres_wx_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x);
+        else minres_wx_kernel<NB, false><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x);
+    });
     check_launch();
 }
 
