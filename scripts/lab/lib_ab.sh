@@ -14,7 +14,7 @@ d=json.loads(open("gpurun_out/lib_ab.json").read().strip().splitlines()[-1])
 print("$v streams=$s", round(d["value"],1), "K5 us", round(d["roofline"]["avg_kernel_ms"]*1e3,1), round(d["roofline"]["frac"],3), "iso", round(d["roofline"]["isolated"]["frac"],3), "solver", round(d["roofline"]["solver"]["frac"],3))
 PY
   done
-  if [ $rep = 1 ]; then
+  if [ $rep = 1 ] && [ -z "$NO_R6" ]; then
   python bench.py --refine 6 --streams 1 --steps 6 --warmup 2 --no-cpu-baseline --no-mlmc --no-r6 > gpurun_out/lib_ab.json 2> gpurun_out/lib_ab.err
   python - <<PY
 import json
