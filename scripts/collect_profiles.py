@@ -54,7 +54,7 @@ for refine, nvec in ((5, 595968), (6, 4743168)):
             for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
                 f.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.3f}\n")
     # one lane alone on the GPU splits the Lanczos update into a u-row and an s-row launch (two streams): compare totals
-    lv = [x for k, vals in fetch.items() if "lincomb3_kernel<16>" in k for x in vals]
+    lv = [x for k, vals in fetch.items() if "lincomb3_kernel<16" in k for x in vals]
     split = len(set(round(x / 1024.0) for x in lv)) > 1 and max(lv) > 1.5 * min(lv)
     lf = sum(lv) / len(lv) * (2 if split else 1)
     read_kb = 3 * nvec * 16 * 8 / 1024.0
