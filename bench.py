@@ -196,7 +196,7 @@ def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters
     return out
 
 
-def mlmc_config3(seed, lanes=4, opts=None, farm=None):
+def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=32):
     """Secondary figure (BASELINE config 3): MLMC_Manager::InitRun with the SPDE sampler + Darcy QoI on cube_hex
     64^3 / 32^3 / 16^3, fixed sample counts, `lanes` concurrent streams.  Reported under "extra", never as `value`.
     farm = (world, rank, comm_ctx, device): the realizations of every level are sharded over the ranks and the accumulators
@@ -211,21 +211,23 @@ def mlmc_config3(seed, lanes=4, opts=None, farm=None):
     ctxs = ([farm[2]] if farm else []) + [capi.Context(dev, seed=seed) for _ in range(lanes - (1 if farm else 0))]
     sm = [capi.PDESampler(c, sp, opts) for c in ctxs]
     dr = [capi.DarcySolver(c, dp, opts) for c in ctxs]
-    mgr = host_api.MLMCManager(3, sampler=sm[0], solver=dr[0], wall_time=True, batch=16)
+    # batch = realizations per plugin call; the library solves them 32 at a time on levels small enough to be bound by
+    # launch latency and 16 at a time on the others (batch_width in csrc/solver.hip)
+    mgr = host_api.MLMCManager(3, sampler=sm[0], solver=dr[0], wall_time=True, batch=batch)
     for i in range(1, lanes):
         mgr.add_lane(sm[i], dr[i])
     world = 1
     if farm:
         world, rank = farm[0], farm[1]
         mgr.set_farm(world, rank, None)              # reduce == NULL -> pmc_allreduce_sum_f64 (RCCL) of ctxs[0]
-    mgr.InitRun([16 * lanes * world] * 3)       # warm-up: allocations
+    mgr.InitRun([batch * lanes * world] * 3)    # warm-up: allocations
     mgr.Reset()
     ns = [64 * world, 256 * world, 1024 * world]
     t0 = time.perf_counter()
     r = mgr.InitRun(ns)
     dt = time.perf_counter() - t0
     out = {"workload": "MLMC Darcy + SPDE sampler, cube_hex 64^3/32^3/16^3 (1 060 864 / 134 144 / 17 152 DoF), lognormal, "
-                       f"eff_perm QoI, InitRun {ns}, {lanes} lanes x 16" + (f", sharded over {world} ranks" if farm else ""),
+                       f"eff_perm QoI, InitRun {ns}, {lanes} lanes x {batch}" + (f", sharded over {world} ranks" if farm else ""),
            "realizations_per_s": sum(ns) / dt, "seconds": dt, "estimate": r["estimate"],
            "nsamples_after_allreduce": [int(x) for x in r["nsamples"]],
            "seconds_per_sample_per_level": [float(x) for x in r["cost"]], "varY": [float(x) for x in r["varY"]]}

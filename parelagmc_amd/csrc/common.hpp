@@ -185,8 +185,12 @@ struct Ctx {
     void activate() const;
 };
 
-static constexpr int kMaxBatch = 16;
-inline bool valid_batch(int nb) { return nb == 1 || nb == 2 || nb == 4 || nb == 8 || nb == 16; }
+// Interleaved batch width of a level with `rows` unknowns (saddle-point system): levels small enough to be bound by launch
+// latency rather than bandwidth take kMaxBatch realizations per launch, the others 16 (PMC_WIDE_ROWS overrides the limit,
+// 0 = always 16).
+int batch_width(size_t rows);
+static constexpr int kMaxBatch = 32;   // widest interleaved batch (levels small enough to be launch-latency bound); large levels use 16
+inline bool valid_batch(int nb) { return nb == 1 || nb == 2 || nb == 4 || nb == 8 || nb == 16 || nb == 32; }
 
 }  // namespace pmc
 

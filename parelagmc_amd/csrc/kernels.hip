@@ -37,7 +37,7 @@ int dot_capacity(int nrows) {
 // access) each, so a group of T lanes touches NB*8 contiguous bytes and a wavefront G = 64/T rows.
 template <int NB>
 struct Lay {
-    static constexpr int C = NB >= 2 ? 2 : 1;
+    static constexpr int C = NB >= 32 ? 4 : (NB >= 2 ? 2 : 1);   // NB = 32: two 16 B accesses per lane, still 8 lanes per row
     static constexpr int T = NB / C;
     static constexpr int G = kWave / T;
 };
@@ -47,15 +47,22 @@ __device__ __forceinline__ void load_c(const double* __restrict__ p, double (&v)
     if constexpr (C == 1) {
         v[0] = p[0];
     } else {
-        const double2 t = *reinterpret_cast<const double2*>(p);
-        v[0] = t.x;
-        v[1] = t.y;
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) {
+            const double2 t = reinterpret_cast<const double2*>(p)[i];
+            v[2 * i] = t.x;
+            v[2 * i + 1] = t.y;
+        }
     }
 }
 template <int C>
 __device__ __forceinline__ void store_c(double* __restrict__ p, const double (&v)[C]) {
-    if constexpr (C == 1) p[0] = v[0];
-    else *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]);
+    if constexpr (C == 1) {
+        p[0] = v[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) reinterpret_cast<double2*>(p)[i] = make_double2(v[2 * i], v[2 * i + 1]);
+    }
 }
 
 // Vector streams without reuse inside the iteration (MINRES w / x updates of large levels): non-temporal variants, so that a
@@ -65,8 +72,8 @@ __device__ __forceinline__ void store_c(double* __restrict__ p, const double (&v
 template <bool NT, int C>
 __device__ __forceinline__ void load_c_nt(const double* __restrict__ p, double (&v)[C]) {
     if constexpr (NT) {
-        v[0] = __builtin_nontemporal_load(p);
-        if constexpr (C == 2) v[1] = __builtin_nontemporal_load(p + 1);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = __builtin_nontemporal_load(p + i);
     } else {
         load_c<C>(p, v);
     }
@@ -74,8 +81,8 @@ __device__ __forceinline__ void load_c_nt(const double* __restrict__ p, double (
 template <bool NT, int C>
 __device__ __forceinline__ void store_c_nt(double* __restrict__ p, const double (&v)[C]) {
     if constexpr (NT) {
-        __builtin_nontemporal_store(v[0], p);
-        if constexpr (C == 2) __builtin_nontemporal_store(v[1], p + 1);
+#pragma unroll
+        for (int i = 0; i < C; ++i) __builtin_nontemporal_store(v[i], p + i);
     } else {
         store_c<C>(p, v);
     }
@@ -89,8 +96,8 @@ __device__ __forceinline__ void store_c_nt(double* __restrict__ p, const double 
 template <bool NT, int C>
 __device__ __forceinline__ void store_c_stream(double* __restrict__ p, const double (&v)[C]) {
     if constexpr (NT) {
-        __builtin_nontemporal_store(v[0], p);
-        if constexpr (C == 2) __builtin_nontemporal_store(v[1], p + 1);
+#pragma unroll
+        for (int i = 0; i < C; ++i) __builtin_nontemporal_store(v[i], p + i);
     } else {
         store_c<C>(p, v);
     }
@@ -1819,12 +1826,14 @@ __global__ __launch_bounds__(kTailThreads) void mini_sampler_kernel(MiniSamplerP
         case 4: { constexpr int NB = 4; __VA_ARGS__; } break;             \
         case 8: { constexpr int NB = 8; __VA_ARGS__; } break;             \
         case 16: { constexpr int NB = 16; __VA_ARGS__; } break;           \
+        case 32: { constexpr int NB = 32; __VA_ARGS__; } break;           \
         default: throw Error(PMC_ERR_INTERNAL, "unsupported batch width"); \
     }
 
 static inline dim3 grid_rows(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 static inline dim3 grid_slices(int nslices) { return dim3((unsigned)((nslices + kBlock / kWave - 1) / (kBlock / kWave))); }
-static inline size_t flat_count(int n, int nb) { return (size_t)n * nb / (nb >= 2 ? 2 : 1); }
+static inline int lay_c(int nb) { return nb >= 32 ? 4 : (nb >= 2 ? 2 : 1); }   // = Lay<nb>::C
+static inline size_t flat_count(int n, int nb) { return (size_t)n * nb / lay_c(nb); }
 static inline dim3 grid_flat(int n, int nb) { return dim3((unsigned)((flat_count(n, nb) + kBlock - 1) / kBlock)); }
 static inline void check_launch() { PMC_HIP(hipGetLastError()); }
 // flat vector kernels stream non-temporally once one vector exceeds PMC_NT_FLAT_MB MiB (default 8; 0 = never)
@@ -2068,7 +2077,7 @@ int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, cons
 void scale_cols_bv(hipStream_t st, int nb, int64_t nslots, const int* cols, const double* vals, const double* colscale,
                    double* out) {
     if (nslots == 0) return;
-    const size_t nf = (size_t)nslots * nb / (nb >= 2 ? 2 : 1);
+    const size_t nf = (size_t)nslots * nb / lay_c(nb);
     const unsigned g = (unsigned)std::min<size_t>((nf + kBlock - 1) / kBlock, 8192);
     PMC_DISPATCH_NB(nb, { scale_cols_bv_kernel<NB><<<g, kBlock, 0, st>>>(nf, cols, vals, colscale, out); });
     check_launch();

@@ -504,7 +504,7 @@ void Sampler::eval(int level, int xi_level, int nbatch, const double* xi, double
     }
     int done = 0;
     while (done < nbatch) {
-        int nb = 16;
+        int nb = batch_width((size_t)lv[level].n_u + lv[level].n_s);
         while (nb > nbatch - done) nb >>= 1;
         const double* xi_d = xi + (size_t)done * n_xi;
         const double* init_d = use_init ? init_s + (size_t)done * n_init : nullptr;

@@ -270,6 +270,14 @@ static bool stage_on() {
     }();
     return v;
 }
+int batch_width(size_t rows) {
+    static const size_t limit = [] {
+        const char* e = getenv("PMC_WIDE_ROWS");
+        return e ? (size_t)atoll(e) : (size_t)300000;
+    }();
+    return rows <= limit ? kMaxBatch : 16;
+}
+
 // PMC_LATE_WX=0 keeps the w / x update inside its own iteration also on two streams (A/B switch)
 static bool late_wx() {
     static const bool v = [] {

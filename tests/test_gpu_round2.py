@@ -255,3 +255,38 @@ def test_full_size_config5_spe10_box_four_levels(gpu_ctx):
     mgr.close()
     ds.close()
     smp.close()
+
+
+def test_wide_batches_of_32_on_small_levels(gpu_ctx, hex_hierarchy, seeded_rng):
+    """Levels small enough to be launch-latency bound are solved 32 realizations per launch (batch_width in
+    csrc/solver.hip): one call with 32 realizations == two calls with 16 (same xi) to solver tolerance and == the oracle's
+    direct solve, for the sampler on every level and for Darcy; PMC_WIDE_ROWS = 0 would switch the wide path off."""
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp_ = build_sampler_problem(hex_hierarchy, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    o = capi.solver_opts(rel_tol=1e-12, abs_tol=1e-14)
+    smp, ds = capi.PDESampler(gpu_ctx, sp_, o), capi.DarcySolver(gpu_ctx, dp, o)
+    so, do = SamplerOracle(sp_), DarcyOracle(dp)
+    xi = seeded_rng.standard_normal((32, sp_.levels[0].n_s))
+    for lvl in range(3):
+        s32, st = smp.Eval(lvl, xi, xi_level=0, return_stats=True)
+        assert all(t[1] == 1 for t in st)
+        s16 = np.vstack([smp.Eval(lvl, xi[:16], xi_level=0), smp.Eval(lvl, xi[16:], xi_level=0)])
+        assert np.allclose(s32, s16, rtol=1e-9, atol=0)
+        for b in (0, 17, 31):
+            ref = so.eval(lvl, 0, xi[b])[0]
+            assert np.linalg.norm(s32[b] - ref) <= 1e-8 * np.linalg.norm(ref)
+        Q32, _, stq = ds.SolveFwd(lvl, s32, return_stats=True)
+        assert all(t[1] == 1 for t in stq)
+        Q16 = np.concatenate([ds.SolveFwd(lvl, s32[:16])[0], ds.SolveFwd(lvl, s32[16:])[0]])
+        assert np.allclose(Q32, Q16, rtol=1e-9)
+        for b in (3, 30):
+            assert abs(Q32[b] - do.solve_fwd(lvl, s32[b])[0]) <= 1e-8 * abs(Q32[b])
+    # ragged: 32 + 8 + 2 + 1
+    s43 = smp.Eval(1, np.vstack([xi, xi[:11]]), xi_level=0)
+    assert np.allclose(s43[32:], s43[:11], rtol=1e-9)
+    ds.close()
+    smp.close()
