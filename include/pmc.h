@@ -203,6 +203,9 @@ int pmc_sampler_apply_operator(pmc_sampler* s, int level, int nbatch, const doub
  * timed).  pmc_sampler_operator_time returns and clears the accumulated kernel time [ms] and launch count. */
 int pmc_sampler_set_operator_timing(pmc_sampler* s, int on);
 int pmc_sampler_operator_time(pmc_sampler* s, double* total_ms, int64_t* launches);
+/* Behind every timed launch an EMPTY event bracket is recorded as well: returns and clears the sum of those [ms] - what
+ * the event pair itself adds to a bracket on that stream (call before pmc_sampler_operator_time clears the count). */
+int pmc_sampler_operator_event_overhead(pmc_sampler* s, double* total_ms);
 
 /* ---- DarcySolver ------------------------------------------------------------------------ */
 int pmc_darcy_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_darcy_level* levels,

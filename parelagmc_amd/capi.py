@@ -91,6 +91,7 @@ SYMBOLS = {
                                              C.POINTER(C.c_double)]),
     "pmc_sampler_set_operator_timing": (C.c_int, [_VP, C.c_int]),
     "pmc_sampler_operator_time": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pmc_sampler_operator_event_overhead": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "pmc_darcy_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_darcy_level), C.c_int,
                                    C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
     "pmc_darcy_destroy": (None, [_VP]),
@@ -419,6 +420,12 @@ class PDESampler:
         ms, n = C.c_double(0.0), C.c_int64(0)
         _check(self.ctx.lib.pmc_sampler_operator_time(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def operator_event_overhead(self):
+        """total ms of the empty event brackets recorded behind the timed launches since the last call."""
+        ms = C.c_double(0.0)
+        _check(self.ctx.lib.pmc_sampler_operator_event_overhead(self.h, C.byref(ms)))
+        return ms.value
 
     def Mult(self, level, x, repeat=1):
         """y = [M Bt; B -aW] x (the block operator's Mult).  x: (nbatch, n_u+n_s) numpy or a

@@ -342,6 +342,14 @@ int pmc_sampler_operator_time(pmc_sampler* s, double* total_ms, int64_t* launche
     });
 }
 
+int pmc_sampler_operator_event_overhead(pmc_sampler* s, double* total_ms) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr && total_ms != nullptr, "operator_event_overhead: bad arguments");
+        *total_ms = s->impl.work.op_gap_ms;
+        s->impl.work.op_gap_ms = 0.0;
+    });
+}
+
 // ---- Darcy ------------------------------------------------------------------------------------
 int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_level* levels, int k_divides,
                      const pmc_solver_opts* opts, pmc_darcy** out) {

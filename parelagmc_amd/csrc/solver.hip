@@ -357,7 +357,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     k::DotParts dp_op;
     auto apply_op = [&](const double* u) {
         if (timing) {
-            while (w.ev.size() < ev_used + 2) {
+            while (w.ev.size() < ev_used + 3) {
                 hipEvent_t e;
                 PMC_HIP(hipEventCreate(&e));
                 w.ev.push_back(e);
@@ -367,7 +367,8 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         dp_op = A.apply(L, nb, u, q, w.partial_op.p, w.partial_op.p + seg2);
         if (timing) {
             PMC_HIP(hipEventRecord(w.ev[ev_used + 1], st));
-            ev_used += 2;
+            PMC_HIP(hipEventRecord(w.ev[ev_used + 2], st));   // empty bracket: what one event record costs on this stream
+            ev_used += 3;
         }
     };
     // one MINRES iteration with explicit roles of the ping-pong vectors; on entry q = A u1_ and its dot are in place
@@ -501,10 +502,12 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     static_assert(sizeof(k::MinresState) <= 4096 * sizeof(double), "pinned scratch too small");
     PMC_HIP(hipMemcpyAsync(ctx.h_scal, S, sizeof(k::MinresState), hipMemcpyDeviceToHost, st));
     PMC_HIP(hipStreamSynchronize(st));
-    for (size_t e = 0; e + 1 < ev_used; e += 2) {
-        float ms = 0.f;
+    for (size_t e = 0; e + 2 < ev_used; e += 3) {
+        float ms = 0.f, gap = 0.f;
         PMC_HIP(hipEventElapsedTime(&ms, w.ev[e], w.ev[e + 1]));
+        PMC_HIP(hipEventElapsedTime(&gap, w.ev[e + 1], w.ev[e + 2]));
         w.op_ms += ms;
+        w.op_gap_ms += gap;
         ++w.op_launches;
     }
     k::MinresState hs;

@@ -161,6 +161,7 @@ struct MinresWork {
     bool time_operator = false;
     std::vector<hipEvent_t> ev;
     double op_ms = 0.0;
+    double op_gap_ms = 0.0;                  // sum of the empty event brackets recorded right behind each timed launch
     int64_t op_launches = 0;
     MinresWork() = default;
     MinresWork(const MinresWork&) = delete;
