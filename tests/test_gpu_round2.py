@@ -290,3 +290,27 @@ def test_wide_batches_of_32_on_small_levels(gpu_ctx, hex_hierarchy, seeded_rng):
     assert np.allclose(s43[32:], s43[:11], rtol=1e-9)
     ds.close()
     smp.close()
+
+
+def test_manager_sums_do_not_depend_on_the_batch_width(gpu_ctx, hex_hierarchy_small):
+    """MLMC_Manager::InitRun with 32 realizations per plugin call (solved 32 at a time on these small levels) against 16 and
+    5 per call: same realizations, same sums up to the solver tolerance (tight here), same estimate."""
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp_ = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    o = capi.solver_opts(rel_tol=1e-12, abs_tol=1e-14)
+    smp, ds = capi.PDESampler(gpu_ctx, sp_, o), capi.DarcySolver(gpu_ctx, dp, o)
+    out = []
+    for batch in (32, 16, 5):
+        mgr = host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False, batch=batch)
+        out.append(mgr.InitRun([40, 70]))
+        mgr.close()
+    for r in out[1:]:
+        assert np.allclose(r["sums"], out[0]["sums"], rtol=1e-8, atol=1e-10)
+        assert r["estimate"] == pytest.approx(out[0]["estimate"], rel=1e-9)
+        assert list(r["nsamples"]) == list(out[0]["nsamples"])
+    with pytest.raises(Exception):
+        host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False, batch=33)
+    ds.close()
+    smp.close()
