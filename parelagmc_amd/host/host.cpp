@@ -971,7 +971,7 @@ void pmc_mlmc_params_default(pmc_mlmc_params* p) {
     p->init_nsamples = 10;
     p->array_nsamples = nullptr;
     p->wall_time = 1;
-    p->batch = 16;
+    p->batch = 32;
     p->max_rounds = 1000;
     p->log_file = nullptr;
 }

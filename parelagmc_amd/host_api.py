@@ -183,7 +183,7 @@ class RatioManager:
     ML_BayesRatio_Splitting_Manager / SL_BayesRatio_Splitting_Manager."""
 
     def __init__(self, nlevels, sampler=None, solver=None, G_obs=None, noise=None, callbacks=None, likelihood=None,
-                 eps2=0.001, ratio=0.5, init_nsamples=10, wall_time=True, batch=16, max_rounds=1000, splitting=False):
+                 eps2=0.001, ratio=0.5, init_nsamples=10, wall_time=True, batch=32, max_rounds=1000, splitting=False):
         self.lib = load_host_library()
         self.nlevels = nlevels
         p = pmc_mlmc_params()
@@ -316,7 +316,7 @@ class MLMCManager:
     plugin callbacks (`callbacks=dict(sample=, eval=, solve=, xi_size=, sample_size=, ndofs=)`)."""
 
     def __init__(self, nlevels, sampler=None, solver=None, callbacks=None, eps2=0.001, ratio=0.5, init_nsamples=10,
-                 array_nsamples: Optional[Sequence[int]] = None, wall_time=True, batch=16, max_rounds=1000,
+                 array_nsamples: Optional[Sequence[int]] = None, wall_time=True, batch=32, max_rounds=1000,
                  log_file: Optional[str] = None):
         self.lib = load_host_library()
         self.nlevels = nlevels
