@@ -642,7 +642,8 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
 }
 
 // Element-grouped per-realization mass matrix (EgView): acc = c1 * (group 1 row sums) + c2 * (group 2 row sums).
-template <int NB, bool CS>
+// kEgNt: non-temporal matrix / result streams on large levels (hex 64^3, one lane: 28.2 -> 27.3 ms per 16 Darcy solves).
+template <int NB, bool CS, bool kEgNt = false>
 __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, const double* __restrict__ w,
                                                const int* __restrict__ e12, const double* __restrict__ coef, int gw,
                                                const double* __restrict__ x, const double* __restrict__ cs, int nrows,
@@ -651,7 +652,7 @@ __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, con
     const int g = lane / T, t = lane % T;
     const int off = slice * 2 * gw * kWave;
     double a[T][C];
-    sell_row_range<NB, false, CS, true>(cols, w, x, cs, off, gw, lane, a);
+    sell_row_range<NB, false, CS, true, 1, kEgNt>(cols, w, x, cs, off, gw, lane, a);
 #pragma unroll
     for (int rs = 0; rs < T; ++rs) {
         const int row = min(slice * kWave + rs * G + g, nrows - 1);
@@ -660,7 +661,7 @@ __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, con
 #pragma unroll
         for (int c = 0; c < C; ++c) y[rs][c] = c1[c] * a[rs][c];
     }
-    sell_row_range<NB, false, CS, true>(cols, w, x, cs, off + gw * kWave, gw, lane, a);
+    sell_row_range<NB, false, CS, true, 1, kEgNt>(cols, w, x, cs, off + gw * kWave, gw, lane, a);
 #pragma unroll
     for (int rs = 0; rs < T; ++rs) {
         const int row = min(slice * kWave + rs * G + g, nrows - 1);
@@ -671,7 +672,7 @@ __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, con
     }
 }
 
-template <int NB, bool DOT>
+template <int NB, bool DOT, bool kEgNt = false>
 __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
     int nrows, int nslices, int gw, const int* __restrict__ cols1, const double* __restrict__ w1,
     const int* __restrict__ e12, const double* __restrict__ coef, const int* __restrict__ off2,
@@ -687,17 +688,17 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
     const SliceWalk sw = slice_walk(nslices);
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
-        eg_row_product<NB, false>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, acc);
+        eg_row_product<NB, false, kEgNt>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, acc);
         {
             const int o2 = off2[slice];
-            sell_row_range<NB, false, false, false>(cols2, vals2, x2, nullptr, o2, (off2[slice + 1] - o2) >> 6, lane, acc);
+            sell_row_range<NB, false, false, false, 1, kEgNt>(cols2, vals2, x2, nullptr, o2, (off2[slice + 1] - o2) >> 6, lane, acc);
         }
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
             if (row >= nrows) continue;
             const size_t at = (size_t)row * NB + t * C;
-            store_c<C>(y + at, acc[rs]);
+            store_c_stream<kEgNt, C>(y + at, acc[rs]);
             if constexpr (DOT) {
                 double wv[C];
                 load_c<C>(dot_with + at, wv);
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
     if constexpr (DOT) reduce_cols_store<NB>(p, partial);
 }
 
-template <int NB, bool DOT>
+template <int NB, bool DOT, bool kEgNt = false>
 __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices, int gw, const int* __restrict__ cols,
                                                           const double* __restrict__ w, const int* __restrict__ e12,
                                                           const double* __restrict__ coef,
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices
     const SliceWalk sw = slice_walk(nslices);
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
-        eg_row_product<NB, true>(cols, w, e12, coef, gw, r, dinv, nrows, slice, lane, acc);
+        eg_row_product<NB, true, kEgNt>(cols, w, e12, coef, gw, r, dinv, nrows, slice, lane, acc);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices
                 xv[c] = di[c] * (c0 * rv[c] - c1 * acc[rs][c]);
                 if constexpr (DOT) p[c] = fma(rv[c], xv[c], p[c]);
             }
-            store_c<C>(xout + at, xv);
+            store_c_stream<kEgNt, C>(xout + at, xv);
         }
     }
     if constexpr (DOT) reduce_cols_store<NB>(p, partial);
@@ -2035,7 +2036,12 @@ int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, co
         throw Error(PMC_ERR_INTERNAL, "eg_pair_spmm: second operator must share the rows and carry shared values");
     const dim3 g = grid_bounded(grid_slices(M.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
-        if (dot_partial)
+        if (nt_flat((size_t)M.nrows * NB * 2)) {   // from 4 MiB per vector on
+            if (dot_partial)
+                eg_pair_spmm_kernel<NB, true, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial);
+            else
+                eg_pair_spmm_kernel<NB, false, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr);
+        } else if (dot_partial)
             eg_pair_spmm_kernel<NB, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial);
         else
             eg_pair_spmm_kernel<NB, false><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr);
@@ -2049,7 +2055,12 @@ int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const 
     if (M.nrows == 0) return 0;
     const dim3 g = grid_bounded(grid_slices(M.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
-        if (dot_partial)
+        if (nt_flat((size_t)M.nrows * NB * 2)) {
+            if (dot_partial)
+                eg_poly2_kernel<NB, true, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial);
+            else
+                eg_poly2_kernel<NB, false, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr);
+        } else if (dot_partial)
             eg_poly2_kernel<NB, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial);
         else
             eg_poly2_kernel<NB, false><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr);
