@@ -20,7 +20,7 @@ else:
 print("dofs", dp.levels[0].n_u + dp.levels[0].n_p, flush=True)
 ctx = capi.Context(0, seed=5)
 ds = capi.DarcySolver(ctx, dp)
-nb = 16
+nb = int(__import__("os").environ.get("NB", "16"))
 k = ctx.array(np.exp(np.random.default_rng(0).standard_normal(nb * dp.levels[0].n_p)))
 ds.SolveFwd(0, k, nbatch=nb)
 ctx.timer_start()
