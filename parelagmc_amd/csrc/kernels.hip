@@ -1441,6 +1441,10 @@ __global__ __launch_bounds__(kBlock) void broadcast_kernel(int n, const double* 
 // launches per V-cycle); here one workgroup per realization sweeps all of them with __syncthreads()
 // between phases.  Vectors live in LDS ([r | x | d] per level), matrices are read from global memory (L2).
 static constexpr int kTailThreads = 1024;
+// The tail's device functions are inlined into their two kernels: as real calls they cost ~50 callee-saved registers spilled
+// at every entry and a register allocation split at the call boundary (Darcy iteration on a 16^3 level 168 -> 147 us,
+// config 3 +5 %).
+#define PMC_TAIL_INLINE __device__ __forceinline__
 static constexpr size_t kTailLdsBytes = 160 * 1024 - 1024;   // dynamic LDS budget (static reduction scratch on top)
 
 __device__ __forceinline__ double tail_row_dot(const int* __restrict__ off, const int* __restrict__ cols,
@@ -1553,7 +1557,7 @@ __device__ bool tail_cheb_cached(const TailLevelDev& L, int bv, int nb, int k, i
 // Chebyshev iteration on one tail level, in place: x (zero or given) -> x.  All threads participate.
 // (A variant that cached each thread's matrix rows in registers across the steps spilled to scratch under
 // hipcc 7.2 and was not faster; the matrix is re-read from L2 every step.)
-__device__ void tail_cheb(const TailLevelDev& L, int bv, int nb, int k, int degree, double ratio, bool zero_guess,
+PMC_TAIL_INLINE void tail_cheb(const TailLevelDev& L, int bv, int nb, int k, int degree, double ratio, bool zero_guess,
                           const double* r, double* x, double* d) {
     const int n = L.n;
     // value / diagonal addressing: shared, interleaved per realization, or transposed per realization
@@ -1607,7 +1611,7 @@ __device__ void tail_cheb(const TailLevelDev& L, int bv, int nb, int k, int degr
 
 // V-cycle over the tail levels for realization k: the right-hand side is in LDS at lev[0]'s r block on entry, the
 // result in its x block on return.  All kTailThreads threads of the workgroup participate.
-__device__ void tail_vcycle_lds(const TailParams& P, int nb, int k, double* lds) {
+PMC_TAIL_INLINE void tail_vcycle_lds(const TailParams& P, int nb, int k, double* lds) {
     const int nlev = P.nlev;
     // down sweep
     int l = 0;
