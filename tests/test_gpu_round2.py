@@ -314,3 +314,26 @@ def test_manager_sums_do_not_depend_on_the_batch_width(gpu_ctx, hex_hierarchy_sm
         host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False, batch=33)
     ds.close()
     smp.close()
+
+
+def test_in_loop_operator_timing_and_its_event_overhead(gpu_ctx, hex_hierarchy_small, seeded_rng):
+    """pmc_sampler_set_operator_timing brackets every K5 launch of the MINRES loop with HIP events and records an empty
+    bracket behind each one: the accumulated overhead is positive, smaller than the bracketed time, and the launch count
+    equals the operator applications of the solve (prologue + one per iteration but the last)."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    sp_ = build_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    smp = capi.PDESampler(gpu_ctx, sp_, capi.solver_opts(mini_max_rows=0))
+    xi = seeded_rng.standard_normal((16, sp_.levels[0].n_s))
+    ref, st_ref = smp.Eval(0, xi, return_stats=True)
+    smp.set_operator_timing(True)
+    smp.operator_time()
+    s, st = smp.Eval(0, xi, return_stats=True)
+    gap = smp.operator_event_overhead()
+    ms, n = smp.operator_time()
+    smp.set_operator_timing(False)
+    assert np.array_equal(s, ref) and st == st_ref                       # instrumentation never changes a result
+    its = max(t[0] for t in st)
+    assert its - 2 <= n <= its + 2 and 0.0 < gap < ms
+    assert smp.operator_time() == (0.0, 0) and smp.operator_event_overhead() == 0.0
+    smp.close()
