@@ -275,6 +275,44 @@ def darcy_cpu_baseline(sp, dp, seed, per_core=(1, 2, 8)):
                       "[64, 256, 1024] round at these costs"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` (N > 1) started without torchrun: the parent - which never imports torch.cuda and never
+    creates a pmc_ctx - starts N fresh child processes of this script, one rank per GPU, with the torch.distributed
+    environment set (as the reference starts its ranks under mpirun, examples/MLMC.cpp:43-50); rank 0 prints the JSON line
+    on the inherited stdout, the other ranks' stdout goes to stderr; exit code = first non-zero child code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                c = p.poll()
+                if c is None:
+                    continue
+                live.remove(p)
+                if c != 0 and rc == 0:
+                    rc = c
+                    for q in live:       # a failed rank leaves the others waiting in a collective: end them
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,22 +329,28 @@ def main():
     ap.add_argument("--seed", type=int, default=20261003)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process starts the N ranks itself and never touches the GPU
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        print(f"bench: --gpus {args.gpus} but WORLD_SIZE {world}: the launcher must start exactly --gpus ranks", file=sys.stderr)
+        sys.exit(2)
+    ndev = max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # backend nccl = RCCL over xGMI; PMC_BENCH_BACKEND=gloo only exists to rehearse the multi-rank code
-        # path on a box with fewer GPUs than ranks (ranks then share devices round-robin)
-        backend = os.environ.get("PMC_BENCH_BACKEND", "nccl")
-        ndev = max(1, torch.cuda.device_count())
+        # backend nccl = RCCL over xGMI.  gloo only rehearses the multi-rank code path on a box with fewer GPUs than ranks
+        # (ranks then share devices round-robin; RCCL refuses two ranks on one device): chosen by PMC_BENCH_BACKEND, or by
+        # itself when the box has fewer devices than ranks - the line then says so ("devices" < "n_gpus")
+        backend = os.environ.get("PMC_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
         torch.cuda.set_device(local_rank % ndev)
         dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from parelagmc_amd import capi
 
@@ -331,6 +375,7 @@ def main():
         stats += farm.step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     check_stats(stats, "the timed region")
     iters = [t[0] for t in stats]
     # batch-iterations executed: a batch runs until its slowest column has converged
@@ -345,6 +390,15 @@ def main():
         acc = a.cpu().numpy()
     total_samples = args.steps * nb * ns * world
     value = total_samples / dt
+    # what every rank did in the timed region: local realization ids [first, last] of a generator split nparts = world,
+    # mypart = rank, i.e. the global ids first * world + rank, ..., last * world + rank - disjoint by construction
+    mine = {"rank": rank, "device": dev, "samples": args.steps * nb * ns, "seconds": dt_local,
+            "global_ids": [args.warmup * ns * nb * world + rank, ((args.warmup + args.steps) * ns * nb - 1) * world + rank],
+            "id_stride": world}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     out = None
     if rank == 0:
@@ -361,6 +415,7 @@ def main():
                                    f"MINRES 300/1e-6/1e-12, {ns} x {nb} realizations per step, all converged",
                        "mean_minres_iterations": acc[0] / max(acc[1], 1.0), "batch": nb, "streams": ns,
                        "parallelism": f"sample-farm x{world}"},
+            "devices": min(world, ndev), "ranks": per_rank,
             "roofline": operator_roofline(farm, problem, nb, args.refine, next_batch, sbytes, acc[2], dt),
         }
         if world == 1 and not args.no_cpu_baseline:
