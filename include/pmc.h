@@ -191,7 +191,7 @@ int pmc_sampler_eval(pmc_sampler* s, int level, int xi_level, int nbatch, const 
                      pmc_stats* stats);
 
 /* y = A x with A = [M B^T; B -alpha W] of `level` (src/PDESampler.cpp:279-284; the oper->Mult inside the
- * Krylov loop, kernel K5) for nbatch in {1,2,4,8,16,32} vectors of n_u+n_s entries each.  The SpMM kernel is
+ * Krylov loop, kernel K5) for nbatch in {1,2,4,8,16,32,64,128,256} vectors of n_u+n_s entries each.  The SpMM kernel is
  * launched `repeat` >= 1 times between two HIP events on the ctx stream; avg_ms (may be NULL) receives the
  * mean kernel duration, bytes (may be NULL) the algorithmic bytes of ONE launch:
  * 12 nnz + 4 nrows + nbatch * 8 * (nrows + ncols). */

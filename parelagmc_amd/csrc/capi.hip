@@ -131,7 +131,7 @@ int pmc_ctx_create(int device_id, pmc_ctx** out) {
         PMC_HIP(hipEventCreate(&c->ev0));
         PMC_HIP(hipEventCreate(&c->ev1));
         PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_flag), sizeof(int) * 16, hipHostMallocDefault));
-        PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(double) * 4096, hipHostMallocDefault));
+        PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(double) * pmc::Ctx::kHostScratch, hipHostMallocDefault));
         g_live_ctx[device_id & 63].fetch_add(1);
         *out = c.release();
     });

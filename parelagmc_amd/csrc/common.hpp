@@ -181,16 +181,21 @@ struct Ctx {
     int nranks = 1, rank = 0;
     DevBuf<double> comm_buf;
     int* h_flag = nullptr;         // pinned host word for convergence polls
-    double* h_scal = nullptr;      // pinned host scratch (>= 4096 doubles)
+    double* h_scal = nullptr;      // pinned host scratch (kHostScratch doubles)
+    static constexpr size_t kHostScratch = 8192;
     void activate() const;
 };
 
-// Interleaved batch width of a level with `rows` unknowns (saddle-point system): levels small enough to be bound by launch
-// latency rather than bandwidth take kMaxBatch realizations per launch, the others 16 (PMC_WIDE_ROWS overrides the limit,
-// 0 = always 16).
+// Interleaved batch width of a level with `rows` unknowns (saddle-point system).  Large levels are bandwidth-bound at 16
+// realizations per launch; levels small enough to be bound by launch latency take 32 (PMC_WIDE_ROWS: limit, default
+// 300 000 rows, 0 = always 16), and the smaller the level the more column groups of 32 one launch carries - 64, 128 or 256
+// realizations (PMC_W64_ROWS / PMC_W128_ROWS / PMC_W256_ROWS: limits, 0 = never) - until a launch fills the chip.
 int batch_width(size_t rows);
-static constexpr int kMaxBatch = 32;   // widest interleaved batch (levels small enough to be launch-latency bound); large levels use 16
-inline bool valid_batch(int nb) { return nb == 1 || nb == 2 || nb == 4 || nb == 8 || nb == 16 || nb == 32; }
+static constexpr int kGroup = 32;      // widest compile-time interleave (Lay<32>); wider batches are column groups of it
+static constexpr int kMaxBatch = 256;  // widest batch of one launch: 8 column groups
+inline bool valid_batch(int nb) {
+    return nb == 1 || nb == 2 || nb == 4 || nb == 8 || nb == 16 || nb == 32 || nb == 64 || nb == 128 || nb == 256;
+}
 
 }  // namespace pmc
 

@@ -134,10 +134,7 @@ std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, 
         m.n = pat.nrows;
         m.bv = true;
         m.lmax = 1.0;                        // dinv carries the per-realization Gershgorin bound (k::gersh_scale_bv)
-        sell_build(m.S, pat, false, true, st);
-        m.vals_bv.alloc((size_t)m.S.nslots * kMaxBatch);
-        m.vals_scaled.alloc((size_t)m.S.nslots * kMaxBatch);
-        m.dinv.alloc((size_t)m.n * kMaxBatch);
+        sell_build(m.S, pat, false, true, st);   // per-realization values: sized by Darcy::ensure for the width in use
         {
             std::vector<int> ptr, idx;
             std::vector<double> w;
@@ -403,10 +400,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         m.n = d.n_p;
         m.bv = true;
         m.lmax = 2.0 * 1.0001;   // weakly diagonally dominant M-matrix: spec(D^-1 S) in (0, 2]
-        sell_build(m.S, pattern[l], false, true, st);
-        m.vals_bv.alloc((size_t)m.S.nslots * kMaxBatch);
-        m.vals_scaled.alloc((size_t)m.S.nslots * kMaxBatch);
-        m.dinv.alloc((size_t)m.n * kMaxBatch);
+        sell_build(m.S, pattern[l], false, true, st);   // per-realization values: sized by Darcy::ensure for the width in use
         // own Schur lists mapped onto the (possibly larger) level pattern
         {
             // map own CSR nnz -> level-pattern CSR nnz by (row, col) search
@@ -480,6 +474,19 @@ bool Darcy::use_eg(const DarcyLevel& d) const {
 void Darcy::ensure(int level, int nb) {
     DarcyLevel& d = lv[level];
     const size_t n = (size_t)d.n_u + d.n_p;
+    // per-realization values of the Schur hierarchy this solve walks, at the width it runs with (a large level is solved
+    // 16 at a time: it never pays for the 256 columns of the small ones)
+    auto size_values = [nb, this](Multigrid& g, size_t first) {
+        g.ensure_bv_tail_width(ctx.stream, nb);
+        for (size_t l = first; l < g.L.size(); ++l) {
+            MgLevel& m = g.L[l];
+            m.vals_bv.ensure((size_t)m.S.nslots * nb);
+            m.vals_scaled.ensure((size_t)m.S.nslots * nb);
+            m.dinv.ensure((size_t)m.n * nb);
+        }
+    };
+    if (level < (int)chains.size() && chains[level]) size_values(chains[level]->mg, 0);
+    else size_values(mg, (size_t)level);
     d.coef.ensure((size_t)(d.n_p + 1) * nb);     // + the constant-one row of the element-grouped layout
     if (!use_eg(d)) {
         d.mvals.ensure((size_t)d.M.nslots * nb);
@@ -494,7 +501,7 @@ void Darcy::ensure(int level, int nb) {
     cd.ensure((size_t)d.n_u * nb);
     stage_k.ensure((size_t)d.n_p * nb);
     stage_sol.ensure(n * nb);
-    qpartial.ensure((size_t)dot_capacity((int)n) * kMaxBatch);
+    qpartial.ensure((size_t)dot_capacity((int)n, nb) * nb);
     qout.ensure(kMaxBatch);
 }
 

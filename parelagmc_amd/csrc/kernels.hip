@@ -28,9 +28,15 @@ static constexpr int kWave = 64;
 #endif
 static constexpr bool kK5TwoColumns = PMC_K5_TWO_COLUMNS != 0;   // tuning build: K5 steps two slice columns at a time (see sell_row_range); measured slower, off
 
-int dot_capacity(int nrows) {
-    // upper bound on the partial blocks any (fused) dot over nrows rows writes, for every batch width
-    return (nrows + 63) / 64 / (kBlock / kWave) + (int)(((size_t)nrows * kMaxBatch / 2 + kBlock - 1) / kBlock) + 2;
+static unsigned dot_grid_bound();
+int dot_capacity(int nrows, int nb) {
+    // upper bound on the partial blocks (of nb doubles each) any fused dot over nrows rows of a batch of nb writes: slice
+    // kernels one block per 4 slices, flat kernels one per kBlock threads, both bounded by dot_grid_bound() - except the
+    // block operator's two-stage reduction, which keeps every slice block behind kCompressBlocks compressed ones (k::spmm)
+    const size_t slice_blocks = ((size_t)nrows + 63) / 64 / (kBlock / kWave) + 1;
+    const size_t flat_blocks = ((size_t)nrows * nb / (nb >= 32 ? 4 : (nb >= 2 ? 2 : 1)) + kBlock - 1) / kBlock;
+    const size_t bounded = std::min<size_t>(std::max(slice_blocks, flat_blocks), dot_grid_bound());
+    return (int)std::max<size_t>(bounded, 256 + slice_blocks) + 2;
 }
 
 // Batch layout helper.  A row of NB interleaved values is handled by T lanes, C = 2 doubles (one 16 B
@@ -41,6 +47,22 @@ struct Lay {
     static constexpr int T = NB / C;
     static constexpr int G = kWave / T;
 };
+
+// Column groups (super-batches).  A batch wider than kGroup realizations is ONE interleaved vector with row stride
+// ld = nb doubles, worked on as nb / kGroup groups of kGroup columns: group g owns the columns [g kGroup, (g + 1) kGroup) of
+// every row, blockIdx.y names the group, and every launch carries all groups - a level too small to fill the chip with 32
+// realizations is solved 64 ... 256 at a time.  Only the widest instantiation (NB == kGroup) is group-capable; the
+// narrower ones keep the compile-time row stride NB (ld is ignored, gridDim.y == 1).
+template <int NB>
+__device__ __forceinline__ int row_ld(int ld) {
+    if constexpr (NB == kGroup) return ld;
+    else return NB;
+}
+template <int NB>
+__device__ __forceinline__ int col0() {
+    if constexpr (NB == kGroup) return (int)blockIdx.y * NB;
+    else return 0;
+}
 
 template <int C>
 __device__ __forceinline__ void load_c(const double* __restrict__ p, double (&v)[C]) {
@@ -140,9 +162,9 @@ __device__ __forceinline__ void store_row(double* __restrict__ p, const double (
 
 // Column-wise block reduction.  Every lane holds partial sums p[0..C) for columns (lane % T)*C + c.
 // Deterministic: fixed xor tree over the lanes that share a column, fixed order over the 4 wavefronts.
-// Writes partial[blockIdx.x*NB + k].
+// Writes partial[blockIdx.x*LD + k] (partial already points at the group's first column).
 template <int NB>
-__device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], double* __restrict__ partial) {
+__device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], double* __restrict__ partial, int LD = NB) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T;
     __shared__ double lds[kBlock / kWave][NB];
 #pragma unroll
@@ -162,8 +184,33 @@ __device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], doubl
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kBlock / kWave; ++w) s += lds[w][threadIdx.x];
-        partial[(size_t)blockIdx.x * NB + threadIdx.x] = s;
+        partial[(size_t)blockIdx.x * LD + threadIdx.x] = s;
     }
+}
+
+// The same for the flat kernels on a batch of W = ld > kGroup columns (runtime width, W divides 4 * kBlock): thread t owns the
+// columns (4 t) % W + c of the rows it visits; LDS holds every thread's four sums, thread j < W adds the 4 kBlock / W
+// entries of column j in index order (deterministic).  Writes partial[blockIdx.x * W + j].
+__device__ __forceinline__ void reduce_cols_store_wide(const double (&p)[4], double* __restrict__ partial, int W) {
+    __shared__ double lds[kBlock * 4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds[threadIdx.x * 4 + c] = p[c];
+    __syncthreads();
+    if ((int)threadIdx.x < W) {
+        double s = 0.0;
+        for (int m = threadIdx.x; m < kBlock * 4; m += W) s += lds[m];
+        partial[(size_t)blockIdx.x * W + threadIdx.x] = s;
+    }
+}
+template <int NB>
+__device__ __forceinline__ void reduce_flat_store(double (&p)[Lay<NB>::C], double* __restrict__ partial, int W) {
+    if constexpr (NB == kGroup) {
+        if (W > NB) {
+            reduce_cols_store_wide(p, partial, W);
+            return;
+        }
+    }
+    reduce_cols_store<NB>(p, partial);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -182,7 +229,7 @@ __device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], doubl
 template <int NB, bool BV, bool CS, bool ZERO, int JC = 1, bool NT = false>
 __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
                                                const double* __restrict__ x, const double* __restrict__ cs, int off,
-                                               int width, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C],
+                                               int width, int lane, int LD, double (&acc)[Lay<NB>::T][Lay<NB>::C],
                                                double (*xlast)[Lay<NB>::C] = nullptr) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int g = lane / T, t = lane % T;
@@ -213,9 +260,9 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
             double xv[JU][C], av[JU][C], sv[JU][C];
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
-                load_c<C>(x + (size_t)cc[u] * NB, xv[u]);
-                if constexpr (CS) load_c<C>(cs + (size_t)cc[u] * NB, sv[u]);
-                if constexpr (BV) load_c<C>(vals + (size_t)(j + u < width ? slot + u * kWave : slot) * NB, av[u]);
+                load_c<C>(x + (size_t)cc[u] * LD, xv[u]);
+                if constexpr (CS) load_c<C>(cs + (size_t)cc[u] * LD, sv[u]);
+                if constexpr (BV) load_c<C>(vals + (size_t)(j + u < width ? slot + u * kWave : slot) * LD, av[u]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -275,8 +322,8 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rs = 0; rs < T; ++rs) {
-                load_c<C>(x + (size_t)cc0[rs] * NB + t * C, x0[rs]);
-                load_c<C>(x + (size_t)cc1[rs] * NB + t * C, x1[rs]);
+                load_c<C>(x + (size_t)cc0[rs] * LD + t * C, x0[rs]);
+                load_c<C>(x + (size_t)cc1[rs] * LD + t * C, x1[rs]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -323,9 +370,9 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise re-serialises load -> wait -> fma
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
-            load_c<C>(x + (size_t)cc[rs] * NB + t * C, xv[rs]);
-            if constexpr (CS) load_c<C>(cs + (size_t)cc[rs] * NB + t * C, sv[rs]);
-            if constexpr (BV) load_c<C>(vals + (size_t)(slot - lane + rs * G + g) * NB + t * C, av[rs]);
+            load_c<C>(x + (size_t)cc[rs] * LD + t * C, xv[rs]);
+            if constexpr (CS) load_c<C>(cs + (size_t)cc[rs] * LD + t * C, sv[rs]);
+            if constexpr (BV) load_c<C>(vals + (size_t)(slot - lane + rs * G + g) * LD + t * C, av[rs]);
         }
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -351,10 +398,10 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
 template <int NB, bool BV>
 __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_off, const int* __restrict__ cols,
                                                  const double* __restrict__ vals, const double* __restrict__ x,
-                                                 int slice, int lane, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
+                                                 int slice, int lane, int LD, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
     const int off = slice_off[slice];
     const int width = (slice_off[slice + 1] - off) >> 6;
-    sell_row_range<NB, BV, false, true>(cols, vals, x, nullptr, off, width, lane, acc);
+    sell_row_range<NB, BV, false, true>(cols, vals, x, nullptr, off, width, lane, LD, acc);
 }
 
 // XCD-aware slice assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (block b runs on XCD b % 8),
@@ -398,8 +445,18 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                                                            const double* __restrict__ x, double* __restrict__ y,
                                                            const double* __restrict__ r,
                                                            const double* __restrict__ dot_with,
-                                                           double* __restrict__ partial) {
+                                                           double* __restrict__ partial, int ld) {
     static_assert(!R8 || (MODE == 2 && !DOT), "fused restriction goes with the residual");
+    const int LD = row_ld<NB>(ld);
+    {
+        const int c0 = col0<NB>();   // this group's columns of every interleaved operand
+        x += c0;
+        y += c0;
+        if constexpr (BV) vals += c0;
+        if constexpr (MODE == 2) r += c0;
+        if constexpr (DOT && !DL) dot_with += c0;
+        if constexpr (DOT || R8) partial += c0;
+    }
     static_assert(!DL || (DOT && !BV && Lay<NB>::T > 1), "diagonal-last serves the fused <x, Ax> of shared-value operators");
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int lane = threadIdx.x & (kWave - 1);
@@ -415,21 +472,21 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
         if constexpr (DL) {
             const int off = slice_off[slice];
             sell_row_range<NB, false, false, true, 1, NT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane,
-                                                         acc, xd);
+                                                         LD, acc, xd);
         } else if constexpr (TAG != 0 && !BV && T > 1 && kK5TwoColumns) {
             const int off = slice_off[slice];
-            sell_row_range<NB, false, false, true, 2>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, acc);
+            sell_row_range<NB, false, false, true, 2>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
         } else if constexpr (NT) {
             const int off = slice_off[slice];
-            sell_row_range<NB, BV, false, true, 1, true>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, acc);
+            sell_row_range<NB, BV, false, true, 1, true>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
         } else {
-            sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, acc);
+            sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, LD, acc);
         }
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
             if (row < nrows) {
-                const size_t at = (size_t)row * NB + t * C;
+                const size_t at = (size_t)row * LD + t * C;
                 if constexpr (MODE == 1) {
                     double old[C];
                     load_c<C>(y + at, old);
@@ -466,11 +523,11 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                     v += __shfl_xor(v, 4 * T, kWave);
                     s[c] = v;
                 }
-                if ((g & 7) == 0 && row < nrows) store_c<C>(partial + (size_t)(row >> 3) * NB + t * C, s);
+                if ((g & 7) == 0 && row < nrows) store_c<C>(partial + (size_t)(row >> 3) * LD + t * C, s);
             }
         }
     }
-    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
 // Chebyshev / Jacobi step: d = a d + b dinv (r - A xin); xout = xin + d ; DOT: partials of <r, xout>
@@ -483,8 +540,15 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
                                                            const double* __restrict__ r,
                                                            const double* __restrict__ xin, double* __restrict__ d,
                                                            double* __restrict__ xout, double a, double b,
-                                                           double* __restrict__ partial) {
+                                                           double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int LD = row_ld<NB>(ld);
+    {
+        const int c0 = col0<NB>();
+        r += c0; xin += c0; d += c0; xout += c0;
+        if constexpr (BV) { vals += c0; dinv += c0; }
+        if constexpr (DOT) partial += c0;
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
     double p[C];
@@ -494,12 +558,12 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
     for (int si = sw.begin; si < sw.end; si += sw.stride) {
         const int slice = sched ? sched[si] : si;
         double acc[T][C];
-        sell_row_product<NB, BV>(slice_off, cols, vals, xin, slice, lane, acc);
+        sell_row_product<NB, BV>(slice_off, cols, vals, xin, slice, lane, LD, acc);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
             if (row >= nrows) continue;
-            const size_t at = (size_t)row * NB + t * C;
+            const size_t at = (size_t)row * LD + t * C;
             double rv[C], dv[C], xv[C], di[C];
             load_c<C>(r + at, rv);
             load_c<C>(xin + at, xv);
@@ -526,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
             store_c<C>(xout + at, xv);
         }
     }
-    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
 // Degree-2 Chebyshev polynomial from a ZERO initial guess in ONE pass.  With t = D^-1 r the two steps
@@ -546,8 +610,18 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
                                                             double c0, double c1, double* __restrict__ partial,
                                                             const double* xadd, const double* __restrict__ dot_with,
                                                             const int* __restrict__ padd_idx,
-                                                            const double* __restrict__ padd_x) {
+                                                            const double* __restrict__ padd_x, int ld) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int LD = row_ld<NB>(ld);
+    {
+        const int c0 = col0<NB>();
+        r += c0; xout += c0;
+        if constexpr (BV) { vals_scaled += c0; dinv += c0; }
+        if (xadd) xadd += c0;
+        if (dot_with) dot_with += c0;
+        if (padd_x) padd_x += c0;
+        if constexpr (DOT) partial += c0;
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
     double p[C];
@@ -560,15 +634,15 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
         if constexpr (NT) {
             const int off = slice_off[slice];
             sell_row_range<NB, BV, false, true, 1, true>(cols, vals_scaled, r, nullptr, off, (slice_off[slice + 1] - off) >> 6,
-                                                        lane, acc);
+                                                        lane, LD, acc);
         } else {
-            sell_row_product<NB, BV>(slice_off, cols, vals_scaled, r, slice, lane, acc);
+            sell_row_product<NB, BV>(slice_off, cols, vals_scaled, r, slice, lane, LD, acc);
         }
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
             if (row >= nrows) continue;
-            const size_t at = (size_t)row * NB + t * C;
+            const size_t at = (size_t)row * LD + t * C;
             double rv[C], xv[C], di[C];
             load_c<C>(r + at, rv);
             if constexpr (BV) {
@@ -588,7 +662,7 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
             }
             if (padd_idx) {   // + (P xc)_row for an injection-type prolongator: xc[parent[row]]
                 double pc[C];
-                load_c<C>(padd_x + (size_t)padd_idx[row] * NB + t * C, pc);
+                load_c<C>(padd_x + (size_t)padd_idx[row] * LD + t * C, pc);
 #pragma unroll
                 for (int c = 0; c < C; ++c) xv[c] += pc[c];
             }
@@ -600,7 +674,7 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
             store_c_stream<NT, C>(xout + at, xv);
         }
     }
-    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
 // y = A1 x1 + A2 x2 over the SAME rows: A1 with per-realization values, A2 with shared values (the u-rows
@@ -610,8 +684,14 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
     int nrows, int nslices, const int* __restrict__ off1, const int* __restrict__ cols1, const double* __restrict__ vals1,
     const int* __restrict__ off2, const int* __restrict__ cols2, const double* __restrict__ vals2,
     const double* __restrict__ x1, const double* __restrict__ x2, double* __restrict__ y,
-    const double* __restrict__ dot_with, double* __restrict__ partial) {
+    const double* __restrict__ dot_with, double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int LD = row_ld<NB>(ld);
+    {
+        const int c0 = col0<NB>();
+        vals1 += c0; x1 += c0; x2 += c0; y += c0;
+        if constexpr (DOT) { dot_with += c0; partial += c0; }
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
     double p[C];
@@ -620,13 +700,13 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
     const SliceWalk sw = slice_walk(nslices);
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C], acc2[T][C];
-        sell_row_product<NB, true>(off1, cols1, vals1, x1, slice, lane, acc);
-        sell_row_product<NB, false>(off2, cols2, vals2, x2, slice, lane, acc2);
+        sell_row_product<NB, true>(off1, cols1, vals1, x1, slice, lane, LD, acc);
+        sell_row_product<NB, false>(off2, cols2, vals2, x2, slice, lane, LD, acc2);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
             if (row >= nrows) continue;
-            const size_t at = (size_t)row * NB + t * C;
+            const size_t at = (size_t)row * LD + t * C;
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[rs][c] += acc2[rs][c];
             store_c<C>(y + at, acc[rs]);
@@ -638,7 +718,7 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
             }
         }
     }
-    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
 // Element-grouped per-realization mass matrix (EgView): acc = c1 * (group 1 row sums) + c2 * (group 2 row sums).
@@ -647,26 +727,26 @@ template <int NB, bool CS, bool kEgNt = false>
 __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, const double* __restrict__ w,
                                                const int* __restrict__ e12, const double* __restrict__ coef, int gw,
                                                const double* __restrict__ x, const double* __restrict__ cs, int nrows,
-                                               int slice, int lane, double (&y)[Lay<NB>::T][Lay<NB>::C]) {
+                                               int slice, int lane, int LD, double (&y)[Lay<NB>::T][Lay<NB>::C]) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int g = lane / T, t = lane % T;
     const int off = slice * 2 * gw * kWave;
     double a[T][C];
-    sell_row_range<NB, false, CS, true, 1, kEgNt>(cols, w, x, cs, off, gw, lane, a);
+    sell_row_range<NB, false, CS, true, 1, kEgNt>(cols, w, x, cs, off, gw, lane, LD, a);
 #pragma unroll
     for (int rs = 0; rs < T; ++rs) {
         const int row = min(slice * kWave + rs * G + g, nrows - 1);
         double c1[C];
-        load_c<C>(coef + (size_t)e12[2 * row] * NB + t * C, c1);
+        load_c<C>(coef + (size_t)e12[2 * row] * LD + t * C, c1);
 #pragma unroll
         for (int c = 0; c < C; ++c) y[rs][c] = c1[c] * a[rs][c];
     }
-    sell_row_range<NB, false, CS, true, 1, kEgNt>(cols, w, x, cs, off + gw * kWave, gw, lane, a);
+    sell_row_range<NB, false, CS, true, 1, kEgNt>(cols, w, x, cs, off + gw * kWave, gw, lane, LD, a);
 #pragma unroll
     for (int rs = 0; rs < T; ++rs) {
         const int row = min(slice * kWave + rs * G + g, nrows - 1);
         double c2[C];
-        load_c<C>(coef + (size_t)e12[2 * row + 1] * NB + t * C, c2);
+        load_c<C>(coef + (size_t)e12[2 * row + 1] * LD + t * C, c2);
 #pragma unroll
         for (int c = 0; c < C; ++c) y[rs][c] = fma(c2[c], a[rs][c], y[rs][c]);
     }
@@ -678,8 +758,14 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
     const int* __restrict__ e12, const double* __restrict__ coef, const int* __restrict__ off2,
     const int* __restrict__ cols2, const double* __restrict__ vals2, const double* __restrict__ x1,
     const double* __restrict__ x2, double* __restrict__ y, const double* __restrict__ dot_with,
-    double* __restrict__ partial) {
+    double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int LD = row_ld<NB>(ld);
+    {
+        const int c0 = col0<NB>();
+        coef += c0; x1 += c0; x2 += c0; y += c0;
+        if constexpr (DOT) { dot_with += c0; partial += c0; }
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
     double p[C];
@@ -688,16 +774,16 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
     const SliceWalk sw = slice_walk(nslices);
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
-        eg_row_product<NB, false, kEgNt>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, acc);
+        eg_row_product<NB, false, kEgNt>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, LD, acc);
         {
             const int o2 = off2[slice];
-            sell_row_range<NB, false, false, false, 1, kEgNt>(cols2, vals2, x2, nullptr, o2, (off2[slice + 1] - o2) >> 6, lane, acc);
+            sell_row_range<NB, false, false, false, 1, kEgNt>(cols2, vals2, x2, nullptr, o2, (off2[slice + 1] - o2) >> 6, lane, LD, acc);
         }
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
             if (row >= nrows) continue;
-            const size_t at = (size_t)row * NB + t * C;
+            const size_t at = (size_t)row * LD + t * C;
             store_c_stream<kEgNt, C>(y + at, acc[rs]);
             if constexpr (DOT) {
                 double wv[C];
@@ -707,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
             }
         }
     }
-    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
 template <int NB, bool DOT, bool kEgNt = false>
@@ -716,8 +802,14 @@ __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices
                                                           const double* __restrict__ coef,
                                                           const double* __restrict__ dinv, const double* __restrict__ r,
                                                           double* __restrict__ xout, double c0, double c1,
-                                                          double* __restrict__ partial) {
+                                                          double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int LD = row_ld<NB>(ld);
+    {
+        const int g0 = col0<NB>();
+        coef += g0; dinv += g0; r += g0; xout += g0;
+        if constexpr (DOT) partial += g0;
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
     double p[C];
@@ -726,12 +818,12 @@ __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices
     const SliceWalk sw = slice_walk(nslices);
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
-        eg_row_product<NB, true, kEgNt>(cols, w, e12, coef, gw, r, dinv, nrows, slice, lane, acc);
+        eg_row_product<NB, true, kEgNt>(cols, w, e12, coef, gw, r, dinv, nrows, slice, lane, LD, acc);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
             if (row >= nrows) continue;
-            const size_t at = (size_t)row * NB + t * C;
+            const size_t at = (size_t)row * LD + t * C;
             double rv[C], di[C], xv[C];
             load_c<C>(r + at, rv);
             load_c<C>(dinv + at, di);
@@ -743,7 +835,7 @@ __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices
             store_c_stream<kEgNt, C>(xout + at, xv);
         }
     }
-    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
 // out[slot][k] = vals[slot][k] * colscale[cols[slot]][k]   (per-realization column scaling A(k) D(k)^-1)
@@ -751,15 +843,16 @@ template <int NB>
 __global__ __launch_bounds__(kBlock) void scale_cols_bv_kernel(size_t nflat, const int* __restrict__ cols,
                                                                const double* __restrict__ vals,
                                                                const double* __restrict__ colscale,
-                                                               double* __restrict__ out) {
+                                                               double* __restrict__ out, int ld) {
     constexpr int C = Lay<NB>::C;
+    const int W = row_ld<NB>(ld);   // flat kernel: a wide batch is simply a wider row
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nflat; i += (size_t)gridDim.x * kBlock) {
         const size_t e = i * C;
-        const size_t slot = e / NB;
-        const int k0 = (int)(e % NB);
+        const size_t slot = e / W;
+        const int k0 = (int)(e % W);
         double v[C], sc[C];
         load_c<C>(vals + e, v);
-        load_c<C>(colscale + (size_t)cols[slot] * NB + k0, sc);
+        load_c<C>(colscale + (size_t)cols[slot] * W + k0, sc);
 #pragma unroll
         for (int c = 0; c < C; ++c) v[c] *= sc[c];
         store_c<C>(out + e, v);
@@ -772,15 +865,16 @@ __global__ __launch_bounds__(kBlock) void minres_wx_idx_kernel(size_t nflat, con
                                                                const double* __restrict__ c0, const double* __restrict__ u,
                                                                const double* __restrict__ c1, double* __restrict__ w0,
                                                                const double* __restrict__ c2, const double* __restrict__ w1,
-                                                               const double* __restrict__ c3, double* __restrict__ x) {
+                                                               const double* __restrict__ c3, double* __restrict__ x, int ld) {
     constexpr int C = Lay<NB>::C;
+    const int W = row_ld<NB>(ld);
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nflat) return;
     const size_t e = i * C;
-    const size_t sel = e / NB;
-    const int k0 = (int)(e % NB);
+    const size_t sel = e / W;
+    const int k0 = (int)(e % W);
     double uv[C], w0v[C], w1v[C], xv[C];
-    load_c<C>(u + (size_t)rows[sel] * NB + k0, uv);
+    load_c<C>(u + (size_t)rows[sel] * W + k0, uv);
     load_c<C>(w0 + e, w0v);
     load_c<C>(w1 + e, w1v);
     load_c<C>(x + e, xv);
@@ -800,8 +894,9 @@ template <int NB, bool BV, bool DOT>
 __global__ __launch_bounds__(kBlock) void cheb_first_kernel(size_t nflat, const double* __restrict__ dinv,
                                                             const double* __restrict__ r, double* __restrict__ d,
                                                             double* __restrict__ x, double b,
-                                                            double* __restrict__ partial) {
+                                                            double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C;
+    const int W = row_ld<NB>(ld);
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
@@ -812,7 +907,7 @@ __global__ __launch_bounds__(kBlock) void cheb_first_kernel(size_t nflat, const 
         if constexpr (BV) {
             load_c<C>(dinv + e, di);
         } else {
-            const double s = dinv[e / NB];
+            const double s = dinv[e / W];
 #pragma unroll
             for (int c = 0; c < C; ++c) di[c] = s;
         }
@@ -824,12 +919,12 @@ __global__ __launch_bounds__(kBlock) void cheb_first_kernel(size_t nflat, const 
         store_c<C>(d + e, xv);
         store_c<C>(x + e, xv);
     }
-    if constexpr (DOT) reduce_cols_store<NB>(p, partial);
+    if constexpr (DOT) reduce_flat_store<NB>(p, partial, W);
 }
 
 template <int NB>
 __global__ __launch_bounds__(kBlock) void dot_kernel(size_t nflat, const double* __restrict__ a,
-                                                     const double* __restrict__ b, double* __restrict__ partial) {
+                                                     const double* __restrict__ b, double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C;
     double p[C];
 #pragma unroll
@@ -842,19 +937,19 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(size_t nflat, const double*
 #pragma unroll
         for (int c = 0; c < C; ++c) p[c] = fma(av[c], bv[c], p[c]);
     }
-    reduce_cols_store<NB>(p, partial);
+    reduce_flat_store<NB>(p, partial, row_ld<NB>(ld));
 }
 
 template <int NB, bool NT = false>
 __global__ __launch_bounds__(kBlock) void lincomb3_kernel(size_t nflat, const double* __restrict__ c0,
                                                           const double* __restrict__ a, const double* __restrict__ c1,
                                                           const double* __restrict__ b, const double* __restrict__ c2,
-                                                          double* __restrict__ y) {
+                                                          double* __restrict__ y, int ld) {
     constexpr int C = Lay<NB>::C;
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nflat) return;
     const size_t e = i * C;
-    const int k0 = (int)(e % NB);
+    const int k0 = (int)(e % row_ld<NB>(ld));
     double av[C], bv[C], yv[C];
     load_c_nt<NT, C>(a + e, av);   // the three inputs are read once; the result is gathered by the next kernels
     load_c_nt<NT, C>(b + e, bv);
@@ -869,12 +964,12 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const d
                                                            const double* __restrict__ u, const double* __restrict__ c1,
                                                            double* __restrict__ w0, const double* __restrict__ c2,
                                                            const double* __restrict__ w1, const double* __restrict__ c3,
-                                                           double* __restrict__ x) {
+                                                           double* __restrict__ x, int ld) {
     constexpr int C = Lay<NB>::C;
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nflat) return;
     const size_t e = i * C;
-    const int k0 = (int)(e % NB);
+    const int k0 = (int)(e % row_ld<NB>(ld));
     double uv[C], w0v[C], w1v[C], xv[C];
     load_c_nt<NT, C>(u + e, uv);
     load_c_nt<NT, C>(w0 + e, w0v);
@@ -892,19 +987,20 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const d
 // partial sums of <w, x[:,k]> with a shared (non-batched) weight vector w   (K15 QoI)
 template <int NB>
 __global__ __launch_bounds__(kBlock) void wdot_kernel(size_t nflat, const double* __restrict__ w,
-                                                      const double* __restrict__ x, double* __restrict__ partial) {
+                                                      const double* __restrict__ x, double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C;
+    const int W = row_ld<NB>(ld);
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nflat; i += (size_t)gridDim.x * kBlock) {
         double xv[C];
         load_c<C>(x + i * C, xv);
-        const double ww = w[(i * C) / NB];
+        const double ww = w[(i * C) / W];
 #pragma unroll
         for (int c = 0; c < C; ++c) p[c] = fma(ww, xv[c], p[c]);
     }
-    reduce_cols_store<NB>(p, partial);
+    reduce_flat_store<NB>(p, partial, W);
 }
 
 __global__ void fill_kernel(size_t n, double* __restrict__ x, double v) {
@@ -965,9 +1061,8 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
 
 __device__ __forceinline__ void count_active(k::MinresState* st, int nb, bool bump) {
     __syncthreads();
+    const int na = __syncthreads_count((int)threadIdx.x < nb && st->active[threadIdx.x] != 0);
     if (threadIdx.x == 0) {
-        int na = 0;
-        for (int k = 0; k < nb; ++k) na += st->active[k];
         st->n_active = na;
         st->it = bump ? st->it + 1 : 0;
     }
@@ -1095,8 +1190,8 @@ __global__ __launch_bounds__(256) void stage_partials_kernel(const double* __res
     lds[0][threadIdx.x] = chunk(pa, na) + chunk(pa2, na2);
     lds[1][threadIdx.x] = chunk(pb, nbk) + chunk(pb2, nbk2);
     __syncthreads();
-    if ((int)threadIdx.x < 2 * nb) {
-        const int list = threadIdx.x / nb, c = threadIdx.x % nb;
+    for (int e = threadIdx.x; e < 2 * nb; e += 256) {   // nb up to 256: two entries per thread
+        const int list = e / nb, c = e % nb;
         double t = 0.0;
         for (int j = 0; j < nq; ++j) t += lds[list][j * nb + c];
         stage[((size_t)list * kStageBlocks + g) * nb + c] = t;
@@ -1197,14 +1292,15 @@ __global__ __launch_bounds__(kBlock) void normal_fill_kernel(int n, int nbatch, 
 template <int NB>
 __global__ __launch_bounds__(kBlock) void interleave_kernel(int n, const double* __restrict__ in,
                                                             const double* __restrict__ w, double scale,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, int ld) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    const int LD = row_ld<NB>(ld), c0 = col0<NB>();
     const double f = w ? scale * w[i] : scale;
     double v[NB];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) v[k] = f * in[(size_t)k * n + i];
-    store_row<NB>(out + (size_t)i * NB, v);
+    for (int k = 0; k < NB; ++k) v[k] = f * in[(size_t)(c0 + k) * n + i];
+    store_row<NB>(out + (size_t)i * LD + c0, v);
 }
 
 // out[k*m + i] = post( rowscale[i] * in[idx ? idx[i] : i][k] ),  post = exp if do_exp   (K9, K10)
@@ -1212,18 +1308,19 @@ template <int NB>
 __global__ __launch_bounds__(kBlock) void deinterleave_kernel(int m, const double* __restrict__ in,
                                                               const int* __restrict__ idx,
                                                               const double* __restrict__ rowscale, int do_exp,
-                                                              double* __restrict__ out) {
+                                                              double* __restrict__ out, int ld) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
+    const int LD = row_ld<NB>(ld), c0 = col0<NB>();
     const int src = idx ? idx[i] : i;
     double v[NB];
-    load_row<NB>(in + (size_t)src * NB, v);
+    load_row<NB>(in + (size_t)src * LD + c0, v);
     const double f = rowscale ? rowscale[i] : 1.0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         double t = f * v[k];
         if (do_exp) t = exp(t);
-        out[(size_t)k * m + i] = t;
+        out[(size_t)(c0 + k) * m + i] = t;
     }
 }
 
@@ -1232,17 +1329,18 @@ __global__ __launch_bounds__(kBlock) void deinterleave_kernel(int m, const doubl
 // coef[e*NB+k] = 1/k or k.
 template <int NB>
 __global__ __launch_bounds__(kBlock) void darcy_coef_kernel(int n, const double* __restrict__ kfield, int k_divides,
-                                                            double* __restrict__ coef) {
-    // kfield sample-major [NB][n] -> interleaved coefficient
+                                                            double* __restrict__ coef, int ld) {
+    // kfield sample-major [nb][n] -> interleaved coefficient
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    const int LD = row_ld<NB>(ld), c0 = col0<NB>();
     double v[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        const double t = kfield[(size_t)k * n + i];
+        const double t = kfield[(size_t)(c0 + k) * n + i];
         v[k] = k_divides ? 1.0 / t : t;
     }
-    store_row<NB>(coef + (size_t)i * NB, v);
+    store_row<NB>(coef + (size_t)i * LD + c0, v);
 }
 
 // One lane per row of the SELL-stored M: raw values from element contributions, essential
@@ -1253,7 +1351,13 @@ __global__ __launch_bounds__(kBlock) void darcy_assemble_kernel(
     const int* __restrict__ slot_src, const int* __restrict__ c_ptr, const int* __restrict__ c_elem,
     const double* __restrict__ c_val, const double* __restrict__ coef, const unsigned char* __restrict__ ess,
     const double* __restrict__ ess_data, const double* __restrict__ rhs0, double* __restrict__ mvals,
-    double* __restrict__ diag, double* __restrict__ l1inv, double* __restrict__ rhs_bc) {
+    double* __restrict__ diag, double* __restrict__ l1inv, double* __restrict__ rhs_bc, int ld) {
+    const int LD = row_ld<NB>(ld);
+    {
+        const int c0 = col0<NB>();
+        coef += c0; diag += c0; l1inv += c0; rhs_bc += c0;
+        if (mvals) mvals += c0;
+    }
     const int row = blockIdx.x * kBlock + threadIdx.x;
     const int slice = row >> 6, lane = row & 63;
     if (slice >= nslices) return;
@@ -1275,7 +1379,7 @@ __global__ __launch_bounds__(kBlock) void darcy_assemble_kernel(
             for (int t = c_ptr[p]; t < c_ptr[p + 1]; ++t) {
                 const double cv = c_val[t];
                 double ce[NB];
-                load_row<NB>(coef + (size_t)c_elem[t] * NB, ce);
+                load_row<NB>(coef + (size_t)c_elem[t] * LD, ce);
 #pragma unroll
                 for (int k = 0; k < NB; ++k) v[k] = fma(ce[k], cv, v[k]);
             }
@@ -1296,7 +1400,7 @@ __global__ __launch_bounds__(kBlock) void darcy_assemble_kernel(
                 if (c == row) dg[k] = v[k];
             }
         }
-        if (mvals) store_row<NB>(mvals + (size_t)slot * NB, v);
+        if (mvals) store_row<NB>(mvals + (size_t)slot * LD, v);
     }
     if (!live) return;
     double rb[NB];
@@ -1306,9 +1410,9 @@ __global__ __launch_bounds__(kBlock) void darcy_assemble_kernel(
         rb[k] = row_ess ? r0 : r0 - fix[k];
         l1[k] = 1.0 / l1[k];
     }
-    store_row<NB>(diag + (size_t)row * NB, dg);
-    store_row<NB>(l1inv + (size_t)row * NB, l1);
-    store_row<NB>(rhs_bc + (size_t)row * NB, rb);
+    store_row<NB>(diag + (size_t)row * LD, dg);
+    store_row<NB>(l1inv + (size_t)row * LD, l1);
+    store_row<NB>(rhs_bc + (size_t)row * LD, rb);
 }
 
 // Generic numeric refresh of a derived matrix on a fixed pattern:
@@ -1319,33 +1423,37 @@ template <int NB>
 __global__ __launch_bounds__(kBlock) void refresh_kernel(int64_t nslots, const int* __restrict__ ptr,
                                                          const int* __restrict__ idx, const double* __restrict__ w,
                                                          const double* __restrict__ src, int recip,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, int ld) {
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (slot >= nslots) return;
+    const int LD = row_ld<NB>(ld);
+    src += col0<NB>();
+    out += col0<NB>();
     double acc[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) acc[k] = 0.0;
     for (int t = ptr[slot]; t < ptr[slot + 1]; ++t) {
         double s[NB];
-        load_row<NB>(src + (size_t)idx[t] * NB, s);
+        load_row<NB>(src + (size_t)idx[t] * LD, s);
         const double wt = w[t];
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = fma(wt, recip ? 1.0 / s[k] : s[k], acc[k]);
     }
-    store_row<NB>(out + (size_t)slot * NB, acc);
+    store_row<NB>(out + (size_t)slot * LD, acc);
 }
 
 // dinv[row][k] = 1 / vals[diag_slot[row]][k]
 template <int NB>
 __global__ __launch_bounds__(kBlock) void diag_inv_kernel(int n, const int* __restrict__ diag_slot,
-                                                          const double* __restrict__ vals, double* __restrict__ dinv) {
+                                                          const double* __restrict__ vals, double* __restrict__ dinv, int ld) {
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= n) return;
+    const int LD = row_ld<NB>(ld), c0 = col0<NB>();
     double v[NB];
-    load_row<NB>(vals + (size_t)diag_slot[row] * NB, v);
+    load_row<NB>(vals + (size_t)diag_slot[row] * LD + c0, v);
 #pragma unroll
     for (int k = 0; k < NB; ++k) v[k] = 1.0 / v[k];
-    store_row<NB>(dinv + (size_t)row * NB, v);
+    store_row<NB>(dinv + (size_t)row * LD + c0, v);
 }
 
 // Per-realization Gershgorin bound of D^-1 S on batched values:  g[k] = max_i dinv[i][k] * sum_j |S_ij(k)|  (atomic max
@@ -1354,8 +1462,13 @@ __global__ __launch_bounds__(kBlock) void diag_inv_kernel(int n, const int* __re
 template <int NB>
 __global__ __launch_bounds__(kBlock) void gersh_bv_kernel(int nrows, const int* __restrict__ slice_off,
                                                           const double* __restrict__ vals, const double* __restrict__ dinv,
-                                                          unsigned long long* __restrict__ g) {
+                                                          unsigned long long* __restrict__ g, int ld) {
     const int row = blockIdx.x * kBlock + threadIdx.x;
+    const int LD = row_ld<NB>(ld);
+    {
+        const int c0 = col0<NB>();
+        vals += c0; dinv += c0; g += c0;
+    }
     double acc[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) acc[k] = 0.0;
@@ -1365,12 +1478,12 @@ __global__ __launch_bounds__(kBlock) void gersh_bv_kernel(int nrows, const int* 
         const int width = (slice_off[slice + 1] - off) >> 6;
         for (int j = 0; j < width; ++j) {
             double v[NB];
-            load_row<NB>(vals + ((size_t)off + (size_t)j * 64 + lane) * NB, v);
+            load_row<NB>(vals + ((size_t)off + (size_t)j * 64 + lane) * LD, v);
 #pragma unroll
             for (int k = 0; k < NB; ++k) acc[k] += fabs(v[k]);
         }
         double d[NB];
-        load_row<NB>(dinv + (size_t)row * NB, d);
+        load_row<NB>(dinv + (size_t)row * LD, d);
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] *= fabs(d[k]);
     }
@@ -1384,19 +1497,20 @@ __global__ __launch_bounds__(kBlock) void gersh_bv_kernel(int nrows, const int* 
 
 template <int NB>
 __global__ __launch_bounds__(kBlock) void gersh_scale_kernel(int nrows, const unsigned long long* __restrict__ g,
-                                                             double* __restrict__ dinv) {
+                                                             double* __restrict__ dinv, int ld) {
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= nrows) return;
+    const int LD = row_ld<NB>(ld), c0 = col0<NB>();
     double d[NB];
-    load_row<NB>(dinv + (size_t)row * NB, d);
+    load_row<NB>(dinv + (size_t)row * LD + c0, d);
 #pragma unroll
-    for (int k = 0; k < NB; ++k) d[k] /= 1.0001 * __longlong_as_double((long long)g[k]);
-    store_row<NB>(dinv + (size_t)row * NB, d);
+    for (int k = 0; k < NB; ++k) d[k] /= 1.0001 * __longlong_as_double((long long)g[c0 + k]);
+    store_row<NB>(dinv + (size_t)row * LD + c0, d);
 }
 
 // First stage of a two-stage reduction for launches with many partial blocks: block j of kCompressBlocks sums the input
 // blocks j, j + kCompressBlocks, ... (fixed order: deterministic) into out[j][k].
-static constexpr int kCompressBlocks = 256;
+static constexpr int kCompressBlocks = 256;   // dot_capacity() reserves this many blocks ahead of the uncompressed ones
 __global__ __launch_bounds__(256) void compress_partials_kernel(const double* __restrict__ in, int nblocks, int nb,
                                                                 double* __restrict__ out) {
     __shared__ double lds[256];
@@ -1426,14 +1540,15 @@ __global__ __launch_bounds__(kScalBlock) void reduce_final_kernel(const double* 
 
 // out[i*NB+k] = a[i] (broadcast a shared vector into an interleaved batch)
 template <int NB>
-__global__ __launch_bounds__(kBlock) void broadcast_kernel(int n, const double* __restrict__ a, double* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void broadcast_kernel(int n, const double* __restrict__ a, double* __restrict__ out,
+                                                           int ld) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     double v[NB];
     const double t = a[i];
 #pragma unroll
     for (int k = 0; k < NB; ++k) v[k] = t;
-    store_row<NB>(out + (size_t)i * NB, v);
+    store_row<NB>(out + (size_t)i * row_ld<NB>(ld) + col0<NB>(), v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1831,10 +1946,14 @@ __global__ __launch_bounds__(kTailThreads) void mini_sampler_kernel(MiniSamplerP
         case 4: { constexpr int NB = 4; __VA_ARGS__; } break;             \
         case 8: { constexpr int NB = 8; __VA_ARGS__; } break;             \
         case 16: { constexpr int NB = 16; __VA_ARGS__; } break;           \
-        case 32: { constexpr int NB = 32; __VA_ARGS__; } break;           \
+        case 32: case 64: case 128: case 256: { constexpr int NB = 32; __VA_ARGS__; } break;   /* column groups of 32 */ \
         default: throw Error(PMC_ERR_INTERNAL, "unsupported batch width"); \
     }
 
+// grid of a group-capable kernel: y = number of column groups of a batch of nb realizations (1 up to kGroup)
+static inline dim3 groups(dim3 g, int nb) { return dim3(g.x, nb > kGroup ? (unsigned)(nb / kGroup) : 1u); }
+static inline dim3 groups(unsigned g, int nb) { return groups(dim3(g), nb); }
+static inline dim3 groups(int g, int nb) { return groups(dim3((unsigned)g), nb); }
 static inline dim3 grid_rows(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 static inline dim3 grid_slices(int nslices) { return dim3((unsigned)((nslices + kBlock / kWave - 1) / (kBlock / kWave))); }
 static inline int lay_c(int nb) { return nb >= 32 ? 4 : (nb >= 2 ? 2 : 1); }   // = Lay<nb>::C
@@ -1850,8 +1969,6 @@ static inline bool nt_flat(size_t doubles) {
     return limit > 0.0 && (double)doubles * 8.0 > limit;
 }
 
-namespace k {
-
 // kernels with a fused dot write one partial per block; the bound trades occupancy of the SpMM against the length of
 // the single-block final reduction (PMC_DOT_GRID overrides it for tuning runs)
 static unsigned dot_grid_bound() {
@@ -1862,6 +1979,9 @@ static unsigned dot_grid_bound() {
     }();
     return v;
 }
+
+namespace k {
+
 static inline dim3 grid_bounded(dim3 g, bool bounded) { return bounded ? dim3(std::min(g.x, dot_grid_bound())) : g; }
 
 // non-temporal matrix / result streams for the block operator once its operands no longer fit the Infinity Cache.  Inside
@@ -1891,40 +2011,40 @@ static inline bool nt_poly(const SellView& A, int nb) {
 }
 
 template <int NB, int TAG>
-static void spmm_launch(hipStream_t st, dim3 g, const SellView& A, const double* x, double* y, bool accumulate,
+static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const double* x, double* y, bool accumulate,
                         double* dot_partial, const double* dot_with) {
     // <x, Ax> with a diagonal-last matrix: x_i is what the row's last slice column gathers
     const bool dl = TAG == 1 && Lay<NB>::T > 1 && A.diag_last && dot_with == x;
     if (A.bv) {
         if (dot_partial)
-            sell_spmm_kernel<NB, true, 0, true, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+            sell_spmm_kernel<NB, true, 0, true, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (accumulate)
-            sell_spmm_kernel<NB, true, 1, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+            sell_spmm_kernel<NB, true, 1, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
         else
-            sell_spmm_kernel<NB, true, 0, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+            sell_spmm_kernel<NB, true, 0, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
     } else if (TAG != 0 && nt_streams(A, NB, dot_partial != nullptr)) {
         if (dot_partial && dl)
-            sell_spmm_kernel<NB, false, 0, true, TAG, true, false, (Lay<NB>::T > 1)><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+            sell_spmm_kernel<NB, false, 0, true, TAG, true, false, (Lay<NB>::T > 1)><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (dot_partial)
-            sell_spmm_kernel<NB, false, 0, true, TAG, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+            sell_spmm_kernel<NB, false, 0, true, TAG, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (accumulate)
-            sell_spmm_kernel<NB, false, 1, false, TAG, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+            sell_spmm_kernel<NB, false, 1, false, TAG, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
         else
-            sell_spmm_kernel<NB, false, 0, false, TAG, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+            sell_spmm_kernel<NB, false, 0, false, TAG, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
     } else {
         if (dot_partial && dl)
-            sell_spmm_kernel<NB, false, 0, true, TAG, false, false, (Lay<NB>::T > 1)><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+            sell_spmm_kernel<NB, false, 0, true, TAG, false, false, (Lay<NB>::T > 1)><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (dot_partial)
-            sell_spmm_kernel<NB, false, 0, true, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial);
+            sell_spmm_kernel<NB, false, 0, true, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (accumulate)
-            sell_spmm_kernel<NB, false, 1, false, TAG><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+            sell_spmm_kernel<NB, false, 1, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
         else {
             // tuning probe: unused dynamic LDS limits the workgroups per CU (occupancy experiment on the isolated launches)
             static const size_t probe_lds = [] {
                 const char* e = getenv("PMC_K5_LDS");
                 return e ? (size_t)atol(e) : (size_t)0;
             }();
-            sell_spmm_kernel<NB, false, 0, false, TAG><<<g, kBlock, TAG == 2 ? probe_lds : 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr);
+            sell_spmm_kernel<NB, false, 0, false, TAG><<<groups(g, nb), kBlock, TAG == 2 ? probe_lds : 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
         }
     }
 }
@@ -1944,9 +2064,9 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
         kernel_partial = dot_partial + (size_t)kCompressBlocks * nb;
     }
     PMC_DISPATCH_NB(nb, {
-        if (A.tag == 1) spmm_launch<NB, 1>(st, g, A, x, y, accumulate, kernel_partial, dot_with);
-        else if (A.tag == 2) spmm_launch<NB, 2>(st, g, A, x, y, accumulate, kernel_partial, dot_with);
-        else spmm_launch<NB, 0>(st, g, A, x, y, accumulate, kernel_partial, dot_with);
+        if (A.tag == 1) spmm_launch<NB, 1>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
+        else if (A.tag == 2) spmm_launch<NB, 2>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
+        else spmm_launch<NB, 0>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
     });
     check_launch();
     if (two_stage) {
@@ -1964,9 +2084,9 @@ void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double*
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
         if (A.bv)
-            sell_spmm_kernel<NB, true, 2, false, 0, false, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse);
+            sell_spmm_kernel<NB, true, 2, false, 0, false, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
         else
-            sell_spmm_kernel<NB, false, 2, false, 0, false, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse);
+            sell_spmm_kernel<NB, false, 2, false, 0, false, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
     });
     check_launch();
 }
@@ -1976,9 +2096,9 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
         if (A.bv)
-            sell_spmm_kernel<NB, true, 2, false, 0><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr);
+            sell_spmm_kernel<NB, true, 2, false, 0><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
         else
-            sell_spmm_kernel<NB, false, 2, false, 0><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr);
+            sell_spmm_kernel<NB, false, 2, false, 0><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
     });
     check_launch();
 }
@@ -1991,14 +2111,14 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
     PMC_DISPATCH_NB(nb, {
         if (A.bv) {
             if (dot_partial)
-                sell_cheb_kernel<NB, true, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial);
+                sell_cheb_kernel<NB, true, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
             else
-                sell_cheb_kernel<NB, true, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr);
+                sell_cheb_kernel<NB, true, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
         } else {
             if (dot_partial)
-                sell_cheb_kernel<NB, false, true><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial);
+                sell_cheb_kernel<NB, false, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
             else
-                sell_cheb_kernel<NB, false, false><<<g, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr);
+                sell_cheb_kernel<NB, false, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
         }
     });
     check_launch();
@@ -2014,19 +2134,19 @@ int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool d
     PMC_DISPATCH_NB(nb, {
         if (As.bv) {
             if (dot_partial)
-                sell_poly2_kernel<NB, true, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
+                sell_poly2_kernel<NB, true, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, true, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x);
+                sell_poly2_kernel<NB, true, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         } else if (nt_poly(As, NB)) {
             if (dot_partial)
-                sell_poly2_kernel<NB, false, true, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
+                sell_poly2_kernel<NB, false, true, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, false, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x);
+                sell_poly2_kernel<NB, false, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         } else {
             if (dot_partial)
-                sell_poly2_kernel<NB, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
+                sell_poly2_kernel<NB, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, false, false><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x);
+                sell_poly2_kernel<NB, false, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         }
     });
     check_launch();
@@ -2042,13 +2162,13 @@ int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, co
     PMC_DISPATCH_NB(nb, {
         if (nt_flat((size_t)M.nrows * NB * 2)) {   // from 4 MiB per vector on
             if (dot_partial)
-                eg_pair_spmm_kernel<NB, true, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial);
+                eg_pair_spmm_kernel<NB, true, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
             else
-                eg_pair_spmm_kernel<NB, false, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr);
+                eg_pair_spmm_kernel<NB, false, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
         } else if (dot_partial)
-            eg_pair_spmm_kernel<NB, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial);
+            eg_pair_spmm_kernel<NB, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
         else
-            eg_pair_spmm_kernel<NB, false><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr);
+            eg_pair_spmm_kernel<NB, false><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;
@@ -2061,13 +2181,13 @@ int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const 
     PMC_DISPATCH_NB(nb, {
         if (nt_flat((size_t)M.nrows * NB * 2)) {
             if (dot_partial)
-                eg_poly2_kernel<NB, true, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial);
+                eg_poly2_kernel<NB, true, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
             else
-                eg_poly2_kernel<NB, false, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr);
+                eg_poly2_kernel<NB, false, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
         } else if (dot_partial)
-            eg_poly2_kernel<NB, true><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial);
+            eg_poly2_kernel<NB, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
         else
-            eg_poly2_kernel<NB, false><<<g, kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr);
+            eg_poly2_kernel<NB, false><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;
@@ -2081,9 +2201,9 @@ int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, cons
     const dim3 g = grid_bounded(grid_slices(A1.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (dot_partial)
-            sell_pair_spmm_kernel<NB, true><<<g, kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial);
+            sell_pair_spmm_kernel<NB, true><<<groups(g, nb), kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
         else
-            sell_pair_spmm_kernel<NB, false><<<g, kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr);
+            sell_pair_spmm_kernel<NB, false><<<groups(g, nb), kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;
@@ -2094,14 +2214,14 @@ void scale_cols_bv(hipStream_t st, int nb, int64_t nslots, const int* cols, cons
     if (nslots == 0) return;
     const size_t nf = (size_t)nslots * nb / lay_c(nb);
     const unsigned g = (unsigned)std::min<size_t>((nf + kBlock - 1) / kBlock, 8192);
-    PMC_DISPATCH_NB(nb, { scale_cols_bv_kernel<NB><<<g, kBlock, 0, st>>>(nf, cols, vals, colscale, out); });
+    PMC_DISPATCH_NB(nb, { scale_cols_bv_kernel<NB><<<g, kBlock, 0, st>>>(nf, cols, vals, colscale, out, nb); });
     check_launch();
 }
 
 void minres_wx_idx(hipStream_t st, int nb, int nsel, const int* rows, const double* c0, const double* u, const double* c1,
                    double* w0, const double* c2, const double* w1, const double* c3, double* x) {
     if (nsel == 0) return;
-    PMC_DISPATCH_NB(nb, { minres_wx_idx_kernel<NB><<<grid_flat(nsel, nb), kBlock, 0, st>>>(flat_count(nsel, nb), rows, c0, u, c1, w0, c2, w1, c3, x); });
+    PMC_DISPATCH_NB(nb, { minres_wx_idx_kernel<NB><<<grid_flat(nsel, nb), kBlock, 0, st>>>(flat_count(nsel, nb), rows, c0, u, c1, w0, c2, w1, c3, x, nb); });
     check_launch();
 }
 
@@ -2112,11 +2232,11 @@ int cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, 
     const dim3 g = grid_bounded(grid_flat(n, nb), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (dinv_bv) {
-            if (dot_partial) cheb_first_kernel<NB, true, true><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, dot_partial);
-            else cheb_first_kernel<NB, true, false><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, nullptr);
+            if (dot_partial) cheb_first_kernel<NB, true, true><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, dot_partial, nb);
+            else cheb_first_kernel<NB, true, false><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, nullptr, nb);
         } else {
-            if (dot_partial) cheb_first_kernel<NB, false, true><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, dot_partial);
-            else cheb_first_kernel<NB, false, false><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, nullptr);
+            if (dot_partial) cheb_first_kernel<NB, false, true><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, dot_partial, nb);
+            else cheb_first_kernel<NB, false, false><<<g, kBlock, 0, st>>>(nf, dinv, r, d, x, b, nullptr, nb);
         }
     });
     check_launch();
@@ -2127,14 +2247,14 @@ static inline dim3 grid_dot(int n, int nb) { return dim3(std::min(grid_flat(n, n
 
 int dot(hipStream_t st, int nb, int n, const double* a, const double* b, double* partial) {
     const dim3 g = grid_dot(n, nb);
-    PMC_DISPATCH_NB(nb, { dot_kernel<NB><<<g, kBlock, 0, st>>>(flat_count(n, nb), a, b, partial); });
+    PMC_DISPATCH_NB(nb, { dot_kernel<NB><<<g, kBlock, 0, st>>>(flat_count(n, nb), a, b, partial, nb); });
     check_launch();
     return (int)g.x;
 }
 
 int wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial) {
     const dim3 g = grid_dot(n, nb);
-    PMC_DISPATCH_NB(nb, { wdot_kernel<NB><<<g, kBlock, 0, st>>>(flat_count(n, nb), w, x, partial); });
+    PMC_DISPATCH_NB(nb, { wdot_kernel<NB><<<g, kBlock, 0, st>>>(flat_count(n, nb), w, x, partial, nb); });
     check_launch();
     return (int)g.x;
 }
@@ -2150,8 +2270,8 @@ void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, 
     static const bool nt_on = [] { const char* e = getenv("PMC_NT_LINCOMB"); return !e || atoi(e) != 0; }();
     const bool nt = nt_on && nt_flat((size_t)n * nb);
     PMC_DISPATCH_NB(nb, {
-        if (nt) lincomb3_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y);
-        else lincomb3_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y);
+        if (nt) lincomb3_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y, nb);
+        else lincomb3_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y, nb);
     });
     check_launch();
 }
@@ -2160,8 +2280,8 @@ void minres_wx(hipStream_t st, int nb, int n, const double* c0, const double* u,
                const double* c2, const double* w1, const double* c3, double* x) {
     const bool nt = nt_flat((size_t)n * nb);
     PMC_DISPATCH_NB(nb, {
-        if (nt) minres_wx_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x);
-        else minres_wx_kernel<NB, false><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x);
+        if (nt) minres_wx_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x, nb);
+        else minres_wx_kernel<NB, false><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x, nb);
     });
     check_launch();
 }
@@ -2216,24 +2336,24 @@ void normal_fill(hipStream_t st, int n, int nbatch, uint64_t seed, uint64_t firs
 }
 
 void interleave(hipStream_t st, int nb, int n, const double* in, const double* w, double scale, double* out) {
-    PMC_DISPATCH_NB(nb, { interleave_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, in, w, scale, out); });
+    PMC_DISPATCH_NB(nb, { interleave_kernel<NB><<<groups(grid_rows(n), nb), kBlock, 0, st>>>(n, in, w, scale, out, nb); });
     check_launch();
 }
 
 void deinterleave(hipStream_t st, int nb, int m, const double* in, const int* idx, const double* rowscale, bool do_exp,
                   double* out) {
     if (m == 0) return;
-    PMC_DISPATCH_NB(nb, { deinterleave_kernel<NB><<<grid_rows(m), kBlock, 0, st>>>(m, in, idx, rowscale, do_exp ? 1 : 0, out); });
+    PMC_DISPATCH_NB(nb, { deinterleave_kernel<NB><<<groups(grid_rows(m), nb), kBlock, 0, st>>>(m, in, idx, rowscale, do_exp ? 1 : 0, out, nb); });
     check_launch();
 }
 
 void broadcast(hipStream_t st, int nb, int n, const double* a, double* out) {
-    PMC_DISPATCH_NB(nb, { broadcast_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, a, out); });
+    PMC_DISPATCH_NB(nb, { broadcast_kernel<NB><<<groups(grid_rows(n), nb), kBlock, 0, st>>>(n, a, out, nb); });
     check_launch();
 }
 
 void darcy_coef(hipStream_t st, int nb, int n, const double* kfield, bool k_divides, double* coef) {
-    PMC_DISPATCH_NB(nb, { darcy_coef_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, kfield, k_divides ? 1 : 0, coef); });
+    PMC_DISPATCH_NB(nb, { darcy_coef_kernel<NB><<<groups(grid_rows(n), nb), kBlock, 0, st>>>(n, kfield, k_divides ? 1 : 0, coef, nb); });
     check_launch();
 }
 
@@ -2242,8 +2362,9 @@ void darcy_assemble(hipStream_t st, int nb, const SellView& Mp, const int* slot_
                     const double* rhs0, double* mvals, double* diag, double* l1inv, double* rhs_bc) {
     const dim3 g = grid_rows(Mp.nslices * kWave);
     PMC_DISPATCH_NB(nb, {
-        darcy_assemble_kernel<NB><<<g, kBlock, 0, st>>>(Mp.nrows, Mp.nslices, Mp.slice_off, Mp.cols, slot_src, c_ptr, c_elem,
-                                                       c_val, coef, ess, ess_data, rhs0, mvals, diag, l1inv, rhs_bc);
+        darcy_assemble_kernel<NB><<<groups(g, nb), kBlock, 0, st>>>(Mp.nrows, Mp.nslices, Mp.slice_off, Mp.cols, slot_src, c_ptr,
+                                                                   c_elem, c_val, coef, ess, ess_data, rhs0, mvals, diag, l1inv,
+                                                                   rhs_bc, nb);
     });
     check_launch();
 }
@@ -2253,8 +2374,8 @@ void gersh_scale_bv(hipStream_t st, int nb, const SellView& S, double* dinv, dou
     PMC_HIP(hipMemsetAsync(g, 0, sizeof(unsigned long long) * kMaxBatch, st));
     const int grid = (S.nrows + kBlock - 1) / kBlock;
     PMC_DISPATCH_NB(nb, {
-        gersh_bv_kernel<NB><<<grid, kBlock, 0, st>>>(S.nrows, S.slice_off, S.vals, dinv, g);
-        gersh_scale_kernel<NB><<<grid, kBlock, 0, st>>>(S.nrows, g, dinv);
+        gersh_bv_kernel<NB><<<groups(grid, nb), kBlock, 0, st>>>(S.nrows, S.slice_off, S.vals, dinv, g, nb);
+        gersh_scale_kernel<NB><<<groups(grid, nb), kBlock, 0, st>>>(S.nrows, g, dinv, nb);
     });
     PMC_HIP(hipGetLastError());
 }
@@ -2263,12 +2384,12 @@ void refresh(hipStream_t st, int nb, int64_t nslots, const int* ptr, const int* 
              bool recip, double* out) {
     if (nslots == 0) return;
     const dim3 g((unsigned)((nslots + kBlock - 1) / kBlock));
-    PMC_DISPATCH_NB(nb, { refresh_kernel<NB><<<g, kBlock, 0, st>>>(nslots, ptr, idx, w, src, recip ? 1 : 0, out); });
+    PMC_DISPATCH_NB(nb, { refresh_kernel<NB><<<groups(g, nb), kBlock, 0, st>>>(nslots, ptr, idx, w, src, recip ? 1 : 0, out, nb); });
     check_launch();
 }
 
 void diag_inv(hipStream_t st, int nb, int n, const int* diag_slot, const double* vals, double* dinv) {
-    PMC_DISPATCH_NB(nb, { diag_inv_kernel<NB><<<grid_rows(n), kBlock, 0, st>>>(n, diag_slot, vals, dinv); });
+    PMC_DISPATCH_NB(nb, { diag_inv_kernel<NB><<<groups(grid_rows(n), nb), kBlock, 0, st>>>(n, diag_slot, vals, dinv, nb); });
     check_launch();
 }
 

@@ -1,5 +1,6 @@
 // Launchers of the CDNA4 kernels (kernels.hip).  All vectors are "interleaved" batches:
-// row i, column (realization) k of a batch of NB lives at v[i*NB + k], NB in {1,2,4,8,16}.
+// row i, column (realization) k of a batch of nb lives at v[i*nb + k], nb in {1,2,4,8,16,32} or - as 2, 4, 8 column groups
+// of 32 handled by one launch (gridDim.y) - 64, 128, 256.
 #pragma once
 #include "common.hpp"
 
@@ -37,8 +38,9 @@ struct EgView {
     const int* e12 = nullptr;      // [nrows][2] coefficient rows (n_elem = constant-one row for eliminated dofs)
 };
 
-// capacity (in blocks) of a partial-sum buffer for (fused) dots over nrows rows: allocate dot_capacity*kMaxBatch doubles
-int dot_capacity(int nrows);
+// capacity (in blocks of nb doubles) of a partial-sum buffer for (fused) dots over nrows rows of a batch of nb columns:
+// allocate dot_capacity(nrows, nb) * nb doubles
+int dot_capacity(int nrows, int nb);
 
 namespace k {
 

@@ -448,7 +448,7 @@ void Sampler::apply_operator(int level, int nb, const double* x, double* y, int 
     const size_t flush_bytes = e_flush ? (size_t)atol(e_flush) << 20 : 0;
     DevBuf<double> flush, part;
     if (flush_bytes) flush.alloc(flush_bytes / sizeof(double));
-    if (e_dot && atoi(e_dot)) part.alloc((size_t)dot_capacity((int)n) * kMaxBatch);
+    if (e_dot && atoi(e_dot)) part.alloc((size_t)dot_capacity((int)n, nb) * nb);
     double total_ms = 0.0;
     if (!flush_bytes) {
         PMC_HIP(hipEventRecord(ctx.ev0, st));
@@ -497,7 +497,8 @@ void Sampler::eval(int level, int xi_level, int nbatch, const double* xi, double
     // init_level a chunk's embed rows (n_s each) would overwrite init rows (n_init < n_s each) of later chunks before
     // they are read: keep a private copy of init_s for the whole call then.
     DevBuf<double> init_copy;
-    if (use_init && memspace == PMC_MEM_DEVICE && emb_out == init_s && nbatch > 16 && n_init != n_s) {
+    if (use_init && memspace == PMC_MEM_DEVICE && emb_out == init_s && n_init != n_s &&
+        nbatch > std::min(16, batch_width((size_t)lv[level].n_u + lv[level].n_s))) {
         init_copy.alloc((size_t)n_init * nbatch);
         PMC_HIP(hipMemcpyAsync(init_copy.p, init_s, sizeof(double) * n_init * nbatch, hipMemcpyDeviceToDevice, st));
         init_s = init_copy.p;

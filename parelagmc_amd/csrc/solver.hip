@@ -84,12 +84,26 @@ void MgLevel::ensure(int nb) {
 }
 
 void Multigrid::enable_bv_tail(int max_rows) {
+    bv_tail_width = kGroup;
     for (MgLevel& m : L) {
         if (!m.bv || m.n > max_rows) continue;
-        m.vals_t.alloc((size_t)m.S.nslots * kMaxBatch);
-        m.scaled_t.alloc((size_t)m.S.nslots * kMaxBatch);
-        m.dinv_t.alloc((size_t)m.n * kMaxBatch);
+        m.vals_t.alloc((size_t)m.S.nslots * bv_tail_width);
+        m.scaled_t.alloc((size_t)m.S.nslots * bv_tail_width);
+        m.dinv_t.alloc((size_t)m.n * bv_tail_width);
     }
+}
+
+void Multigrid::ensure_bv_tail_width(hipStream_t st, int nb) {
+    if (bv_tail_width == 0 || nb <= bv_tail_width) return;
+    PMC_HIP(hipStreamSynchronize(st));           // nothing in flight reads the old copies
+    bv_tail_width = nb;
+    for (MgLevel& m : L) {
+        if (!m.vals_t.p) continue;
+        m.vals_t.alloc((size_t)m.S.nslots * nb);
+        m.scaled_t.alloc((size_t)m.S.nslots * nb);
+        m.dinv_t.alloc((size_t)m.n * nb);
+    }
+    build_tails(st);
 }
 
 void Multigrid::refresh_bv_tail(hipStream_t st, int nb, int first_level) {
@@ -234,8 +248,8 @@ void MinresWork::ensure(int n, int nb) {
     v0.ensure(need); v1.ensure(need); u0.ensure(need); u1.ensure(need);
     w0.ensure(need); w1.ensure(need); q.ensure(need);
     // two segments each (see k::DotParts): [0, cap) and [cap, 2 cap)
-    partial.ensure((size_t)2 * dot_capacity(n) * kMaxBatch);
-    partial_op.ensure((size_t)2 * dot_capacity(n) * kMaxBatch);
+    partial.ensure((size_t)2 * dot_capacity(n, nb) * nb);
+    partial_op.ensure((size_t)2 * dot_capacity(n, nb) * nb);
     if (!state.p) state.alloc(1);
     stage.ensure(k::scal_stage_doubles());
 }
@@ -271,11 +285,17 @@ static bool stage_on() {
     return v;
 }
 int batch_width(size_t rows) {
-    static const size_t limit = [] {
-        const char* e = getenv("PMC_WIDE_ROWS");
-        return e ? (size_t)atoll(e) : (size_t)300000;
-    }();
-    return rows <= limit ? kMaxBatch : 16;
+    static const auto lim = [](const char* name, size_t dflt) {
+        const char* e = getenv(name);
+        return e ? (size_t)atoll(e) : dflt;
+    };
+    static const size_t l32 = lim("PMC_WIDE_ROWS", 300000), l64 = lim("PMC_W64_ROWS", 150000),
+                        l128 = lim("PMC_W128_ROWS", 40000), l256 = lim("PMC_W256_ROWS", 20000);
+    if (rows > l32) return 16;
+    if (rows <= l256) return 256;
+    if (rows <= l128) return 128;
+    if (rows <= l64) return 64;
+    return 32;
 }
 
 // PMC_LATE_WX=0 keeps the w / x update inside its own iteration also on two streams (A/B switch)
@@ -316,7 +336,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     if (x_row0 < 0 || x_nrows < 0 || (!x_rows && x_row0 + x_nrows > n))
         throw Error(PMC_ERR_INTERNAL, "minres: bad solution row range");
     const size_t xoff = (size_t)x_row0 * nb;
-    const size_t seg2 = (size_t)dot_capacity(n) * kMaxBatch;
+    const size_t seg2 = (size_t)dot_capacity(n, nb) * nb;
     k::DotParts dp = prec(L, nb, v1, u1, w.partial.p, w.partial.p + seg2);
     if (dp.total() == 0) dp = k::DotParts{w.partial.p, k::dot(st, nb, n, v1, u1, w.partial.p)};
     k::minres_init(st, nb, S, dp, o.rel_tol, o.abs_tol);
@@ -499,7 +519,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         flush_wx(st);
     }
     out.iterations = it;
-    static_assert(sizeof(k::MinresState) <= 4096 * sizeof(double), "pinned scratch too small");
+    static_assert(sizeof(k::MinresState) <= Ctx::kHostScratch * sizeof(double), "pinned scratch too small");
     PMC_HIP(hipMemcpyAsync(ctx.h_scal, S, sizeof(k::MinresState), hipMemcpyDeviceToHost, st));
     PMC_HIP(hipStreamSynchronize(st));
     for (size_t e = 0; e + 2 < ev_used; e += 3) {

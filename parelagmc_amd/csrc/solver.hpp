@@ -50,11 +50,11 @@ inline int cheb_flips(const ChebParams& cp, bool zero_guess) {
 struct MgLevel {
     int n = 0;
     Sell S;                      // pattern (+ shared values for the sampler)
-    DevBuf<double> dinv;         // shared: n ; batched: n*kMaxBatch
-    DevBuf<double> vals_bv;      // batched values (Darcy): nslots*kMaxBatch
-    DevBuf<double> vals_scaled;  // S D^-1 on S's pattern (shared, or nslots*kMaxBatch when bv): one-pass pre-smoothing
+    DevBuf<double> dinv;         // shared: n ; batched: n*nb
+    DevBuf<double> vals_bv;      // batched values (Darcy): nslots*nb, sized by the owner for the width in use
+    DevBuf<double> vals_scaled;  // S D^-1 on S's pattern (shared, or nslots*nb when bv): one-pass pre-smoothing
     // small per-realization levels: column-major copies [nb][...] for the LDS tail kernel (allocated by
-    // Multigrid::enable_bv_tail, refreshed by refresh_bv_tail after the level's values changed)
+    // Multigrid::enable_bv_tail / ensure_bv_tail_width, refreshed by refresh_bv_tail after the level's values changed)
     DevBuf<double> vals_t, scaled_t, dinv_t;
     bool bv = false;
     double lmax = 2.0;
@@ -95,6 +95,10 @@ struct Multigrid {
     // per-realization hierarchies: give every level of at most max_rows rows transposed value copies so that
     // build_tails can include them; refresh_bv_tail(nb) re-fills the copies (call after every numeric refresh)
     void enable_bv_tail(int max_rows = 8192);
+    // the transposed copies hold bv_tail_width realizations; a wider batch re-allocates them and rebuilds the tail
+    // descriptors (which carry their addresses) - once per handle and width
+    int bv_tail_width = 0;
+    void ensure_bv_tail_width(hipStream_t st, int nb);
     void refresh_bv_tail(hipStream_t st, int nb, int first_level = 0);
     // hash of the work-buffer pointers a V-cycle from level l0 touches (for GraphHint::sig)
     uint64_t signature(int l0) const;

@@ -262,7 +262,7 @@ MLMC_Manager::MLMC_Manager(pmc_ctx* ctx, int memspace, int nlevels_, PhysicalMLS
       max_rounds_(p.max_rounds) {
     lanes_.emplace_back(new Lane(ctx, memspace, &sampler_, &pSolver_));
     if (nlevels < 1) throw std::invalid_argument("MLMC_Manager: nlevels < 1");
-    if (batch_ < 1 || batch_ > 32) throw std::invalid_argument("MLMC_Manager: batch must be in 1..32");
+    if (batch_ < 1 || batch_ > 256) throw std::invalid_argument("MLMC_Manager: batch must be in 1..256");
     if (!(ratio > 0.0 && ratio < 1.0)) throw std::invalid_argument("MLMC_Manager: ratio must be in (0,1)");
     if (p.array_nsamples) v_init_nsamples.assign(p.array_nsamples, p.array_nsamples + nlevels);
     else v_init_nsamples.assign(nlevels, p.init_nsamples);
@@ -677,7 +677,7 @@ ML_BayesRatio_Manager::ML_BayesRatio_Manager(pmc_ctx* ctx, int memspace, int nle
       zparam(ctx, memspace),
       sparam(ctx, memspace) {
     if (nlevels < 1) throw std::invalid_argument("ML_BayesRatio_Manager: nlevels < 1");
-    if (batch_ < 1 || batch_ > 32) throw std::invalid_argument("ML_BayesRatio_Manager: batch must be in 1..32");
+    if (batch_ < 1 || batch_ > 256) throw std::invalid_argument("ML_BayesRatio_Manager: batch must be in 1..256");
     if (!(ratio > 0.0 && ratio < 1.0)) throw std::invalid_argument("ML_BayesRatio_Manager: ratio must be in (0,1)");
     M.resize(nlevels);
     for (int i = 0; i < nlevels; ++i) M[i] = problem.GetGlobalNumberOfDofs(i);

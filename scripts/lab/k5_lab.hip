@@ -141,7 +141,7 @@ int main(int argc, char** argv) {
     std::vector<double> hx(len);
     uint64_t s = 88172645463325252ull;
     for (size_t i = 0; i < len; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; hx[i] = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
-    DevBuf<double> x(len), y0(len), y1(len), part((size_t)dot_capacity(n) * kMaxBatch);
+    DevBuf<double> x(len), y0(len), y1(len), part((size_t)dot_capacity(n, nb) * nb);
     PMC_HIP(hipMemcpy(x.p, hx.data(), len * 8, hipMemcpyHostToDevice));
     const size_t fl = (size_t)48 << 20;   // double2 elements: 768 MB read + 768 MB written
     DevBuf<double> fa(fl * 2), fb(fl * 2);

@@ -330,7 +330,7 @@ def test_mlmc_manager_on_device_matches_oracle_loop(gpu_ctx, hex_hierarchy_small
 
 
 # ---------------------------------------------------------------------------------- K5: block operator SpMV
-@pytest.mark.parametrize("nb", [1, 2, 4, 8, 16, 32])
+@pytest.mark.parametrize("nb", [1, 2, 4, 8, 16, 32, 64, 128, 256])
 def test_block_operator_spmv_matches_csr(gpu_ctx, hexprob, seeded_rng, nb):
     """y = [M Bt; B -aW] x on the device (SELL-64 SpMM) against scipy's CSR product of the oracle's
     block operator: same sums in a different order -> agreement at rounding level."""

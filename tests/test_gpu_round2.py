@@ -311,7 +311,7 @@ def test_manager_sums_do_not_depend_on_the_batch_width(gpu_ctx, hex_hierarchy_sm
         assert r["estimate"] == pytest.approx(out[0]["estimate"], rel=1e-9)
         assert list(r["nsamples"]) == list(out[0]["nsamples"])
     with pytest.raises(Exception):
-        host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False, batch=33)
+        host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False, batch=257)
     ds.close()
     smp.close()
 

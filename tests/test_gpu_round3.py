@@ -42,3 +42,87 @@ def test_bench_starts_its_own_ranks():
     assert abs(out["value"] - 2 * ranks[0]["samples"] / (out["ms_per_step"] * 1e-3 * out["steps"])) < 1e-6 * out["value"]
     assert "mlmc_farm" in out["extra"]
     assert "cpu_baseline" not in out and "r6" not in out["extra"]
+
+
+def test_super_batches_match_narrow_batches_and_the_oracle(gpu_ctx, hex_hierarchy, seeded_rng):
+    """Levels too small to fill the chip with 32 realizations are solved as column groups of 32 in ONE launch (gridDim.y;
+    batch_width in csrc/solver.hip: 64 / 128 / 256 realizations).  200 realizations in one call (chunks of 128 + 64 + 8)
+    == the same realizations 32 per call == the oracle's direct solves, for the sampler on every level (the two coarse
+    ones run the persistent one-workgroup-per-realization solver) and for Darcy; per-column freeze makes the longer joint
+    iteration exact.  The loop being restated is src/MLMC_Manager.cpp:113-173."""
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp_ = build_sampler_problem(hex_hierarchy, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    o = capi.solver_opts(rel_tol=1e-12, abs_tol=1e-14)
+    smp, ds = capi.PDESampler(gpu_ctx, sp_, o), capi.DarcySolver(gpu_ctx, dp, o)
+    so, do = SamplerOracle(sp_), DarcyOracle(dp)
+    nreal = 200
+    xi = seeded_rng.standard_normal((nreal, sp_.levels[0].n_s))
+    probe = (0, 31, 32, 63, 64, 127, 128, 191, 192, 199)        # both sides of every group / chunk boundary
+    for lvl in range(3):
+        sw, st = smp.Eval(lvl, xi, xi_level=0, return_stats=True)
+        assert len(st) == nreal and all(t[1] == 1 for t in st)
+        sn = np.vstack([smp.Eval(lvl, xi[i:i + 32], xi_level=0) for i in range(0, nreal, 32)])
+        assert np.allclose(sw, sn, rtol=1e-9, atol=0)
+        for b in probe:
+            ref = so.eval(lvl, 0, xi[b])[0]
+            assert np.linalg.norm(sw[b] - ref) <= 1e-8 * np.linalg.norm(ref), (lvl, b)
+        Qw, Cw, stq = ds.SolveFwd(lvl, sw, return_stats=True)
+        assert all(t[1] == 1 for t in stq) and np.all(Cw == dp.levels[lvl].ndofs)
+        Qn = np.concatenate([ds.SolveFwd(lvl, sw[i:i + 32])[0] for i in range(0, nreal, 32)])
+        assert np.allclose(Qw, Qn, rtol=1e-9)
+        for b in probe[::2]:
+            assert abs(Qw[b] - do.solve_fwd(lvl, sw[b])[0]) <= 1e-8 * abs(Qw[b]), (lvl, b)
+    # warm start + coarse xi through the wide path: the level pair as the manager calls it, ONE device buffer for the
+    # initial guess (in) and the embedded Gaussian field (out) over several chunks (src/MLMC_Manager.cpp:150-156)
+    n0, n1 = sp_.levels[0].n_s, sp_.levels[1].n_s
+    d_xi = gpu_ctx.array(xi)
+    d_s, buf = gpu_ctx.empty(nreal * n0), gpu_ctx.empty(nreal * n0)
+    smp.Eval(1, d_xi, xi_level=0, s_out=d_s, embed_out=buf)
+    coarse = d_s.download()[: nreal * n1].reshape(nreal, n1)
+    gauss1 = buf.download()[: nreal * n1].reshape(nreal, n1)
+    assert np.allclose(np.exp(gauss1), coarse, rtol=1e-12)
+    _, _, st = smp.Eval(0, d_xi, xi_level=0, init_s=buf, init_level=1, use_init=True, s_out=d_s, embed_out=buf,
+                        return_stats=True)
+    assert all(t[1] == 1 for t in st)
+    cold = smp.Eval(0, xi, xi_level=0)
+    assert np.allclose(d_s.download().reshape(nreal, n0), cold, rtol=1e-8)
+    assert np.allclose(np.exp(buf.download().reshape(nreal, n0)), cold, rtol=1e-8)
+    # K1: the white noise of a wide batch is the same stream as narrow batches
+    a = smp.Sample(2, first_id=5, nbatch=256)
+    b = np.vstack([smp.Sample(2, first_id=5 + i, nbatch=32) for i in range(0, 256, 32)])
+    assert np.array_equal(a, b)
+    ds.close()
+    smp.close()
+
+
+def test_manager_sums_do_not_depend_on_the_super_batch_width(gpu_ctx, hex_hierarchy):
+    """MLMC_Manager::InitRun with 256 / 96 / 32 realizations per plugin call: same realization ids, same sums to the
+    (tight) solver tolerance, same estimate; two lanes as well."""
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp_ = build_sampler_problem(hex_hierarchy, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    o = capi.solver_opts(rel_tol=1e-12, abs_tol=1e-14)
+    smp, ds = capi.PDESampler(gpu_ctx, sp_, o), capi.DarcySolver(gpu_ctx, dp, o)
+    out = []
+    for batch in (256, 96, 32):
+        mgr = host_api.MLMCManager(3, sampler=smp, solver=ds, wall_time=False, batch=batch)
+        out.append(mgr.InitRun([70, 300, 520]))
+        mgr.close()
+    c2 = capi.Context(0, seed=20261003)
+    smp2, ds2 = capi.PDESampler(c2, sp_, o), capi.DarcySolver(c2, dp, o)
+    mgr = host_api.MLMCManager(3, sampler=smp, solver=ds, wall_time=False, batch=128)
+    mgr.add_lane(smp2, ds2)
+    out.append(mgr.InitRun([70, 300, 520]))
+    mgr.close()
+    for r in out[1:]:
+        assert np.allclose(r["sums"], out[0]["sums"], rtol=1e-8, atol=1e-10)
+        assert r["estimate"] == pytest.approx(out[0]["estimate"], rel=1e-9)
+        assert list(r["nsamples"]) == list(out[0]["nsamples"])
+    for h in (ds2, smp2, ds, smp):
+        h.close()
+    c2.close()
