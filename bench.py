@@ -204,7 +204,7 @@ def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters
     return out
 
 
-def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=32):
+def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=256):
     """Secondary figure (BASELINE config 3): MLMC_Manager::InitRun with the SPDE sampler + Darcy QoI on cube_hex
     64^3 / 32^3 / 16^3, fixed sample counts, `lanes` concurrent streams.  Reported under "extra", never as `value`.
     farm = (world, rank, comm_ctx, device): the realizations of every level are sharded over the ranks and the accumulators
@@ -219,8 +219,9 @@ def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=32):
     ctxs = ([farm[2]] if farm else []) + [capi.Context(dev, seed=seed) for _ in range(lanes - (1 if farm else 0))]
     sm = [capi.PDESampler(c, sp, opts) for c in ctxs]
     dr = [capi.DarcySolver(c, dp, opts) for c in ctxs]
-    # batch = realizations per plugin call; the library solves them 32 at a time on levels small enough to be bound by
-    # launch latency and 16 at a time on the others (batch_width in csrc/solver.hip)
+    # batch = upper limit of realizations per plugin call; per level the manager hands over what the plugins prefer
+    # (pmc_sampler_batch_width: 16 at a time on the bandwidth-bound 64^3 level, 64 on 32^3, 256 - eight column groups of 32
+    # in one launch - on 16^3), cut so that every lane gets a share
     mgr = host_api.MLMCManager(3, sampler=sm[0], solver=dr[0], wall_time=True, batch=batch)
     for i in range(1, lanes):
         mgr.add_lane(sm[i], dr[i])
@@ -228,14 +229,15 @@ def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=32):
     if farm:
         world, rank = farm[0], farm[1]
         mgr.set_farm(world, rank, None)              # reduce == NULL -> pmc_allreduce_sum_f64 (RCCL) of ctxs[0]
-    mgr.InitRun([batch * lanes * world] * 3)    # warm-up: allocations
+    mgr.InitRun([64 * world, 256 * world, 1024 * world])    # warm-up: allocations at the widths of the timed round
     mgr.Reset()
     ns = [64 * world, 256 * world, 1024 * world]
     t0 = time.perf_counter()
     r = mgr.InitRun(ns)
     dt = time.perf_counter() - t0
     out = {"workload": "MLMC Darcy + SPDE sampler, cube_hex 64^3/32^3/16^3 (1 060 864 / 134 144 / 17 152 DoF), lognormal, "
-                       f"eff_perm QoI, InitRun {ns}, {lanes} lanes x {batch}" + (f", sharded over {world} ranks" if farm else ""),
+                       f"eff_perm QoI, InitRun {ns}, {lanes} lanes, realizations per launch per level "
+                       f"{[sm[0].BatchWidth(l) for l in range(3)]}" + (f", sharded over {world} ranks" if farm else ""),
            "realizations_per_s": sum(ns) / dt, "seconds": dt, "estimate": r["estimate"],
            "nsamples_after_allreduce": [int(x) for x in r["nsamples"]],
            "seconds_per_sample_per_level": [float(x) for x in r["cost"]], "varY": [float(x) for x in r["varY"]]}

@@ -172,6 +172,10 @@ int pmc_sampler_num_levels(const pmc_sampler* s);
 int pmc_sampler_xi_size(const pmc_sampler* s, int level);     /* size Sample() fills            */
 int pmc_sampler_sample_size(const pmc_sampler* s, int level); /* SampleSize(): size of Eval's s */
 int64_t pmc_sampler_nnz(const pmc_sampler* s, int level);     /* GetNNZ()                       */
+/* Realizations of `level` ONE launch of the solver kernels carries (16 on large levels, 32 on small ones, 64 / 128 / 256 -
+ * column groups of 32 - on the smallest): pmc_sampler_eval cuts any nbatch into chunks of this width, so callers that
+ * can choose (the managers' realizations per plugin call) should hand over multiples of it. */
+int pmc_sampler_batch_width(const pmc_sampler* s, int level);
 /* GetTrueP(level) (src/MLSampler.hpp:85-87, src/PDESampler.hpp:153-156): the prolongator of the s-space from level+1 to
  * level as handed over at create time; the pointers stay valid for the life of the handle.  Error on the last level. */
 int pmc_sampler_true_p(const pmc_sampler* s, int level, pmc_csr* out);
@@ -214,6 +218,7 @@ void pmc_darcy_destroy(pmc_darcy* d);
 int pmc_darcy_num_dofs(const pmc_darcy* d, int level); /* GetGlobalNumberOfDofs() */
 int pmc_darcy_num_pressure_dofs(const pmc_darcy* d, int level); /* GetSizeOfStochasticData(): entries of k */
 int64_t pmc_darcy_nnz(const pmc_darcy* d, int level);  /* GetNNZ()                */
+int pmc_darcy_batch_width(const pmc_darcy* d, int level);  /* as pmc_sampler_batch_width */
 /* SolveFwd(level, k, Q, C) (src/DarcySolver.cpp:416-437).  k: nbatch x n_p(level) in
  * `memspace`; Q, C: host arrays of nbatch; sol_out (may be NULL): nbatch x (n_u+n_p) in
  * `memspace` (SolveFwd_RtnPressure, :439-470, reads its p-block). */

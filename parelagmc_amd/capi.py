@@ -82,6 +82,8 @@ SYMBOLS = {
     "pmc_sampler_num_levels": (C.c_int, [_VP]),
     "pmc_sampler_xi_size": (C.c_int, [_VP, C.c_int]),
     "pmc_sampler_sample_size": (C.c_int, [_VP, C.c_int]),
+    "pmc_sampler_batch_width": (C.c_int, [_VP, C.c_int]),
+    "pmc_darcy_batch_width": (C.c_int, [_VP, C.c_int]),
     "pmc_sampler_nnz": (C.c_int64, [_VP, C.c_int]),
     "pmc_sampler_true_p": (C.c_int, [_VP, C.c_int, C.POINTER(pmc_csr)]),
     "pmc_sampler_sample": (C.c_int, [_VP, C.c_int, C.c_uint64, C.c_int, _DP, C.c_int]),
@@ -354,6 +356,10 @@ class PDESampler:
     def SampleSize(self, level):
         return self.ctx.lib.pmc_sampler_sample_size(self.h, level)
 
+    def BatchWidth(self, level):
+        """realizations of `level` one launch of the solver kernels carries (pmc_sampler_batch_width)"""
+        return self.ctx.lib.pmc_sampler_batch_width(self.h, level)
+
     def GetNNZ(self, level):
         return self.ctx.lib.pmc_sampler_nnz(self.h, level)
 
@@ -484,6 +490,9 @@ class DarcySolver:
 
     def GetNNZ(self, level):
         return self.ctx.lib.pmc_darcy_nnz(self.h, level)
+
+    def BatchWidth(self, level):
+        return self.ctx.lib.pmc_darcy_batch_width(self.h, level)
 
     def SolveFwd(self, level, k, nbatch=None, want_solution=False, sol_out=None, return_stats=False):
         """Returns (Q, C) arrays of length nbatch (plus solution / stats on request)."""

@@ -289,6 +289,10 @@ int pmc_sampler_sample_size(const pmc_sampler* s, int level) {
     if (!s || level < 0 || level >= s->impl.nlevels) return PMC_ERR_INVALID;
     return s->impl.lv[level].out_size;
 }
+int pmc_sampler_batch_width(const pmc_sampler* s, int level) {
+    if (!s || level < 0 || level >= s->impl.nlevels) return PMC_ERR_INVALID;
+    return batch_width((size_t)s->impl.lv[level].n_u + s->impl.lv[level].n_s);
+}
 int pmc_sampler_true_p(const pmc_sampler* s, int level, pmc_csr* out) {
     return guarded([&] {
         PMC_REQUIRE(s != nullptr && out != nullptr, "pmc_sampler_true_p: NULL argument");
@@ -378,6 +382,10 @@ int pmc_darcy_num_dofs(const pmc_darcy* d, int level) {
 int pmc_darcy_num_pressure_dofs(const pmc_darcy* d, int level) {
     if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
     return d->impl.lv[level].n_p;
+}
+int pmc_darcy_batch_width(const pmc_darcy* d, int level) {
+    if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
+    return batch_width((size_t)d->impl.lv[level].n_u + d->impl.lv[level].n_p);
 }
 int64_t pmc_darcy_nnz(const pmc_darcy* d, int level) {
     if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;

@@ -305,8 +305,18 @@ void MLMC_Manager::AddLane(pmc_ctx* ctx, PhysicalMLSolver& solver, MLSampler& sm
     lanes_.emplace_back(new Lane(ctx, memspace_, &smp, &solver));
 }
 
+int MLMC_Manager::level_batch(int ilevel, int nsamples) const {
+    int b = batch_;
+    for (int pref : {sampler.PreferredBatch(ilevel), pSolver.PreferredBatch(ilevel)})
+        if (pref > 0) b = std::min(b, pref);
+    const int workers = nranks_ * (int)lanes_.size();
+    const int share = (nsamples + workers - 1) / workers;     // what a worker gets if the level is dealt evenly
+    return std::max(1, std::min(b, share));
+}
+
 void MLMC_Manager::run_level(int ilevel, int nsamples) {
     const uint64_t base = (uint64_t)level_nsamples[ilevel];
+    const int batch_ = level_batch(ilevel, nsamples);          // shadows the member: this level's plugin-call size
     const int nblocks = (nsamples + batch_ - 1) / batch_;
     const int nlanes = (int)lanes_.size();
     std::vector<std::vector<double>> lane_sums(nlanes, std::vector<double>(NVAR, 0.0));
@@ -379,9 +389,10 @@ void MLMC_Manager::run_round_overlapped(const std::vector<int>& ns_init) {
         const int ns = ns_init[ilevel];
         if (ns < 0) throw std::invalid_argument("InitRun: negative sample count");
         yv[ilevel].assign(ns, 0.0); qv[ilevel].assign(ns, 0.0); qcv[ilevel].assign(ns, 0.0); cv[ilevel].assign(ns, 0.0);
-        const int nblocks = (ns + batch_ - 1) / batch_;
+        const int lb = level_batch(ilevel, ns);
+        const int nblocks = (ns + lb - 1) / lb;
         for (int blk = rank_; blk < nblocks; blk += nranks_)
-            tasks.push_back({ilevel, blk * batch_, std::min(batch_, ns - blk * batch_)});
+            tasks.push_back({ilevel, blk * lb, std::min(lb, ns - blk * lb)});
     }
     const int nlanes = (int)lanes_.size();
     std::vector<std::vector<double>> lane_seconds(nlanes, std::vector<double>(nlevels, 0.0));
@@ -430,9 +441,10 @@ void MLMC_Manager::run_round_overlapped(const std::vector<int>& ns_init) {
     for (int ilevel = nlevels - 1; ilevel >= 0; --ilevel) {
         double* psum = pending_.data() + (size_t)ilevel * NVAR;
         const int ns = ns_init[ilevel];
-        const int nblocks = (ns + batch_ - 1) / batch_;
+        const int lb = level_batch(ilevel, ns);
+        const int nblocks = (ns + lb - 1) / lb;
         for (int blk = rank_; blk < nblocks; blk += nranks_)
-            for (int i = blk * batch_; i < std::min(ns, (blk + 1) * batch_); ++i) {
+            for (int i = blk * lb; i < std::min(ns, (blk + 1) * lb); ++i) {
                 const double y = yv[ilevel][i], q = qv[ilevel][i];
                 psum[Y3] += y * y * y;
                 psum[Y4] += y * y * y * y;
@@ -971,7 +983,7 @@ void pmc_mlmc_params_default(pmc_mlmc_params* p) {
     p->init_nsamples = 10;
     p->array_nsamples = nullptr;
     p->wall_time = 1;
-    p->batch = 32;
+    p->batch = 256;
     p->max_rounds = 1000;
     p->log_file = nullptr;
 }

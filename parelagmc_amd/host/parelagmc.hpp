@@ -71,6 +71,10 @@ class MLSampler {
     /// Prolongator of the sample space from level+1 to level (src/MLSampler.hpp:85-87; a HypreParMatrix there, a CSR
     /// view with host pointers owned by the sampler here).  Default: not available.
     virtual pmc_csr GetTrueP(int /*level*/) const { throw std::runtime_error("GetTrueP: not provided by this sampler"); }
+    /// Realizations of `level` the plugin processes at once most efficiently (0 = no preference).  The managers cut a
+    /// level's realizations into plugin calls of at most this many (device plugins: 16 on large levels, up to 256 on the
+    /// smallest - pmc_sampler_batch_width).
+    virtual int PreferredBatch(int /*level*/) const { return 0; }
 };
 
 class PhysicalMLSolver {
@@ -96,6 +100,8 @@ class PhysicalMLSolver {
     virtual int GetNumberOfDofs(int ilevel) const = 0;
     virtual int GetGlobalNumberOfDofs(int ilevel) const = 0;
     virtual int GetNNZ(int ilevel) const = 0;
+    /// see MLSampler::PreferredBatch
+    virtual int PreferredBatch(int /*ilevel*/) const { return 0; }
 };
 
 /// Uncorrelated N(mu, sigma2) variates (counter-based generator on the device).
@@ -128,6 +134,7 @@ class PDESampler : public MLSampler {
     size_t GetNNZ(int level) const override;
     void BuildHierarchy() override;
     pmc_csr GetTrueP(int level) const override;
+    int PreferredBatch(int level) const override { return pmc_sampler_batch_width(h_, level); }
     int GetNumIters() const { return last_iters_; }   // the reference returns -1 (PDESampler.hpp:142-145)
 
   private:
@@ -149,6 +156,7 @@ class DarcySolver : public PhysicalMLSolver {
     int GetNumberOfDofs(int ilevel) const override;
     int GetGlobalNumberOfDofs(int ilevel) const override;
     int GetNNZ(int ilevel) const override;
+    int PreferredBatch(int ilevel) const override { return pmc_darcy_batch_width(h_, ilevel); }
 
   private:
     pmc_ctx* ctx_;
@@ -240,6 +248,10 @@ class MLMC_Manager {
     // several lanes: all levels of one InitRun round go through one task queue (finest level first), so the
     // launch-latency-bound batches of the coarse levels overlap the bandwidth-bound batches of the fine ones
     void run_round_overlapped(const std::vector<int>& level_nsamples_init);
+    // realizations per plugin call on `ilevel` when `nsamples` new ones are due: at most `batch`, at most what the plugins
+    // prefer for that level (PreferredBatch: 16 on large levels ... 256 on the smallest), and small enough that every lane
+    // of every rank gets a share.  A function of (level, nsamples, ranks, lanes) only: identical on all ranks.
+    int level_batch(int ilevel, int nsamples) const;
     double& S(int l, int v) { return sums[(size_t)l * NVAR + v]; }
 
     pmc_ctx* ctx_;

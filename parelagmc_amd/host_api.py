@@ -316,7 +316,7 @@ class MLMCManager:
     plugin callbacks (`callbacks=dict(sample=, eval=, solve=, xi_size=, sample_size=, ndofs=)`)."""
 
     def __init__(self, nlevels, sampler=None, solver=None, callbacks=None, eps2=0.001, ratio=0.5, init_nsamples=10,
-                 array_nsamples: Optional[Sequence[int]] = None, wall_time=True, batch=32, max_rounds=1000,
+                 array_nsamples: Optional[Sequence[int]] = None, wall_time=True, batch=256, max_rounds=1000,
                  log_file: Optional[str] = None):
         self.lib = load_host_library()
         self.nlevels = nlevels
