@@ -99,12 +99,40 @@ def solver_bytes_per_iteration(problem, nb):
     return total
 
 
+def lib_sha256():
+    import hashlib
+    with open(os.path.join(ROOT, "parelagmc_amd", "lib", "libpmc.so"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+_TRAFFIC = {}
+
+
 def traffic_entry(key):
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        return json.load(open(tfile)).get(key, {}).get("hbm_bytes_per_launch")
-    except Exception:   # noqa: BLE001
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json, written by scripts/collect_profiles.py
+    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs).  The file is stamped with the sha256 of the libpmc.so those
+    passes ran: a different library -> the counters describe other kernels -> traffic is null (and a warning), never a stale
+    number."""
+    if not _TRAFFIC:
+        try:
+            _TRAFFIC.update(json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))))
+        except Exception:   # noqa: BLE001
+            _TRAFFIC["error"] = True
+        stamp = _TRAFFIC.get("libpmc_sha256")
+        _TRAFFIC["_ok"] = bool(stamp) and stamp == lib_sha256()
+        if not _TRAFFIC["_ok"]:
+            print("bench: profiles/pmc_traffic.json was not collected with this libpmc.so (stamp "
+                  f"{str(stamp)[:12]}, library {lib_sha256()[:12]}): roofline.traffic = null; run scripts/make_profiles.sh + "
+                  "scripts/collect_profiles.py", file=sys.stderr)
+    if not _TRAFFIC.get("_ok"):
         return None
+    return _TRAFFIC.get(key, {}).get("hbm_bytes_per_launch")
+
+
+def traffic_provenance():
+    traffic_entry("")
+    return {"file": "profiles/pmc_traffic.json", "matches_running_library": bool(_TRAFFIC.get("_ok")),
+            "libpmc_sha256": _TRAFFIC.get("libpmc_sha256"), "head": _TRAFFIC.get("head")}
 
 
 class SamplerFarm:
@@ -177,20 +205,21 @@ def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters
     x1 = ctx.array(np.random.default_rng(0).standard_normal(L.n_u + L.n_s))
     _, k1_ms, k1_bytes = smp.Mult(0, x1, repeat=50)
     # (hipGraph replay, opts.use_graph, cannot be bracketed by events: fall back to the isolated launches then)
-    # A bracket = event record, launch, event record: it contains what an event record costs on that stream (~6 us), measured
-    # by the empty bracket behind every timed launch.  Net of it the live number agrees with the rocprofv3 average of the
-    # same kernel (profiles/rNN_bench_s1_kernel_stats.csv: 56.5 vs 57.0 us at r = 5); the raw bracket is reported beside it.
+    # The headline is the RAW event bracket (event record, launch, event record): a measurement, and an upper bound of the
+    # kernel's duration.  What an event pair costs on that stream is measured by the empty bracket behind every timed launch;
+    # the bracket net of it is an ESTIMATE (it over-corrects by ~2.5 % against the rocprofv3 average of the same launches,
+    # profiles/rNN_bench_s1_kernel_stats.csv) and is reported beside the headline, never as it.
     raw_ms = solo_ms / solo_launches if solo_launches > 0 else k_ms
     gap = gap_ms / solo_launches if solo_launches > 0 else 0.0
-    loop_ms = raw_ms - gap
-    ach = k_bytes / (loop_ms * 1e-3) / 1e9
-    out = {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, true, 1> (block operator K5 as launched by the "
-                                     "MINRES loop: fused <u, Au>, one lane alone on the GPU)",
+    ach = k_bytes / (raw_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, true, 1, ...> (tag 1 = block operator K5 as launched "
+                                     "by the MINRES loop: fused <u, Au>, diagonal-last, non-temporal streams by size; one lane "
+                                     "alone on the GPU; profile rows with this prefix)",
            "achieved": ach, "peak": PEAK_GBS, "unit": "GB/s", "frac": ach / PEAK_GBS,
-           "traffic": traffic_entry(f"r{refine}_nb{nb}_inloop"),
-           "bytes_per_launch": k_bytes, "avg_kernel_ms": loop_ms, "launches": solo_launches,
-           "raw_event_bracket_ms": raw_ms, "event_overhead_ms": gap,
-           "frac_of_raw_bracket": k_bytes / (raw_ms * 1e-3) / 1e9 / PEAK_GBS,
+           "traffic": traffic_entry(f"r{refine}_nb{nb}_inloop"), "traffic_provenance": traffic_provenance(),
+           "bytes_per_launch": k_bytes, "avg_kernel_ms": raw_ms, "launches": solo_launches,
+           "timing": "raw HIP-event bracket around every in-loop launch",
+           "event_overhead_ms": gap, "frac_net_of_event_overhead": k_bytes / (max(raw_ms - gap, 1e-9) * 1e-3) / 1e9 / PEAK_GBS,
            "isolated": {"kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, false, 2> launched back to back",
                         "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "frac": k_bytes / (k_ms * 1e-3) / 1e9 / PEAK_GBS,
                         "avg_kernel_ms": k_ms, "traffic": traffic_entry(f"r{refine}_nb{nb}")},
@@ -204,7 +233,40 @@ def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters
     return out
 
 
-def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=256):
+def darcy_operator_roofline(ctx, smp, ds, level=0, nb=16):
+    """Roofline block of the Darcy operator (solver->Mult, src/DarcySolver.cpp:479,629-631) as the MINRES loop of SolveFwd
+    launches it: the u-rows y_u = M(k) x_u + B^T x_p with the fused <x, Ax> (eg_pair_spmm_kernel - M(k) element-grouped, never
+    materialised), every in-loop launch of two solo batches of nb realizations bracketed by HIP events on the solve's stream
+    (one lane alone on the GPU).  Algorithmic bytes: pmc_darcy_operator_bytes."""
+    xi = ctx.empty(nb * smp.xi_size(level))
+    s = ctx.empty(nb * smp.SampleSize(level))
+    smp.Sample(level, first_id=900000, nbatch=nb, out=xi)
+    smp.Eval(level, xi, xi_level=level, s_out=s)
+    ds.SolveFwd(level, s, nbatch=nb)                   # warm-up at this width
+    ds.set_operator_timing(True)
+    ds.operator_time()
+    its = []
+    for _ in range(2):
+        _, _, st = ds.SolveFwd(level, s, nbatch=nb, return_stats=True)
+        check_stats(st, "the in-loop Darcy operator pass")
+        its.append(max(t[0] for t in st))
+    ms, n, gap = ds.operator_time()
+    ds.set_operator_timing(False)
+    nbytes = ds.operator_bytes(level, nb)
+    raw = ms / max(n, 1)
+    ach = nbytes / (raw * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": f"pmc::eg_pair_spmm_kernel<{nb}, true, ...> (u-rows [M(k) | B^T] x of the Darcy operator as "
+                                      f"launched by the MINRES loop on level {level}: element-grouped M(k), fused <x, Ax>; one lane "
+                                      "alone on the GPU, p-rows B x_u behind it on the same stream while timed)",
+            "achieved": ach, "peak": PEAK_GBS, "unit": "GB/s", "frac": ach / PEAK_GBS,
+            "traffic": traffic_entry(f"c3_eg_nb{nb}_inloop"), "traffic_provenance": traffic_provenance(),
+            "bytes_per_launch": nbytes, "avg_kernel_ms": raw, "launches": n, "timing": "raw HIP-event bracket around every in-loop launch",
+            "event_overhead_ms": gap / max(n, 1),
+            "frac_net_of_event_overhead": nbytes / (max(raw - gap / max(n, 1), 1e-9) * 1e-3) / 1e9 / PEAK_GBS,
+            "minres_iterations": its}
+
+
+def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=256, roofline=False):
     """Secondary figure (BASELINE config 3): MLMC_Manager::InitRun with the SPDE sampler + Darcy QoI on cube_hex
     64^3 / 32^3 / 16^3, fixed sample counts, `lanes` concurrent streams.  Reported under "extra", never as `value`.
     farm = (world, rank, comm_ctx, device): the realizations of every level are sharded over the ranks and the accumulators
@@ -229,19 +291,36 @@ def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=256):
     if farm:
         world, rank = farm[0], farm[1]
         mgr.set_farm(world, rank, None)              # reduce == NULL -> pmc_allreduce_sum_f64 (RCCL) of ctxs[0]
-    mgr.InitRun([64 * world, 256 * world, 1024 * world])    # warm-up: allocations at the widths of the timed round
-    mgr.Reset()
     ns = [64 * world, 256 * world, 1024 * world]
+    mgr.InitRun(ns)                                  # warm-up: allocations at the widths of the timed round
+    mgr.Reset()
+    ph0 = [mgr.phase_times(l) for l in range(3)]
+    l0 = ctxs[0].lib.pmc_kernel_launches()
     t0 = time.perf_counter()
     r = mgr.InitRun(ns)
     dt = time.perf_counter() - t0
+    launches = int(ctxs[0].lib.pmc_kernel_launches() - l0)
+    ph1 = [mgr.phase_times(l) for l in range(3)]
+    widths = [sm[0].BatchWidth(l) for l in range(3)]
     out = {"workload": "MLMC Darcy + SPDE sampler, cube_hex 64^3/32^3/16^3 (1 060 864 / 134 144 / 17 152 DoF), lognormal, "
-                       f"eff_perm QoI, InitRun {ns}, {lanes} lanes, realizations per launch per level "
-                       f"{[sm[0].BatchWidth(l) for l in range(3)]}" + (f", sharded over {world} ranks" if farm else ""),
+                       f"eff_perm QoI, InitRun {ns}, {lanes} lanes, realizations per launch per level {widths}"
+                       + (f", sharded over {world} ranks" if farm else ""),
            "realizations_per_s": sum(ns) / dt, "seconds": dt, "estimate": r["estimate"],
            "nsamples_after_allreduce": [int(x) for x in r["nsamples"]],
-           "seconds_per_sample_per_level": [float(x) for x in r["cost"]], "varY": [float(x) for x in r["varY"]]}
+           "realizations_per_launch_per_level": widths,
+           "kernel_launches_per_round": launches, "kernel_launches_per_s": launches / dt,
+           "seconds_per_sample_per_level": [float(x) for x in r["cost"]], "varY": [float(x) for x in r["varY"]],
+           # the reference's per-level TimeManager entries (src/PDESampler.cpp:328-333, src/DarcySolver.cpp:231-243): device ms
+           # of the timed round, summed over the lanes of this rank (HIP events, pmc_stats.solve_ms / setup_ms)
+           "phase_timers_ms": [{k: ph1[l][k] - ph0[l][k] for k in ph1[l]} for l in range(3)]}
+    if roofline:
+        try:
+            out["roofline"] = darcy_operator_roofline(ctxs[0], sm[0], dr[0], 0, 16)
+        except Exception as e:   # noqa: BLE001
+            out["roofline"] = {"error": repr(e)}
     mgr.close()
+    for x in dr + sm:
+        x.close()
     for c in ctxs:
         c.close()
     return out, (sp, dp)
@@ -275,6 +354,153 @@ def darcy_cpu_baseline(sp, dp, seed, per_core=(1, 2, 8)):
             "sample": f"{[p * cores for p in per_core]} sampler + Darcy solves on levels 0..2 (Darcy: per-sample M(k), elimination, "
                       "Schur hierarchy refresh, MINRES); a realization of level l < 2 = the pair (l, l+1); rate = the "
                       "[64, 256, 1024] round at these costs"}
+
+
+def level_rates(lanes, levels, nrep, darcy):
+    """The reference's own timing harness shape (examples/SPE10/SPE10_PDESampler_Performance.cpp:163-175: per level,
+    nsamples x (Sample + Eval)), with `lanes` = [(ctx, sampler, darcy solver or None)] working concurrently: every lane
+    draws and evaluates `nrep` batches of the level's launch width (+ SolveFwd when darcy).  Device-resident buffers."""
+    out = []
+    for lvl in levels:
+        w = lanes[0][1].BatchWidth(lvl)
+        bufs = [(c.empty(w * sm.xi_size(lvl)), c.empty(w * sm.SampleSize(lvl))) for c, sm, _ in lanes]
+        res = [None] * len(lanes)
+
+        def work(i, reps, first):
+            c, sm, ds = lanes[i]
+            xi, sf = bufs[i]
+            st_all, sq_all = [], []
+            for r in range(reps):
+                sm.Sample(lvl, first_id=first + (r * len(lanes) + i) * w, nbatch=w, out=xi)
+                st_all += sm.Eval(lvl, xi, xi_level=lvl, s_out=sf, return_stats=True)[1]
+                if ds is not None:
+                    sq_all += ds.SolveFwd(lvl, sf, nbatch=w, return_stats=True)[2]
+            c.synchronize()
+            res[i] = (st_all, sq_all)
+
+        def run(reps, first):
+            th = [threading.Thread(target=work, args=(i, reps, first)) for i in range(len(lanes))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        run(1, 0)                                   # warm-up: allocations at this width
+        t0 = time.perf_counter()
+        run(nrep, 10 ** 6)
+        dt = time.perf_counter() - t0
+        st = [t for r in res for t in r[0]]
+        sq = [t for r in res for t in r[1]]
+        n = nrep * w * len(lanes)
+        e = {"level": lvl, "realizations": n, "realizations_per_launch": w, "realizations_per_s": n / dt,
+             "sampler_iterations_mean": float(np.mean([t[0] for t in st])), "sampler_all_converged": all(t[1] == 1 for t in st)}
+        if darcy:
+            e.update({"darcy_iterations_mean": float(np.mean([t[0] for t in sq])), "darcy_all_converged": all(t[1] == 1 for t in sq)})
+        out.append(e)
+    return out
+
+
+def cpu_level_rates(sp, dp, seed, levels, per_core):
+    """CPU column of a multi-level configuration: the C restatement of the reference's solver (oracle/c/pmc_ref.c) on a
+    bounded sample per level, farmed over the host cores - sampler solve, plus (dp given) per-sample M(k), elimination,
+    preconditioner rebuild and Darcy solve as src/DarcySolver.cpp:472-649 does."""
+    from oracle.cport import CPort, DarcyCPort
+    from oracle.rng_oracle import normal_fill
+    cores = host_cores()
+    cs = CPort(sp)
+    cd = DarcyCPort(dp) if dp is not None else None
+    out = []
+    for lvl, pc in zip(levels, per_core):
+        ns = pc * cores
+        n = sp.levels[lvl].n_s
+        xi = np.stack([normal_fill(n, seed, i, lvl) for i in range(ns)])
+        t0 = time.perf_counter()
+        sol, it = cs.solve(lvl, cs.rhs(lvl, lvl, xi), nthreads=cores)
+        e = {"level": lvl, "realizations": ns, "sampler_iterations_mean": float(np.mean(np.abs(it))),
+             "sampler_all_converged": bool(np.all(it > 0))}
+        if cd is not None:
+            field = sol[:, sp.levels[lvl].n_u:]
+            if dp.levels[lvl].n_p != field.shape[1]:     # projected samplers: the CPU column times the solves, k == exp(0)
+                field = np.zeros((ns, dp.levels[lvl].n_p))
+            _, itd = cd.solve(lvl, np.exp(field), nthreads=cores)
+            e.update({"darcy_iterations_mean": float(np.mean(np.abs(itd))), "darcy_all_converged": bool(np.all(itd > 0))})
+        dt = time.perf_counter() - t0
+        e.update({"seconds": dt, "realizations_per_s": ns / dt})
+        out.append(e)
+    return {"kind": "port", "cores": cores, "levels": out,
+            "sample": f"{[pc * cores for pc in per_core]} realizations on levels {list(levels)} (MINRES 300/1e-6 + BJ[symGS x3 | "
+                      "V-cycle over the caller's levels]; iteration counts negative = cap reached); the reference's BoomerAMG "
+                      "is not available to the C restatement, on stretched cells its geometric V-cycle needs more iterations"}
+
+
+def config4(seed, lanes=4, cpu=True):
+    """BASELINE config 4 at full size on ONE GPU: EmbeddedPDESampler on cube_tet_embed refined 4 x (831 488 tets, 2.5 M DoF
+    on the finest level), 3 Monte Carlo levels, lognormal."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hierarchy, build_sampler_problem, mesh_from_json
+    h = build_hierarchy(mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet_embed.json")), 4)
+    sp = build_sampler_problem(h, corlen=0.1, embedded=True, lognormal=True, n_mc_levels=3)
+    L = []
+    for _ in range(lanes):
+        c = capi.Context(0, seed=seed)
+        L.append((c, capi.PDESampler(c, sp, projection="gather"), None))
+    out = {"workload": "EmbeddedPDESampler cube_tet_embed r=4, DoF " + str([lv.n_u + lv.n_s for lv in sp.levels[:3]]) +
+                       f", original elements {[len(i) for i in sp.orig_index[:3]]}, per level nsamples x (Sample + Eval), {lanes} lanes",
+           "levels": level_rates(L, (0, 1, 2), nrep=4, darcy=False)}
+    for c, sm, _ in L:
+        sm.close()
+        c.close()
+    if cpu:
+        try:
+            out["cpu_baseline"] = cpu_level_rates(sp, None, seed, (0, 1, 2), (1, 2, 8))
+        except Exception as e:   # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+def config5(seed, lanes=2, cpu=True):
+    """BASELINE config 5 at full size on ONE GPU: SPE10-shaped box 1200 x 2200 x 170, 7 x 27 x 10 coarse cells refined 3 x
+    (56 x 216 x 80 = 967 680 elements, 3.9 M Darcy DoF), L2ProjectionPDESampler on the box enlarged by one coarse cell per side,
+    correlation length 100, 4 levels, k_ref == 1 (spe_perm.dat is not shipped)."""
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem, l2_projection_hierarchy
+    nx, ny, nz = 7, 27, 10
+    hx, hy, hz = 1200.0 / nx, 2200.0 / ny, 170.0 / nz
+    ho = build_hierarchy(box_mesh([nx, ny, nz], [1200.0, 2200.0, 170.0], "hex"), 3)
+    he = build_hierarchy(box_mesh([nx + 2, ny + 2, nz + 2], [1200.0 + 2 * hx, 2200.0 + 2 * hy, 170.0 + 2 * hz], "hex",
+                                  origin=[-hx, -hy, -hz]), 3)
+    sp = build_sampler_problem(he, corlen=100.0, lognormal=True)
+    ops = l2_projection_hierarchy(ho, he)
+    dp = build_darcy_problem(ho, [1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0])
+    L = []
+    for _ in range(lanes):
+        c = capi.Context(0, seed=seed)
+        L.append((c, capi.PDESampler(c, sp, projection="l2", l2_ops=ops), capi.DarcySolver(c, dp)))
+    out = {"workload": "SPE10-shaped box 56 x 216 x 80, L2ProjectionPDESampler (sampler DoF " + str([lv.n_u + lv.n_s for lv in sp.levels]) +
+                       ") + DarcySolver (DoF " + str([lv.ndofs for lv in dp.levels]) + f"), 4 levels, algebraic Schur hierarchies "
+                       f"on the stretched cells, per level nsamples x (Sample + Eval + SolveFwd), {lanes} lanes",
+           "levels": level_rates(L, (0, 1, 2, 3), nrep=2, darcy=True)}
+    mgr = host_api.MLMCManager(4, sampler=L[0][1], solver=L[0][2], wall_time=True)
+    for c, sm, ds in L[1:]:
+        mgr.add_lane(sm, ds)
+    ns = [16, 32, 64, 128]
+    mgr.InitRun(ns)
+    mgr.Reset()
+    t0 = time.perf_counter()
+    r = mgr.InitRun(ns)
+    dt = time.perf_counter() - t0
+    out["mlmc_round"] = {"nsamples": ns, "realizations_per_s": sum(ns) / dt, "seconds": dt, "estimate": r["estimate"],
+                         "seconds_per_sample_per_level": [float(x) for x in r["cost"]], "timers": mgr.PrintTimers()}
+    mgr.close()
+    for c, sm, ds in L:
+        ds.close()
+        sm.close()
+        c.close()
+    if cpu:
+        try:
+            out["cpu_baseline"] = cpu_level_rates(sp, dp, seed, (0, 1, 2, 3), (1, 1, 2, 8))
+        except Exception as e:   # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
 
 
 def spawn_ranks(n):
@@ -328,6 +554,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mlmc", action="store_true", help="skip the secondary config-3 (MLMC Darcy+SPDE) figure")
     ap.add_argument("--no-r6", action="store_true", help="skip the HBM-bound point (cube_tet r=6, 4.74 M DoF) under extra.r6")
+    ap.add_argument("--all-configs", action="store_true",
+                    help="also run BASELINE configs 4 (EmbeddedPDESampler, 2.5 M DoF) and 5 (SPE10-shaped Darcy MLMC, 3.9 M DoF) "
+                         "at full size on this GPU with a bounded CPU sample beside each: extra.c4 / extra.c5 (minutes)")
     ap.add_argument("--seed", type=int, default=20261003)
     args = ap.parse_args()
 
@@ -427,7 +656,7 @@ def main():
     if not args.no_mlmc:
         try:
             if world == 1:
-                m, probs = mlmc_config3(args.seed)
+                m, probs = mlmc_config3(args.seed, roofline=True)
                 if not args.no_cpu_baseline:
                     try:
                         m["cpu_baseline"] = darcy_cpu_baseline(probs[0], probs[1], args.seed)
@@ -490,6 +719,12 @@ def main():
             f6.close()
         except Exception as e:   # noqa: BLE001
             extra["r6"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and args.all_configs:
+        for name, fn in (("c4", config4), ("c5", config5)):
+            try:
+                extra[name] = fn(args.seed, cpu=not args.no_cpu_baseline)
+            except Exception as e:   # noqa: BLE001
+                extra[name] = {"error": repr(e)}
     if rank == 0 and extra:
         out["extra"] = extra
     if world > 1:

@@ -59,6 +59,8 @@ typedef struct pmc_csr {
  * V-cycle over the caller's level hierarchy on S = aW + B diag(M)^-1 B^T (instead of
  * BoomerAMG), both fixed SPD linear operators as MINRES requires. */
 typedef struct pmc_solver_opts {
+    int32_t abi_version;      /* = PMC_ABI_VERSION; written by pmc_solver_opts_default, checked by the create functions: a caller
+                                 compiled against another layout of this struct / pmc_stats is refused instead of misread   */
     int32_t max_iter;
     double rel_tol;
     double abs_tol;
@@ -90,10 +92,17 @@ typedef struct pmc_solver_opts {
 /* Per-realization solver report; the reference returns -1 for iteration counts
  * (src/PDESampler.hpp:142-145, src/DarcySolver.hpp:104-107) and is silent on non-convergence. */
 typedef struct pmc_stats {
-    int32_t iterations;
+    int32_t iterations;  /* iterations until THIS realization met the tolerance (the batch keeps iterating until its last one has) */
     int32_t converged;   /* 1 converged, 0 iteration cap reached, -1 breakdown (non-finite data / indefinite preconditioner) */
     double initial_norm; /* preconditioned residual norm before the first iteration */
     double final_norm;   /* |eta| at exit */
+    /* Device time (HIP events on the handle's stream) of the launch group this realization was solved in, divided by the
+     * realizations of that group, so that summing over realizations gives device milliseconds.  The reference's per-level
+     * timers: solve_ms = "Sampler: Mult" (src/PDESampler.cpp:328-333) / "Darcy: Mult" (src/DarcySolver.cpp:231-236) - the
+     * Krylov solve; setup_ms = what precedes it per realization: right-hand side and initial guess (sampler), M(k),
+     * elimination and the Schur-complement hierarchy refresh = "Darcy: Build Solver" (src/DarcySolver.cpp:238-242). */
+    double solve_ms;
+    double setup_ms;
 } pmc_stats;
 
 /* One level of the SPDE sampler hierarchy = the blocks PDESampler::BuildHierarchy assembles
@@ -127,6 +136,10 @@ typedef struct pmc_darcy_level {
 
 /* ---- library / context ---------------------------------------------------------------- */
 int pmc_version(void);
+#define PMC_ABI_VERSION 2 /* layout of pmc_solver_opts / pmc_stats; 2: abi_version field, solve_ms / setup_ms */
+int pmc_abi_version(void); /* the library's PMC_ABI_VERSION */
+/* kernels launched by this process through the library so far (all handles, all host threads): launch-rate diagnostics */
+uint64_t pmc_kernel_launches(void);
 const char* pmc_last_error(void);
 void pmc_solver_opts_default(pmc_solver_opts* opts);
 
@@ -219,6 +232,17 @@ int pmc_darcy_num_dofs(const pmc_darcy* d, int level); /* GetGlobalNumberOfDofs(
 int pmc_darcy_num_pressure_dofs(const pmc_darcy* d, int level); /* GetSizeOfStochasticData(): entries of k */
 int64_t pmc_darcy_nnz(const pmc_darcy* d, int level);  /* GetNNZ()                */
 int pmc_darcy_batch_width(const pmc_darcy* d, int level);  /* as pmc_sampler_batch_width */
+/* In-situ timing of the dominant kernel of the Darcy operator inside the MINRES loop of SolveFwd (solver->Mult,
+ * src/DarcySolver.cpp:629-631): the u-rows y_u = M(k) x_u + B^T x_p with the fused <x, Ax> (eg_pair_spmm_kernel).  With
+ * on != 0 every such launch is bracketed by HIP events on the solve's stream and an empty bracket is recorded behind it;
+ * while timing, the p-rows (B x_u) follow on the same stream instead of running beside it.  pmc_darcy_operator_time returns
+ * and clears the accumulated bracket time, the launch count and the sum of the empty brackets [ms];
+ * pmc_darcy_operator_bytes gives the ALGORITHMIC bytes of one such launch for nbatch realizations: element-grouped M(k)
+ * 12 B per stored slot + 8 B per dof (coefficient rows) + the coefficient table (n_p + 1) x nbatch x 8, B^T 12 B per nonzero,
+ * 4 B per row, vectors 8 nbatch (2 n_u + n_p). */
+int pmc_darcy_set_operator_timing(pmc_darcy* d, int on);
+int pmc_darcy_operator_time(pmc_darcy* d, double* total_ms, int64_t* launches, double* event_overhead_ms);
+int pmc_darcy_operator_bytes(const pmc_darcy* d, int level, int nbatch, double* bytes);
 /* SolveFwd(level, k, Q, C) (src/DarcySolver.cpp:416-437).  k: nbatch x n_p(level) in
  * `memspace`; Q, C: host arrays of nbatch; sol_out (may be NULL): nbatch x (n_u+n_p) in
  * `memspace` (SolveFwd_RtnPressure, :439-470, reads its p-block). */

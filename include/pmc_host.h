@@ -91,6 +91,13 @@ int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* out);
 /* the table MLMC_Manager::ShowMe prints after every InitRun (src/MLMC_Manager.cpp:216-297), same labels / widths /
  * precision, into buf (NUL-terminated, truncated to cap); *needed (may be NULL) receives the full size incl. the NUL */
 int pmc_mlmc_show_me(pmc_mlmc* m, char* buf, size_t cap, size_t* needed);
+/* the per-level timers the reference keeps in parelag::TimeManager and prints at the end of a run (examples/MLMC.cpp:275):
+ * "Sampler: Mult -- Level i" (src/PDESampler.cpp:328-333), "Darcy: Build Solver -- Level i", "Darcy: Mult -- Level i"
+ * (src/DarcySolver.cpp:231-243) - device milliseconds (HIP events, pmc_stats.solve_ms / setup_ms) summed over the lanes of
+ * this rank since the manager was created, as text (same calling convention as pmc_mlmc_show_me) and as numbers */
+int pmc_mlmc_print_timers(pmc_mlmc* m, char* buf, size_t cap, size_t* needed);
+int pmc_mlmc_phase_times(pmc_mlmc* m, int level, double* sampler_mult_ms, double* darcy_setup_ms, double* darcy_mult_ms,
+                         int64_t* sampler_realizations, int64_t* darcy_realizations);
 const char* pmc_host_last_error(void);
 
 /* BayesianInverseProblem::ComputeLikelihood / ComputeLikelihoodAndQ / ComputeR (src/BayesianInverseProblem.cpp:188-218)

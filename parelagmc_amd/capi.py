@@ -30,7 +30,7 @@ class pmc_csr(C.Structure):
 
 
 class pmc_solver_opts(C.Structure):
-    _fields_ = [("max_iter", C.c_int32), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
+    _fields_ = [("abi_version", C.c_int32), ("max_iter", C.c_int32), ("rel_tol", C.c_double), ("abs_tol", C.c_double),
                 ("cheb_degree_M", C.c_int32), ("cheb_ratio_M", C.c_double),
                 ("mg_smooth_degree", C.c_int32), ("mg_smooth_ratio", C.c_double),
                 ("mg_coarse_degree", C.c_int32), ("mg_coarse_ratio", C.c_double), ("check_every", C.c_int32),
@@ -40,7 +40,7 @@ class pmc_solver_opts(C.Structure):
 
 class pmc_stats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("initial_norm", C.c_double),
-                ("final_norm", C.c_double)]
+                ("final_norm", C.c_double), ("solve_ms", C.c_double), ("setup_ms", C.c_double)]
 
 
 class pmc_sampler_level(C.Structure):
@@ -62,6 +62,8 @@ SYMBOLS = {
     "pmc_version": (C.c_int, []),
     "pmc_last_error": (C.c_char_p, []),
     "pmc_solver_opts_default": (None, [C.POINTER(pmc_solver_opts)]),
+    "pmc_abi_version": (C.c_int, []),
+    "pmc_kernel_launches": (C.c_uint64, []),
     "pmc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "pmc_ctx_destroy": (None, [_VP]),
     "pmc_ctx_synchronize": (C.c_int, [_VP]),
@@ -84,6 +86,9 @@ SYMBOLS = {
     "pmc_sampler_sample_size": (C.c_int, [_VP, C.c_int]),
     "pmc_sampler_batch_width": (C.c_int, [_VP, C.c_int]),
     "pmc_darcy_batch_width": (C.c_int, [_VP, C.c_int]),
+    "pmc_darcy_set_operator_timing": (C.c_int, [_VP, C.c_int]),
+    "pmc_darcy_operator_time": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "pmc_darcy_operator_bytes": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pmc_sampler_nnz": (C.c_int64, [_VP, C.c_int]),
     "pmc_sampler_true_p": (C.c_int, [_VP, C.c_int, C.POINTER(pmc_csr)]),
     "pmc_sampler_sample": (C.c_int, [_VP, C.c_int, C.c_uint64, C.c_int, _DP, C.c_int]),
@@ -410,6 +415,8 @@ class PDESampler:
         pemb, _ = _addr(embed_out)
         _check(lib.pmc_sampler_eval(self.h, level, xi_level, nbatch, pxi, ps, pinit,
                                     -1 if init_level is None else init_level, 1 if use_init else 0, pemb, ms, stats))
+        # device milliseconds of this call (HIP events on the handle's stream): (right-hand sides / initial guesses, solves)
+        self.last_phase_ms = (sum(s.setup_ms for s in stats), sum(s.solve_ms for s in stats))
         out = [s_out]
         if want_embed or embed_out is not None:
             out.append(embed_out)
@@ -494,6 +501,21 @@ class DarcySolver:
     def BatchWidth(self, level):
         return self.ctx.lib.pmc_darcy_batch_width(self.h, level)
 
+    def set_operator_timing(self, on: bool):
+        """Bracket every in-loop launch of the u-rows [M(k) | B^T] x (eg_pair_spmm) with HIP events."""
+        _check(self.ctx.lib.pmc_darcy_set_operator_timing(self.h, 1 if on else 0))
+
+    def operator_time(self):
+        """(total bracket ms, launches, total empty-bracket ms) since the last call."""
+        ms, n, gap = C.c_double(0.0), C.c_int64(0), C.c_double(0.0)
+        _check(self.ctx.lib.pmc_darcy_operator_time(self.h, C.byref(ms), C.byref(n), C.byref(gap)))
+        return ms.value, n.value, gap.value
+
+    def operator_bytes(self, level, nbatch):
+        b = C.c_double(0.0)
+        _check(self.ctx.lib.pmc_darcy_operator_bytes(self.h, level, nbatch, C.byref(b)))
+        return b.value
+
     def SolveFwd(self, level, k, nbatch=None, want_solution=False, sol_out=None, return_stats=False):
         """Returns (Q, C) arrays of length nbatch (plus solution / stats on request)."""
         lib = self.ctx.lib
@@ -510,6 +532,8 @@ class DarcySolver:
         psol, _ = _addr(sol_out)
         _check(lib.pmc_darcy_solve_fwd(self.h, level, nbatch, pk, _ptr(Q, C.c_double), _ptr(Cc, C.c_double), psol, ms,
                                        stats))
+        # device milliseconds of this call: ("Darcy: Build Solver" = M(k), elimination, Schur hierarchy refresh; "Darcy: Mult")
+        self.last_phase_ms = (sum(s.setup_ms for s in stats), sum(s.solve_ms for s in stats))
         out = [Q, Cc]
         if want_solution or sol_out is not None:
             out.append(sol_out)

@@ -14,6 +14,17 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string& m) { g_last_error = m; }
 
 void Ctx::activate() const { PMC_HIP(hipSetDevice(device)); }
+void Ctx::phase_mark(int i) const { PMC_HIP(hipEventRecord(ev_phase[i], stream)); }
+void Ctx::phase_report(pmc_stats* stats, int nb) const {
+    PMC_HIP(hipEventSynchronize(ev_phase[2]));
+    float setup = 0.f, solve = 0.f;
+    PMC_HIP(hipEventElapsedTime(&setup, ev_phase[0], ev_phase[1]));
+    PMC_HIP(hipEventElapsedTime(&solve, ev_phase[1], ev_phase[2]));
+    for (int k = 0; k < nb; ++k) {
+        stats[k].setup_ms = (double)setup / nb;
+        stats[k].solve_ms = (double)solve / nb;
+    }
+}
 
 static std::atomic<int> g_live_ctx[64];
 int Ctx::contexts_on_device(int device) { return g_live_ctx[device & 63].load(); }
@@ -91,13 +102,23 @@ using namespace pmc;
 extern "C" {
 
 int pmc_version(void) { return 100; }
+int pmc_abi_version(void) { return PMC_ABI_VERSION; }
+uint64_t pmc_kernel_launches(void) { return kernel_launch_count(); }
 const char* pmc_last_error(void) { return g_last_error.c_str(); }
+
+static void check_abi(const pmc_solver_opts& o) {
+    if (o.abi_version != PMC_ABI_VERSION)
+        throw Error(PMC_ERR_INVALID, "pmc_solver_opts.abi_version is " + std::to_string(o.abi_version) + ", this library has " +
+                                         std::to_string(PMC_ABI_VERSION) +
+                                         ": fill the struct with pmc_solver_opts_default() of the header you compile against");
+}
 
 void pmc_solver_opts_default(pmc_solver_opts* o) {
     if (!o) return;
     o->max_iter = 300;
     o->rel_tol = 1e-6;
     o->abs_tol = 1e-12;
+    o->abi_version = PMC_ABI_VERSION;
     // tuned on MI355X (scripts/sweep.py, cube_tet r=5): degree 2 on M needs no more MINRES iterations than
     // degree 3; smoothing interval [lmax/8, lmax]
     o->cheb_degree_M = 0;
@@ -112,7 +133,6 @@ void pmc_solver_opts_default(pmc_solver_opts* o) {
     o->mini_max_rows = 6000;
     o->two_streams = 0;
     o->use_graph = 0;   // measured: no gain single-stream (kernels are latency-, not launch-bound), slower with 4 lanes
-    if (const char* e = getenv("PMC_USE_GRAPH")) o->use_graph = atoi(e);   // tuning override of the default
 }
 
 int pmc_ctx_create(int device_id, pmc_ctx** out) {
@@ -130,6 +150,7 @@ int pmc_ctx_create(int device_id, pmc_ctx** out) {
         PMC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         PMC_HIP(hipEventCreate(&c->ev0));
         PMC_HIP(hipEventCreate(&c->ev1));
+        for (hipEvent_t& e : c->ev_phase) PMC_HIP(hipEventCreate(&e));
         PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_flag), sizeof(int) * 16, hipHostMallocDefault));
         PMC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(double) * pmc::Ctx::kHostScratch, hipHostMallocDefault));
         g_live_ctx[device_id & 63].fetch_add(1);
@@ -151,6 +172,8 @@ void pmc_ctx_destroy(pmc_ctx* c) {
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ev_phase)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {c->ev_fork, c->ev_join})
         if (e) (void)hipEventDestroy(e);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -259,7 +282,10 @@ int pmc_sampler_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_sampl
         *out = nullptr;
         pmc_solver_opts o;
         pmc_solver_opts_default(&o);
-        if (opts) o = *opts;
+        if (opts) {
+            check_abi(*opts);
+            o = *opts;
+        }
         PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 0 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
                         (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
                     "solver options out of range");
@@ -362,7 +388,10 @@ int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_l
         *out = nullptr;
         pmc_solver_opts o;
         pmc_solver_opts_default(&o);
-        if (opts) o = *opts;
+        if (opts) {
+            check_abi(*opts);
+            o = *opts;
+        }
         PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 0 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
                         (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
                     "solver options out of range");
@@ -382,6 +411,28 @@ int pmc_darcy_num_dofs(const pmc_darcy* d, int level) {
 int pmc_darcy_num_pressure_dofs(const pmc_darcy* d, int level) {
     if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
     return d->impl.lv[level].n_p;
+}
+int pmc_darcy_set_operator_timing(pmc_darcy* d, int on) {
+    return guarded([&] {
+        PMC_REQUIRE(d != nullptr, "darcy handle is NULL");
+        d->impl.op_timer.on = on != 0;
+    });
+}
+int pmc_darcy_operator_time(pmc_darcy* d, double* total_ms, int64_t* launches, double* event_overhead_ms) {
+    return guarded([&] {
+        PMC_REQUIRE(d != nullptr, "darcy handle is NULL");
+        if (total_ms) *total_ms = d->impl.op_timer.ms;
+        if (launches) *launches = d->impl.op_timer.launches;
+        if (event_overhead_ms) *event_overhead_ms = d->impl.op_timer.gap_ms;
+        d->impl.op_timer.clear();
+    });
+}
+int pmc_darcy_operator_bytes(const pmc_darcy* d, int level, int nbatch, double* bytes) {
+    return guarded([&] {
+        PMC_REQUIRE(d != nullptr && bytes != nullptr && level >= 0 && level < d->impl.nlevels && valid_batch(nbatch),
+                    "pmc_darcy_operator_bytes: bad arguments");
+        *bytes = d->impl.operator_bytes(level, nbatch);
+    });
 }
 int pmc_darcy_batch_width(const pmc_darcy* d, int level) {
     if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;

@@ -166,6 +166,12 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // second stream of the same handle (see Lanes)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // brackets of one launch group of a solve: [0] start, [1] right-hand side / per-realization operators done, [2] Krylov
+    // solve done (pmc_stats.setup_ms / solve_ms)
+    hipEvent_t ev_phase[3] = {nullptr, nullptr, nullptr};
+    void phase_mark(int i) const;
+    // fills setup_ms / solve_ms of the nb stats entries from the three marks (synchronises on the last one)
+    void phase_report(pmc_stats* stats, int nb) const;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // split: spread a solve over two streams.  The second stream is created on first use, and only a handle that is the
     // only one on its device ever asks for it (contexts_on_device): every additional HIP stream changes how the runtime

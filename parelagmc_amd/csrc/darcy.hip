@@ -466,6 +466,19 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
     }
 }
 
+double Darcy::operator_bytes(int level, int nb) const {
+    // ALGORITHMIC bytes of one launch of the u-rows [M(k) | B^T] x with the fused <x, Ax>, every operand
+    // once.  Element-grouped M(k): 12 B per stored (column, shared element entry) slot + the two coefficient rows per dof
+    // (8 B), the coefficient table once ((n_p + 1) x nb doubles); otherwise 4 B per column index + 8 nb B per value.  B^T: 12 B
+    // per nonzero.  4 B per row of slice offsets.  Vectors: x_u and x_p read, y_u written (the dot takes x_u from the same read).
+    const DarcyLevel& d = lv[level];
+    const double V = 8.0 * nb;
+    double b = 12.0 * (double)d.Bt.nnz + 4.0 * d.n_u + V * (2.0 * d.n_u + d.n_p);
+    if (use_eg(d)) b += 12.0 * (double)d.Meg.nslots + 8.0 * d.n_u + V * (d.n_p + 1.0);
+    else b += (4.0 + V) * (double)d.M.nnz;
+    return b;
+}
+
 bool Darcy::use_eg(const DarcyLevel& d) const {
     static const bool off = getenv("PMC_DARCY_NO_EG") != nullptr;   // tuning / A-B switch
     return d.has_eg && (opts.cheb_degree_M == 2 || opts.cheb_degree_M == 0) && !off;   // 0 (automatic) = 2 here: the element-grouped form is degree 2
@@ -576,6 +589,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     DarcyLevel& d = lv[level];
     const int n_u = d.n_u, n_p = d.n_p, n = n_u + n_p;
     ensure(level, nb);
+    if (stats) ctx.phase_mark(0);
     // K12/K13: M(k), elimination, rhs_bc
     const bool eg = use_eg(d);
     k::darcy_coef(st, nb, n_p, k_d, k_divides, d.coef.p);
@@ -614,6 +628,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
         }
         mg.refresh_bv_tail(st, nb, level);
     }
+    if (stats) ctx.phase_mark(1);   // "Darcy: Build Solver" ends here: everything below is the solve
     // operator [M(k) Bt; B 0] and block-diagonal preconditioner
     const SellView Mv = view_bv(d.M, d.mvals.p);
     const SellView Bv = view(d.B), Btv = view(d.Bt);
@@ -622,14 +637,18 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     LinOp A;
     A.n = n;
     A.n0 = n_u;
+    OpTimer* tm = &op_timer;
     A.apply = [=](const Lanes& L, int nb_, const double* x, double* y, double* partial, double* partial2) {
         // u-rows: M(k) x_u + B^T x_p in one pass; p-rows: B x_u (beside it on the second stream); <x, Ax> fused into both
         const double* xp = x + (size_t)n_u * nb_;
-        L.fork();
+        const bool timed = tm->on && partial != nullptr;      // the in-loop launches (fused dot) only
+        if (timed) tm->begin(L.main);                          // timed: the p-rows follow on the same stream, not beside it
+        else L.fork();
         const int nu_blk = eg ? k::eg_pair_spmm(L.main, nb_, Mg, coefp, x, Btv, xp, y, partial, x)
                               : k::pair_spmm(L.main, nb_, Mv, x, Btv, xp, y, partial, x);
-        const int np_blk = k::spmm(L.side(), nb_, Bv, x, y + (size_t)n_u * nb_, false, partial2, xp);
-        L.join();
+        if (timed) tm->end(L.main);
+        const int np_blk = k::spmm(timed ? L.main : L.side(), nb_, Bv, x, y + (size_t)n_u * nb_, false, partial2, xp);
+        if (!timed) L.join();
         return k::DotParts{partial, nu_blk, partial2, np_blk};
     };
     ChebParams cpM{opts.cheb_degree_M > 0 ? opts.cheb_degree_M : 2, 1.0, d.ratio_M, d.mvals_scaled.p};
@@ -677,8 +696,12 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     MinresResult res = compact ? minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol_compact.p, true, opts, work, 0, ncomp,
                                               comp_rows, hint)
                                : minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol.p, true, opts, work, 0, n, nullptr, hint);
-    if (stats)
+    if (stats) {
+        ctx.phase_mark(2);
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
+        ctx.phase_report(stats, nb);
+    }
+    if (op_timer.on) op_timer.harvest();   // minres_solve has synchronised the stream
     // K15: Q = <obs, sol>
     const int qblocks = compact ? k::wdot(st, nb, ncomp, comp_w, sol_compact.p, qpartial.p)
                                 : k::wdot(st, nb, n, d.obs.p, sol.p, qpartial.p);

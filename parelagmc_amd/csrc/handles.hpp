@@ -116,6 +116,10 @@ struct Darcy {
     double anisotropy = 1.0;
     DevBuf<double> gwork;
     MinresWork work;
+    // in-loop timing of the dominant kernel of the Darcy operator: the u-rows [M(k) | B^T] (k::eg_pair_spmm with the fused
+    // <x, Ax>; k::pair_spmm when the element-grouped form is not available)
+    OpTimer op_timer;
+    double operator_bytes(int level, int nb) const;   // algorithmic bytes of ONE such launch
     DevBuf<double> sol, sol_compact, cx, cd, stage_k, stage_sol, qpartial, qout, gtmp, gout;
     bool use_eg(const DarcyLevel& d) const;
     void set_observations(int level, const pmc_csr* Gobs);

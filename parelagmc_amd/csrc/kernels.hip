@@ -1596,7 +1596,7 @@ __device__ __forceinline__ double tail_row_dot(const int* __restrict__ off, cons
 // Same recurrences and summation order as tail_cheb: bit-identical results.  Returns false (nothing done) when the
 // level does not fit R rows per thread x W entries per row.
 template <int R, int W>
-__device__ bool tail_cheb_cached(const TailLevelDev& L, int bv, int nb, int k, int degree, double ratio, const double* r,
+PMC_TAIL_INLINE bool tail_cheb_cached(const TailLevelDev& L, int bv, int nb, int k, int degree, double ratio, const double* r,
                                  double* x, double* d) {
     const int n = L.n;
     if (n > R * kTailThreads) return false;
@@ -1669,9 +1669,8 @@ __device__ bool tail_cheb_cached(const TailLevelDev& L, int bv, int nb, int k, i
     return true;
 }
 
-// Chebyshev iteration on one tail level, in place: x (zero or given) -> x.  All threads participate.
-// (A variant that cached each thread's matrix rows in registers across the steps spilled to scratch under
-// hipcc 7.2 and was not faster; the matrix is re-read from L2 every step.)
+// Chebyshev iteration on one tail level, in place: x (zero or given) -> x.  All threads participate.  The matrix is re-read
+// from L2 every step; the many-step solve of the LAST tail level runs on register-cached rows instead (tail_cheb_cached).
 PMC_TAIL_INLINE void tail_cheb(const TailLevelDev& L, int bv, int nb, int k, int degree, double ratio, bool zero_guess,
                           const double* r, double* x, double* d) {
     const int n = L.n;
@@ -1934,6 +1933,8 @@ __global__ __launch_bounds__(kTailThreads) void mini_sampler_kernel(MiniSamplerP
         stats[k].converged = flag != 0 ? -1 : (fabs(eta) <= goal ? 1 : 0);   // -1: indefinite preconditioner / NaN
         stats[k].initial_norm = eta0;
         stats[k].final_norm = fabs(eta);
+        stats[k].solve_ms = 0.0;      // filled on the host from the launch's events
+        stats[k].setup_ms = 0.0;
     }
 }
 
@@ -1959,7 +1960,13 @@ static inline dim3 grid_slices(int nslices) { return dim3((unsigned)((nslices + 
 static inline int lay_c(int nb) { return nb >= 32 ? 4 : (nb >= 2 ? 2 : 1); }   // = Lay<nb>::C
 static inline size_t flat_count(int n, int nb) { return (size_t)n * nb / lay_c(nb); }
 static inline dim3 grid_flat(int n, int nb) { return dim3((unsigned)((flat_count(n, nb) + kBlock - 1) / kBlock)); }
-static inline void check_launch() { PMC_HIP(hipGetLastError()); }
+static std::atomic<uint64_t> g_kernel_launches{0};
+uint64_t kernel_launch_count() { return g_kernel_launches.load(std::memory_order_relaxed); }
+void count_kernel_launches(int n) { g_kernel_launches.fetch_add((uint64_t)n, std::memory_order_relaxed); }
+static inline void check_launch(int n = 1) {
+    PMC_HIP(hipGetLastError());
+    count_kernel_launches(n);
+}
 // flat vector kernels stream non-temporally once one vector exceeds PMC_NT_FLAT_MB MiB (default 8; 0 = never)
 static inline bool nt_flat(size_t doubles) {
     static const double limit = [] {
@@ -2377,7 +2384,7 @@ void gersh_scale_bv(hipStream_t st, int nb, const SellView& S, double* dinv, dou
         gersh_bv_kernel<NB><<<groups(grid, nb), kBlock, 0, st>>>(S.nrows, S.slice_off, S.vals, dinv, g, nb);
         gersh_scale_kernel<NB><<<groups(grid, nb), kBlock, 0, st>>>(S.nrows, g, dinv, nb);
     });
-    PMC_HIP(hipGetLastError());
+    check_launch(2);
 }
 
 void refresh(hipStream_t st, int nb, int64_t nslots, const int* ptr, const int* idx, const double* w, const double* src,

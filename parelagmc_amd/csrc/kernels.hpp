@@ -41,6 +41,9 @@ struct EgView {
 // capacity (in blocks of nb doubles) of a partial-sum buffer for (fused) dots over nrows rows of a batch of nb columns:
 // allocate dot_capacity(nrows, nb) * nb doubles
 int dot_capacity(int nrows, int nb);
+// kernels this process has launched through the library so far (all handles, all threads): launch-rate diagnostics
+uint64_t kernel_launch_count();
+void count_kernel_launches(int n);
 
 namespace k {
 

@@ -296,6 +296,7 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     SamplerLevel& d = lv[level];
     const int n_u = d.n_u, n_s = d.n_s, n = n_u + n_s;
     ensure(level, nb);
+    if (stats) ctx.phase_mark(0);
     // rhs_s = -g W^{1/2} xi on xi_level, restricted with Ps^T (PDESampler.cpp:423-438); rhs_u = 0 (:441-442)
     k::fill(st, (size_t)n_u * nb, rhs.p, 0.0);
     double* rhs_s = rhs.p + (size_t)n_u * nb;
@@ -330,6 +331,7 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
         }
         zero_guess = false;
     }
+    if (stats) ctx.phase_mark(1);
     const bool use_amg = level < (int)amg.size() && amg[level];
     Multigrid* mgp = use_amg ? amg[level].get() : &mg;
     const int mg_l0 = use_amg ? 0 : level;
@@ -364,9 +366,11 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
         mini_stats.ensure(kMaxBatch);
         k::mini_sampler_solve(st, nb, mp, mgp->tail_lds[mg_l0], rhs.p, sol.p, zero_guess, mini_scratch.p, mini_stats.p);
         if (stats) {
+            ctx.phase_mark(2);
             PMC_HIP(hipMemcpyAsync(ctx.h_scal, mini_stats.p, sizeof(pmc_stats) * nb, hipMemcpyDeviceToHost, st));
             PMC_HIP(hipStreamSynchronize(st));
             std::memcpy(stats, ctx.h_scal, sizeof(pmc_stats) * nb);
+            ctx.phase_report(stats, nb);
         }
     } else {
     LinOp A;
@@ -404,8 +408,11 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     hint.key = hash_mix(hash_mix(0x5a, (uint64_t)level + 1), (uint64_t)nb);
     hint.sig = hash_ptr(hash_ptr(mgp->signature(mg_l0), cx.p), cd.p);
     MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work, n_u, n_s, nullptr, hint);
-    if (stats)
+    if (stats) {
+        ctx.phase_mark(2);
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
+        ctx.phase_report(stats, nb);
+    }
     }
     // outputs (:526-533 and the embedded variants' maps)
     const double* sol_s = sol.p + (size_t)n_u * nb;

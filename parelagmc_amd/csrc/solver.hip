@@ -266,6 +266,7 @@ static void axpby(hipStream_t st, size_t n, double a, const double* x, double b,
     const unsigned g = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
     axpby_kernel<<<g, 256, 0, st>>>(n, a, x, b, y);
     PMC_HIP(hipGetLastError());
+    count_kernel_launches(1);
 }
 
 // Rows x batch width from which a solve uses both streams of its handle (PMC_SPLIT_MIN overrides; 0 = never split)
@@ -446,6 +447,8 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         auto f = w.iter_hint.find(hint_key);
         if (f != w.iter_hint.end()) first_poll = std::max(0, f->second - 4);
     }
+    const int poll_step = graphs ? 2 : every;
+    const int mid_poll = first_poll >= 8 ? (first_poll / 2 / poll_step) * poll_step : -1;   // see the sparse poll below
     if (n_active > 0 && o.max_iter > 0) {
         apply_op(u1);
         k::minres_scal1(st, nb, S, dp_op);
@@ -492,7 +495,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             while (n_active > 0 && it + 2 <= o.max_iter) {
                 PMC_HIP(hipGraphLaunch(ge.exec, st));
                 it += 2;
-                if (it >= first_poll) n_active = poll();
+                if (it >= first_poll || it == mid_poll) n_active = poll();
             }
         }
         if (n_active > 0 && it < o.max_iter) {   // odd max_iter: one last eager iteration
@@ -514,7 +517,9 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             }
             std::swap(v0, v1);
             std::swap(w0, w1);
-            if ((it % every == 0 && it >= first_poll) || it == o.max_iter) n_active = poll();
+            // one sparse poll half way to the hinted count: a solve that converges much earlier than its predecessor
+            // (warm start after a cold solve, an easier batch) stops there instead of running blind up to the hint
+            if ((it % every == 0 && (it >= first_poll || it == mid_poll)) || it == o.max_iter) n_active = poll();
         }
         flush_wx(st);
     }
@@ -535,6 +540,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     int max_it = 0;
     for (int kcol = 0; kcol < nb; ++kcol) {
         pmc_stats& s = out.col[kcol];
+        s.solve_ms = s.setup_ms = 0.0;   // filled by the caller from its phase events
         s.iterations = hs.iters[kcol];
         max_it = std::max(max_it, s.iterations);
         s.initial_norm = hs.eta0[kcol];

@@ -149,6 +149,48 @@ inline uint64_t hash_mix(uint64_t h, uint64_t v) {
 }
 inline uint64_t hash_ptr(uint64_t h, const void* p) { return hash_mix(h, (uint64_t)(uintptr_t)p); }
 
+// In-situ kernel timing with HIP events on the launching stream: begin / end bracket one launch, and an EMPTY bracket is
+// recorded right behind it (what the event pair itself costs on that stream); harvest() - after the stream has been
+// synchronised - accumulates both.
+struct OpTimer {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    double ms = 0.0, gap_ms = 0.0;
+    int64_t launches = 0;
+    OpTimer() = default;
+    OpTimer(const OpTimer&) = delete;
+    OpTimer& operator=(const OpTimer&) = delete;
+    ~OpTimer() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+    void begin(hipStream_t st) {
+        while (ev.size() < used + 3) {
+            hipEvent_t e;
+            PMC_HIP(hipEventCreate(&e));
+            ev.push_back(e);
+        }
+        PMC_HIP(hipEventRecord(ev[used], st));
+    }
+    void end(hipStream_t st) {
+        PMC_HIP(hipEventRecord(ev[used + 1], st));
+        PMC_HIP(hipEventRecord(ev[used + 2], st));
+        used += 3;
+    }
+    void harvest() {
+        for (size_t e = 0; e + 2 < used; e += 3) {
+            float a = 0.f, g = 0.f;
+            PMC_HIP(hipEventElapsedTime(&a, ev[e], ev[e + 1]));
+            PMC_HIP(hipEventElapsedTime(&g, ev[e + 1], ev[e + 2]));
+            ms += a;
+            gap_ms += g;
+            ++launches;
+        }
+        used = 0;
+    }
+    void clear() { ms = gap_ms = 0.0; launches = 0; }
+};
+
 struct MinresWork {
     DevBuf<double> v0, v1, u0, u1, w0, w1, q, partial;
     DevBuf<double> stage;                    // first-stage sums of the scalar kernel (k::minres_scal21)

@@ -198,7 +198,7 @@ void sell_schedule_two_blocks(Sell& S, int n0, hipStream_t st, const HostCsr* A)
         if (A) {
             double sum = 0.0;
             int64_t cnt = 0;
-            for (int r = n0 + j * 64; r < std::min(A->nrows, n0 + (j + 1) * 64); ++r)
+            for (int r = std::max(n0, (s0 + j) * 64); r < std::min(A->nrows, (s0 + j + 1) * 64); ++r)   // the rows of slice s0 + j
                 for (int p = A->rowptr[r]; p < A->rowptr[r + 1]; ++p)
                     if (A->colind[p] < n0) { sum += A->colind[p] / 64.0; ++cnt; }
             if (cnt) pos = sum / cnt + 0.5;

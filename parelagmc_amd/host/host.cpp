@@ -93,7 +93,7 @@ void PDESampler::Eval(const int level, const Vector& xi, Vector& s) {
     check(pmc_sampler_eval(h_, level, xi_level, xi.Batch(), xi.GetData(), s.GetData(), nullptr, -1, 0, nullptr,
                            xi.MemSpace(), st.data()),
           "PDESampler::Eval");
-    last_iters_ = st[0].iterations;
+    record(level, st);
 }
 void PDESampler::Eval(const int level, const Vector& xi, Vector& s, Vector& u, bool use_init) {
     const int xi_level = level_of_xi(xi.Size());
@@ -121,7 +121,7 @@ void PDESampler::Eval(const int level, const Vector& xi, Vector& s, Vector& u, b
                                use_init ? 1 : 0, u.GetData(), xi.MemSpace(), st.data()),
               "PDESampler::Eval");
     }
-    last_iters_ = st[0].iterations;
+    record(level, st);
 }
 void PDESampler::BuildHierarchy() {
     if (!h_ || pmc_sampler_num_levels(h_) < 1) throw std::runtime_error("PDESampler::BuildHierarchy: no device handle");
@@ -136,17 +136,21 @@ size_t PDESampler::GetNNZ(int level) const { return (size_t)pmc_sampler_nnz(h_, 
 
 // ---- DarcySolver ------------------------------------------------------------------------------
 void DarcySolver::SolveFwd(int ilevel, Vector& k, double* Q, double* C) {
-    check(pmc_darcy_solve_fwd(h_, ilevel, k.Batch(), k.GetData(), Q, C, nullptr, k.MemSpace(), nullptr),
+    std::vector<pmc_stats> st(k.Batch());
+    check(pmc_darcy_solve_fwd(h_, ilevel, k.Batch(), k.GetData(), Q, C, nullptr, k.MemSpace(), st.data()),
           "DarcySolver::SolveFwd");
+    record(ilevel, st);
 }
 void DarcySolver::SolveFwd_RtnPressure(int ilevel, Vector& k, Vector& P, double* C, double* Q, bool compute_Q) {
     const int np = pmc_darcy_num_pressure_dofs(h_, ilevel);
     if (np < 0) throw std::out_of_range("DarcySolver::SolveFwd_RtnPressure: level");
     if (P.MemSpace() != k.MemSpace()) throw std::invalid_argument("SolveFwd_RtnPressure: k and P must share a memory space");
     P.SetSize(np, k.Batch());
+    std::vector<pmc_stats> st(k.Batch());
     check(pmc_darcy_solve_fwd_pressure(h_, ilevel, k.Batch(), k.GetData(), P.GetData(), C, Q, compute_Q ? 1 : 0, k.MemSpace(),
-                                       nullptr),
+                                       st.data()),
           "DarcySolver::SolveFwd_RtnPressure");
+    record(ilevel, st);
 }
 int DarcySolver::GetSizeOfStochasticData(int l) const { return pmc_darcy_num_pressure_dofs(h_, l); }
 int DarcySolver::GetNumberOfDofs(int l) const { return pmc_darcy_num_dofs(h_, l); }
@@ -464,6 +468,48 @@ void MLMC_Manager::run_round_overlapped(const std::vector<int>& ns_init) {
         for (int l = 0; l < nlanes; ++l) sec += lane_seconds[l][ilevel];
         pending_[(size_t)nlevels * NVAR + ilevel] += sec / nlanes;
     }
+}
+
+void MLMC_Manager::PhaseTimesOfLevel(int level, double* sampler_mult_ms, double* darcy_setup_ms, double* darcy_mult_ms,
+                                     int64_t* sampler_realizations, int64_t* darcy_realizations) const {
+    if (level < 0 || level >= nlevels) throw std::out_of_range("PhaseTimesOfLevel: level");
+    PhaseTimes s, d;
+    for (const auto& L : lanes_) {
+        const PhaseTimes a = L->sampler->GetPhaseTimes(level), b = L->solver->GetPhaseTimes(level);
+        s.mult_ms += a.mult_ms; s.realizations += a.realizations;
+        d.mult_ms += b.mult_ms; d.setup_ms += b.setup_ms; d.realizations += b.realizations;
+    }
+    if (sampler_mult_ms) *sampler_mult_ms = s.mult_ms;
+    if (darcy_setup_ms) *darcy_setup_ms = d.setup_ms;
+    if (darcy_mult_ms) *darcy_mult_ms = d.mult_ms;
+    if (sampler_realizations) *sampler_realizations = s.realizations;
+    if (darcy_realizations) *darcy_realizations = d.realizations;
+}
+
+void MLMC_Manager::PrintTimers(std::ostream& os) const {
+    // layout of parelag::TimeManager::Print: one line per named timer
+    const std::streamsize old_prec = os.precision(6);
+    os << std::string(79, '=') << '\n'
+       << std::setw(44) << std::left << "Timer (device time, all lanes of this rank)" << std::setw(14) << std::right
+       << "realizations" << std::setw(16) << "total [ms]" << '\n'
+       << std::string(79, '-') << '\n';
+    auto line = [&](const std::string& name, int64_t n, double ms) {
+        os << std::setw(44) << std::left << name << std::setw(14) << std::right << n << std::setw(16) << ms << '\n';
+    };
+    for (int l = 0; l < nlevels; ++l) {
+        PhaseTimes s, d;
+        for (const auto& L : lanes_) {
+            const PhaseTimes a = L->sampler->GetPhaseTimes(l), b = L->solver->GetPhaseTimes(l);
+            s.mult_ms += a.mult_ms; s.setup_ms += a.setup_ms; s.realizations += a.realizations;
+            d.mult_ms += b.mult_ms; d.setup_ms += b.setup_ms; d.realizations += b.realizations;
+        }
+        const std::string lv = " -- Level " + std::to_string(l);
+        line("Sampler: Mult" + lv, s.realizations, s.mult_ms);
+        line("Darcy: Build Solver" + lv, d.realizations, d.setup_ms);
+        line("Darcy: Mult" + lv, d.realizations, d.mult_ms);
+    }
+    os << std::string(79, '=') << std::endl;
+    os.precision(old_prec);
 }
 
 void MLMC_Manager::ShowMe(std::ostream& os) const {
@@ -1087,6 +1133,28 @@ int pmc_mlmc_show_me(pmc_mlmc* m, char* buf, size_t cap, size_t* needed) {
             std::memcpy(buf, t.data(), k);
             buf[k] = '\0';
         }
+    });
+}
+int pmc_mlmc_print_timers(pmc_mlmc* m, char* buf, size_t cap, size_t* needed) {
+    return hguard([&] {
+        if (!m) throw std::invalid_argument("manager is NULL");
+        std::ostringstream ss;
+        m->mgr->PrintTimers(ss);
+        const std::string t = ss.str();
+        if (needed) *needed = t.size() + 1;
+        if (buf && cap) {
+            const size_t k = std::min(cap - 1, t.size());
+            std::memcpy(buf, t.data(), k);
+            buf[k] = '\0';
+        }
+    });
+}
+int pmc_mlmc_phase_times(pmc_mlmc* m, int level, double* sampler_mult_ms, double* darcy_setup_ms, double* darcy_mult_ms,
+                         int64_t* sampler_realizations, int64_t* darcy_realizations) {
+    return hguard([&] {
+        if (!m) throw std::invalid_argument("manager is NULL");
+        m->mgr->PhaseTimesOfLevel(level, sampler_mult_ms, darcy_setup_ms, darcy_mult_ms, sampler_realizations,
+                                  darcy_realizations);
     });
 }
 int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* r) {

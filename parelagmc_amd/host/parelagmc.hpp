@@ -54,6 +54,19 @@ class Vector {
     int size_ = 0, nbatch_ = 1;
 };
 
+/// Accumulated device time of one plugin on one level: the reference's TimeManager entries "Sampler: Mult -- Level i"
+/// (src/PDESampler.cpp:328-333), "Darcy: Mult -- Level i" and "Darcy: Build Solver -- Level i" (src/DarcySolver.cpp:231-243),
+/// measured with HIP events on the plugin's stream (pmc_stats.solve_ms / setup_ms).
+struct PhaseTimes {
+    double mult_ms = 0.0;    // Krylov solves
+    double setup_ms = 0.0;   // per-realization work ahead of them (rhs / M(k), elimination, Schur hierarchy refresh)
+    int64_t realizations = 0;
+    void add(const pmc_stats* st, int n) {
+        for (int i = 0; i < n; ++i) { mult_ms += st[i].solve_ms; setup_ms += st[i].setup_ms; }
+        realizations += n;
+    }
+};
+
 class MLSampler {
   public:
     virtual ~MLSampler() = default;
@@ -75,6 +88,9 @@ class MLSampler {
     /// level's realizations into plugin calls of at most this many (device plugins: 16 on large levels, up to 256 on the
     /// smallest - pmc_sampler_batch_width).
     virtual int PreferredBatch(int /*level*/) const { return 0; }
+    /// Device time spent on `level` since construction / ResetPhaseTimes (zero for plugins that do not measure)
+    virtual PhaseTimes GetPhaseTimes(int /*level*/) const { return PhaseTimes(); }
+    virtual void ResetPhaseTimes() {}
 };
 
 class PhysicalMLSolver {
@@ -102,6 +118,8 @@ class PhysicalMLSolver {
     virtual int GetNNZ(int ilevel) const = 0;
     /// see MLSampler::PreferredBatch
     virtual int PreferredBatch(int /*ilevel*/) const { return 0; }
+    virtual PhaseTimes GetPhaseTimes(int /*ilevel*/) const { return PhaseTimes(); }
+    virtual void ResetPhaseTimes() {}
 };
 
 /// Uncorrelated N(mu, sigma2) variates (counter-based generator on the device).
@@ -135,14 +153,22 @@ class PDESampler : public MLSampler {
     void BuildHierarchy() override;
     pmc_csr GetTrueP(int level) const override;
     int PreferredBatch(int level) const override { return pmc_sampler_batch_width(h_, level); }
+    PhaseTimes GetPhaseTimes(int level) const override { return level < (int)times_.size() ? times_[level] : PhaseTimes(); }
+    void ResetPhaseTimes() override { times_.clear(); }
     int GetNumIters() const { return last_iters_; }   // the reference returns -1 (PDESampler.hpp:142-145)
 
   private:
     int level_of_xi(int size) const;
     int level_of_field(int size) const;
+    void record(int level, const std::vector<pmc_stats>& st) {
+        if ((int)times_.size() <= level) times_.resize(level + 1);
+        times_[level].add(st.data(), (int)st.size());
+        last_iters_ = st.empty() ? -1 : st[0].iterations;
+    }
     pmc_ctx* ctx_;
     pmc_sampler* h_;
     int last_iters_ = -1;
+    std::vector<PhaseTimes> times_;
 };
 
 class DarcySolver : public PhysicalMLSolver {
@@ -157,10 +183,17 @@ class DarcySolver : public PhysicalMLSolver {
     int GetGlobalNumberOfDofs(int ilevel) const override;
     int GetNNZ(int ilevel) const override;
     int PreferredBatch(int ilevel) const override { return pmc_darcy_batch_width(h_, ilevel); }
+    PhaseTimes GetPhaseTimes(int ilevel) const override { return ilevel < (int)times_.size() ? times_[ilevel] : PhaseTimes(); }
+    void ResetPhaseTimes() override { times_.clear(); }
 
   private:
+    void record(int level, const std::vector<pmc_stats>& st) {
+        if ((int)times_.size() <= level) times_.resize(level + 1);
+        times_[level].add(st.data(), (int)st.size());
+    }
     pmc_ctx* ctx_;
     pmc_darcy* h_;
+    std::vector<PhaseTimes> times_;
 };
 
 /// Plugins backed by C callbacks (host memory).
@@ -231,6 +264,11 @@ class MLMC_Manager {
     /// Resume: rebuild the sums table and sample counters from a per-sample log of an earlier run
     int64_t ReplayLog(const std::string& path);
     void ShowMe(std::ostream& os) const;
+    /// The reference's TimeManager::Print (examples/MLMC.cpp:275) for the per-realization path: "Sampler: Mult", "Darcy: Build
+    /// Solver" and "Darcy: Mult" per level, device milliseconds summed over all lanes of this rank, with realization counts
+    void PrintTimers(std::ostream& os) const;
+    void PhaseTimesOfLevel(int level, double* sampler_mult_ms, double* darcy_setup_ms, double* darcy_mult_ms,
+                           int64_t* sampler_realizations, int64_t* darcy_realizations) const;
 
     bool wallTime;   // public switch, src/MLMC_Manager.hpp:61
 

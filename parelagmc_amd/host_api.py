@@ -61,6 +61,9 @@ HOST_SYMBOLS = {
     "pmc_mlmc_init_run": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
     "pmc_mlmc_result_get": (C.c_int, [_VP, C.POINTER(pmc_mlmc_result)]),
     "pmc_mlmc_show_me": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pmc_mlmc_print_timers": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pmc_mlmc_phase_times": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pmc_bayes_likelihood": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_int, _DPTR, C.c_int, C.c_double, _DPTR, _DPTR, _DPTR,
                                        _DPTR]),
     "pmc_ratio_create": (C.c_int, [_VP, _VP, _VP, C.c_int, _DPTR, C.c_int, C.c_double, C.POINTER(pmc_mlmc_params),
@@ -424,6 +427,22 @@ class MLMCManager:
         buf = C.create_string_buffer(need.value)
         _hcheck(self.lib.pmc_mlmc_show_me(self.h, buf, need.value, None))
         return buf.value.decode("utf-8", "replace")
+
+    def PrintTimers(self) -> str:
+        """TimeManager::Print of the per-realization path: "Sampler: Mult", "Darcy: Build Solver", "Darcy: Mult" per level."""
+        need = C.c_size_t(0)
+        _hcheck(self.lib.pmc_mlmc_print_timers(self.h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        _hcheck(self.lib.pmc_mlmc_print_timers(self.h, buf, need.value, None))
+        return buf.value.decode("utf-8", "replace")
+
+    def phase_times(self, level):
+        """dict of device milliseconds and realization counts of `level`, summed over the lanes of this rank"""
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        n1, n2 = C.c_int64(0), C.c_int64(0)
+        _hcheck(self.lib.pmc_mlmc_phase_times(self.h, level, C.byref(a), C.byref(b), C.byref(c), C.byref(n1), C.byref(n2)))
+        return {"sampler_mult_ms": a.value, "darcy_build_ms": b.value, "darcy_mult_ms": c.value,
+                "sampler_realizations": n1.value, "darcy_realizations": n2.value}
 
     def Reset(self):
         _hcheck(self.lib.pmc_mlmc_reset(self.h))

@@ -19,7 +19,7 @@ for arg in sys.argv[1:] or ["4:32"]:
     mgr = host_api.MLMCManager(3, sampler=sm[0], solver=dr[0], wall_time=True, batch=batch)
     for i in range(1, lanes):
         mgr.add_lane(sm[i], dr[i])
-    mgr.InitRun([batch * lanes] * 3)
+    mgr.InitRun(list(ns))      # warm-up: allocations at the widths of the timed round
     best = None
     for rep in range(2):
         mgr.Reset()

@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def find(d, suffix):
@@ -23,7 +23,9 @@ def find(d, suffix):
 
 
 for src, dst, what in (("prof_bench", "bench", "python bench.py"),
-                       ("prof_s1", "bench_s1", "python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-mlmc --no-r6")):
+                       ("prof_s1", "bench_s1", "python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-mlmc --no-r6"),
+                       ("prof_s1_r6", "bench_s1_r6", "python bench.py --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-mlmc"),
+                       ("prof_c3", "c3_darcy_op", "python scripts/c3_darcy_op.py")):
     shutil.copy(find(src, "kernel_stats.csv"), os.path.join(P, f"{tag}_{dst}_kernel_stats.csv"))
     with open(os.path.join(G, f"{src}.log")) as f:
         lines = [ln for ln in f if ln.startswith("{")]
@@ -69,6 +71,35 @@ for refine, nvec in ((5, 595968), (6, 4743168)):
                     "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
     out[f"r{refine}_correction"] = ("FETCH_SIZE x2 on gfx950; cross-check in the same pass on the flat lincomb3_kernel<16>: raw "
                                     f"{lf:.0f} KB for {read_kb:.0f} KB actually read (ratio {read_kb / lf:.3f})")
+# Darcy operator of config 3 (u-rows [M(k) | B^T] x with the fused dot, in the MINRES loop)
+try:
+    fetch = per_kernel(find("pmc_fetch_c3", "counter_collection.csv"))
+    write = per_kernel(find("pmc_write_c3", "counter_collection.csv"))
+    for name, acc in (("fetch_size", fetch), ("write_size", write)):
+        with open(os.path.join(P, f"{tag}_pmc_{name}_c3.csv"), "w") as f:
+            f.write("kernel,launches,mean_counter_value_KB\n")
+            for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+                f.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.3f}\n")
+    kern = "eg_pair_spmm_kernel<16, true, true>"
+    fr, n = mean(fetch, kern)
+    wr, _ = mean(write, kern)
+    out["c3_eg_nb16_inloop"] = {"kernel": f"pmc::{kern} (u-rows of the Darcy operator, level 0 of config 3)",
+                                "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB_raw": wr,
+                                "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
+except FileNotFoundError as e:
+    print("no config-3 Darcy operator passes:", e)
+# provenance: the library the passes ran (the built .so travels to the GPU box with the snapshot) and the commit
+import hashlib
+import subprocess
+with open(os.path.join(ROOT, "parelagmc_amd", "lib", "libpmc.so"), "rb") as f:
+    out["libpmc_sha256"] = hashlib.sha256(f.read()).hexdigest()
+try:
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "parelagmc_amd/csrc", "include"],
+                           capture_output=True, text=True).stdout.strip()
+    out["head"] = head + (" + uncommitted source changes" if dirty else "")
+except Exception:   # noqa: BLE001
+    out["head"] = None
 out["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py [--refine 6] --steps 2 --warmup 1 "
                   "--streams 1 --no-cpu-baseline --no-mlmc (separate passes, scripts/make_profiles.sh)")
 json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)

@@ -126,3 +126,114 @@ def test_manager_sums_do_not_depend_on_the_super_batch_width(gpu_ctx, hex_hierar
     for h in (ds2, smp2, ds, smp):
         h.close()
     c2.close()
+
+
+def test_phase_timers_operator_timing_and_abi_version(gpu_ctx, hex_hierarchy_small, seeded_rng):
+    """(i) pmc_stats.solve_ms / setup_ms: device time of every solve, accumulated by the managers under the reference's
+    TimeManager names "Sampler: Mult", "Darcy: Build Solver", "Darcy: Mult" -- Level i (src/PDESampler.cpp:328-333,
+    src/DarcySolver.cpp:231-243, printed at examples/MLMC.cpp:275).  (ii) pmc_darcy_set_operator_timing brackets every in-loop
+    launch of the u-rows [M(k) | B^T] x without changing a result; pmc_darcy_operator_bytes restates DESIGN section 4.
+    (iii) a pmc_solver_opts of another ABI version is refused."""
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp_ = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    assert gpu_ctx.lib.pmc_abi_version() == 2
+    bad = capi.solver_opts()
+    bad.abi_version = 1
+    with pytest.raises(capi.PmcError):
+        capi.PDESampler(gpu_ctx, sp_, bad)
+    with pytest.raises(capi.PmcError):
+        capi.DarcySolver(gpu_ctx, dp, bad)
+    smp, ds = capi.PDESampler(gpu_ctx, sp_, capi.solver_opts(mini_max_rows=0)), capi.DarcySolver(gpu_ctx, dp)
+    xi = seeded_rng.standard_normal((16, sp_.levels[0].n_s))
+    s = smp.Eval(0, xi)
+    setup_ms, solve_ms = smp.last_phase_ms
+    assert 0.0 < setup_ms < solve_ms < 1e4
+    n0 = gpu_ctx.lib.pmc_kernel_launches()
+    Q, C, st = ds.SolveFwd(0, s, return_stats=True)
+    launches = gpu_ctx.lib.pmc_kernel_launches() - n0
+    its = max(t[0] for t in st)
+    assert launches > 5 * its                                   # several kernels per MINRES iteration
+    build_ms, mult_ms = ds.last_phase_ms
+    assert build_ms > 0.0 and mult_ms > build_ms
+    # in-loop operator timing: same results, one bracket per operator application of the loop
+    ds.set_operator_timing(True)
+    ds.operator_time()
+    Q2, _, st2 = ds.SolveFwd(0, s, return_stats=True)
+    ms, n, gap = ds.operator_time()
+    ds.set_operator_timing(False)
+    assert np.allclose(Q2, Q, rtol=1e-12) and [t[:2] for t in st2] == [t[:2] for t in st]
+    assert its - 2 <= n <= its + 2 and 0.0 < gap < ms
+    assert ds.operator_time() == (0.0, 0, 0.0)
+    L = dp.levels[0]
+    nb = 16
+    bytes_ = ds.operator_bytes(0, nb)
+    lower = 8.0 * nb * (2 * L.n_u + L.n_p)                      # x_u, x_p read, y_u written
+    assert lower < bytes_ < 4 * lower and ds.operator_bytes(0, 32) > bytes_
+    # managers: per-level timers of a round
+    mgr = host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False)
+    mgr.InitRun([20, 40])
+    t0, t1 = mgr.phase_times(0), mgr.phase_times(1)
+    assert t0["sampler_realizations"] == 20 and t0["darcy_realizations"] == 20
+    assert t1["sampler_realizations"] == 40 + 20 and t1["darcy_realizations"] == 40 + 20   # level 1 also serves the pairs of level 0
+    for t in (t0, t1):
+        assert t["sampler_mult_ms"] > 0 and t["darcy_build_ms"] > 0 and t["darcy_mult_ms"] > 0
+    txt = mgr.PrintTimers()
+    for name in ("Sampler: Mult -- Level 0", "Darcy: Build Solver -- Level 1", "Darcy: Mult -- Level 1"):
+        assert name in txt
+    mgr.close()
+    ds.close()
+    smp.close()
+
+
+def test_device_farm_of_two_ranks_matches_the_serial_manager(gpu_ctx, hex_hierarchy_small, tmp_path):
+    """The real sample farm (src/MLMC_Manager.cpp:103-179 run under mpirun, examples/MLMC.cpp:43-50): two fresh processes
+    share device 0, each with device PDESampler + DarcySolver plugins on two lanes, MLMC_Manager::SetFarm(2, r, reduce) with
+    a gloo SUM all-reduce.  Sharded InitRun == serial InitRun: identical counts and allocation on both ranks, sums to 1e-12
+    (same realizations, other summation order), every realization computed exactly once, and the rank-sharded logs replay to
+    the same table."""
+    import socket
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "farm_worker.py"), str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    sp_ = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    o = capi.solver_opts(rel_tol=1e-12, abs_tol=1e-14)
+    smp, ds = capi.PDESampler(gpu_ctx, sp_, o), capi.DarcySolver(gpu_ctx, dp, o)
+    serial = host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False, eps2=1e-3)
+    s1 = serial.InitRun([19, 37])
+    s2 = serial.InitRun([6, 0])
+    for r in res:
+        assert np.allclose(r["sums1"], s1["sums"], rtol=1e-12, atol=1e-13)
+        assert np.allclose(r["sums"], s2["sums"], rtol=1e-12, atol=1e-13)
+        assert list(r["nsamples"]) == [25, 37] == list(s2["nsamples"])
+        assert list(r["missing"]) == list(s2["missing"])                # both ranks derive the same allocation
+        assert np.allclose(r["varY"], s2["varY"], rtol=1e-10) and float(r["estimate"]) == pytest.approx(s2["estimate"], rel=1e-12)
+        assert int(r["reductions"]) == 2                                 # ONE all-reduce per InitRun round
+    # the work was split: level-0 realizations 19 + 6 = 25 over the two ranks, none twice, none missing
+    loc = [r["local_realizations"] for r in res]
+    assert loc[0][0] + loc[1][0] == 25 and 0 < loc[0][0] < 25
+    assert loc[0][1] + loc[1][1] == 37 + 25                              # level 1 also serves the level-0 pairs
+    # rank-sharded logs -> one table
+    log = str(tmp_path / "MLMC.dat")
+    assert os.path.exists(log) and os.path.exists(log + ".rank1")
+    b = host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False, eps2=1e-3)
+    b.set_farm(2, 0, lambda buf: None)
+    assert b.ReplayLog(log) == 25 + 37
+    rb = b.result()
+    assert np.allclose(rb["sums"], s2["sums"], rtol=1e-12, atol=1e-13) and list(rb["nsamples"]) == [25, 37]
+    b.close()
+    serial.close()
+    ds.close()
+    smp.close()
