@@ -52,7 +52,7 @@ typedef struct pmc_mlmc_params {
     int32_t init_nsamples;    /* "Number of samples", default 10                            */
     const int32_t* array_nsamples; /* "Array number of samples" (nlevels) or NULL           */
     int32_t wall_time;        /* public member wallTime (src/MLMC_Manager.hpp:61), default 1 */
-    int32_t batch;            /* upper limit of realizations per plugin call (1..256), default 256.  The managers cut a level's realizations into calls of at most this many, at most what the plugins prefer for the level (pmc_sampler_batch_width: 16 on large levels ... 256 on the smallest) and small enough that every lane gets a share */
+    int32_t batch;            /* upper limit of realizations per plugin call (1..256), default 256.  The managers cut a level's realizations into calls of at most this many, at most what the plugins prefer for the level (pmc_sampler_batch_width: 16 on large levels ... 256 on the smallest), cut so that every rank of a farm gets a share - independent of the lane count, so a realization's result does not depend on how many lanes share a GPU */
     int32_t max_rounds;       /* safety bound on the adaptive loop, default 1000            */
     const char* log_file;     /* "Output filename for MC managers" or NULL                  */
 } pmc_mlmc_params;

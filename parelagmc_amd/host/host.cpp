@@ -313,8 +313,7 @@ int MLMC_Manager::level_batch(int ilevel, int nsamples) const {
     int b = batch_;
     for (int pref : {sampler.PreferredBatch(ilevel), pSolver.PreferredBatch(ilevel)})
         if (pref > 0) b = std::min(b, pref);
-    const int workers = nranks_ * (int)lanes_.size();
-    const int share = (nsamples + workers - 1) / workers;     // what a worker gets if the level is dealt evenly
+    const int share = (nsamples + nranks_ - 1) / nranks_;     // what a rank gets if the level is dealt evenly
     return std::max(1, std::min(b, share));
 }
 

@@ -286,9 +286,10 @@ class MLMC_Manager {
     // several lanes: all levels of one InitRun round go through one task queue (finest level first), so the
     // launch-latency-bound batches of the coarse levels overlap the bandwidth-bound batches of the fine ones
     void run_round_overlapped(const std::vector<int>& level_nsamples_init);
-    // realizations per plugin call on `ilevel` when `nsamples` new ones are due: at most `batch`, at most what the plugins
-    // prefer for that level (PreferredBatch: 16 on large levels ... 256 on the smallest), and small enough that every lane
-    // of every rank gets a share.  A function of (level, nsamples, ranks, lanes) only: identical on all ranks.
+    // realizations per plugin call on `ilevel`: at most `batch`, at most what the plugins prefer for that level
+    // (PreferredBatch: 16 on large levels ... 256 on the smallest), and small enough that every RANK of a farm gets a share.
+    // Independent of the number of lanes: on a given farm the blocks of realization ids - and with them every realization's
+    // bits - do not depend on how many lanes share a GPU.  Identical on all ranks.
     int level_batch(int ilevel, int nsamples) const;
     double& S(int l, int v) { return sums[(size_t)l * NVAR + v]; }
 
