@@ -111,64 +111,6 @@ std::vector<int> diag_slots(const Sell& S, const HostCsr& pat) {
     return ds;
 }
 
-// On-the-fly form of S(k) = B diag(M(k))^-1 B^T for one level (EgsView, kernels.hpp): possible when every flux dof of B
-// touches at most two elements and the diagonal of M(k) at that dof is assembled from exactly those elements.  B has its
-// essential columns removed.  Returns false (level keeps reading its per-realization values) otherwise.
-bool build_egs(MgLevel& m, const HostCsr& B, const HostCsr& Bt, const HostCsr& Mp, const pmc_darcy_level& L, hipStream_t st) {
-    static const bool off = getenv("PMC_DARCY_NO_EGS") != nullptr;   // A/B switch
-    if (off) return false;
-    const int n_p = B.nrows;
-    std::vector<int> dpos(Mp.nrows, -1);                             // CSR position of the diagonal entry of M's pattern
-    for (int f = 0; f < Mp.nrows; ++f)
-        for (int p = Mp.rowptr[f]; p < Mp.rowptr[f + 1]; ++p)
-            if (Mp.colind[p] == f) dpos[f] = p;
-    HostCsr E;
-    E.nrows = E.ncols = n_p;
-    E.rowptr.assign(n_p + 1, 0);
-    std::vector<double> a, b, rho;
-    for (int e = 0; e < n_p; ++e) {
-        for (int p = B.rowptr[e]; p < B.rowptr[e + 1]; ++p) {
-            const int f = B.colind[p];
-            const double bef = B.vals[p];
-            if (bef == 0.0) continue;
-            const int cnt = Bt.rowptr[f + 1] - Bt.rowptr[f];
-            if (cnt > 2 || dpos[f] < 0) return false;
-            int other = -1;
-            double bother = 0.0;
-            for (int q = Bt.rowptr[f]; q < Bt.rowptr[f + 1]; ++q)
-                if (Bt.colind[q] != e) { other = Bt.colind[q]; bother = Bt.vals[q]; }
-            double d_self = 0.0, d_other = 0.0;
-            for (int t = L.c_ptr[dpos[f]]; t < L.c_ptr[dpos[f] + 1]; ++t) {
-                if (L.c_elem[t] == e) d_self += L.c_val[t];
-                else if (L.c_elem[t] == other) d_other += L.c_val[t];
-                else return false;                                   // a third element contributes to diag(M)_f
-            }
-            if (!(d_self > 0.0) || (other >= 0 && !(d_other > 0.0))) return false;
-            const double s2 = bef * bef;
-            E.colind.push_back(other >= 0 ? other : e);
-            a.push_back(d_self / s2);
-            b.push_back(other >= 0 ? d_other / s2 : 0.0);
-            rho.push_back(other >= 0 ? -bother / bef : 0.0);
-        }
-        E.rowptr[e + 1] = (int)E.colind.size();
-    }
-    E.vals.assign(E.colind.size(), 0.0);
-    sell_build(m.egs_pat, E, false, true, st);
-    std::vector<double> sa(m.egs_pat.nslots, 1e300), sb(m.egs_pat.nslots, 0.0), sr(m.egs_pat.nslots, 0.0);   // padding: weight ~0
-    for (int64_t s = 0; s < m.egs_pat.nslots; ++s) {
-        const int p = m.egs_pat.h_src[s];
-        if (p >= 0) { sa[s] = a[p]; sb[s] = b[p]; sr[s] = rho[p]; }
-    }
-    m.egs_a.upload(sa, st);
-    m.egs_b.upload(sb, st);
-    m.egs_rho.upload(sr, st);
-    PMC_HIP(hipStreamSynchronize(st));
-    m.egs_pat.h_src.clear(); m.egs_pat.h_src.shrink_to_fit();
-    m.egs_pat.h_cols.clear(); m.egs_pat.h_cols.shrink_to_fit();
-    m.has_egs = true;
-    return true;
-}
-
 // chain of one MC level: own Schur lists `own` (over diag(M)), prolongators from the k == 1 operator K1
 std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, const pmc_solver_opts& o, hipStream_t st) {
     std::vector<AmgLevelHost> lvh = sa_hierarchy(K1, std::vector<double>(), /*passes=*/2, /*theta=*/0.25,
@@ -404,10 +346,6 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         }
         schur[l] = build_symbolic(L.n_p, tr);
         clk.lap("uploads + symbolic Schur", l);
-        if (l < n_mc && d.has_eg) {
-            build_egs(mg.L[l], B, Bt, Mp, L, st);       // the V-cycle of MC level l starts on mg.L[l]
-            clk.lap("on-the-fly Schur slots", l);
-        }
         if (l < n_mc && o.mg_coarsening != 0) {
             // algebraic hierarchy of this MC level, prolongators from the k == 1 operator (c(1) = 1 either way)
             std::vector<double> dM1(L.n_u, 1.0);
@@ -423,7 +361,6 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
             if (o.mg_coarsening == 1 || anisotropy > 10.0) {
                 if ((int)chains.size() < n_mc) chains.resize(n_mc);
                 chains[l] = build_chain(schur[l], K1, o, st);
-                if (d.has_eg) build_egs(chains[l]->mg.L[0], B, Bt, Mp, L, st);   // chain level 0 is S_l(k) itself
             }
             clk.lap("algebraic chain", l);
         }
@@ -552,14 +489,12 @@ void Darcy::ensure(int level, int nb) {
     const size_t n = (size_t)d.n_u + d.n_p;
     // per-realization values of the Schur hierarchy this solve walks, at the width it runs with (a large level is solved
     // 16 at a time: it never pays for the 256 columns of the small ones)
-    const bool eg_level = use_eg(d);
-    auto size_values = [nb, eg_level, this](Multigrid& g, size_t first) {
+    auto size_values = [nb, this](Multigrid& g, size_t first) {
         g.ensure_bv_tail_width(ctx.stream, nb);
         for (size_t l = first; l < g.L.size(); ++l) {
             MgLevel& m = g.L[l];
             m.vals_bv.ensure((size_t)m.S.nslots * nb);
-            // a start level that applies S(k) on the fly (Multigrid::egs_start) needs no column-scaled copy of its values
-            if (!(l == first && eg_level && g.egs_start((int)first))) m.vals_scaled.ensure((size_t)m.S.nslots * nb);
+            m.vals_scaled.ensure((size_t)m.S.nslots * nb);
             m.dinv.ensure((size_t)m.n * nb);
         }
     };
@@ -675,15 +610,14 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
             k::refresh(st, nb, m.S.nslots, c.ptr.p, c.idx.p, c.w.p, src, j == 0, m.vals_bv.p);
             k::diag_inv(st, nb, m.n, c.diag_slot.p, m.vals_bv.p, m.dinv.p);
             k::gersh_scale_bv(st, nb, view_bv(m.S, m.vals_bv.p), m.dinv.p, gwork.p);
-            if (!(j == 0 && eg && chain->mg.egs_start(0)))
-                k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
+            k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
         }
         chain->mg.refresh_bv_tail(st, nb);
     } else {
         MgLevel& m = mg.L[level];
         k::refresh(st, nb, m.S.nslots, d.s_ptr.p, d.s_idx.p, d.s_w.p, d.diagM.p, true, m.vals_bv.p);
         k::diag_inv(st, nb, m.n, d.s_diag_slot.p, m.vals_bv.p, m.dinv.p);
-        if (!(eg && mg.egs_start(level))) k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
+        k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
         for (int l = level; l + 1 < nlevels; ++l) {
             MgLevel& f = mg.L[l];
             MgLevel& c = mg.L[l + 1];
@@ -723,7 +657,6 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     double* cdp = cd.p;
     Multigrid* mgp = chain ? &chain->mg : &mg;
     const int mg_l0 = chain ? 0 : level;
-    mgp->L[mg_l0].egs_coef = (eg && mgp->egs_start(mg_l0)) ? d.coef.p : nullptr;   // this batch's coefficient rows
     PrecFn prec = [=](const Lanes& L, int nb_, const double* r, double* z, double* dot_partial, double* dot_partial2) {
         const int flips = cheb_flips(cpM, true);
         double* start = (flips % 2 == 0) ? z : cxp;

@@ -838,174 +838,6 @@ __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices
     if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
-// On-the-fly Schur complement S(k) = B diag(M(k))^-1 B^T (EgsView): acc_e = sum_j (x_e - rho_j x_c) / (coef_e a_j + coef_c b_j).
-// CS: x is multiplied by a second per-realization vector cs on the fly (own row and gathered rows): S(k) (cs .* x).
-// Same lane layout as sell_row_range: every lane loads the (column, a, b, rho) of "its" row for slice column j, the
-// wavefront sweeps the slice in T steps of G rows and fetches the row's slot data with cross-lane shuffles; the x and
-// coefficient rows of the neighbouring element are contiguous NB*8-byte gathers.
-template <int NB, bool CS>
-__device__ __forceinline__ void egs_row_product(const int* __restrict__ slice_off, const int* __restrict__ cols,
-                                                const double* __restrict__ sa, const double* __restrict__ sb,
-                                                const double* __restrict__ srho, const double* __restrict__ coef,
-                                                const double* __restrict__ x, const double* __restrict__ cs, int nrows,
-                                                int slice, int lane, int LD, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
-    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
-    const int g = lane / T, t = lane % T;
-    const int off = slice_off[slice];
-    const int width = (slice_off[slice + 1] - off) >> 6;
-    double xe[T][C], ce[T][C];
-#pragma unroll
-    for (int rs = 0; rs < T; ++rs) {
-        const int row = min(slice * kWave + rs * G + g, nrows - 1);
-        const size_t at = (size_t)row * LD + t * C;
-        load_c<C>(x + at, xe[rs]);
-        load_c<C>(coef + at, ce[rs]);
-        if constexpr (CS) {
-            double s[C];
-            load_c<C>(cs + at, s);
-#pragma unroll
-            for (int c = 0; c < C; ++c) xe[rs][c] *= s[c];
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
-    }
-    int slot = off + lane;
-    int cj = 0;
-    double aj = 1.0, bj = 0.0, rj = 0.0;
-    if (width > 0) {
-        cj = cols[slot];
-        aj = sa[slot];
-        bj = sb[slot];
-        rj = srho[slot];
-    }
-    for (int j = 0; j < width; ++j, slot += kWave) {
-        int cn = cj;
-        double an = aj, bn = bj, rn = rj;
-        if (j + 1 < width) {          // next slice column's slot data requested under this column's gathers
-            cn = cols[slot + kWave];
-            an = sa[slot + kWave];
-            bn = sb[slot + kWave];
-            rn = srho[slot + kWave];
-        }
-        int cc[T];
-        double aa[T], bb[T], rr[T];
-#pragma unroll
-        for (int rs = 0; rs < T; ++rs) {
-            const int src = rs * G + g;
-            cc[rs] = (T == 1) ? cj : __shfl(cj, src, kWave);
-            aa[rs] = (T == 1) ? aj : __shfl(aj, src, kWave);
-            bb[rs] = (T == 1) ? bj : __shfl(bj, src, kWave);
-            rr[rs] = (T == 1) ? rj : __shfl(rj, src, kWave);
-        }
-        double xv[T][C], cv[T][C], sv[T][C];
-        if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rs = 0; rs < T; ++rs) {
-            const size_t at = (size_t)cc[rs] * LD + t * C;
-            load_c<C>(x + at, xv[rs]);
-            load_c<C>(coef + at, cv[rs]);
-            if constexpr (CS) load_c<C>(cs + at, sv[rs]);
-        }
-        if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rs = 0; rs < T; ++rs) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                if constexpr (CS) xv[rs][c] *= sv[rs][c];
-                const double den = fma(cv[rs][c], bb[rs], ce[rs][c] * aa[rs]);
-                acc[rs][c] += (xe[rs][c] - rr[rs] * xv[rs][c]) / den;
-            }
-        }
-        cj = cn;
-        aj = an;
-        bj = bn;
-        rj = rn;
-    }
-}
-
-// MODE 0: out = r - S(k) x   (R8: rows also summed in groups of 8 into coarse, see sell_spmm_kernel)
-// MODE 1: out = dinv (c0 r - c1 S(k) (dinv r)) (+ xadd); DOT: partials of <dot_with ? dot_with : r, out>
-template <int NB, int MODE, bool DOT, bool R8>
-__global__ __launch_bounds__(kBlock) void egs_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
-                                                     const int* __restrict__ cols, const double* __restrict__ sa,
-                                                     const double* __restrict__ sb, const double* __restrict__ srho,
-                                                     const double* __restrict__ coef, const double* __restrict__ dinv,
-                                                     const double* __restrict__ r, const double* __restrict__ x, double* out,
-                                                     double c0, double c1, const double* xadd,
-                                                     const double* __restrict__ dot_with, double* __restrict__ partial, int ld) {
-    static_assert(!R8 || (MODE == 0 && !DOT), "fused restriction goes with the residual");
-    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
-    const int LD = row_ld<NB>(ld);
-    {
-        const int g0 = col0<NB>();
-        coef += g0; r += g0; out += g0;
-        if constexpr (MODE == 0) x += g0;
-        if constexpr (MODE == 1) dinv += g0;
-        if (xadd) xadd += g0;
-        if (dot_with) dot_with += g0;
-        if constexpr (DOT || R8) partial += g0;
-    }
-    const int lane = threadIdx.x & (kWave - 1);
-    const int g = lane / T, t = lane % T;
-    double p[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) p[c] = 0.0;
-    const SliceWalk sw = slice_walk(nslices);
-    for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
-        double acc[T][C];
-        if constexpr (MODE == 0) egs_row_product<NB, false>(slice_off, cols, sa, sb, srho, coef, x, nullptr, nrows, slice, lane, LD, acc);
-        else egs_row_product<NB, true>(slice_off, cols, sa, sb, srho, coef, r, dinv, nrows, slice, lane, LD, acc);
-#pragma unroll
-        for (int rs = 0; rs < T; ++rs) {
-            const int row = slice * kWave + rs * G + g;
-            if (row < nrows) {
-                const size_t at = (size_t)row * LD + t * C;
-                double rv[C], ov[C];
-                load_c<C>(r + at, rv);
-                if constexpr (MODE == 0) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) ov[c] = rv[c] - acc[rs][c];
-                } else {
-                    double di[C];
-                    load_c<C>(dinv + at, di);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) ov[c] = di[c] * (c0 * rv[c] - c1 * acc[rs][c]);
-                    if (xadd) {
-                        double x0[C];
-                        load_c<C>(xadd + at, x0);
-#pragma unroll
-                        for (int c = 0; c < C; ++c) ov[c] += x0[c];
-                    }
-                }
-                if constexpr (DOT) {
-                    if (dot_with) load_c<C>(dot_with + at, rv);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) p[c] = fma(rv[c], ov[c], p[c]);
-                }
-                store_c<C>(out + at, ov);
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[rs][c] = ov[c];
-            } else if constexpr (R8) {
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
-            }
-            if constexpr (R8) {
-                double s[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    double v = acc[rs][c];
-                    v += __shfl_xor(v, T, kWave);
-                    v += __shfl_xor(v, 2 * T, kWave);
-                    v += __shfl_xor(v, 4 * T, kWave);
-                    s[c] = v;
-                }
-                if ((g & 7) == 0 && row < nrows) store_c<C>(partial + (size_t)(row >> 3) * LD + t * C, s);
-            }
-        }
-    }
-    if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
-}
-
 // out[slot][k] = vals[slot][k] * colscale[cols[slot]][k]   (per-realization column scaling A(k) D(k)^-1)
 template <int NB>
 __global__ __launch_bounds__(kBlock) void scale_cols_bv_kernel(size_t nflat, const int* __restrict__ cols,
@@ -2363,34 +2195,6 @@ int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const 
             eg_poly2_kernel<NB, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
         else
             eg_poly2_kernel<NB, false><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
-    });
-    check_launch();
-    return dot_partial ? (int)g.x : 0;
-}
-
-void egs_residual(hipStream_t st, int nb, const EgsView& S, const double* coef, const double* r, const double* x, double* out,
-                  double* coarse) {
-    if (S.nrows == 0) return;
-    if (coarse && S.nrows % 8 != 0) throw Error(PMC_ERR_INTERNAL, "egs_residual: rows are not groups of 8");
-    const dim3 g = grid_slices(S.nslices);
-    PMC_DISPATCH_NB(nb, {
-        if (coarse)
-            egs_kernel<NB, 0, false, true><<<groups(g, nb), kBlock, 0, st>>>(S.nrows, S.nslices, S.slice_off, S.cols, S.a, S.b, S.rho, coef, nullptr, r, x, out, 0.0, 0.0, nullptr, nullptr, coarse, nb);
-        else
-            egs_kernel<NB, 0, false, false><<<groups(g, nb), kBlock, 0, st>>>(S.nrows, S.nslices, S.slice_off, S.cols, S.a, S.b, S.rho, coef, nullptr, r, x, out, 0.0, 0.0, nullptr, nullptr, nullptr, nb);
-    });
-    check_launch();
-}
-
-int egs_poly2(hipStream_t st, int nb, const EgsView& S, const double* coef, const double* dinv, const double* r, double* xout,
-              double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with) {
-    if (S.nrows == 0) return 0;
-    const dim3 g = grid_bounded(grid_slices(S.nslices), dot_partial != nullptr);
-    PMC_DISPATCH_NB(nb, {
-        if (dot_partial)
-            egs_kernel<NB, 1, true, false><<<groups(g, nb), kBlock, 0, st>>>(S.nrows, S.nslices, S.slice_off, S.cols, S.a, S.b, S.rho, coef, dinv, r, nullptr, xout, c0, c1, xadd, dot_with, dot_partial, nb);
-        else
-            egs_kernel<NB, 1, false, false><<<groups(g, nb), kBlock, 0, st>>>(S.nrows, S.nslices, S.slice_off, S.cols, S.a, S.b, S.rho, coef, dinv, r, nullptr, xout, c0, c1, xadd, nullptr, nullptr, nb);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;

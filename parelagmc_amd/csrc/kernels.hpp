@@ -38,23 +38,6 @@ struct EgView {
     const int* e12 = nullptr;      // [nrows][2] coefficient rows (n_elem = constant-one row for eliminated dofs)
 };
 
-// On-the-fly Schur complement of the Darcy preconditioner, S(k) = B diag(M(k))^-1 B^T, for hierarchies in which every flux dof
-// belongs to at most two elements (the same condition as EgView).  A face f between the elements e and e' has
-// diag(M(k))_f = coef_e d_e + coef_e' d_e' (the two element-matrix diagonals), so row e of S(k) x is
-//     sum over the faces j of e:  (x_e - rho_j x_{c_j}) / (coef_e a_j + coef_{c_j} b_j)
-// with SHARED per-slot data (c_j = the element across the face, a_j = d_e / B_ef^2, b_j = d_e' / B_ef^2, rho_j = -B_e'f / B_ef;
-// boundary faces: c_j = e, b_j = rho_j = 0; padding: a_j huge) and the realization entering only through the coefficient
-// rows - 28 B per slot for the whole batch instead of 8 B per slot per realization (twice: S and S D^-1), and the
-// per-realization values of the level never have to be read by the V-cycle.  SELL-64 over the rows of S.
-struct EgsView {
-    int nrows = 0, nslices = 0;
-    const int* slice_off = nullptr;
-    const int* cols = nullptr;
-    const double* a = nullptr;
-    const double* b = nullptr;
-    const double* rho = nullptr;
-};
-
 // capacity (in blocks of nb doubles) of a partial-sum buffer for (fused) dots over nrows rows of a batch of nb columns:
 // allocate dot_capacity(nrows, nb) * nb doubles
 int dot_capacity(int nrows, int nb);
@@ -155,14 +138,6 @@ int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, co
 // matrix: xout = dinv (c0 r - c1 M(k) (dinv r)); dot_partial != nullptr: partials of <r, xout>
 int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, double* xout,
              double c0, double c1, double* dot_partial);
-
-// out = r - S(k) x on the fly (EgsView); coarse != nullptr: also the restriction over groups of 8 consecutive rows
-void egs_residual(hipStream_t st, int nb, const EgsView& S, const double* coef, const double* r, const double* x, double* out,
-                  double* coarse);
-// one-pass degree-2 polynomial with the on-the-fly S(k): xout = dinv (c0 r - c1 S(k) (dinv r)) (+ xadd);
-// dot_partial != nullptr: partials of <dot_with ? dot_with : r, xout>.  Returns the partial-block count.
-int egs_poly2(hipStream_t st, int nb, const EgsView& S, const double* coef, const double* dinv, const double* r, double* xout,
-              double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with);
 
 // per-realization Gershgorin scaling of dinv (batched values): afterwards spec(diag(dinv) S) lies in (0, 1] for every
 // realization; gwork = kMaxBatch doubles of scratch

@@ -107,8 +107,6 @@ void Multigrid::ensure_bv_tail_width(hipStream_t st, int nb) {
 }
 
 void Multigrid::refresh_bv_tail(hipStream_t st, int nb, int first_level) {
-    // a start level that applies its operator on the fly is in no tail and keeps no current scaled copy: skip it
-    if (egs_start(first_level)) ++first_level;
     for (size_t l = (size_t)first_level; l < L.size(); ++l) {   // levels finer than the one being solved hold stale values
         MgLevel& m = L[l];
         if (!m.vals_t.p) continue;
@@ -167,13 +165,6 @@ void Multigrid::build_tails(hipStream_t st) {
     }
 }
 
-bool Multigrid::egs_start(int l0) const {
-    const MgLevel& lv = L[l0];
-    const bool tail_here = use_tail && l0 < (int)tail.size() && tail[l0].p;
-    const bool last = l0 == (int)L.size() - 1 || lv.is_last;
-    return lv.bv && lv.has_egs && !tail_here && !last && smooth_degree == 2;
-}
-
 double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, double* dot_partial,
                          int* dot_blocks, const std::function<void()>* side) {
     MgLevel& lv = L[l];
@@ -188,30 +179,6 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     }
     const SellView A = lv.sview();
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
-    // start level of a Darcy cycle with the on-the-fly Schur complement: the level's per-realization values are never read
-    if (l == l0 && lv.egs_coef && egs_start(l)) {
-        const EgsView E = lv.egs_view();
-        const double* coef = lv.egs_coef;
-        double c0, c1;
-        cheb2_coefficients(lv.lmax, smooth_ratio, &c0, &c1);
-        double* x = target ? target : lv.xa.p;
-        k::egs_poly2(st, nb, E, coef, lv.dinv.p, r, x, c0, c1, nullptr, nullptr, nullptr);          // pre-smoothing from zero
-        MgLevel& lc = L[l + 1];
-        lc.ensure(nb);
-        if (lv.p_oct) {
-            k::egs_residual(st, nb, E, coef, r, x, lv.res.p, lc.r.p);
-        } else {
-            k::egs_residual(st, nb, E, coef, r, x, lv.res.p, nullptr);
-            k::spmm(st, nb, view(lv.Pt), lv.res.p, lc.r.p, false, nullptr, nullptr);
-        }
-        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, side);
-        k::spmm(st, nb, view(lv.P), xc, x, true, nullptr, nullptr);
-        // post-smoothing: x <- x + p2(r - S x)
-        k::egs_residual(st, nb, E, coef, r, x, lv.d.p, nullptr);
-        const int nblk = k::egs_poly2(st, nb, E, coef, lv.dinv.p, lv.d.p, x, c0, c1, dot_partial, x, r);
-        if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
-        return x;
-    }
     const int last_deg = lv.is_last ? lv.last_degree : coarse_degree;
     const double last_rat = lv.is_last ? lv.last_ratio : coarse_ratio;
     const double* sv = lv.vals_scaled.p;   // shared (sampler) or per-realization (Darcy) column-scaled values

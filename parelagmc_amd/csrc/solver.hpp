@@ -75,16 +75,6 @@ struct MgLevel {
     // P has exactly the children 8 i .. 8 i + 7 of parent i with unit weights (uniform refinement with contiguous
     // children): the restriction is fused into the residual kernel (k::residual_restrict8)
     bool p_oct = false;
-    // On-the-fly form of this level's operator (EgsView, Darcy: S(k) = B diag(M(k))^-1 B^T from the coefficient rows): used
-    // by the V-cycle when this level is the one the cycle STARTS on (deeper levels hold Galerkin values of the start
-    // level's operator) and egs_coef points at the current batch's coefficient rows
-    Sell egs_pat;                // SELL pattern of the slots (slice offsets + neighbour columns)
-    DevBuf<double> egs_a, egs_b, egs_rho;
-    bool has_egs = false;
-    const double* egs_coef = nullptr;
-    EgsView egs_view() const {
-        return {egs_pat.nrows, egs_pat.nslices, egs_pat.slice_off.p, egs_pat.cols.p, egs_a.p, egs_b.p, egs_rho.p};
-    }
     DevBuf<double> r, xa, xb, d, res;
     void ensure(int nb);
     SellView sview() const { return bv ? view_bv(S, vals_bv.p) : view(S); }
@@ -110,11 +100,6 @@ struct Multigrid {
     int bv_tail_width = 0;
     void ensure_bv_tail_width(hipStream_t st, int nb);
     void refresh_bv_tail(hipStream_t st, int nb, int first_level = 0);
-    // true when a cycle started on level l0 applies that level's operator on the fly (MgLevel::egs_*) - i.e. never reads the
-    // level's per-realization values or their column-scaled copy: the level has the slot data, is neither handled by the
-    // LDS tail nor the last level, and the smoother is the one-pass degree-2 polynomial.  (The owner then need not keep the
-    // scaled copy of that level current; MgLevel::egs_coef must point at the batch's coefficient rows.)
-    bool egs_start(int l0) const;
     // hash of the work-buffer pointers a V-cycle from level l0 touches (for GraphHint::sig)
     uint64_t signature(int l0) const;
     // x = V(r) starting at level l0 with zero initial guess; result written to xout (n(l0)*nb).
