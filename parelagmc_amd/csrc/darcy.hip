@@ -17,6 +17,16 @@ namespace pmc {
 
 namespace {
 
+// PMC_DARCY_F32=0: keep the per-realization values of the Schur-complement hierarchy in fp64 also for the V-cycle kernels
+// (A/B switch; default: fp32 copies, see MgLevel::f32)
+bool precond_f32() {
+    static const bool v = [] {
+        const char* e = getenv("PMC_DARCY_F32");
+        return !e || atoi(e) != 0;
+    }();
+    return v;
+}
+
 struct Triple { int r, c, idx; double w; };
 
 // pattern + contribution lists from a bag of (row, col, idx, w) tuples; `extra` pattern entries
@@ -133,6 +143,7 @@ std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, 
         const HostCsr& pat = sym.pat;
         m.n = pat.nrows;
         m.bv = true;
+        m.f32 = precond_f32();
         m.lmax = 1.0;                        // dinv carries the per-realization Gershgorin bound (k::gersh_scale_bv)
         sell_build(m.S, pat, false, true, st);   // per-realization values: sized by Darcy::ensure for the width in use
         {
@@ -399,6 +410,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         MgLevel& m = mg.L[l];
         m.n = d.n_p;
         m.bv = true;
+        m.f32 = precond_f32();
         m.lmax = 2.0 * 1.0001;   // weakly diagonally dominant M-matrix: spec(D^-1 S) in (0, 2]
         sell_build(m.S, pattern[l], false, true, st);   // per-realization values: sized by Darcy::ensure for the width in use
         // own Schur lists mapped onto the (possibly larger) level pattern
@@ -494,7 +506,12 @@ void Darcy::ensure(int level, int nb) {
         for (size_t l = first; l < g.L.size(); ++l) {
             MgLevel& m = g.L[l];
             m.vals_bv.ensure((size_t)m.S.nslots * nb);
-            m.vals_scaled.ensure((size_t)m.S.nslots * nb);
+            if (m.f32) {
+                m.vals32.ensure((size_t)m.S.nslots * nb);
+                m.scaled32.ensure((size_t)m.S.nslots * nb);
+            } else {
+                m.vals_scaled.ensure((size_t)m.S.nslots * nb);
+            }
             m.dinv.ensure((size_t)m.n * nb);
         }
     };
@@ -599,6 +616,11 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
                       d.rhs_u0.p, eg ? nullptr : d.mvals.p, d.diagM.p, d.l1invM.p, d.rhs_bc.p);
     k::broadcast(st, nb, n_p, d.rhs_p.p, d.rhs_bc.p + (size_t)n_u * nb);
     // K14: Schur complement values on the level hierarchy
+    // what the V-cycle kernels read of a level: S D^-1 (one-pass smoothers) and S itself - in fp32 when the level says so
+    auto scaled_copies = [&](MgLevel& m) {
+        if (m.f32) k::scale_cols_bv32(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.scaled32.p, m.vals32.p);
+        else k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
+    };
     DarcyChain* chain = (level < (int)chains.size()) ? chains[level].get() : nullptr;
     if (!eg) k::scale_cols_bv(st, nb, d.M.nslots, d.M.cols.p, d.mvals.p, d.l1invM.p, d.mvals_scaled.p);
     if (chain) {
@@ -610,21 +632,21 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
             k::refresh(st, nb, m.S.nslots, c.ptr.p, c.idx.p, c.w.p, src, j == 0, m.vals_bv.p);
             k::diag_inv(st, nb, m.n, c.diag_slot.p, m.vals_bv.p, m.dinv.p);
             k::gersh_scale_bv(st, nb, view_bv(m.S, m.vals_bv.p), m.dinv.p, gwork.p);
-            k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
+            scaled_copies(m);
         }
         chain->mg.refresh_bv_tail(st, nb);
     } else {
         MgLevel& m = mg.L[level];
         k::refresh(st, nb, m.S.nslots, d.s_ptr.p, d.s_idx.p, d.s_w.p, d.diagM.p, true, m.vals_bv.p);
         k::diag_inv(st, nb, m.n, d.s_diag_slot.p, m.vals_bv.p, m.dinv.p);
-        k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
+        scaled_copies(m);
         for (int l = level; l + 1 < nlevels; ++l) {
             MgLevel& f = mg.L[l];
             MgLevel& c = mg.L[l + 1];
             DarcyLevel& dc = lv[l + 1];
             k::refresh(st, nb, c.S.nslots, dc.g_ptr.p, dc.g_idx.p, dc.g_w.p, f.vals_bv.p, false, c.vals_bv.p);
             k::diag_inv(st, nb, c.n, dc.s_diag_slot.p, c.vals_bv.p, c.dinv.p);
-            k::scale_cols_bv(st, nb, c.S.nslots, c.S.cols.p, c.vals_bv.p, c.dinv.p, c.vals_scaled.p);
+            scaled_copies(c);
         }
         mg.refresh_bv_tail(st, nb, level);
     }

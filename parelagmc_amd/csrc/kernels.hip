@@ -87,6 +87,41 @@ __device__ __forceinline__ void store_c(double* __restrict__ p, const double (&v
     }
 }
 
+// Per-realization matrix values of the PRECONDITIONER (Darcy: the Schur-complement hierarchy S(k)) may be stored in fp32
+// (BV == 2; BV == 1: fp64): the preconditioner stays a fixed symmetric linear operator - MINRES converges to the same
+// solution at the same tolerance - while the dominant stream of its kernels halves.  Arithmetic stays fp64.
+template <int C>
+__device__ __forceinline__ void load_cf(const float* __restrict__ p, double (&v)[C]) {
+    if constexpr (C == 1) {
+        v[0] = (double)p[0];
+    } else if constexpr (C == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = (double)t.x;
+        v[1] = (double)t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i) {
+            const float4 t = reinterpret_cast<const float4*>(p)[i];
+            v[4 * i] = (double)t.x;
+            v[4 * i + 1] = (double)t.y;
+            v[4 * i + 2] = (double)t.z;
+            v[4 * i + 3] = (double)t.w;
+        }
+    }
+}
+// values of batched matrix entry `idx` (in units of one value): fp64 or fp32 storage
+template <int BV, int C>
+__device__ __forceinline__ void load_bv(const double* __restrict__ vals, size_t idx, double (&v)[C]) {
+    if constexpr (BV == 2) load_cf<C>(reinterpret_cast<const float*>(vals) + idx, v);
+    else load_c<C>(vals + idx, v);
+}
+// advance a batched-value pointer by c columns
+template <int BV>
+__device__ __forceinline__ const double* shift_bv(const double* vals, int c) {
+    if constexpr (BV == 2) return reinterpret_cast<const double*>(reinterpret_cast<const float*>(vals) + c);
+    else return vals + c;
+}
+
 // Vector streams without reuse inside the iteration (MINRES w / x updates of large levels): non-temporal variants, so that a
 // flat kernel running beside a gather kernel (second stream, other lanes) does not sweep that kernel's rows out of L2.
 // Measured at 0.6 M rows x 16: one lane 1096 -> 1112, four lanes 1446 -> 1454 samples/s; small levels keep the cached
@@ -226,7 +261,7 @@ __device__ __forceinline__ void reduce_flat_store(double (&p)[Lay<NB>::C], doubl
 // every row ends with its diagonal entry and is padded with zero-weight copies of it) gathers x[row] there, so a fused
 // <x, Ax> needs no second read of x - which by the end of a slice has long left the L2 (measured at 0.6 M rows: 25 MB of
 // 280 MB per launch).
-template <int NB, bool BV, bool CS, bool ZERO, int JC = 1, bool NT = false>
+template <int NB, int BV, bool CS, bool ZERO, int JC = 1, bool NT = false>
 __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
                                                const double* __restrict__ x, const double* __restrict__ cs, int off,
                                                int width, int lane, int LD, double (&acc)[Lay<NB>::T][Lay<NB>::C],
@@ -262,7 +297,7 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
             for (int u = 0; u < JU; ++u) {
                 load_c<C>(x + (size_t)cc[u] * LD, xv[u]);
                 if constexpr (CS) load_c<C>(cs + (size_t)cc[u] * LD, sv[u]);
-                if constexpr (BV) load_c<C>(vals + (size_t)(j + u < width ? slot + u * kWave : slot) * LD, av[u]);
+                if constexpr (BV) load_bv<BV, C>(vals, (size_t)(j + u < width ? slot + u * kWave : slot) * LD, av[u]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -372,7 +407,7 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         for (int rs = 0; rs < T; ++rs) {
             load_c<C>(x + (size_t)cc[rs] * LD + t * C, xv[rs]);
             if constexpr (CS) load_c<C>(cs + (size_t)cc[rs] * LD + t * C, sv[rs]);
-            if constexpr (BV) load_c<C>(vals + (size_t)(slot - lane + rs * G + g) * LD + t * C, av[rs]);
+            if constexpr (BV) load_bv<BV, C>(vals, (size_t)(slot - lane + rs * G + g) * LD + t * C, av[rs]);
         }
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -395,7 +430,7 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
     }
 }
 
-template <int NB, bool BV>
+template <int NB, int BV>
 __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_off, const int* __restrict__ cols,
                                                  const double* __restrict__ vals, const double* __restrict__ x,
                                                  int slice, int lane, int LD, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
@@ -437,7 +472,7 @@ __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
 // 8 i .. 8 i + 7 with unit weights (uniformly refined tetrahedra / hexahedra): a slice holds 8 whole groups, the sum is
 // a fixed xor tree over the lanes of a row step, and the separate restriction kernel (13 us of dependent latency for a
 // few MB) disappears from the V-cycle.
-template <int NB, bool BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false, bool DL = false>
+template <int NB, int BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false, bool DL = false>
 __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
@@ -452,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
         const int c0 = col0<NB>();   // this group's columns of every interleaved operand
         x += c0;
         y += c0;
-        if constexpr (BV) vals += c0;
+        if constexpr (BV) vals = shift_bv<BV>(vals, c0);
         if constexpr (MODE == 2) r += c0;
         if constexpr (DOT && !DL) dot_with += c0;
         if constexpr (DOT || R8) partial += c0;
@@ -531,7 +566,7 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
 }
 
 // Chebyshev / Jacobi step: d = a d + b dinv (r - A xin); xout = xin + d ; DOT: partials of <r, xout>
-template <int NB, bool BV, bool DOT>
+template <int NB, int BV, bool DOT>
 __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
@@ -546,7 +581,7 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
     {
         const int c0 = col0<NB>();
         r += c0; xin += c0; d += c0; xout += c0;
-        if constexpr (BV) { vals += c0; dinv += c0; }
+        if constexpr (BV) { vals = shift_bv<BV>(vals, c0); dinv += c0; }
         if constexpr (DOT) partial += c0;
     }
     const int lane = threadIdx.x & (kWave - 1);
@@ -600,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
 // 3 + 5 vector passes of cheb_first + cheb_step.  DOT: partials of <r, x2>.
 // From a NONZERO guess x0 the same polynomial acts on the residual: x2 = x0 + p2(r - A x0); then r is that residual,
 // xadd = x0 (may alias xout: no gathers on it) and the dot is taken with dot_with (the right-hand side).
-template <int NB, bool BV, bool DOT, bool NT = false>
+template <int NB, int BV, bool DOT, bool NT = false>
 __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                             const int* __restrict__ sched,
                                                             const int* __restrict__ cols,
@@ -616,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
     {
         const int c0 = col0<NB>();
         r += c0; xout += c0;
-        if constexpr (BV) { vals_scaled += c0; dinv += c0; }
+        if constexpr (BV) { vals_scaled = shift_bv<BV>(vals_scaled, c0); dinv += c0; }
         if (xadd) xadd += c0;
         if (dot_with) dot_with += c0;
         if (padd_x) padd_x += c0;
@@ -856,6 +891,31 @@ __global__ __launch_bounds__(kBlock) void scale_cols_bv_kernel(size_t nflat, con
 #pragma unroll
         for (int c = 0; c < C; ++c) v[c] *= sc[c];
         store_c<C>(out + e, v);
+    }
+}
+
+// fp32 copies for the preconditioner kernels: out_scaled[slot][k] = (float)(vals[slot][k] * colscale[cols[slot]][k]),
+// out_vals[slot][k] = (float)vals[slot][k]
+template <int NB>
+__global__ __launch_bounds__(kBlock) void scale_cols_bv32_kernel(size_t nflat, const int* __restrict__ cols,
+                                                                 const double* __restrict__ vals,
+                                                                 const double* __restrict__ colscale,
+                                                                 float* __restrict__ out_scaled, float* __restrict__ out_vals,
+                                                                 int ld) {
+    constexpr int C = Lay<NB>::C;
+    const int W = row_ld<NB>(ld);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nflat; i += (size_t)gridDim.x * kBlock) {
+        const size_t e = i * C;
+        const size_t slot = e / W;
+        const int k0 = (int)(e % W);
+        double v[C], sc[C];
+        load_c<C>(vals + e, v);
+        load_c<C>(colscale + (size_t)cols[slot] * W + k0, sc);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            out_vals[e + c] = (float)v[c];
+            out_scaled[e + c] = (float)(v[c] * sc[c]);
+        }
     }
 }
 
@@ -2022,7 +2082,14 @@ static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const
                         double* dot_partial, const double* dot_with) {
     // <x, Ax> with a diagonal-last matrix: x_i is what the row's last slice column gathers
     const bool dl = TAG == 1 && Lay<NB>::T > 1 && A.diag_last && dot_with == x;
-    if (A.bv) {
+    if (A.bv && A.f32) {
+        if (dot_partial)
+            sell_spmm_kernel<NB, 2, 0, true, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+        else if (accumulate)
+            sell_spmm_kernel<NB, 2, 1, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+        else
+            sell_spmm_kernel<NB, 2, 0, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+    } else if (A.bv) {
         if (dot_partial)
             sell_spmm_kernel<NB, true, 0, true, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (accumulate)
@@ -2090,7 +2157,9 @@ void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double*
     if (A.nrows % 8 != 0) throw Error(PMC_ERR_INTERNAL, "residual_restrict8: rows are not groups of 8");
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
-        if (A.bv)
+        if (A.bv && A.f32)
+            sell_spmm_kernel<NB, 2, 2, false, 0, false, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
+        else if (A.bv)
             sell_spmm_kernel<NB, true, 2, false, 0, false, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
         else
             sell_spmm_kernel<NB, false, 2, false, 0, false, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
@@ -2102,7 +2171,9 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
     if (A.nrows == 0) return;
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
-        if (A.bv)
+        if (A.bv && A.f32)
+            sell_spmm_kernel<NB, 2, 2, false, 0><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
+        else if (A.bv)
             sell_spmm_kernel<NB, true, 2, false, 0><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
         else
             sell_spmm_kernel<NB, false, 2, false, 0><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
@@ -2116,7 +2187,12 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
     if (A.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "cheb_step: value/diagonal batching mismatch");
     const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
-        if (A.bv) {
+        if (A.bv && A.f32) {
+            if (dot_partial)
+                sell_cheb_kernel<NB, 2, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
+            else
+                sell_cheb_kernel<NB, 2, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
+        } else if (A.bv) {
             if (dot_partial)
                 sell_cheb_kernel<NB, true, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
             else
@@ -2139,7 +2215,12 @@ int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool d
     if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
-        if (As.bv) {
+        if (As.bv && As.f32) {
+            if (dot_partial)
+                sell_poly2_kernel<NB, 2, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
+            else
+                sell_poly2_kernel<NB, 2, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
+        } else if (As.bv) {
             if (dot_partial)
                 sell_poly2_kernel<NB, true, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
@@ -2222,6 +2303,15 @@ void scale_cols_bv(hipStream_t st, int nb, int64_t nslots, const int* cols, cons
     const size_t nf = (size_t)nslots * nb / lay_c(nb);
     const unsigned g = (unsigned)std::min<size_t>((nf + kBlock - 1) / kBlock, 8192);
     PMC_DISPATCH_NB(nb, { scale_cols_bv_kernel<NB><<<g, kBlock, 0, st>>>(nf, cols, vals, colscale, out, nb); });
+    check_launch();
+}
+
+void scale_cols_bv32(hipStream_t st, int nb, int64_t nslots, const int* cols, const double* vals, const double* colscale,
+                     float* out_scaled, float* out_vals) {
+    if (nslots == 0) return;
+    const size_t nf = (size_t)nslots * nb / lay_c(nb);
+    const unsigned g = (unsigned)std::min<size_t>((nf + kBlock - 1) / kBlock, 8192);
+    PMC_DISPATCH_NB(nb, { scale_cols_bv32_kernel<NB><<<g, kBlock, 0, st>>>(nf, cols, vals, colscale, out_scaled, out_vals, nb); });
     check_launch();
 }
 
@@ -2423,6 +2513,22 @@ __global__ __launch_bounds__(kBlock) void transpose_bv_kernel(size_t count, int 
     const size_t i = e / nb;
     const int k = (int)(e % nb);
     out[(size_t)k * count + i] = in[e];
+}
+
+__global__ __launch_bounds__(kBlock) void transpose_bv32_kernel(size_t count, int nb, const float* __restrict__ in,
+                                                                double* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= count * nb) return;
+    const size_t i = e / nb;
+    const int k = (int)(e % nb);
+    out[(size_t)k * count + i] = (double)in[e];
+}
+
+void transpose_bv32(hipStream_t st, int nb, size_t count, const float* in, double* out) {
+    if (count == 0) return;
+    const size_t total = count * nb;
+    transpose_bv32_kernel<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, st>>>(count, nb, in, out);
+    check_launch();
 }
 
 void transpose_bv(hipStream_t st, int nb, size_t count, const double* in, double* out) {

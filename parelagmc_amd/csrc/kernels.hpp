@@ -18,12 +18,18 @@ struct SellView {
     int tag = 0;                  // 1 = block saddle-point operator (own kernel instantiation / profile row)
     int ncols_hint = 0;           // number of columns (rows of x): kernels with 32-bit gather offsets check it
     bool diag_last = false;       // see Sell::diag_last
+    bool f32 = false;             // bv only: vals points at fp32 values (per-realization values of a PRECONDITIONER matrix)
 };
 inline SellView view(const Sell& S) {
     return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, S.vals.p, false, S.sched.p, 0, S.ncols, S.diag_last};
 }
 inline SellView view_bv(const Sell& S, const double* vals) {
     return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, vals, true, S.sched.p, 0, S.ncols};
+}
+inline SellView view_bv32(const Sell& S, const float* vals) {
+    SellView v = view_bv(S, reinterpret_cast<const double*>(vals));
+    v.f32 = true;
+    return v;
 }
 
 // Element-grouped SELL view of a per-realization mass matrix M(k) = sum_e c(k_e) M_e: every row stores its entries in
@@ -82,6 +88,9 @@ int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, cons
 // out[slot][k] = vals[slot][k] * colscale[cols[slot]][k]
 void scale_cols_bv(hipStream_t st, int nb, int64_t nslots, const int* cols, const double* vals, const double* colscale,
                    double* out);
+// the fp32 copies the preconditioner kernels read: out_scaled = (float)(vals * colscale[cols]), out_vals = (float)vals
+void scale_cols_bv32(hipStream_t st, int nb, int64_t nslots, const int* cols, const double* vals, const double* colscale,
+                     float* out_scaled, float* out_vals);
 // MINRES w/x update on an index list of rows (w0, w1, x compact [nsel][nb]; u full)
 void minres_wx_idx(hipStream_t st, int nb, int nsel, const int* rows, const double* c0, const double* u, const double* c1,
                    double* w0, const double* c2, const double* w1, const double* c3, double* x);
@@ -199,5 +208,6 @@ int mg_tail(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_dou
 // out[k][i] = in[i][k]: per-realization values of a small level re-laid column-major for the tail kernel, whose
 // workgroup k then streams only its own realization's values
 void transpose_bv(hipStream_t st, int nb, size_t count, const double* in, double* out);
+void transpose_bv32(hipStream_t st, int nb, size_t count, const float* in, double* out);   // fp32 source
 }  // namespace k
 }  // namespace pmc

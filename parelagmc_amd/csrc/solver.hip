@@ -111,7 +111,8 @@ void Multigrid::refresh_bv_tail(hipStream_t st, int nb, int first_level) {
         MgLevel& m = L[l];
         if (!m.vals_t.p) continue;
         k::transpose_bv(st, nb, (size_t)m.S.nslots, m.vals_bv.p, m.vals_t.p);
-        k::transpose_bv(st, nb, (size_t)m.S.nslots, m.vals_scaled.p, m.scaled_t.p);
+        if (m.f32) k::transpose_bv32(st, nb, (size_t)m.S.nslots, m.scaled32.p, m.scaled_t.p);
+        else k::transpose_bv(st, nb, (size_t)m.S.nslots, m.vals_scaled.p, m.scaled_t.p);
         k::transpose_bv(st, nb, (size_t)m.n, m.dinv.p, m.dinv_t.p);
     }
 }
@@ -181,7 +182,7 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
     const int last_deg = lv.is_last ? lv.last_degree : coarse_degree;
     const double last_rat = lv.is_last ? lv.last_ratio : coarse_ratio;
-    const double* sv = lv.vals_scaled.p;   // shared (sampler) or per-realization (Darcy) column-scaled values
+    const double* sv = lv.scaled_ptr();   // shared (sampler) or per-realization (Darcy: fp32 storage) column-scaled values
     const ChebParams cp_last{last_deg, lv.lmax, last_rat, sv};
     const ChebParams cp_smooth{smooth_degree, lv.lmax, smooth_ratio, sv};
     const int flips = last ? cheb_flips(cp_last, true) : cheb_flips(cp_smooth, true) + cheb_flips(cp_smooth, false);
@@ -239,6 +240,7 @@ uint64_t Multigrid::signature(int l0) const {
         h = hash_ptr(h, m.r.p); h = hash_ptr(h, m.xa.p); h = hash_ptr(h, m.xb.p); h = hash_ptr(h, m.d.p);
         h = hash_ptr(h, m.SP.vals.p); h = hash_ptr(h, m.parent.p);
         h = hash_ptr(h, m.res.p); h = hash_ptr(h, m.vals_bv.p); h = hash_ptr(h, m.vals_scaled.p); h = hash_ptr(h, m.dinv.p);
+        h = hash_ptr(h, m.vals32.p); h = hash_ptr(h, m.scaled32.p);
     }
     return h;
 }

@@ -56,6 +56,11 @@ struct MgLevel {
     // small per-realization levels: column-major copies [nb][...] for the LDS tail kernel (allocated by
     // Multigrid::enable_bv_tail / ensure_bv_tail_width, refreshed by refresh_bv_tail after the level's values changed)
     DevBuf<double> vals_t, scaled_t, dinv_t;
+    // f32 (bv levels of a preconditioner hierarchy): the SpMM-type kernels of the V-cycle read fp32 copies of the values
+    // (vals32) and of the column-scaled values (scaled32) - half the bytes of their dominant stream; vals_bv (fp64) stays the
+    // master the Galerkin refresh and the diagonals are computed from, and vals_scaled is not kept at all.
+    DevBuf<float> vals32, scaled32;
+    bool f32 = false;
     bool bv = false;
     double lmax = 2.0;
     // Coarsest-level treatment: `is_last` levels end the recursion with a Chebyshev solve of degree
@@ -77,7 +82,9 @@ struct MgLevel {
     bool p_oct = false;
     DevBuf<double> r, xa, xb, d, res;
     void ensure(int nb);
-    SellView sview() const { return bv ? view_bv(S, vals_bv.p) : view(S); }
+    SellView sview() const { return bv ? (f32 ? view_bv32(S, vals32.p) : view_bv(S, vals_bv.p)) : view(S); }
+    // column-scaled values in the storage sview() uses
+    const double* scaled_ptr() const { return (bv && f32) ? reinterpret_cast<const double*>(scaled32.p) : vals_scaled.p; }
 };
 
 struct Multigrid {

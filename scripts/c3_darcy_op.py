@@ -15,7 +15,9 @@ h = build_hierarchy(box_mesh([4, 4, 4], [2, 2, 2], "hex"), 4)
 sp = build_sampler_problem(h, corlen=0.1, lognormal=True, n_mc_levels=3)
 dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], n_mc_levels=3)
 ctx = capi.Context(0, seed=20261003)
-smp, ds = capi.PDESampler(ctx, sp), capi.DarcySolver(ctx, dp)
+ts = int(os.environ.get("C3_TWO_STREAMS", "0"))        # 2 = one stream only: per-kernel times without overlap (profiling aid)
+opts = capi.solver_opts(two_streams=ts) if ts else None
+smp, ds = capi.PDESampler(ctx, sp, opts), capi.DarcySolver(ctx, dp, opts)
 print(json.dumps(darcy_operator_roofline(ctx, smp, ds, 0, 16)))
 ds.close()
 smp.close()
