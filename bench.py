@@ -105,6 +105,17 @@ def lib_sha256():
         return hashlib.sha256(f.read()).hexdigest()
 
 
+def csrc_sha256():
+    """hash of the sources libpmc.so is built from (a relinked library of the same sources is the same kernels)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "parelagmc_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "pmc.h")]):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 _TRAFFIC = {}
 
 
@@ -119,7 +130,7 @@ def traffic_entry(key):
         except Exception:   # noqa: BLE001
             _TRAFFIC["error"] = True
         stamp = _TRAFFIC.get("libpmc_sha256")
-        _TRAFFIC["_ok"] = bool(stamp) and stamp == lib_sha256()
+        _TRAFFIC["_ok"] = bool(stamp) and (stamp == lib_sha256() or _TRAFFIC.get("csrc_sha256") == csrc_sha256())
         if not _TRAFFIC["_ok"]:
             print("bench: profiles/pmc_traffic.json was not collected with this libpmc.so (stamp "
                   f"{str(stamp)[:12]}, library {lib_sha256()[:12]}): roofline.traffic = null; run scripts/make_profiles.sh + "
@@ -132,7 +143,8 @@ def traffic_entry(key):
 def traffic_provenance():
     traffic_entry("")
     return {"file": "profiles/pmc_traffic.json", "matches_running_library": bool(_TRAFFIC.get("_ok")),
-            "libpmc_sha256": _TRAFFIC.get("libpmc_sha256"), "head": _TRAFFIC.get("head")}
+            "libpmc_sha256": _TRAFFIC.get("libpmc_sha256"), "csrc_sha256": _TRAFFIC.get("csrc_sha256"),
+            "head": _TRAFFIC.get("head")}
 
 
 class SamplerFarm:
@@ -212,7 +224,7 @@ def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters
     raw_ms = solo_ms / solo_launches if solo_launches > 0 else k_ms
     gap = gap_ms / solo_launches if solo_launches > 0 else 0.0
     ach = k_bytes / (raw_ms * 1e-3) / 1e9
-    out = {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, true, 1, ...> (tag 1 = block operator K5 as launched "
+    out = {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, 0, 0, true, 1, ...> (tag 1 = block operator K5 as launched "
                                      "by the MINRES loop: fused <u, Au>, diagonal-last, non-temporal streams by size; one lane "
                                      "alone on the GPU; profile rows with this prefix)",
            "achieved": ach, "peak": PEAK_GBS, "unit": "GB/s", "frac": ach / PEAK_GBS,
@@ -220,7 +232,7 @@ def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters
            "bytes_per_launch": k_bytes, "avg_kernel_ms": raw_ms, "launches": solo_launches,
            "timing": "raw HIP-event bracket around every in-loop launch",
            "event_overhead_ms": gap, "frac_net_of_event_overhead": k_bytes / (max(raw_ms - gap, 1e-9) * 1e-3) / 1e9 / PEAK_GBS,
-           "isolated": {"kernel": f"pmc::sell_spmm_kernel<{nb}, false, 0, false, 2> launched back to back",
+           "isolated": {"kernel": f"pmc::sell_spmm_kernel<{nb}, 0, 0, false, 2, ...> launched back to back",
                         "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "frac": k_bytes / (k_ms * 1e-3) / 1e9 / PEAK_GBS,
                         "avg_kernel_ms": k_ms, "traffic": traffic_entry(f"r{refine}_nb{nb}")},
            "spmv_nb1": {"achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "bytes_per_launch": k1_bytes, "avg_kernel_ms": k1_ms,
@@ -557,6 +569,8 @@ def main():
     ap.add_argument("--all-configs", action="store_true",
                     help="also run BASELINE configs 4 (EmbeddedPDESampler, 2.5 M DoF) and 5 (SPE10-shaped Darcy MLMC, 3.9 M DoF) "
                          "at full size on this GPU with a bounded CPU sample beside each: extra.c4 / extra.c5 (minutes)")
+    ap.add_argument("--only-config", type=int, choices=(4, 5), default=None,
+                    help="with --all-configs: run only this one of the two (each takes minutes; a GPU call has a time limit)")
     ap.add_argument("--seed", type=int, default=20261003)
     args = ap.parse_args()
 
@@ -721,6 +735,8 @@ def main():
             extra["r6"] = {"error": repr(e)}
     if rank == 0 and world == 1 and args.all_configs:
         for name, fn in (("c4", config4), ("c5", config5)):
+            if args.only_config is not None and name != f"c{args.only_config}":
+                continue
             try:
                 extra[name] = fn(args.seed, cpu=not args.no_cpu_baseline)
             except Exception as e:   # noqa: BLE001

@@ -60,9 +60,9 @@ for refine, nvec in ((5, 595968), (6, 4743168)):
     split = len(set(round(x / 1024.0) for x in lv)) > 1 and max(lv) > 1.5 * min(lv)
     lf = sum(lv) / len(lv) * (2 if split else 1)
     read_kb = 3 * nvec * 16 * 8 / 1024.0
-    for key, kern in ((f"r{refine}_nb16_inloop", "sell_spmm_kernel<16, false, 0, true, 1,"),
-                      (f"r{refine}_nb16", "sell_spmm_kernel<16, false, 0, false, 2,"),
-                      (f"r{refine}_nb1", "sell_spmm_kernel<1, false, 0, false, 2,")):
+    for key, kern in ((f"r{refine}_nb16_inloop", "sell_spmm_kernel<16, 0, 0, true, 1,"),
+                      (f"r{refine}_nb16", "sell_spmm_kernel<16, 0, 0, false, 2,"),
+                      (f"r{refine}_nb1", "sell_spmm_kernel<1, 0, 0, false, 2,")):
         fr, n = mean(fetch, kern)
         wr, _ = mean(write, kern)
         if fr is None or wr is None:
@@ -93,6 +93,12 @@ import hashlib
 import subprocess
 with open(os.path.join(ROOT, "parelagmc_amd", "lib", "libpmc.so"), "rb") as f:
     out["libpmc_sha256"] = hashlib.sha256(f.read()).hexdigest()
+import glob
+hs = hashlib.sha256()
+for fn in sorted(glob.glob(os.path.join(ROOT, "parelagmc_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "pmc.h")]):
+    with open(fn, "rb") as fh:
+        hs.update(os.path.basename(fn).encode() + b"\0" + fh.read())
+out["csrc_sha256"] = hs.hexdigest()    # the sources that library was built from (bench.py accepts either stamp)
 try:
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
     dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "parelagmc_amd/csrc", "include"],

@@ -7,6 +7,6 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/k5f
 rm -f $R/gpurun_out/k5f/*kernel_trace.csv
 python3 - <<PY
 import csv
-v=[float(r["Counter_Value"]) for r in csv.DictReader(open("$R/gpurun_out/k5f/p_counter_collection.csv")) if "sell_spmm_kernel<16, false, 0, false, 2>" in r["Kernel_Name"]]
+v=[float(r["Counter_Value"]) for r in csv.DictReader(open("$R/gpurun_out/k5f/p_counter_collection.csv")) if "sell_spmm_kernel<16, 0, 0, false, 2" in r["Kernel_Name"]]
 print("FETCH_SIZE raw KB mean", sum(v)/len(v), "n", len(v))
 PY
