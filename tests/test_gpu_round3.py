@@ -237,3 +237,67 @@ def test_device_farm_of_two_ranks_matches_the_serial_manager(gpu_ctx, hex_hierar
     serial.close()
     ds.close()
     smp.close()
+
+
+def test_super_batch_edges_projections_and_observation_operator(gpu_ctx, hex_hierarchy_small, seeded_rng):
+    """Edge cases of the column-group path (MLMC_Manager hands over whatever a round needs, src/MLMC_Manager.cpp:204-208):
+    257 realizations on a 256-wide level (chunks 256 + 1), embedded (gather) and L2-projected outputs of a wide batch
+    (src/EmbeddedPDESampler.cpp:552-556, src/L2ProjectionPDESampler.cpp:738-750), the full solution vector and the Bayesian
+    observation operator (src/BayesianInverseProblem.cpp:178-186) of a wide Darcy batch - all against narrow batches and the
+    oracle."""
+    from oracle.bayes_oracle import compute_G, observation_functionals
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import (box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem, l2_projection_ops)
+    tight = dict(rel_tol=1e-12, abs_tol=1e-14)
+    # (1) 257 = 256 + 1 on the coarsest level; stats of every realization; same stream as narrow batches
+    sp_ = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    smp = capi.PDESampler(gpu_ctx, sp_, capi.solver_opts(**tight))
+    assert smp.BatchWidth(1) == 256 and smp.BatchWidth(0) == 256
+    xi = smp.Sample(1, first_id=3, nbatch=257)
+    s, st = smp.Eval(1, xi, return_stats=True)
+    assert s.shape == (257, sp_.levels[1].n_s) and len(st) == 257 and all(t[1] == 1 for t in st)
+    s32 = np.vstack([smp.Eval(1, xi[i:i + 32]) for i in range(0, 257, 32)])
+    assert np.allclose(s, s32, rtol=1e-9, atol=0)
+    so = SamplerOracle(sp_)
+    for b in (0, 255, 256):
+        assert rel(s[b], so.eval(1, 1, xi[b])[0]) < 1e-8
+    smp.close()
+    # (2) projections of a wide batch
+    m = box_mesh([6, 6, 6], [3.0, 3.0, 3.0], "hex", origin=[-0.5, -0.5, -0.5])
+    cen = m.verts[m.elems].mean(1)
+    m.elem_attr[:] = np.where(np.all((cen > 0) & (cen < 2), axis=1), 1, 2)
+    h = build_hierarchy(m, 1)
+    spe = build_sampler_problem(h, corlen=0.1, embedded=True, lognormal=True)
+    soe = SamplerOracle(spe)
+    ga = capi.PDESampler(gpu_ctx, spe, capi.solver_opts(**tight), projection="gather")
+    pr = capi.PDESampler(gpu_ctx, spe, capi.solver_opts(**tight), projection="l2", l2_ops=l2_projection_ops(h, spe.orig_index))
+    xe = seeded_rng.standard_normal((96, spe.levels[0].n_s))             # 96 = 64 + 32
+    for lvl in range(2):
+        a, emb = ga.Eval(lvl, xe, xi_level=0, want_embed=True)
+        b = pr.Eval(lvl, xe, xi_level=0)
+        assert rel(a, b) < 1e-12 and a.shape == (96, len(spe.orig_index[lvl]))
+        assert np.allclose(np.exp(emb[:, spe.orig_index[lvl]]), a, rtol=1e-12)
+        for i in (0, 63, 64, 95):
+            assert rel(a[i], soe.eval(lvl, 0, xe[i], projection=("gather", spe.orig_index[lvl]))[0]) < 1e-8
+    ga.close()
+    pr.close()
+    # (3) Darcy: full solution and observation operator of a wide batch
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    do = DarcyOracle(dp)
+    Gobs = observation_functionals(hex_hierarchy_small, np.array([[0.5, 0.5, 0.5], [1.5, 1.0, 0.4], [1.0, 1.6, 1.7]]), eps=0.3)
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**tight))
+    k = np.exp(0.5 * seeded_rng.standard_normal((70, dp.levels[0].n_p)))                # 70 = 64 + 4 + 2
+    Q, C, sol = ds.SolveFwd(0, k, want_solution=True)
+    assert sol.shape == (70, dp.levels[0].ndofs)
+    for i in (0, 63, 64, 69):
+        qr, _, ref = do.solve_fwd(0, k[i], return_solution=True)
+        assert abs(Q[i] - qr) <= 1e-8 * abs(qr) and rel(sol[i], ref) < 1e-7
+    assert np.allclose(sol @ dp.levels[0].obs, Q, rtol=1e-10)                           # Q = <obs, solution>
+    ds.SetObservations(0, Gobs[0])
+    G, _, Qg = ds.ComputeG(0, k)
+    assert np.allclose(Qg, Q, rtol=1e-9)
+    for i in (0, 64, 69):
+        assert np.allclose(G[i], compute_G(do, Gobs, 0, k[i])[0], rtol=1e-8, atol=1e-10)
+    ds.close()
