@@ -82,7 +82,8 @@ def solver_bytes_per_iteration(problem, nb):
     total = mat(L[0].nnz, n) + V * 2 * n                      # K5: q = A u (the dot takes u from the gathers)
     total += V * 4 * n                                         # v_new = c0 q + c1 v1 + c2 v0
     total += mat(L[0].M.nnz, n_u) + 8.0 * n_u + V * 2 * n_u    # M-block: one-pass degree-2 polynomial
-    total += V * 6 * n_s                                       # w / x update on the s-block
+    total += V * (4 + 5) / 4.0 * n_s                           # w / x updates on the s-block, four iterations per pass (kWxDefer):
+    #                                                            reads 4 u + w0 + w1 + x, writes w0 + w1 + x = 9 streams per 4 iterations
     # V-cycle on the Schur block, level by level until the first level handled by the LDS tail (<= ~6k rows) / last level
     for lv in range(len(L)):
         ns_l = L[lv].n_s

@@ -358,25 +358,25 @@ int pmc_sampler_apply_operator(pmc_sampler* s, int level, int nbatch, const doub
 int pmc_sampler_set_operator_timing(pmc_sampler* s, int on) {
     return guarded([&] {
         PMC_REQUIRE(s != nullptr, "sampler is NULL");
-        s->impl.work.time_operator = on != 0;
+        s->impl.work.op_timer.on = on != 0;
     });
 }
 
 int pmc_sampler_operator_time(pmc_sampler* s, double* total_ms, int64_t* launches) {
     return guarded([&] {
         PMC_REQUIRE(s != nullptr, "sampler is NULL");
-        if (total_ms) *total_ms = s->impl.work.op_ms;
-        if (launches) *launches = s->impl.work.op_launches;
-        s->impl.work.op_ms = 0.0;
-        s->impl.work.op_launches = 0;
+        if (total_ms) *total_ms = s->impl.work.op_timer.ms;
+        if (launches) *launches = s->impl.work.op_timer.launches;
+        s->impl.work.op_timer.ms = 0.0;
+        s->impl.work.op_timer.launches = 0;
     });
 }
 
 int pmc_sampler_operator_event_overhead(pmc_sampler* s, double* total_ms) {
     return guarded([&] {
         PMC_REQUIRE(s != nullptr && total_ms != nullptr, "operator_event_overhead: bad arguments");
-        *total_ms = s->impl.work.op_gap_ms;
-        s->impl.work.op_gap_ms = 0.0;
+        *total_ms = s->impl.work.op_timer.gap_ms;
+        s->impl.work.op_timer.gap_ms = 0.0;
     });
 }
 

@@ -188,7 +188,7 @@ struct Ctx {
     DevBuf<double> comm_buf;
     int* h_flag = nullptr;         // pinned host word for convergence polls
     double* h_scal = nullptr;      // pinned host scratch (kHostScratch doubles)
-    static constexpr size_t kHostScratch = 8192;
+    static constexpr size_t kHostScratch = 16384;
     void activate() const;
 };
 

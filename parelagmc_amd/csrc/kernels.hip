@@ -11,6 +11,7 @@
 //   darcy_*                                    : K12-K15 per-sample M(k), BC elimination, Schur refresh, QoI
 #include "kernels.hpp"
 
+#include <cstddef>
 #include <cstdlib>
 
 #include <algorithm>
@@ -1044,6 +1045,43 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const d
     store_c_nt<NT, C>(x + e, xv);
 }
 
+// The w / x updates of B.cnt <= kWxDefer iterations in one pass (see kWxDefer): the u vectors of all pending iterations are
+// requested first, the recurrences then run in registers in iteration order - the same operations in the same order as
+// cnt successive minres_wx launches.
+template <int NB, bool NT>
+__global__ __launch_bounds__(kBlock) void minres_wx_deferred_kernel(size_t nflat, k::WxDeferred B,
+                                                                    const double* __restrict__ cW, double* __restrict__ w0,
+                                                                    double* __restrict__ w1, double* __restrict__ x, int ld) {
+    constexpr int C = Lay<NB>::C;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nflat) return;
+    const size_t e = i * C;
+    const int k0 = (int)(e % row_ld<NB>(ld));
+    double uv[k::kWxDefer][C], a[C], b[C], xv[C];
+#pragma unroll
+    for (int j = 0; j < k::kWxDefer; ++j)
+        if (j < B.cnt) load_c_nt<NT, C>(B.u[j] + e, uv[j]);
+    load_c_nt<NT, C>(w0 + e, a);
+    load_c_nt<NT, C>(w1 + e, b);
+    load_c_nt<NT, C>(x + e, xv);
+#pragma unroll
+    for (int j = 0; j < k::kWxDefer; ++j) {
+        if (j < B.cnt) {
+            const double* cj = cW + (size_t)B.slot[j] * 4 * kMaxBatch + k0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double wn = cj[c] * uv[j][c] + cj[kMaxBatch + c] * a[c] + cj[2 * kMaxBatch + c] * b[c];
+                xv[c] += cj[3 * kMaxBatch + c] * wn;
+                a[c] = b[c];
+                b[c] = wn;
+            }
+        }
+    }
+    store_c_nt<NT, C>(w0 + e, a);
+    store_c_nt<NT, C>(w1 + e, b);
+    store_c_nt<NT, C>(x + e, xv);
+}
+
 // partial sums of <w, x[:,k]> with a shared (non-batched) weight vector w   (K15 QoI)
 template <int NB>
 __global__ __launch_bounds__(kBlock) void wdot_kernel(size_t nflat, const double* __restrict__ w,
@@ -1130,7 +1168,8 @@ __device__ __forceinline__ void count_active(k::MinresState* st, int nb, bool bu
 
 __global__ __launch_bounds__(kScalBlock) void minres_init_kernel(k::MinresState* st, const double* __restrict__ partial,
                                                              int nblocks, int nb, double rel_tol, double abs_tol,
-                                                             const double* __restrict__ partial2, int nblocks2) {
+                                                             const double* __restrict__ partial2, int nblocks2, int ring) {
+    if (threadIdx.x == 0) st->ring = ring;
     const double d = reduce_partials(partial, nblocks, nb, partial2, nblocks2);
     const int k = threadIdx.x;
     if (k < nb) {
@@ -1174,12 +1213,13 @@ __device__ __forceinline__ void scal2_body(k::MinresState* st, int k, double d2)
         const double delta = st->delta[k];
         const double rho1 = hypot(delta, beta_new);
         const double ir = rho1 > 0.0 ? 1.0 / rho1 : 0.0;
-        st->cW[0][k] = ir / st->beta[k];
-        st->cW[1][k] = -st->rho3[k] * ir;
-        st->cW[2][k] = -st->rho2[k] * ir;
+        double (*cW)[kMaxBatch] = st->cW[st->it % st->ring];   // this iteration's coefficient set
+        cW[0][k] = ir / st->beta[k];
+        cW[1][k] = -st->rho3[k] * ir;
+        cW[2][k] = -st->rho2[k] * ir;
         st->gamma0[k] = st->gamma1[k];
         st->gamma1[k] = delta * ir;
-        st->cW[3][k] = st->gamma1[k] * st->eta[k];
+        cW[3][k] = st->gamma1[k] * st->eta[k];
         st->sigma0[k] = st->sigma1[k];
         st->sigma1[k] = beta_new * ir;
         st->eta[k] = -st->sigma1[k] * st->eta[k];
@@ -1188,7 +1228,8 @@ __device__ __forceinline__ void scal2_body(k::MinresState* st, int k, double d2)
         st->iters[k] = st->it + 1;
         if (fabs(st->eta[k]) <= st->goal[k] || beta_new == 0.0 || st->flag[k] != 0) st->active[k] = 0;
     } else {
-        st->cW[0][k] = st->cW[1][k] = st->cW[2][k] = st->cW[3][k] = 0.0;
+        double (*cW)[kMaxBatch] = st->cW[st->it % st->ring];
+        cW[0][k] = cW[1][k] = cW[2][k] = cW[3][k] = 0.0;
     }
 }
 
@@ -2383,6 +2424,19 @@ void minres_wx(hipStream_t st, int nb, int n, const double* c0, const double* u,
     check_launch();
 }
 
+void minres_wx_deferred(hipStream_t st, int nb, int n, const MinresState* s, const WxDeferred& B, double* w0, double* w1,
+                        double* x) {
+    if (n == 0 || B.cnt == 0) return;
+    if (B.cnt < 0 || B.cnt > kWxDefer) throw Error(PMC_ERR_INTERNAL, "minres_wx_deferred: bad count");
+    const double* cW = reinterpret_cast<const double*>(reinterpret_cast<const char*>(s) + offsetof(MinresState, cW));
+    const bool nt = nt_flat((size_t)n * nb);
+    PMC_DISPATCH_NB(nb, {
+        if (nt) minres_wx_deferred_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), B, cW, w0, w1, x, nb);
+        else minres_wx_deferred_kernel<NB, false><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), B, cW, w0, w1, x, nb);
+    });
+    check_launch();
+}
+
 void fill(hipStream_t st, size_t n, double* x, double v) {
     if (n == 0) return;
     if (v == 0.0) {
@@ -2398,8 +2452,8 @@ void copy(hipStream_t st, size_t n, const double* src, double* dst) {
     if (n && src != dst) PMC_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, st));
 }
 
-void minres_init(hipStream_t st, int nb, MinresState* s, const DotParts& d, double rel_tol, double abs_tol) {
-    minres_init_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, rel_tol, abs_tol, d.p2, d.n2);
+void minres_init(hipStream_t st, int nb, MinresState* s, const DotParts& d, double rel_tol, double abs_tol, int ring) {
+    minres_init_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, rel_tol, abs_tol, d.p2, d.n2, ring);
     check_launch();
 }
 void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d) {

@@ -53,15 +53,27 @@ void count_kernel_launches(int n);
 
 namespace k {
 
+// The w / x updates of up to kWxDefer consecutive MINRES iterations are applied in ONE pass over the vectors
+// (minres_wx_deferred): nothing reads w or x before the solve ends, and every update needs only its own iteration's
+// coefficients and preconditioned vector.  One pass costs (kWxDefer + 5) vector streams instead of 6 kWxDefer.
+static constexpr int kWxDefer = 4;
+struct WxDeferred {
+    const double* u[kWxDefer];   // preconditioned vectors of the pending iterations (rows of the maintained block), oldest first
+    int slot[kWxDefer];          // coefficient set (MinresState::cW ring) of each
+    int cnt;
+};
+
 // Device-resident MINRES scalars, one entry per batch column.
 struct MinresState {
     double beta[kMaxBatch], beta_old[kMaxBatch], eta[kMaxBatch], eta0[kMaxBatch];
     double gamma0[kMaxBatch], gamma1[kMaxBatch], sigma0[kMaxBatch], sigma1[kMaxBatch];
     double goal[kMaxBatch], alpha[kMaxBatch], delta[kMaxBatch], rho2[kMaxBatch], rho3[kMaxBatch];
     double cV[3][kMaxBatch];  // v_new = cV0*q + cV1*v1 + cV2*v0
-    double cW[4][kMaxBatch];  // w_new = cW0*u1 + cW1*w0 + cW2*w1 ; x += cW3*w_new
+    // w_new = cW0*u1 + cW1*w0 + cW2*w1 ; x += cW3*w_new.  Iteration i (0-based) writes set i % ring: ring == 1 when the
+    // update follows its iteration at once, kWxDefer when updates are deferred
+    double cW[kWxDefer][4][kMaxBatch];
     int active[kMaxBatch], iters[kMaxBatch], flag[kMaxBatch];
-    int n_active, it;
+    int n_active, it, ring;
 };
 
 // y = A x (accumulate=false) or y += A x.  If dot_partial != nullptr (accumulate must be false) also
@@ -117,7 +129,11 @@ struct DotParts {
     int n2 = 0;
     int total() const { return n1 + n2; }
 };
-void minres_init(hipStream_t st, int nb, MinresState* s, const DotParts& d, double rel_tol, double abs_tol);
+void minres_init(hipStream_t st, int nb, MinresState* s, const DotParts& d, double rel_tol, double abs_tol, int ring = 1);
+// the pending w / x updates of B.cnt iterations on n rows: for j < cnt  w = cW0 u_j + cW1 w0 + cW2 w1; x += cW3 w;
+// (w0, w1) <- (w1, w).  w0 is the OLDER direction on entry and on return (no role swap by the caller).
+void minres_wx_deferred(hipStream_t st, int nb, int n, const MinresState* s, const WxDeferred& B, double* w0, double* w1,
+                        double* x);
 void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d);
 void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d);
 // scal2 of this iteration followed by scal1 of the next one (d1 = partials of the next operator product) in one launch

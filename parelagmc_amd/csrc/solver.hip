@@ -230,7 +230,6 @@ int Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* x
 MinresWork::~MinresWork() {
     for (auto& kv : graphs)
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
 }
 
 uint64_t Multigrid::signature(int l0) const {
@@ -301,6 +300,15 @@ int batch_width(size_t rows) {
     return 32;
 }
 
+// PMC_WX_DEFER=0: one w / x update launch per iteration (A/B switch for k::minres_wx_deferred)
+static bool wx_defer_on() {
+    static const bool v = [] {
+        const char* e = getenv("PMC_WX_DEFER");
+        return !e || atoi(e) != 0;
+    }();
+    return v;
+}
+
 // PMC_LATE_WX=0 keeps the w / x update inside its own iteration also on two streams (A/B switch)
 static bool late_wx() {
     static const bool v = [] {
@@ -342,7 +350,14 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     const size_t seg2 = (size_t)dot_capacity(n, nb) * nb;
     k::DotParts dp = prec(L, nb, v1, u1, w.partial.p, w.partial.p + seg2);
     if (dp.total() == 0) dp = k::DotParts{w.partial.p, k::dot(st, nb, n, v1, u1, w.partial.p)};
-    k::minres_init(st, nb, S, dp, o.rel_tol, o.abs_tol);
+    const int every = o.check_every > 0 ? o.check_every : 1;
+    const bool graphs = hint.key != 0 && o.use_graph != 0 && every == 2;
+    const bool late = L.split && !graphs && A.n0 > 0 && A.n0 < n && late_wx();
+    // w / x updates of kWxDefer iterations in one pass (see k::minres_wx_deferred): whenever the update is a plain vector
+    // kernel on this stream - not the compact index-list update of the Darcy solves (a few rows), not the two-stream
+    // schedule (its update already runs beside other work) and not inside a captured graph
+    const bool defer = !graphs && !late && !x_rows && wx_defer_on();
+    k::minres_init(st, nb, S, dp, o.rel_tol, o.abs_tol, defer ? k::kWxDefer : 1);
     k::fill(st, len, v0, 0.0);
     k::fill(st, len, w0, 0.0);
     k::fill(st, len, w1, 0.0);
@@ -364,35 +379,20 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     };
 
     MinresResult out;
-    const int every = o.check_every > 0 ? o.check_every : 1;
-    const bool graphs = hint.key != 0 && o.use_graph != 0 && every == 2;
-    const bool late = L.split && !graphs && A.n0 > 0 && A.n0 < n && late_wx();
     double* u2 = nullptr;
     if (late) {
         w.u2.ensure(len);
         u2 = w.u2.p;
     }
-    size_t ev_used = 0;
-    const bool timing = w.time_operator && !(hint.key != 0 && o.use_graph != 0);
+    const bool timing = w.op_timer.on && !(hint.key != 0 && o.use_graph != 0);
     // q = A u, d1 = <u, A u>.  The product for iteration i+1 is issued right after the preconditioner of iteration i has
     // written u (both blocks of u are then the most recently written data on the chip), before the scalar recurrences
     // and the w / x update of iteration i, which do not depend on it.
     k::DotParts dp_op;
     auto apply_op = [&](const double* u) {
-        if (timing) {
-            while (w.ev.size() < ev_used + 3) {
-                hipEvent_t e;
-                PMC_HIP(hipEventCreate(&e));
-                w.ev.push_back(e);
-            }
-            PMC_HIP(hipEventRecord(w.ev[ev_used], st));
-        }
+        if (timing) w.op_timer.begin(st);
         dp_op = A.apply(L, nb, u, q, w.partial_op.p, w.partial_op.p + seg2);
-        if (timing) {
-            PMC_HIP(hipEventRecord(w.ev[ev_used + 1], st));
-            PMC_HIP(hipEventRecord(w.ev[ev_used + 2], st));   // empty bracket: what one event record costs on this stream
-            ev_used += 3;
-        }
+        if (timing) w.op_timer.end(st);   // + an empty bracket: what one event record costs on this stream
     };
     // one MINRES iteration with explicit roles of the ping-pong vectors; on entry q = A u1_ and its dot are in place
     // (the first scalar step of an iteration - alpha and the Lanczos coefficients from <u, Au> - has already been done: by
@@ -430,6 +430,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         } else {
             k::minres_scal2(st, nb, S, d2);
         }
+        if (defer) return;                       // the caller queues the update (k::WxDeferred)
         if (late && !last) pend = PendingWx{u1_, w0_, w1_};
         else wx(st, u1_, w0_, w1_);
     };
@@ -505,6 +506,31 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             ++it;
             n_active = poll();
         }
+    } else if (defer) {
+        // ring of kWxDefer + 1 preconditioned vectors: the pending iterations' z stay alive until their updates are flushed
+        constexpr int R = k::kWxDefer + 1;
+        w.u2.ensure(len);
+        w.u3.ensure(len);
+        w.u4.ensure(len);
+        double* ub[R] = {u1, u0, w.u2.p, w.u3.p, w.u4.p};
+        static_assert(R == 5, "ring buffers of the deferred w / x update");
+        int c = 0;                                   // ub[c] holds the preconditioned vector of the current Lanczos vector
+        k::WxDeferred pending{};
+        auto flush = [&]() {
+            k::minres_wx_deferred(st, nb, x_nrows, S, pending, w0, w1, x + xoff);
+            pending.cnt = 0;
+        };
+        while (n_active > 0 && it < o.max_iter) {
+            ++it;
+            iteration(ub[(c + 1) % R], ub[c], v0, v1, w0, w1, it == o.max_iter);
+            pending.u[pending.cnt] = ub[c] + xoff;
+            pending.slot[pending.cnt] = (it - 1) % k::kWxDefer;
+            if (++pending.cnt == k::kWxDefer) flush();
+            c = (c + 1) % R;
+            std::swap(v0, v1);
+            if ((it % every == 0 && (it >= first_poll || it == mid_poll)) || it == o.max_iter) n_active = poll();
+        }
+        flush();
     } else {
         while (n_active > 0 && it < o.max_iter) {
             ++it;
@@ -529,14 +555,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     static_assert(sizeof(k::MinresState) <= Ctx::kHostScratch * sizeof(double), "pinned scratch too small");
     PMC_HIP(hipMemcpyAsync(ctx.h_scal, S, sizeof(k::MinresState), hipMemcpyDeviceToHost, st));
     PMC_HIP(hipStreamSynchronize(st));
-    for (size_t e = 0; e + 2 < ev_used; e += 3) {
-        float ms = 0.f, gap = 0.f;
-        PMC_HIP(hipEventElapsedTime(&ms, w.ev[e], w.ev[e + 1]));
-        PMC_HIP(hipEventElapsedTime(&gap, w.ev[e + 1], w.ev[e + 2]));
-        w.op_ms += ms;
-        w.op_gap_ms += gap;
-        ++w.op_launches;
-    }
+    if (timing) w.op_timer.harvest();
     k::MinresState hs;
     std::memcpy(&hs, ctx.h_scal, sizeof(hs));
     int max_it = 0;

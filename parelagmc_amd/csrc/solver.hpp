@@ -202,6 +202,7 @@ struct MinresWork {
     DevBuf<double> v0, v1, u0, u1, w0, w1, q, partial;
     DevBuf<double> stage;                    // first-stage sums of the scalar kernel (k::minres_scal21)
     DevBuf<double> u2;                       // third preconditioned vector: only when the w / x update runs one iteration late
+    DevBuf<double> u3, u4;                   // ring of the deferred w / x update (with u0, u1, u2: kWxDefer + 1 vectors)
     DevBuf<double> partial_op;               // partials of the operator's fused <u, Au> (the preconditioner's live in `partial`)
     std::map<uint64_t, int> iter_hint;       // per solver configuration: iterations its previous solve needed
     DevBuf<k::MinresState> state;
@@ -211,11 +212,7 @@ struct MinresWork {
     };
     std::map<uint64_t, GraphEntry> graphs;   // two MINRES iterations per graph, see minres_solve
     // optional in-situ timing of the operator launches (K5) with HIP events on the solve's own stream
-    bool time_operator = false;
-    std::vector<hipEvent_t> ev;
-    double op_ms = 0.0;
-    double op_gap_ms = 0.0;                  // sum of the empty event brackets recorded right behind each timed launch
-    int64_t op_launches = 0;
+    OpTimer op_timer;
     MinresWork() = default;
     MinresWork(const MinresWork&) = delete;
     MinresWork& operator=(const MinresWork&) = delete;

@@ -319,22 +319,22 @@ int MLMC_Manager::level_batch(int ilevel, int nsamples) const {
 
 void MLMC_Manager::run_level(int ilevel, int nsamples) {
     const uint64_t base = (uint64_t)level_nsamples[ilevel];
-    const int batch_ = level_batch(ilevel, nsamples);          // shadows the member: this level's plugin-call size
-    const int nblocks = (nsamples + batch_ - 1) / batch_;
+    const int lb = level_batch(ilevel, nsamples);              // this level's plugin-call size
+    const int nblocks = (nsamples + lb - 1) / lb;
     const int nlanes = (int)lanes_.size();
     std::vector<std::vector<double>> lane_sums(nlanes, std::vector<double>(NVAR, 0.0));
     std::vector<std::string> lane_err(nlanes);
     std::mutex log_mutex;
     const double t0 = now_s();
-    // blocks of `batch_` consecutive realization ids: dealt round-robin to ranks, then to this rank's lanes
+    // blocks of `lb` consecutive realization ids: dealt round-robin to ranks, then to this rank's lanes
     auto work = [&](int lane) {
         try {
             Lane& L = *lanes_[lane];
             double* psum = lane_sums[lane].data();
-            std::vector<double> q(batch_), c(batch_), qc(batch_), cc(batch_);
+            std::vector<double> q(lb), c(lb), qc(lb), cc(lb);
             for (int blk = rank_ + lane * nranks_; blk < nblocks; blk += nranks_ * nlanes) {
-                const int first = blk * batch_;
-                const int m = std::min(batch_, nsamples - first);
+                const int first = blk * lb;
+                const int m = std::min(lb, nsamples - first);
                 L.sampler->Sample(ilevel, L.xi, base + (uint64_t)first, m);
                 if (ilevel == nlevels - 1) {
                     L.sampler->Eval(ilevel, L.xi, L.sparam);
