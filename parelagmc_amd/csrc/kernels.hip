@@ -757,35 +757,102 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
     if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
-// Element-grouped per-realization mass matrix (EgView): acc = c1 * (group 1 row sums) + c2 * (group 2 row sums).
+// sell_row_range for the TH row steps rs0 .. rs0 + TH - 1 of a slice only (shared values).  A kernel that sweeps a slice in
+// T / TH such passes keeps TH instead of T rows' accumulators, gathers and shuffled slot data alive - the element-grouped
+// kernels below, which carry two accumulators and up to three gathered vectors per row, drop from 206-246 VGPRs (two waves per
+// SIMD) to four waves per SIMD; the (index, value) pairs of the later passes come from L1.
+template <int NB, bool CS, bool ZERO, bool NT, int TH>
+__device__ __forceinline__ void sell_row_part(const int* __restrict__ cols, const double* __restrict__ vals,
+                                              const double* __restrict__ x, const double* __restrict__ cs, int off, int width,
+                                              int lane, int LD, int rs0, double (&acc)[TH][Lay<NB>::C]) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int g = lane / T, t = lane % T;
+    if constexpr (ZERO) {
+#pragma unroll
+        for (int q = 0; q < TH; ++q)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[q][c] = 0.0;
+    }
+    int slot = off + lane;
+    int cj = 0;
+    double vj = 0.0;
+    if (width > 0) {
+        cj = load_stream<NT>(cols + slot);
+        vj = load_stream<NT>(vals + slot);
+    }
+    for (int j = 0; j < width; ++j, slot += kWave) {
+        int cn = cj;
+        double vn = vj;
+        if (j + 1 < width) {
+            cn = load_stream<NT>(cols + slot + kWave);
+            vn = load_stream<NT>(vals + slot + kWave);
+        }
+        int cc[TH];
+        double aa[TH];
+#pragma unroll
+        for (int q = 0; q < TH; ++q) {
+            const int src = (rs0 + q) * G + g;
+            cc[q] = (T == 1) ? cj : __shfl(cj, src, kWave);
+            aa[q] = (T == 1) ? vj : __shfl(vj, src, kWave);
+        }
+        double xv[TH][C], sv[TH][C];
+        if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < TH; ++q) {
+            load_c<C>(x + (size_t)cc[q] * LD + t * C, xv[q]);
+            if constexpr (CS) load_c<C>(cs + (size_t)cc[q] * LD + t * C, sv[q]);
+        }
+        if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < TH; ++q)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if constexpr (CS) xv[q][c] *= sv[q][c];
+                acc[q][c] = fma(aa[q], xv[q][c], acc[q][c]);
+            }
+        cj = cn;
+        vj = vn;
+    }
+}
+
+// row steps per pass of the element-grouped kernels
+template <int NB>
+struct EgPass {
+    static constexpr int TH = NB >= 32 ? 4 : Lay<NB>::T;   // only the widest instantiation (256 VGPRs, one wave per SIMD otherwise)
+};
+
+// Element-grouped per-realization mass matrix (EgView): acc = c1 * (group 1 row sums) + c2 * (group 2 row sums), for the row
+// steps rs0 .. rs0 + TH - 1 of the slice.  The two coefficient rows are requested before the sweeps they scale.
 // kEgNt: non-temporal matrix / result streams on large levels (hex 64^3, one lane: 28.2 -> 27.3 ms per 16 Darcy solves).
-template <int NB, bool CS, bool kEgNt = false>
+template <int NB, bool CS, bool kEgNt, int TH>
 __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, const double* __restrict__ w,
                                                const int* __restrict__ e12, const double* __restrict__ coef, int gw,
                                                const double* __restrict__ x, const double* __restrict__ cs, int nrows,
-                                               int slice, int lane, int LD, double (&y)[Lay<NB>::T][Lay<NB>::C]) {
+                                               int slice, int lane, int LD, int rs0, double (&y)[TH][Lay<NB>::C]) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int g = lane / T, t = lane % T;
     const int off = slice * 2 * gw * kWave;
-    double a[T][C];
-    sell_row_range<NB, false, CS, true, 1, kEgNt>(cols, w, x, cs, off, gw, lane, LD, a);
+    double a[TH][C], c1[TH][C];
 #pragma unroll
-    for (int rs = 0; rs < T; ++rs) {
-        const int row = min(slice * kWave + rs * G + g, nrows - 1);
-        double c1[C];
-        load_c<C>(coef + (size_t)e12[2 * row] * LD + t * C, c1);
-#pragma unroll
-        for (int c = 0; c < C; ++c) y[rs][c] = c1[c] * a[rs][c];
+    for (int q = 0; q < TH; ++q) {
+        const int row = min(slice * kWave + (rs0 + q) * G + g, nrows - 1);
+        load_c<C>(coef + (size_t)e12[2 * row] * LD + t * C, c1[q]);
     }
-    sell_row_range<NB, false, CS, true, 1, kEgNt>(cols, w, x, cs, off + gw * kWave, gw, lane, LD, a);
+    sell_row_part<NB, CS, true, kEgNt, TH>(cols, w, x, cs, off, gw, lane, LD, rs0, a);
 #pragma unroll
-    for (int rs = 0; rs < T; ++rs) {
-        const int row = min(slice * kWave + rs * G + g, nrows - 1);
-        double c2[C];
-        load_c<C>(coef + (size_t)e12[2 * row + 1] * LD + t * C, c2);
+    for (int q = 0; q < TH; ++q)
 #pragma unroll
-        for (int c = 0; c < C; ++c) y[rs][c] = fma(c2[c], a[rs][c], y[rs][c]);
+        for (int c = 0; c < C; ++c) y[q][c] = c1[q][c] * a[q][c];
+#pragma unroll
+    for (int q = 0; q < TH; ++q) {
+        const int row = min(slice * kWave + (rs0 + q) * G + g, nrows - 1);
+        load_c<C>(coef + (size_t)e12[2 * row + 1] * LD + t * C, c1[q]);
     }
+    sell_row_part<NB, CS, true, kEgNt, TH>(cols, w, x, cs, off + gw * kWave, gw, lane, LD, rs0, a);
+#pragma unroll
+    for (int q = 0; q < TH; ++q)
+#pragma unroll
+        for (int c = 0; c < C; ++c) y[q][c] = fma(c1[q][c], a[q][c], y[q][c]);
 }
 
 template <int NB, bool DOT, bool kEgNt = false>
@@ -807,25 +874,28 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
+    constexpr int TH = EgPass<NB>::TH;
     const SliceWalk sw = slice_walk(nslices);
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
-        double acc[T][C];
-        eg_row_product<NB, false, kEgNt>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, LD, acc);
-        {
-            const int o2 = off2[slice];
-            sell_row_range<NB, false, false, false, 1, kEgNt>(cols2, vals2, x2, nullptr, o2, (off2[slice + 1] - o2) >> 6, lane, LD, acc);
-        }
+        const int o2 = off2[slice];
+        const int w2 = (off2[slice + 1] - o2) >> 6;
+#pragma unroll 1
+        for (int rs0 = 0; rs0 < T; rs0 += TH) {
+            double acc[TH][C];
+            eg_row_product<NB, false, kEgNt, TH>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, LD, rs0, acc);
+            sell_row_part<NB, false, false, kEgNt, TH>(cols2, vals2, x2, nullptr, o2, w2, lane, LD, rs0, acc);
 #pragma unroll
-        for (int rs = 0; rs < T; ++rs) {
-            const int row = slice * kWave + rs * G + g;
-            if (row >= nrows) continue;
-            const size_t at = (size_t)row * LD + t * C;
-            store_c_stream<kEgNt, C>(y + at, acc[rs]);
-            if constexpr (DOT) {
-                double wv[C];
-                load_c<C>(dot_with + at, wv);
+            for (int q = 0; q < TH; ++q) {
+                const int row = slice * kWave + (rs0 + q) * G + g;
+                if (row >= nrows) continue;
+                const size_t at = (size_t)row * LD + t * C;
+                store_c_stream<kEgNt, C>(y + at, acc[q]);
+                if constexpr (DOT) {
+                    double wv[C];
+                    load_c<C>(dot_with + at, wv);
 #pragma unroll
-                for (int c = 0; c < C; ++c) p[c] = fma(wv[c], acc[rs][c], p[c]);
+                    for (int c = 0; c < C; ++c) p[c] = fma(wv[c], acc[q][c], p[c]);
+                }
             }
         }
     }
@@ -851,24 +921,28 @@ __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices
     double p[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] = 0.0;
+    constexpr int TH = EgPass<NB>::TH;
     const SliceWalk sw = slice_walk(nslices);
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
-        double acc[T][C];
-        eg_row_product<NB, true, kEgNt>(cols, w, e12, coef, gw, r, dinv, nrows, slice, lane, LD, acc);
+#pragma unroll 1
+        for (int rs0 = 0; rs0 < T; rs0 += TH) {
+            double acc[TH][C];
+            eg_row_product<NB, true, kEgNt, TH>(cols, w, e12, coef, gw, r, dinv, nrows, slice, lane, LD, rs0, acc);
 #pragma unroll
-        for (int rs = 0; rs < T; ++rs) {
-            const int row = slice * kWave + rs * G + g;
-            if (row >= nrows) continue;
-            const size_t at = (size_t)row * LD + t * C;
-            double rv[C], di[C], xv[C];
-            load_c<C>(r + at, rv);
-            load_c<C>(dinv + at, di);
+            for (int q = 0; q < TH; ++q) {
+                const int row = slice * kWave + (rs0 + q) * G + g;
+                if (row >= nrows) continue;
+                const size_t at = (size_t)row * LD + t * C;
+                double rv[C], di[C], xv[C];
+                load_c<C>(r + at, rv);
+                load_c<C>(dinv + at, di);
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                xv[c] = di[c] * (c0 * rv[c] - c1 * acc[rs][c]);
-                if constexpr (DOT) p[c] = fma(rv[c], xv[c], p[c]);
+                for (int c = 0; c < C; ++c) {
+                    xv[c] = di[c] * (c0 * rv[c] - c1 * acc[q][c]);
+                    if constexpr (DOT) p[c] = fma(rv[c], xv[c], p[c]);
+                }
+                store_c_stream<kEgNt, C>(xout + at, xv);
             }
-            store_c_stream<kEgNt, C>(xout + at, xv);
         }
     }
     if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
