@@ -11,11 +11,18 @@ h = build_hierarchy(box_mesh([4, 4, 4], [2, 2, 2], "hex"), 4)
 sp = build_sampler_problem(h, corlen=0.1, lognormal=True, n_mc_levels=3)
 dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], n_mc_levels=3)
 ns = [int(x) for x in os.environ.get("C3_NS", "64,256,1024").split(",")]
+okw = {}
+if os.environ.get("C3_SMOOTH"):        # V-cycle smoothing degree (and optionally its interval ratio: "1" or "1:4")
+    parts = os.environ["C3_SMOOTH"].split(":")
+    okw["mg_smooth_degree"] = int(parts[0])
+    if len(parts) > 1:
+        okw["mg_smooth_ratio"] = float(parts[1])
+opts = capi.solver_opts(**okw) if okw else None
 for arg in sys.argv[1:] or ["4:32"]:
     lanes, batch = (int(x) for x in arg.split(":"))
     ctxs = [capi.Context(0, seed=20261003) for _ in range(lanes)]
-    sm = [capi.PDESampler(c, sp) for c in ctxs]
-    dr = [capi.DarcySolver(c, dp) for c in ctxs]
+    sm = [capi.PDESampler(c, sp, opts) for c in ctxs]
+    dr = [capi.DarcySolver(c, dp, opts) for c in ctxs]
     mgr = host_api.MLMCManager(3, sampler=sm[0], solver=dr[0], wall_time=True, batch=batch)
     for i in range(1, lanes):
         mgr.add_lane(sm[i], dr[i])
