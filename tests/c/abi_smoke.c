@@ -30,11 +30,13 @@ static double rel_err(const double* a, const double* b, size_t n) {
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: abi_smoke problem.bin\n"); return 2; }
     t_problem p = t_load(argv[1]);
-    printf("pmc version %d\n", pmc_version());
+    printf("pmc version %d, ABI %d\n", pmc_version(), pmc_abi_version());
+    if (pmc_abi_version() != PMC_ABI_VERSION) { fprintf(stderr, "header / library ABI mismatch\n"); return 1; }
     pmc_ctx* ctx = NULL;
     CHECK(pmc_ctx_create(0, &ctx));
     pmc_solver_opts opts;
     pmc_solver_opts_default(&opts);
+    if (opts.abi_version != PMC_ABI_VERSION) { fprintf(stderr, "defaults carry the wrong ABI version\n"); return 1; }
     opts.rel_tol = 1e-12;
     opts.abs_tol = 1e-30;
     opts.max_iter = 400;
@@ -58,6 +60,11 @@ int main(int argc, char** argv) {
         const double e = rel_err(s, p.s_expect[l], (size_t)p.nbatch * ns);
         printf("sampler level %d: rel. error vs oracle %.2e, %d iterations, converged %d\n", l, e, st[0].iterations, st[0].converged);
         if (!(e < 1e-9) || st[0].converged != 1) return 1;
+        /* ABI 2: device time of the solve ("Sampler: Mult"), the realizations one launch carries on this level */
+        if (!(st[0].solve_ms > 0.0) || !(st[0].setup_ms > 0.0) || pmc_sampler_batch_width(smp, l) < 16) {
+            fprintf(stderr, "phase times / batch width on level %d\n", l);
+            return 1;
+        }
         /* the same through device buffers */
         void *dxi = NULL, *ds = NULL;
         CHECK(pmc_malloc(ctx, 8 * (size_t)p.nbatch * p.sl[0].n_s, &dxi));
@@ -70,6 +77,15 @@ int main(int argc, char** argv) {
         CHECK(pmc_free(ctx, dxi));
         CHECK(pmc_free(ctx, ds));
         free(s); free(s2); free(st);
+    }
+    {   /* a struct of another ABI version is refused, not misread */
+        pmc_solver_opts old = opts;
+        pmc_sampler* none = NULL;
+        old.abi_version = 1;
+        if (pmc_sampler_create(ctx, p.s_nlevels, p.s_nlevels, sl, p.alpha, p.g, p.lognormal, &old, &none) == PMC_OK) {
+            fprintf(stderr, "ABI version 1 options accepted\n");
+            return 1;
+        }
     }
     /* error paths return codes, never abort */
     if (pmc_sampler_eval(smp, p.s_nlevels, 0, 1, p.xi, p.xi, NULL, -1, 0, NULL, PMC_MEM_HOST, NULL) == PMC_OK) {
@@ -98,11 +114,25 @@ int main(int argc, char** argv) {
     for (int l = 0; l < p.d_nlevels; ++l) {
         double* Q = (double*)malloc(8 * (size_t)p.nbatch);
         double* C = (double*)malloc(8 * (size_t)p.nbatch);
-        CHECK(pmc_darcy_solve_fwd(dar, l, p.nbatch, p.k[l], Q, C, NULL, PMC_MEM_HOST, NULL));
+        pmc_stats* st = (pmc_stats*)calloc((size_t)p.nbatch, sizeof(pmc_stats));
+        const uint64_t launches0 = pmc_kernel_launches();
+        CHECK(pmc_darcy_set_operator_timing(dar, 1));
+        CHECK(pmc_darcy_solve_fwd(dar, l, p.nbatch, p.k[l], Q, C, NULL, PMC_MEM_HOST, st));
+        CHECK(pmc_darcy_set_operator_timing(dar, 0));
         const double e = rel_err(Q, p.q_expect[l], (size_t)p.nbatch);
         printf("darcy level %d: Q[0] = %.12g, rel. error vs oracle %.2e, C = %g\n", l, Q[0], e, C[0]);
         if (!(e < 1e-8) || C[0] != (double)(p.dl[l].n_u + p.dl[l].n_p)) return 1;
-        free(Q); free(C);
+        /* ABI 2: "Darcy: Build Solver" / "Darcy: Mult" device times, in-loop operator timing, launch counter */
+        double op_ms = 0.0, gap_ms = 0.0, op_bytes = 0.0;
+        int64_t op_launches = 0;
+        CHECK(pmc_darcy_operator_time(dar, &op_ms, &op_launches, &gap_ms));
+        CHECK(pmc_darcy_operator_bytes(dar, l, 16, &op_bytes));
+        if (!(st[0].solve_ms > 0.0) || !(st[0].setup_ms > 0.0) || st[0].converged != 1 || op_launches < st[0].iterations - 2 ||
+            !(op_ms > 0.0) || !(op_bytes > 0.0) || pmc_kernel_launches() <= launches0 || pmc_darcy_batch_width(dar, l) < 16) {
+            fprintf(stderr, "timers / operator timing / launch counter on Darcy level %d\n", l);
+            return 1;
+        }
+        free(Q); free(C); free(st);
     }
     pmc_darcy_destroy(dar);
     pmc_sampler_destroy(smp);
