@@ -713,6 +713,196 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
     if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
+// ------------------------------------------------------------------------------------------
+// V-cycle kernels with fp32 INTERMEDIATES (shared-value hierarchies: the sampler).  The vectors that live only inside one
+// application of the preconditioner - the pre-smoothed iterate and the residuals of a level - are stored in fp32; the
+// preconditioner's input and output, every coarse right-hand side / correction and all arithmetic stay fp64.  A
+// preconditioner whose result carries fp32-sized rounding does not limit what MINRES attains: its search directions are
+// the preconditioned vectors themselves, q = A z is formed from the z actually delivered, so the residual recurrence stays
+// consistent - measured (z rounded to fp32 after every application, cube_tet r = 4): identical iteration counts at 1e-6 ...
+// 1e-12 and fields equal to the unrounded run's to 7e-16.  What it saves is 87 MB of the 1 089 MB an iteration moves at r = 5.
+template <int C>
+__device__ __forceinline__ void load_v(const double* __restrict__ p, double (&v)[C]) { load_c<C>(p, v); }
+template <int C>
+__device__ __forceinline__ void load_v(const float* __restrict__ p, double (&v)[C]) { load_cf<C>(p, v); }
+template <int C>
+__device__ __forceinline__ void store_v(double* __restrict__ p, const double (&v)[C]) { store_c<C>(p, v); }
+template <int C>
+__device__ __forceinline__ void store_v(float* __restrict__ p, const double (&v)[C]) {
+    if constexpr (C == 1) {
+        p[0] = (float)v[0];
+    } else if constexpr (C == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2((float)v[0], (float)v[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i)
+            reinterpret_cast<float4*>(p)[i] = make_float4((float)v[4 * i], (float)v[4 * i + 1], (float)v[4 * i + 2], (float)v[4 * i + 3]);
+    }
+}
+
+// acc = A x for one slice, shared fp64 values, gathered vector of type XT (the T > 1 schedule of sell_row_range; T == 1
+// walks the slice columns one by one)
+template <int NB, typename XT>
+__device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, const double* __restrict__ vals,
+                                                 const XT* __restrict__ x, int off, int width, int lane, int LD,
+                                                 double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int g = lane / T, t = lane % T;
+#pragma unroll
+    for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
+    int slot = off + lane;
+    int cj = 0;
+    double vj = 0.0;
+    if (width > 0) {
+        cj = cols[slot];
+        vj = vals[slot];
+    }
+    for (int j = 0; j < width; ++j, slot += kWave) {
+        int cn = cj;
+        double vn = vj;
+        if (j + 1 < width) {
+            cn = cols[slot + kWave];
+            vn = vals[slot + kWave];
+        }
+        int cc[T];
+        double aa[T];
+#pragma unroll
+        for (int rs = 0; rs < T; ++rs) {
+            const int src = rs * G + g;
+            cc[rs] = (T == 1) ? cj : __shfl(cj, src, kWave);
+            aa[rs] = (T == 1) ? vj : __shfl(vj, src, kWave);
+        }
+        double xv[T][C];
+        if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rs = 0; rs < T; ++rs) load_v<C>(x + (size_t)cc[rs] * LD + t * C, xv[rs]);
+        if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[rs][c] = fma(aa[rs], xv[rs][c], acc[rs][c]);
+        cj = cn;
+        vj = vn;
+    }
+}
+
+// out = dinv (c0 r - c1 As r) (+ xadd) (+ padd_x[padd_idx]) with r of type XT (gathered and read at the own row), out of
+// type OT, xadd of type AT; DOT: partials of <dot_with, out> (dot_with fp64).  See sell_poly2_kernel.
+template <int NB, typename XT, typename OT, typename AT, bool DOT>
+__global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+                                                          const int* __restrict__ cols, const double* __restrict__ vals_scaled,
+                                                          const double* __restrict__ dinv, const XT* __restrict__ r, OT* xout,
+                                                          double c0, double c1, double* __restrict__ partial, const AT* xadd,
+                                                          const double* __restrict__ dot_with,
+                                                          const int* __restrict__ padd_idx, const double* __restrict__ padd_x,
+                                                          int ld) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int LD = row_ld<NB>(ld);
+    {
+        const int g0 = col0<NB>();
+        r += g0; xout += g0;
+        if (xadd) xadd += g0;
+        if (dot_with) dot_with += g0;
+        if (padd_x) padd_x += g0;
+        if constexpr (DOT) partial += g0;
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = lane / T, t = lane % T;
+    double p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = 0.0;
+    const SliceWalk sw = slice_walk(nslices);
+    for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
+        double acc[T][C];
+        const int off = slice_off[slice];
+        sell_row_range_t<NB, XT>(cols, vals_scaled, r, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+#pragma unroll
+        for (int rs = 0; rs < T; ++rs) {
+            const int row = slice * kWave + rs * G + g;
+            if (row >= nrows) continue;
+            const size_t at = (size_t)row * LD + t * C;
+            double rv[C], xv[C];
+            load_v<C>(r + at, rv);
+            const double di = dinv[row];
+#pragma unroll
+            for (int c = 0; c < C; ++c) xv[c] = di * (c0 * rv[c] - c1 * acc[rs][c]);
+            if (xadd) {
+                double x0[C];
+                load_v<C>(xadd + at, x0);
+#pragma unroll
+                for (int c = 0; c < C; ++c) xv[c] += x0[c];
+            }
+            if (padd_idx) {
+                double pc[C];
+                load_c<C>(padd_x + (size_t)padd_idx[row] * LD + t * C, pc);
+#pragma unroll
+                for (int c = 0; c < C; ++c) xv[c] += pc[c];
+            }
+            if constexpr (DOT) {
+                double wv[C];
+                load_c<C>(dot_with + at, wv);
+#pragma unroll
+                for (int c = 0; c < C; ++c) p[c] = fma(wv[c], xv[c], p[c]);
+            }
+            store_v<C>(xout + at, xv);
+        }
+    }
+    if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
+}
+
+// y = r - A x with x of type XT (gathered), r of type RT, y of type YT; R8: rows also summed in groups of 8 into `coarse`
+// (fp64), see sell_spmm_kernel
+template <int NB, typename XT, typename RT, typename YT, bool R8>
+__global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+                                                             const int* __restrict__ cols, const double* __restrict__ vals,
+                                                             const XT* __restrict__ x, const RT* r, YT* y,
+                                                             double* __restrict__ coarse, int ld) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    const int LD = row_ld<NB>(ld);
+    {
+        const int g0 = col0<NB>();
+        x += g0; r += g0; y += g0;
+        if constexpr (R8) coarse += g0;
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = lane / T, t = lane % T;
+    const SliceWalk sw = slice_walk(nslices);
+    for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
+        double acc[T][C];
+        const int off = slice_off[slice];
+        sell_row_range_t<NB, XT>(cols, vals, x, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+#pragma unroll
+        for (int rs = 0; rs < T; ++rs) {
+            const int row = slice * kWave + rs * G + g;
+            if (row < nrows) {
+                const size_t at = (size_t)row * LD + t * C;
+                double rv[C];
+                load_v<C>(r + at, rv);
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[rs][c] = rv[c] - acc[rs][c];
+                store_v<C>(y + at, acc[rs]);
+            } else if constexpr (R8) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
+            }
+            if constexpr (R8) {
+                double s[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    double v = acc[rs][c];
+                    v += __shfl_xor(v, T, kWave);
+                    v += __shfl_xor(v, 2 * T, kWave);
+                    v += __shfl_xor(v, 4 * T, kWave);
+                    s[c] = v;
+                }
+                if ((g & 7) == 0 && row < nrows) store_c<C>(coarse + (size_t)(row >> 3) * LD + t * C, s);
+            }
+        }
+    }
+}
+
 // y = A1 x1 + A2 x2 over the SAME rows: A1 with per-realization values, A2 with shared values (the u-rows
 // [M(k) | B^T] of the Darcy operator in one pass); DOT: partials of <dot_with, y>.
 template <int NB, bool DOT>
@@ -2351,6 +2541,53 @@ int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool d
             else
                 sell_poly2_kernel<NB, false, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         }
+    });
+    check_launch();
+    return dot_partial ? (int)g.x : 0;
+}
+
+void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, float* xout, double c0,
+                    double c1) {
+    if (As.nrows == 0) return;
+    if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_presmooth32: shared values expected");
+    const dim3 g = grid_slices(As.nslices);
+    PMC_DISPATCH_NB(nb, {
+        vc_poly2_kernel<NB, double, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+    });
+    check_launch();
+}
+
+void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out,
+                              double* coarse) {
+    if (A.nrows == 0) return;
+    if (A.bv || A.nrows % 8 != 0) throw Error(PMC_ERR_INTERNAL, "vc_residual_restrict8_32: shared values and groups of 8 rows expected");
+    const dim3 g = grid_slices(A.nslices);
+    PMC_DISPATCH_NB(nb, {
+        vc_residual_kernel<NB, float, double, float, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, coarse, nb);
+    });
+    check_launch();
+}
+
+void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res, const double* xc) {
+    if (SP.nrows == 0) return;
+    if (SP.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual_coarse32: shared values expected");
+    const dim3 g = grid_slices(SP.nslices);
+    PMC_DISPATCH_NB(nb, {
+        vc_residual_kernel<NB, double, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(SP.nrows, SP.nslices, SP.slice_off, SP.cols, SP.vals, xc, res, res, nullptr, nb);
+    });
+    check_launch();
+}
+
+int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
+                    double* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial) {
+    if (As.nrows == 0) return 0;
+    if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_postsmooth32: shared values expected");
+    const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
+    PMC_DISPATCH_NB(nb, {
+        if (dot_partial)
+            vc_poly2_kernel<NB, float, double, float, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
+        else
+            vc_poly2_kernel<NB, float, double, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;

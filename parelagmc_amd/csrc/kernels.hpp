@@ -94,6 +94,16 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
 int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
           double c0, double c1, double* dot_partial = nullptr, const double* xadd = nullptr,
           const double* dot_with = nullptr, const int* padd_idx = nullptr, const double* padd_x = nullptr);
+// V-cycle level with fp32 intermediates (shared values; see vc_poly2_kernel): pre-smoothing from zero into an fp32 iterate,
+// residual + restriction over groups of 8 rows from it (fp32 residual, fp64 coarse right-hand side), res -= (S P) xc, and the
+// post-smoothing x + xc[parent] + p2(res) -> fp64 result with the fused <r, result>
+void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, float* xout, double c0,
+                    double c1);
+void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out,
+                              double* coarse);
+void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res, const double* xc);
+int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
+                    double* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial);
 // y = A1 x1 + A2 x2 (A1 per-realization values, A2 shared values, same rows); optional fused dot
 int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, const SellView& A2, const double* x2, double* y,
               double* dot_partial, const double* dot_with);

@@ -166,6 +166,15 @@ void Multigrid::build_tails(hipStream_t st) {
     }
 }
 
+// PMC_VCYCLE_F32=0: fp64 intermediates in the V-cycle of shared-value hierarchies (A/B switch for the k::vc_* kernels)
+static bool vcycle_f32() {
+    static const bool v = [] {
+        const char* e = getenv("PMC_VCYCLE_F32");
+        return !e || atoi(e) != 0;
+    }();
+    return v;
+}
+
 double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, double* dot_partial,
                          int* dot_blocks, const std::function<void()>* side) {
     MgLevel& lv = L[l];
@@ -180,6 +189,28 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     }
     const SellView A = lv.sview();
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
+    // Shared-value level with an injection prolongator over groups of 8 (uniform refinement) and the one-pass degree-2
+    // smoothers: the iterate and the residuals of the level - vectors that live only inside this application of the
+    // preconditioner - are kept in fp32 (k::vc_* kernels; the buffers xb / res hold them).  Input, output, coarse vectors and
+    // all arithmetic stay fp64.
+    if (!last && !lv.bv && lv.has_sp && lv.p_oct && smooth_degree == 2 && lv.vals_scaled.p && vcycle_f32()) {
+        double c0, c1;
+        cheb2_coefficients(lv.lmax, smooth_ratio, &c0, &c1);
+        SellView As = A;
+        As.vals = lv.vals_scaled.p;
+        float* xf = reinterpret_cast<float*>(lv.xb.p);
+        float* resf = reinterpret_cast<float*>(lv.res.p);
+        double* out = target ? target : lv.xa.p;
+        k::vc_presmooth32(st, nb, As, lv.dinv.p, r, xf, c0, c1);
+        MgLevel& lc = L[l + 1];
+        lc.ensure(nb);
+        k::vc_residual_restrict8_32(st, nb, A, r, xf, resf, lc.r.p);
+        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, side);
+        k::vc_residual_coarse32(st, nb, view(lv.SP), resf, xc);
+        const int nblk = k::vc_postsmooth32(st, nb, As, lv.dinv.p, resf, xf, out, c0, c1, r, lv.parent.p, xc, dot_partial);
+        if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
+        return out;
+    }
     const int last_deg = lv.is_last ? lv.last_degree : coarse_degree;
     const double last_rat = lv.is_last ? lv.last_ratio : coarse_ratio;
     const double* sv = lv.scaled_ptr();   // shared (sampler) or per-realization (Darcy: fp32 storage) column-scaled values
