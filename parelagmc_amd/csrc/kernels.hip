@@ -740,9 +740,21 @@ __device__ __forceinline__ void store_v(float* __restrict__ p, const double (&v)
     }
 }
 
+template <bool NT, int C>
+__device__ __forceinline__ void store_v_stream(double* __restrict__ p, const double (&v)[C]) { store_c_stream<NT, C>(p, v); }
+template <bool NT, int C>
+__device__ __forceinline__ void store_v_stream(float* __restrict__ p, const double (&v)[C]) {
+    if constexpr (NT) {
+#pragma unroll
+        for (int i = 0; i < C; ++i) __builtin_nontemporal_store((float)v[i], p + i);
+    } else {
+        store_v<C>(p, v);
+    }
+}
+
 // acc = A x for one slice, shared fp64 values, gathered vector of type XT (the T > 1 schedule of sell_row_range; T == 1
 // walks the slice columns one by one)
-template <int NB, typename XT>
+template <int NB, typename XT, bool NT = false>
 __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, const double* __restrict__ vals,
                                                  const XT* __restrict__ x, int off, int width, int lane, int LD,
                                                  double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
@@ -756,15 +768,15 @@ __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, c
     int cj = 0;
     double vj = 0.0;
     if (width > 0) {
-        cj = cols[slot];
-        vj = vals[slot];
+        cj = load_stream<NT>(cols + slot);
+        vj = load_stream<NT>(vals + slot);
     }
     for (int j = 0; j < width; ++j, slot += kWave) {
         int cn = cj;
         double vn = vj;
         if (j + 1 < width) {
-            cn = cols[slot + kWave];
-            vn = vals[slot + kWave];
+            cn = load_stream<NT>(cols + slot + kWave);
+            vn = load_stream<NT>(vals + slot + kWave);
         }
         int cc[T];
         double aa[T];
@@ -790,7 +802,7 @@ __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, c
 
 // out = dinv (c0 r - c1 As r) (+ xadd) (+ padd_x[padd_idx]) with r of type XT (gathered and read at the own row), out of
 // type OT, xadd of type AT; DOT: partials of <dot_with, out> (dot_with fp64).  See sell_poly2_kernel.
-template <int NB, typename XT, typename OT, typename AT, bool DOT>
+template <int NB, typename XT, typename OT, typename AT, bool DOT, bool NT = false>
 __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                           const int* __restrict__ cols, const double* __restrict__ vals_scaled,
                                                           const double* __restrict__ dinv, const XT* __restrict__ r, OT* xout,
@@ -817,7 +829,7 @@ __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
         const int off = slice_off[slice];
-        sell_row_range_t<NB, XT>(cols, vals_scaled, r, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+        sell_row_range_t<NB, XT, NT>(cols, vals_scaled, r, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
@@ -846,7 +858,7 @@ __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices
 #pragma unroll
                 for (int c = 0; c < C; ++c) p[c] = fma(wv[c], xv[c], p[c]);
             }
-            store_v<C>(xout + at, xv);
+            store_v_stream<NT, C>(xout + at, xv);
         }
     }
     if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
@@ -2552,7 +2564,10 @@ void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* di
     if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_presmooth32: shared values expected");
     const dim3 g = grid_slices(As.nslices);
     PMC_DISPATCH_NB(nb, {
-        vc_poly2_kernel<NB, double, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+        if (nt_poly(As, NB))
+            vc_poly2_kernel<NB, double, float, float, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+        else
+            vc_poly2_kernel<NB, double, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
     });
     check_launch();
 }
@@ -2584,7 +2599,12 @@ int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* di
     if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_postsmooth32: shared values expected");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
-        if (dot_partial)
+        if (nt_poly(As, NB)) {
+            if (dot_partial)
+                vc_poly2_kernel<NB, float, double, float, true, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
+            else
+                vc_poly2_kernel<NB, float, double, float, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
+        } else if (dot_partial)
             vc_poly2_kernel<NB, float, double, float, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
         else
             vc_poly2_kernel<NB, float, double, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
