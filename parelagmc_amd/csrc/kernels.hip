@@ -754,7 +754,7 @@ __device__ __forceinline__ void store_v_stream(float* __restrict__ p, const doub
 
 // acc = A x for one slice, shared fp64 values, gathered vector of type XT (the T > 1 schedule of sell_row_range; T == 1
 // walks the slice columns one by one)
-template <int NB, typename XT, bool NT = false>
+template <int NB, typename XT, bool NT = false, int BV = 0>
 __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, const double* __restrict__ vals,
                                                  const XT* __restrict__ x, int off, int width, int lane, int LD,
                                                  double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
@@ -769,14 +769,14 @@ __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, c
     double vj = 0.0;
     if (width > 0) {
         cj = load_stream<NT>(cols + slot);
-        vj = load_stream<NT>(vals + slot);
+        if constexpr (BV == 0) vj = load_stream<NT>(vals + slot);
     }
     for (int j = 0; j < width; ++j, slot += kWave) {
         int cn = cj;
         double vn = vj;
         if (j + 1 < width) {
             cn = load_stream<NT>(cols + slot + kWave);
-            vn = load_stream<NT>(vals + slot + kWave);
+            if constexpr (BV == 0) vn = load_stream<NT>(vals + slot + kWave);
         }
         int cc[T];
         double aa[T];
@@ -784,17 +784,23 @@ __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, c
         for (int rs = 0; rs < T; ++rs) {
             const int src = rs * G + g;
             cc[rs] = (T == 1) ? cj : __shfl(cj, src, kWave);
-            aa[rs] = (T == 1) ? vj : __shfl(vj, src, kWave);
+            if constexpr (BV == 0) aa[rs] = (T == 1) ? vj : __shfl(vj, src, kWave);
         }
-        double xv[T][C];
+        double xv[T][C], av[T][C];
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rs = 0; rs < T; ++rs) load_v<C>(x + (size_t)cc[rs] * LD + t * C, xv[rs]);
+        for (int rs = 0; rs < T; ++rs) {
+            load_v<C>(x + (size_t)cc[rs] * LD + t * C, xv[rs]);
+            if constexpr (BV != 0) load_bv<BV, C>(vals, (size_t)(slot - lane + rs * G + g) * LD + t * C, av[rs]);
+        }
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs)
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[rs][c] = fma(aa[rs], xv[rs][c], acc[rs][c]);
+            for (int c = 0; c < C; ++c) {
+                if constexpr (BV != 0) acc[rs][c] = fma(av[rs][c], xv[rs][c], acc[rs][c]);
+                else acc[rs][c] = fma(aa[rs], xv[rs][c], acc[rs][c]);
+            }
         cj = cn;
         vj = vn;
     }
@@ -802,7 +808,7 @@ __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, c
 
 // out = dinv (c0 r - c1 As r) (+ xadd) (+ padd_x[padd_idx]) with r of type XT (gathered and read at the own row), out of
 // type OT, xadd of type AT; DOT: partials of <dot_with, out> (dot_with fp64).  See sell_poly2_kernel.
-template <int NB, typename XT, typename OT, typename AT, bool DOT, bool NT = false>
+template <int NB, typename XT, typename OT, typename AT, bool DOT, bool NT = false, int BV = 0>
 __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                           const int* __restrict__ cols, const double* __restrict__ vals_scaled,
                                                           const double* __restrict__ dinv, const XT* __restrict__ r, OT* xout,
@@ -815,6 +821,7 @@ __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices
     {
         const int g0 = col0<NB>();
         r += g0; xout += g0;
+        if constexpr (BV != 0) { vals_scaled = shift_bv<BV>(vals_scaled, g0); dinv += g0; }
         if (xadd) xadd += g0;
         if (dot_with) dot_with += g0;
         if (padd_x) padd_x += g0;
@@ -829,17 +836,23 @@ __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
         const int off = slice_off[slice];
-        sell_row_range_t<NB, XT, NT>(cols, vals_scaled, r, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+        sell_row_range_t<NB, XT, NT, BV>(cols, vals_scaled, r, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
             if (row >= nrows) continue;
             const size_t at = (size_t)row * LD + t * C;
-            double rv[C], xv[C];
+            double rv[C], xv[C], di[C];
             load_v<C>(r + at, rv);
-            const double di = dinv[row];
+            if constexpr (BV != 0) {
+                load_c<C>(dinv + at, di);
+            } else {
+                const double sdi = dinv[row];
 #pragma unroll
-            for (int c = 0; c < C; ++c) xv[c] = di * (c0 * rv[c] - c1 * acc[rs][c]);
+                for (int c = 0; c < C; ++c) di[c] = sdi;
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) xv[c] = di[c] * (c0 * rv[c] - c1 * acc[rs][c]);
             if (xadd) {
                 double x0[C];
                 load_v<C>(xadd + at, x0);
@@ -866,16 +879,20 @@ __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices
 
 // y = r - A x with x of type XT (gathered), r of type RT, y of type YT; R8: rows also summed in groups of 8 into `coarse`
 // (fp64), see sell_spmm_kernel
-template <int NB, typename XT, typename RT, typename YT, bool R8>
+// BV: 0 shared fp64 values, 2 per-realization fp32 values; STORE = false: only the restricted sums are wanted (y unused)
+template <int NB, typename XT, typename RT, typename YT, bool R8, int BV = 0, bool STORE = true>
 __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                              const int* __restrict__ cols, const double* __restrict__ vals,
                                                              const XT* __restrict__ x, const RT* r, YT* y,
                                                              double* __restrict__ coarse, int ld) {
+    static_assert(STORE || R8, "a residual that is neither stored nor restricted");
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int LD = row_ld<NB>(ld);
     {
         const int g0 = col0<NB>();
-        x += g0; r += g0; y += g0;
+        x += g0; r += g0;
+        if constexpr (STORE) y += g0;
+        if constexpr (BV != 0) vals = shift_bv<BV>(vals, g0);
         if constexpr (R8) coarse += g0;
     }
     const int lane = threadIdx.x & (kWave - 1);
@@ -884,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nsli
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
         const int off = slice_off[slice];
-        sell_row_range_t<NB, XT>(cols, vals, x, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+        sell_row_range_t<NB, XT, false, BV>(cols, vals, x, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
@@ -894,7 +911,7 @@ __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nsli
                 load_v<C>(r + at, rv);
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[rs][c] = rv[c] - acc[rs][c];
-                store_v<C>(y + at, acc[rs]);
+                if constexpr (STORE) store_v<C>(y + at, acc[rs]);
             } else if constexpr (R8) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
@@ -913,6 +930,25 @@ __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nsli
             }
         }
     }
+}
+
+// x (fp32) += xc[row >> 3] (fp64): the coarse correction of a prolongator over groups of 8 consecutive rows
+template <int NB>
+__global__ __launch_bounds__(kBlock) void vc_prolong8_kernel(size_t nflat, float* __restrict__ x, const double* __restrict__ xc,
+                                                             int ld) {
+    constexpr int C = Lay<NB>::C;
+    const int W = row_ld<NB>(ld);
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nflat) return;
+    const size_t e = i * C;
+    const size_t row = e / W;
+    const int k0 = (int)(e % W);
+    double xv[C], cv[C];
+    load_cf<C>(x + e, xv);
+    load_c<C>(xc + (row >> 3) * W + k0, cv);
+#pragma unroll
+    for (int c = 0; c < C; ++c) xv[c] += cv[c];
+    store_v<C>(x + e, xv);
 }
 
 // y = A1 x1 + A2 x2 over the SAME rows: A1 with per-realization values, A2 with shared values (the u-rows
@@ -2608,6 +2644,59 @@ int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* di
             vc_poly2_kernel<NB, float, double, float, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
         else
             vc_poly2_kernel<NB, float, double, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
+    });
+    check_launch();
+    return dot_partial ? (int)g.x : 0;
+}
+
+// ---- the same level with per-realization fp32 values (Darcy; SellView::f32) and per-realization diagonals
+void vc_presmooth32_bv(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, float* xout, double c0,
+                       double c1) {
+    if (As.nrows == 0) return;
+    if (!(As.bv && As.f32)) throw Error(PMC_ERR_INTERNAL, "vc_presmooth32_bv: per-realization fp32 values expected");
+    const dim3 g = grid_slices(As.nslices);
+    PMC_DISPATCH_NB(nb, {
+        vc_poly2_kernel<NB, double, float, float, false, false, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+    });
+    check_launch();
+}
+
+void vc_restrict8_32_bv(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, double* coarse) {
+    if (A.nrows == 0) return;
+    if (!(A.bv && A.f32) || A.nrows % 8 != 0) throw Error(PMC_ERR_INTERNAL, "vc_restrict8_32_bv: operand mismatch");
+    const dim3 g = grid_slices(A.nslices);
+    PMC_DISPATCH_NB(nb, {
+        vc_residual_kernel<NB, float, double, float, true, 2, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, nullptr, coarse, nb);
+    });
+    check_launch();
+}
+
+void vc_prolong8_32(hipStream_t st, int nb, int n, float* x, const double* xc) {
+    if (n == 0) return;
+    PMC_DISPATCH_NB(nb, { vc_prolong8_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), x, xc, nb); });
+    check_launch();
+}
+
+void vc_residual32_bv(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out) {
+    if (A.nrows == 0) return;
+    if (!(A.bv && A.f32)) throw Error(PMC_ERR_INTERNAL, "vc_residual32_bv: per-realization fp32 values expected");
+    const dim3 g = grid_slices(A.nslices);
+    PMC_DISPATCH_NB(nb, {
+        vc_residual_kernel<NB, float, double, float, false, 2><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
+    });
+    check_launch();
+}
+
+int vc_postsmooth32_bv(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
+                       double* xout, double c0, double c1, const double* r, double* dot_partial) {
+    if (As.nrows == 0) return 0;
+    if (!(As.bv && As.f32)) throw Error(PMC_ERR_INTERNAL, "vc_postsmooth32_bv: per-realization fp32 values expected");
+    const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
+    PMC_DISPATCH_NB(nb, {
+        if (dot_partial)
+            vc_poly2_kernel<NB, float, double, float, true, false, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, nullptr, nullptr, nb);
+        else
+            vc_poly2_kernel<NB, float, double, float, false, false, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, nullptr, nullptr, nb);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;

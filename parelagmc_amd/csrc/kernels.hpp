@@ -104,6 +104,15 @@ void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const d
 void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res, const double* xc);
 int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
                     double* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial);
+// ... and for a level with per-realization fp32 values and diagonals (Darcy; no S P: the coarse correction is added to the
+// fp32 iterate, then residual and post-smoothing): the fine residual of the restriction is never stored
+void vc_presmooth32_bv(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, float* xout, double c0,
+                       double c1);
+void vc_restrict8_32_bv(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, double* coarse);
+void vc_prolong8_32(hipStream_t st, int nb, int n, float* x, const double* xc);
+void vc_residual32_bv(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out);
+int vc_postsmooth32_bv(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
+                       double* xout, double c0, double c1, const double* r, double* dot_partial);
 // y = A1 x1 + A2 x2 (A1 per-realization values, A2 shared values, same rows); optional fused dot
 int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, const SellView& A2, const double* x2, double* y,
               double* dot_partial, const double* dot_with);

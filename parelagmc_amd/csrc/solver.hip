@@ -211,6 +211,28 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
         return out;
     }
+    // The same for a per-realization level with fp32 values (Darcy): pre-smoothing into an fp32 iterate, restriction of its
+    // residual without storing the fine residual (nothing reads it: there is no S P for per-realization values), the coarse
+    // correction added to the fp32 iterate, residual (fp32) and post-smoothing from it.
+    if (!last && lv.bv && lv.f32 && lv.p_oct && smooth_degree == 2 && lv.scaled32.p && vcycle_f32()) {
+        double c0, c1;
+        cheb2_coefficients(lv.lmax, smooth_ratio, &c0, &c1);
+        SellView As = A;
+        As.vals = lv.scaled_ptr();
+        float* xf = reinterpret_cast<float*>(lv.xb.p);
+        float* df = reinterpret_cast<float*>(lv.d.p);
+        double* out = target ? target : lv.xa.p;
+        k::vc_presmooth32_bv(st, nb, As, lv.dinv.p, r, xf, c0, c1);
+        MgLevel& lc = L[l + 1];
+        lc.ensure(nb);
+        k::vc_restrict8_32_bv(st, nb, A, r, xf, lc.r.p);
+        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, side);
+        k::vc_prolong8_32(st, nb, lv.n, xf, xc);
+        k::vc_residual32_bv(st, nb, A, r, xf, df);
+        const int nblk = k::vc_postsmooth32_bv(st, nb, As, lv.dinv.p, df, xf, out, c0, c1, r, dot_partial);
+        if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
+        return out;
+    }
     const int last_deg = lv.is_last ? lv.last_degree : coarse_degree;
     const double last_rat = lv.is_last ? lv.last_ratio : coarse_ratio;
     const double* sv = lv.scaled_ptr();   // shared (sampler) or per-realization (Darcy: fp32 storage) column-scaled values
