@@ -73,31 +73,40 @@ def solver_bytes_per_iteration(problem, nb):
     import scipy.sparse as sp
     L = problem.levels
     V = 8.0 * nb
+    Z = float(z_bytes()) * nb      # a preconditioned vector z (fp32 storage unless the library is a -DPMC_Z64 build)
+    F = 4.0 * nb                   # an fp32 intermediate of the V-cycle (iterate, residual)
 
     def mat(nnz, nrows):
         return 12.0 * nnz + 4.0 * nrows
 
     n_u, n_s = L[0].n_u, L[0].n_s
     n = n_u + n_s
-    total = mat(L[0].nnz, n) + V * 2 * n                      # K5: q = A u (the dot takes u from the gathers)
+    total = mat(L[0].nnz, n) + (Z + V) * n                    # K5: q = A u (u is a z; the dot takes u from the gathers)
     total += V * 4 * n                                         # v_new = c0 q + c1 v1 + c2 v0
-    total += mat(L[0].M.nnz, n_u) + 8.0 * n_u + V * 2 * n_u    # M-block: one-pass degree-2 polynomial
-    total += V * (4 + 5) / 4.0 * n_s                           # w / x updates on the s-block, four iterations per pass (kWxDefer):
-    #                                                            reads 4 u + w0 + w1 + x, writes w0 + w1 + x = 9 streams per 4 iterations
+    total += mat(L[0].M.nnz, n_u) + 8.0 * n_u + (V + Z) * n_u  # M-block: one-pass degree-2 polynomial, r in, z out
+    total += (4 * Z + 5 * V) / 4.0 * n_s                       # w / x updates on the s-block, four iterations per pass (kWxDefer):
+    #                                                            reads 4 u + w0 + w1 + x, writes w0 + w1 + x per 4 iterations
     # V-cycle on the Schur block, level by level until the first level handled by the LDS tail (<= ~6k rows) / last level
     for lv in range(len(L)):
         ns_l = L[lv].n_s
+        out = Z if lv == 0 else V                              # the cycle's result is the s-block of z
         if ns_l <= 6000 or lv == len(L) - 1:
-            total += V * 2 * ns_l                              # tail: r in, x out (matrices of the tail levels stay in L2)
+            total += (V + out) * ns_l                          # tail: r in, x out (matrices of the tail levels stay in L2)
             break
         B = L[lv].B.tocsr()
         nnzS = ((abs(B) @ abs(B).T) + sp.identity(ns_l)).nnz   # pattern of aW + B diag(M)^-1 B^T
         nc = L[lv + 1].n_s
-        total += mat(nnzS, ns_l) + 8.0 * ns_l + V * 2 * ns_l           # pre-smoothing (one pass)
-        total += mat(nnzS, ns_l) + V * (3 * ns_l + nc)                 # residual with the restriction fused in (octree P)
-        total += mat(nnzS, ns_l) + V * (2 * ns_l + nc)                 # res - (S P) xc   (S P has the pattern of S)
-        total += mat(nnzS, ns_l) + 12.0 * ns_l + V * (4 * ns_l + nc)   # post-smoothing + coarse correction + dot
+        # fp32 intermediates (k::vc_* kernels): the level's iterate x and residual live in fp32
+        total += mat(nnzS, ns_l) + 8.0 * ns_l + (V + F) * ns_l                 # pre-smoothing (one pass): r in, x out
+        total += mat(nnzS, ns_l) + (V + 2 * F) * ns_l + V * nc                 # residual (r, x in; res out) + fused restriction
+        total += mat(nnzS, ns_l) + 2 * F * ns_l + V * nc                       # res - (S P) xc   (S P has the pattern of S)
+        total += mat(nnzS, ns_l) + 12.0 * ns_l + (2 * F + V + out) * ns_l + V * nc   # post-smoothing + coarse correction + dot
     return total
+
+
+def z_bytes():
+    from parelagmc_amd import capi
+    return int(capi.load_library().pmc_krylov_z_bytes())
 
 
 def lib_sha256():
@@ -224,15 +233,17 @@ def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters
     # profiles/rNN_bench_s1_kernel_stats.csv) and is reported beside the headline, never as it.
     raw_ms = solo_ms / solo_launches if solo_launches > 0 else k_ms
     gap = gap_ms / solo_launches if solo_launches > 0 else 0.0
-    ach = k_bytes / (raw_ms * 1e-3) / 1e9
+    # the in-loop launches read their input - a preconditioned vector - in its storage width (fp32), the isolated ones fp64
+    loop_bytes = k_bytes - nb * (8.0 - z_bytes()) * (L.n_u + L.n_s)
+    ach = loop_bytes / (raw_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, 0, 0, true, 1, ...> (tag 1 = block operator K5 as launched "
                                      "by the MINRES loop: fused <u, Au>, diagonal-last, non-temporal streams by size; one lane "
                                      "alone on the GPU; profile rows with this prefix)",
            "achieved": ach, "peak": PEAK_GBS, "unit": "GB/s", "frac": ach / PEAK_GBS,
            "traffic": traffic_entry(f"r{refine}_nb{nb}_inloop"), "traffic_provenance": traffic_provenance(),
-           "bytes_per_launch": k_bytes, "avg_kernel_ms": raw_ms, "launches": solo_launches,
+           "bytes_per_launch": loop_bytes, "avg_kernel_ms": raw_ms, "launches": solo_launches,
            "timing": "raw HIP-event bracket around every in-loop launch",
-           "event_overhead_ms": gap, "frac_net_of_event_overhead": k_bytes / (max(raw_ms - gap, 1e-9) * 1e-3) / 1e9 / PEAK_GBS,
+           "event_overhead_ms": gap, "frac_net_of_event_overhead": loop_bytes / (max(raw_ms - gap, 1e-9) * 1e-3) / 1e9 / PEAK_GBS,
            "isolated": {"kernel": f"pmc::sell_spmm_kernel<{nb}, 0, 0, false, 2, ...> launched back to back",
                         "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "frac": k_bytes / (k_ms * 1e-3) / 1e9 / PEAK_GBS,
                         "avg_kernel_ms": k_ms, "traffic": traffic_entry(f"r{refine}_nb{nb}")},

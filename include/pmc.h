@@ -138,6 +138,10 @@ typedef struct pmc_darcy_level {
 int pmc_version(void);
 #define PMC_ABI_VERSION 2 /* layout of pmc_solver_opts / pmc_stats; 2: abi_version field, solve_ms / setup_ms */
 int pmc_abi_version(void); /* the library's PMC_ABI_VERSION */
+/* bytes per entry of the PRECONDITIONED Krylov vectors inside the MINRES solves (4: fp32 storage, fp64 arithmetic; 8 in a
+ * -DPMC_Z64 build).  The byte counts pmc_sampler_apply_operator reports are for fp64 input; the launches inside the solver loop
+ * read their input vector at this width. */
+int pmc_krylov_z_bytes(void);
 /* kernels launched by this process through the library so far (all handles, all host threads): launch-rate diagnostics */
 uint64_t pmc_kernel_launches(void);
 const char* pmc_last_error(void);
@@ -239,7 +243,7 @@ int pmc_darcy_batch_width(const pmc_darcy* d, int level);  /* as pmc_sampler_bat
  * and clears the accumulated bracket time, the launch count and the sum of the empty brackets [ms];
  * pmc_darcy_operator_bytes gives the ALGORITHMIC bytes of one such launch for nbatch realizations: element-grouped M(k)
  * 12 B per stored slot + 8 B per dof (coefficient rows) + the coefficient table (n_p + 1) x nbatch x 8, B^T 12 B per nonzero,
- * 4 B per row, vectors 8 nbatch (2 n_u + n_p). */
+ * 4 B per row, vectors nbatch (z (n_u + n_p) + 8 n_u) with z = pmc_krylov_z_bytes(). */
 int pmc_darcy_set_operator_timing(pmc_darcy* d, int on);
 int pmc_darcy_operator_time(pmc_darcy* d, double* total_ms, int64_t* launches, double* event_overhead_ms);
 int pmc_darcy_operator_bytes(const pmc_darcy* d, int level, int nbatch, double* bytes);

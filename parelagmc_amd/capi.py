@@ -63,6 +63,7 @@ SYMBOLS = {
     "pmc_last_error": (C.c_char_p, []),
     "pmc_solver_opts_default": (None, [C.POINTER(pmc_solver_opts)]),
     "pmc_abi_version": (C.c_int, []),
+    "pmc_krylov_z_bytes": (C.c_int, []),
     "pmc_kernel_launches": (C.c_uint64, []),
     "pmc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "pmc_ctx_destroy": (None, [_VP]),

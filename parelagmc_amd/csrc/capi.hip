@@ -103,6 +103,7 @@ extern "C" {
 
 int pmc_version(void) { return 100; }
 int pmc_abi_version(void) { return PMC_ABI_VERSION; }
+int pmc_krylov_z_bytes(void) { return (int)sizeof(pmc::zreal); }
 uint64_t pmc_kernel_launches(void) { return kernel_launch_count(); }
 const char* pmc_last_error(void) { return g_last_error.c_str(); }
 

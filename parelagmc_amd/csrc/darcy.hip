@@ -484,8 +484,9 @@ double Darcy::operator_bytes(int level, int nb) const {
     // (8 B), the coefficient table once ((n_p + 1) x nb doubles); otherwise 4 B per column index + 8 nb B per value.  B^T: 12 B
     // per nonzero.  4 B per row of slice offsets.  Vectors: x_u and x_p read, y_u written (the dot takes x_u from the same read).
     const DarcyLevel& d = lv[level];
-    const double V = 8.0 * nb;
-    double b = 12.0 * (double)d.Bt.nnz + 4.0 * d.n_u + V * (2.0 * d.n_u + d.n_p);
+    // the input is a preconditioned vector (zreal storage), the result fp64
+    const double V = 8.0 * nb, Z = (double)sizeof(zreal) * nb;
+    double b = 12.0 * (double)d.Bt.nnz + 4.0 * d.n_u + Z * ((double)d.n_u + d.n_p) + V * d.n_u;
     if (use_eg(d)) b += 12.0 * (double)d.Meg.nslots + 8.0 * d.n_u + V * (d.n_p + 1.0);
     else b += (4.0 + V) * (double)d.M.nnz;
     return b;
@@ -660,29 +661,29 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     A.n = n;
     A.n0 = n_u;
     OpTimer* tm = &op_timer;
-    A.apply = [=](const Lanes& L, int nb_, const double* x, double* y, double* partial, double* partial2) {
+    // (the Darcy solves start from zero: only the product from a preconditioned vector is ever needed)
+    A.apply_z = [=](const Lanes& L, int nb_, const zreal* x, double* y, double* partial, double* partial2) {
         // u-rows: M(k) x_u + B^T x_p in one pass; p-rows: B x_u (beside it on the second stream); <x, Ax> fused into both
-        const double* xp = x + (size_t)n_u * nb_;
+        const zreal* xp = x + (size_t)n_u * nb_;
         const bool timed = tm->on && partial != nullptr;      // the in-loop launches (fused dot) only
         if (timed) tm->begin(L.main);                          // timed: the p-rows follow on the same stream, not beside it
         else L.fork();
-        const int nu_blk = eg ? k::eg_pair_spmm(L.main, nb_, Mg, coefp, x, Btv, xp, y, partial, x)
-                              : k::pair_spmm(L.main, nb_, Mv, x, Btv, xp, y, partial, x);
+        const int nu_blk = eg ? k::eg_pair_spmm_z(L.main, nb_, Mg, coefp, x, Btv, xp, y, partial, x)
+                              : k::pair_spmm_z(L.main, nb_, Mv, x, Btv, xp, y, partial, x);
         if (timed) tm->end(L.main);
-        const int np_blk = k::spmm(timed ? L.main : L.side(), nb_, Bv, x, y + (size_t)n_u * nb_, false, partial2, xp);
+        const int np_blk = k::spmm_z(timed ? L.main : L.side(), nb_, Bv, x, y + (size_t)n_u * nb_, partial2, xp);
         if (!timed) L.join();
         return k::DotParts{partial, nu_blk, partial2, np_blk};
     };
     ChebParams cpM{opts.cheb_degree_M > 0 ? opts.cheb_degree_M : 2, 1.0, d.ratio_M, d.mvals_scaled.p};
     const double* l1 = d.l1invM.p;
+    if (!eg && !cheb_fused(cpM, true)) cx2.ensure((size_t)n_u * nb);
     double* cxp = cx.p;
+    double* cx2p = cx2.p;
     double* cdp = cd.p;
     Multigrid* mgp = chain ? &chain->mg : &mg;
     const int mg_l0 = chain ? 0 : level;
-    PrecFn prec = [=](const Lanes& L, int nb_, const double* r, double* z, double* dot_partial, double* dot_partial2) {
-        const int flips = cheb_flips(cpM, true);
-        double* start = (flips % 2 == 0) ? z : cxp;
-        double* other = (flips % 2 == 0) ? cxp : z;
+    PrecFn prec = [=](const Lanes& L, int nb_, const double* r, zreal* z, double* dot_partial, double* dot_partial2) {
         // independent diagonal blocks: V-cycle of the S-block on the main stream, the M-block polynomial on the second
         // stream beside the V-cycle's coarse levels (see the sampler's preconditioner)
         int nblk_u = 0;
@@ -691,13 +692,12 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
             if (eg) {
                 double c0, c1;
                 cheb2_coefficients(cpM.lmax, cpM.ratio, &c0, &c1);
-                nblk_u = k::eg_poly2(L.side(), nb_, Mg, coefp, l1, r, z, c0, c1, dot_partial2);
+                nblk_u = k::eg_poly2_z(L.side(), nb_, Mg, coefp, l1, r, z, c0, c1, dot_partial2);
             } else {
-                double* res = cheb_apply(L.side(), nb_, Mv, l1, true, cpM, r, start, other, cdp, true, dot_partial2, &nblk_u);
-                if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
+                nblk_u = cheb_apply_z(L.side(), nb_, Mv, l1, true, cpM, r, z, cxp, cx2p, cdp, dot_partial2);
             }
         };
-        const int nblk_s = mgp->vcycle(L.main, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_, dot_partial, m_block);
+        const int nblk_s = mgp->vcycle_z(L.main, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_, dot_partial, m_block);
         L.join();
         return k::DotParts{dot_partial, nblk_s, dot_partial2, nblk_u};
     };
@@ -712,7 +712,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     GraphHint hint;
     hint.key = hash_mix(hash_mix(hash_mix(0xda, (uint64_t)level + 1), (uint64_t)nb), gmode ? 3 : (compact ? 1 : 2));
     hint.sig = mgp->signature(mg_l0);
-    for (const void* p : {(const void*)cx.p, (const void*)cd.p, (const void*)d.mvals.p, (const void*)d.mvals_scaled.p,
+    for (const void* p : {(const void*)cx.p, (const void*)cd.p, (const void*)cx2.p, (const void*)d.mvals.p, (const void*)d.mvals_scaled.p,
                           (const void*)d.l1invM.p, (const void*)d.rhs_bc.p})
         hint.sig = hash_ptr(hint.sig, p);
     MinresResult res = compact ? minres_solve(ctx, nb, A, prec, d.rhs_bc.p, sol_compact.p, true, opts, work, 0, ncomp,

@@ -37,7 +37,7 @@ struct Sampler {
     std::vector<std::unique_ptr<Multigrid>> amg;   // per MC level: internal smoothed-aggregation hierarchy (if selected)
     double anisotropy = 1.0;
     MinresWork work;
-    DevBuf<double> rhs, sol, tA, tB, cx, cd, stage_in, stage_out, stage_emb, mini_scratch;
+    DevBuf<double> rhs, sol, tA, tB, cx, cd, cx2, stage_in, stage_out, stage_emb, mini_scratch;
     DevBuf<pmc_stats> mini_stats;
 
     Sampler(Ctx& c, int nlevels, int n_mc, const pmc_sampler_level* in, double alpha, double g, bool lognormal,
@@ -120,7 +120,7 @@ struct Darcy {
     // <x, Ax>; k::pair_spmm when the element-grouped form is not available)
     OpTimer op_timer;
     double operator_bytes(int level, int nb) const;   // algorithmic bytes of ONE such launch
-    DevBuf<double> sol, sol_compact, cx, cd, stage_k, stage_sol, qpartial, qout, gtmp, gout;
+    DevBuf<double> sol, sol_compact, cx, cd, cx2, stage_k, stage_sol, qpartial, qout, gtmp, gout;
     bool use_eg(const DarcyLevel& d) const;
     void set_observations(int level, const pmc_csr* Gobs);
     void compute_G(int level, int nbatch, const double* k, double* G, double* C, double* Q, int memspace, pmc_stats* stats);

@@ -123,6 +123,36 @@ __device__ __forceinline__ const double* shift_bv(const double* vals, int c) {
     else return vals + c;
 }
 
+// typed vector accesses: fp64 or fp32 storage, fp64 in registers
+template <typename T>
+struct ident { using type = T; };   // keeps a parameter out of template argument deduction (nullptr arguments)
+template <int C>
+__device__ __forceinline__ void load_v(const double* __restrict__ p, double (&v)[C]) { load_c<C>(p, v); }
+template <int C>
+__device__ __forceinline__ void load_v(const float* __restrict__ p, double (&v)[C]) { load_cf<C>(p, v); }
+template <int C>
+__device__ __forceinline__ void store_v(double* __restrict__ p, const double (&v)[C]) { store_c<C>(p, v); }
+template <int C>
+__device__ __forceinline__ void store_v(float* __restrict__ p, const double (&v)[C]) {
+    if constexpr (C == 1) {
+        p[0] = (float)v[0];
+    } else if constexpr (C == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2((float)v[0], (float)v[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i)
+            reinterpret_cast<float4*>(p)[i] = make_float4((float)v[4 * i], (float)v[4 * i + 1], (float)v[4 * i + 2], (float)v[4 * i + 3]);
+    }
+}
+// values an fp32 store will keep: rounding BEFORE a fused dot keeps <., out> consistent with what is stored
+template <typename T, int C>
+__device__ __forceinline__ void round_to(double (&v)[C]) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = (double)(float)v[i];
+    }
+}
+
 // Vector streams without reuse inside the iteration (MINRES w / x updates of large levels): non-temporal variants, so that a
 // flat kernel running beside a gather kernel (second stream, other lanes) does not sweep that kernel's rows out of L2.
 // Measured at 0.6 M rows x 16: one lane 1096 -> 1112, four lanes 1446 -> 1454 samples/s; small levels keep the cached
@@ -134,6 +164,17 @@ __device__ __forceinline__ void load_c_nt(const double* __restrict__ p, double (
         for (int i = 0; i < C; ++i) v[i] = __builtin_nontemporal_load(p + i);
     } else {
         load_c<C>(p, v);
+    }
+}
+template <bool NT, int C>
+__device__ __forceinline__ void load_v_nt(const double* __restrict__ p, double (&v)[C]) { load_c_nt<NT, C>(p, v); }
+template <bool NT, int C>
+__device__ __forceinline__ void load_v_nt(const float* __restrict__ p, double (&v)[C]) {
+    if constexpr (NT) {
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = (double)__builtin_nontemporal_load(p + i);
+    } else {
+        load_cf<C>(p, v);
     }
 }
 template <bool NT, int C>
@@ -169,6 +210,18 @@ template <bool NT>
 __device__ __forceinline__ double load_stream(const double* __restrict__ p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
+}
+
+template <bool NT, int C>
+__device__ __forceinline__ void store_v_stream(double* __restrict__ p, const double (&v)[C]) { store_c_stream<NT, C>(p, v); }
+template <bool NT, int C>
+__device__ __forceinline__ void store_v_stream(float* __restrict__ p, const double (&v)[C]) {
+    if constexpr (NT) {
+#pragma unroll
+        for (int i = 0; i < C; ++i) __builtin_nontemporal_store((float)v[i], p + i);
+    } else {
+        store_v<C>(p, v);
+    }
 }
 
 template <int NB>
@@ -262,9 +315,9 @@ __device__ __forceinline__ void reduce_flat_store(double (&p)[Lay<NB>::C], doubl
 // every row ends with its diagonal entry and is padded with zero-weight copies of it) gathers x[row] there, so a fused
 // <x, Ax> needs no second read of x - which by the end of a slice has long left the L2 (measured at 0.6 M rows: 25 MB of
 // 280 MB per launch).
-template <int NB, int BV, bool CS, bool ZERO, int JC = 1, bool NT = false>
+template <int NB, int BV, bool CS, bool ZERO, int JC = 1, bool NT = false, typename XT = double>
 __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
-                                               const double* __restrict__ x, const double* __restrict__ cs, int off,
+                                               const XT* __restrict__ x, const double* __restrict__ cs, int off,
                                                int width, int lane, int LD, double (&acc)[Lay<NB>::T][Lay<NB>::C],
                                                double (*xlast)[Lay<NB>::C] = nullptr) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
@@ -296,7 +349,7 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
             double xv[JU][C], av[JU][C], sv[JU][C];
 #pragma unroll
             for (int u = 0; u < JU; ++u) {
-                load_c<C>(x + (size_t)cc[u] * LD, xv[u]);
+                load_v<C>(x + (size_t)cc[u] * LD, xv[u]);
                 if constexpr (CS) load_c<C>(cs + (size_t)cc[u] * LD, sv[u]);
                 if constexpr (BV) load_bv<BV, C>(vals, (size_t)(j + u < width ? slot + u * kWave : slot) * LD, av[u]);
             }
@@ -358,8 +411,8 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rs = 0; rs < T; ++rs) {
-                load_c<C>(x + (size_t)cc0[rs] * LD + t * C, x0[rs]);
-                load_c<C>(x + (size_t)cc1[rs] * LD + t * C, x1[rs]);
+                load_v<C>(x + (size_t)cc0[rs] * LD + t * C, x0[rs]);
+                load_v<C>(x + (size_t)cc1[rs] * LD + t * C, x1[rs]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -406,7 +459,7 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise re-serialises load -> wait -> fma
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
-            load_c<C>(x + (size_t)cc[rs] * LD + t * C, xv[rs]);
+            load_v<C>(x + (size_t)cc[rs] * LD + t * C, xv[rs]);
             if constexpr (CS) load_c<C>(cs + (size_t)cc[rs] * LD + t * C, sv[rs]);
             if constexpr (BV) load_bv<BV, C>(vals, (size_t)(slot - lane + rs * G + g) * LD + t * C, av[rs]);
         }
@@ -431,13 +484,13 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
     }
 }
 
-template <int NB, int BV>
+template <int NB, int BV, typename XT = double>
 __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_off, const int* __restrict__ cols,
-                                                 const double* __restrict__ vals, const double* __restrict__ x,
+                                                 const double* __restrict__ vals, const XT* __restrict__ x,
                                                  int slice, int lane, int LD, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
     const int off = slice_off[slice];
     const int width = (slice_off[slice + 1] - off) >> 6;
-    sell_row_range<NB, BV, false, true>(cols, vals, x, nullptr, off, width, lane, LD, acc);
+    sell_row_range<NB, BV, false, true, 1, false, XT>(cols, vals, x, nullptr, off, width, lane, LD, acc);
 }
 
 // XCD-aware slice assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (block b runs on XCD b % 8),
@@ -473,14 +526,15 @@ __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
 // 8 i .. 8 i + 7 with unit weights (uniformly refined tetrahedra / hexahedra): a slice holds 8 whole groups, the sum is
 // a fixed xor tree over the lanes of a row step, and the separate restriction kernel (13 us of dependent latency for a
 // few MB) disappears from the V-cycle.
-template <int NB, int BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false, bool DL = false>
+// XT: storage type of x and dot_with (fp32 for the preconditioned Krylov vectors, zreal)
+template <int NB, int BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false, bool DL = false, typename XT = double>
 __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
                                                            const double* __restrict__ vals,
-                                                           const double* __restrict__ x, double* __restrict__ y,
+                                                           const XT* __restrict__ x, double* __restrict__ y,
                                                            const double* __restrict__ r,
-                                                           const double* __restrict__ dot_with,
+                                                           const typename ident<XT>::type* __restrict__ dot_with,
                                                            double* __restrict__ partial, int ld) {
     static_assert(!R8 || (MODE == 2 && !DOT), "fused restriction goes with the residual");
     const int LD = row_ld<NB>(ld);
@@ -507,16 +561,16 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
         double xd[DL ? T : 1][C];
         if constexpr (DL) {
             const int off = slice_off[slice];
-            sell_row_range<NB, false, false, true, 1, NT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane,
-                                                         LD, acc, xd);
+            sell_row_range<NB, false, false, true, 1, NT, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6,
+                                                             lane, LD, acc, xd);
         } else if constexpr (TAG != 0 && !BV && T > 1 && kK5TwoColumns) {
             const int off = slice_off[slice];
-            sell_row_range<NB, false, false, true, 2>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+            sell_row_range<NB, false, false, true, 2, false, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
         } else if constexpr (NT) {
             const int off = slice_off[slice];
-            sell_row_range<NB, BV, false, true, 1, true>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+            sell_row_range<NB, BV, false, true, 1, true, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
         } else {
-            sell_row_product<NB, BV>(slice_off, cols, vals, x, slice, lane, LD, acc);
+            sell_row_product<NB, BV, XT>(slice_off, cols, vals, x, slice, lane, LD, acc);
         }
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
@@ -540,7 +594,7 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                     for (int c = 0; c < C; ++c) p[c] = fma(xd[rs][c], acc[rs][c], p[c]);
                 } else if constexpr (DOT) {
                     double w[C];
-                    load_c<C>(dot_with + at, w);
+                    load_v<C>(dot_with + at, w);
 #pragma unroll
                     for (int c = 0; c < C; ++c) p[c] = fma(w[c], acc[rs][c], p[c]);
                 }
@@ -636,13 +690,13 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
 // 3 + 5 vector passes of cheb_first + cheb_step.  DOT: partials of <r, x2>.
 // From a NONZERO guess x0 the same polynomial acts on the residual: x2 = x0 + p2(r - A x0); then r is that residual,
 // xadd = x0 (may alias xout: no gathers on it) and the dot is taken with dot_with (the right-hand side).
-template <int NB, int BV, bool DOT, bool NT = false>
+template <int NB, int BV, bool DOT, bool NT = false, typename OT = double>
 __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                             const int* __restrict__ sched,
                                                             const int* __restrict__ cols,
                                                             const double* __restrict__ vals_scaled,
                                                             const double* __restrict__ dinv,
-                                                            const double* __restrict__ r, double* xout,
+                                                            const double* __restrict__ r, OT* xout,
                                                             double c0, double c1, double* __restrict__ partial,
                                                             const double* xadd, const double* __restrict__ dot_with,
                                                             const int* __restrict__ padd_idx,
@@ -702,12 +756,13 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
 #pragma unroll
                 for (int c = 0; c < C; ++c) xv[c] += pc[c];
             }
+            round_to<OT>(xv);
             if constexpr (DOT) {
                 if (dot_with) load_c<C>(dot_with + at, rv);
 #pragma unroll
                 for (int c = 0; c < C; ++c) p[c] = fma(rv[c], xv[c], p[c]);
             }
-            store_c_stream<NT, C>(xout + at, xv);
+            store_v_stream<NT, C>(xout + at, xv);
         }
     }
     if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
@@ -721,36 +776,6 @@ __global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslic
 // the preconditioned vectors themselves, q = A z is formed from the z actually delivered, so the residual recurrence stays
 // consistent - measured (z rounded to fp32 after every application, cube_tet r = 4): identical iteration counts at 1e-6 ...
 // 1e-12 and fields equal to the unrounded run's to 7e-16.  What it saves is 87 MB of the 1 089 MB an iteration moves at r = 5.
-template <int C>
-__device__ __forceinline__ void load_v(const double* __restrict__ p, double (&v)[C]) { load_c<C>(p, v); }
-template <int C>
-__device__ __forceinline__ void load_v(const float* __restrict__ p, double (&v)[C]) { load_cf<C>(p, v); }
-template <int C>
-__device__ __forceinline__ void store_v(double* __restrict__ p, const double (&v)[C]) { store_c<C>(p, v); }
-template <int C>
-__device__ __forceinline__ void store_v(float* __restrict__ p, const double (&v)[C]) {
-    if constexpr (C == 1) {
-        p[0] = (float)v[0];
-    } else if constexpr (C == 2) {
-        *reinterpret_cast<float2*>(p) = make_float2((float)v[0], (float)v[1]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < C / 4; ++i)
-            reinterpret_cast<float4*>(p)[i] = make_float4((float)v[4 * i], (float)v[4 * i + 1], (float)v[4 * i + 2], (float)v[4 * i + 3]);
-    }
-}
-
-template <bool NT, int C>
-__device__ __forceinline__ void store_v_stream(double* __restrict__ p, const double (&v)[C]) { store_c_stream<NT, C>(p, v); }
-template <bool NT, int C>
-__device__ __forceinline__ void store_v_stream(float* __restrict__ p, const double (&v)[C]) {
-    if constexpr (NT) {
-#pragma unroll
-        for (int i = 0; i < C; ++i) __builtin_nontemporal_store((float)v[i], p + i);
-    } else {
-        store_v<C>(p, v);
-    }
-}
 
 // acc = A x for one slice, shared fp64 values, gathered vector of type XT (the T > 1 schedule of sell_row_range; T == 1
 // walks the slice columns one by one)
@@ -865,6 +890,7 @@ __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices
 #pragma unroll
                 for (int c = 0; c < C; ++c) xv[c] += pc[c];
             }
+            round_to<OT>(xv);
             if constexpr (DOT) {
                 double wv[C];
                 load_c<C>(dot_with + at, wv);
@@ -953,12 +979,12 @@ __global__ __launch_bounds__(kBlock) void vc_prolong8_kernel(size_t nflat, float
 
 // y = A1 x1 + A2 x2 over the SAME rows: A1 with per-realization values, A2 with shared values (the u-rows
 // [M(k) | B^T] of the Darcy operator in one pass); DOT: partials of <dot_with, y>.
-template <int NB, bool DOT>
+template <int NB, bool DOT, typename XT = double>
 __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
     int nrows, int nslices, const int* __restrict__ off1, const int* __restrict__ cols1, const double* __restrict__ vals1,
     const int* __restrict__ off2, const int* __restrict__ cols2, const double* __restrict__ vals2,
-    const double* __restrict__ x1, const double* __restrict__ x2, double* __restrict__ y,
-    const double* __restrict__ dot_with, double* __restrict__ partial, int ld) {
+    const XT* __restrict__ x1, const typename ident<XT>::type* __restrict__ x2, double* __restrict__ y,
+    const typename ident<XT>::type* __restrict__ dot_with, double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int LD = row_ld<NB>(ld);
     {
@@ -974,8 +1000,8 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
     const SliceWalk sw = slice_walk(nslices);
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C], acc2[T][C];
-        sell_row_product<NB, true>(off1, cols1, vals1, x1, slice, lane, LD, acc);
-        sell_row_product<NB, false>(off2, cols2, vals2, x2, slice, lane, LD, acc2);
+        sell_row_product<NB, true, XT>(off1, cols1, vals1, x1, slice, lane, LD, acc);
+        sell_row_product<NB, false, XT>(off2, cols2, vals2, x2, slice, lane, LD, acc2);
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
@@ -986,7 +1012,7 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
             store_c<C>(y + at, acc[rs]);
             if constexpr (DOT) {
                 double w[C];
-                load_c<C>(dot_with + at, w);
+                load_v<C>(dot_with + at, w);
 #pragma unroll
                 for (int c = 0; c < C; ++c) p[c] = fma(w[c], acc[rs][c], p[c]);
             }
@@ -999,9 +1025,9 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
 // T / TH such passes keeps TH instead of T rows' accumulators, gathers and shuffled slot data alive - the element-grouped
 // kernels below, which carry two accumulators and up to three gathered vectors per row, drop from 206-246 VGPRs (two waves per
 // SIMD) to four waves per SIMD; the (index, value) pairs of the later passes come from L1.
-template <int NB, bool CS, bool ZERO, bool NT, int TH>
+template <int NB, bool CS, bool ZERO, bool NT, int TH, typename XT = double>
 __device__ __forceinline__ void sell_row_part(const int* __restrict__ cols, const double* __restrict__ vals,
-                                              const double* __restrict__ x, const double* __restrict__ cs, int off, int width,
+                                              const XT* __restrict__ x, const double* __restrict__ cs, int off, int width,
                                               int lane, int LD, int rs0, double (&acc)[TH][Lay<NB>::C]) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int g = lane / T, t = lane % T;
@@ -1037,7 +1063,7 @@ __device__ __forceinline__ void sell_row_part(const int* __restrict__ cols, cons
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < TH; ++q) {
-            load_c<C>(x + (size_t)cc[q] * LD + t * C, xv[q]);
+            load_v<C>(x + (size_t)cc[q] * LD + t * C, xv[q]);
             if constexpr (CS) load_c<C>(cs + (size_t)cc[q] * LD + t * C, sv[q]);
         }
         if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
@@ -1062,10 +1088,10 @@ struct EgPass {
 // Element-grouped per-realization mass matrix (EgView): acc = c1 * (group 1 row sums) + c2 * (group 2 row sums), for the row
 // steps rs0 .. rs0 + TH - 1 of the slice.  The two coefficient rows are requested before the sweeps they scale.
 // kEgNt: non-temporal matrix / result streams on large levels (hex 64^3, one lane: 28.2 -> 27.3 ms per 16 Darcy solves).
-template <int NB, bool CS, bool kEgNt, int TH>
+template <int NB, bool CS, bool kEgNt, int TH, typename XT = double>
 __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, const double* __restrict__ w,
                                                const int* __restrict__ e12, const double* __restrict__ coef, int gw,
-                                               const double* __restrict__ x, const double* __restrict__ cs, int nrows,
+                                               const XT* __restrict__ x, const double* __restrict__ cs, int nrows,
                                                int slice, int lane, int LD, int rs0, double (&y)[TH][Lay<NB>::C]) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int g = lane / T, t = lane % T;
@@ -1076,7 +1102,7 @@ __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, con
         const int row = min(slice * kWave + (rs0 + q) * G + g, nrows - 1);
         load_c<C>(coef + (size_t)e12[2 * row] * LD + t * C, c1[q]);
     }
-    sell_row_part<NB, CS, true, kEgNt, TH>(cols, w, x, cs, off, gw, lane, LD, rs0, a);
+    sell_row_part<NB, CS, true, kEgNt, TH, XT>(cols, w, x, cs, off, gw, lane, LD, rs0, a);
 #pragma unroll
     for (int q = 0; q < TH; ++q)
 #pragma unroll
@@ -1086,20 +1112,20 @@ __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, con
         const int row = min(slice * kWave + (rs0 + q) * G + g, nrows - 1);
         load_c<C>(coef + (size_t)e12[2 * row + 1] * LD + t * C, c1[q]);
     }
-    sell_row_part<NB, CS, true, kEgNt, TH>(cols, w, x, cs, off + gw * kWave, gw, lane, LD, rs0, a);
+    sell_row_part<NB, CS, true, kEgNt, TH, XT>(cols, w, x, cs, off + gw * kWave, gw, lane, LD, rs0, a);
 #pragma unroll
     for (int q = 0; q < TH; ++q)
 #pragma unroll
         for (int c = 0; c < C; ++c) y[q][c] = fma(c1[q][c], a[q][c], y[q][c]);
 }
 
-template <int NB, bool DOT, bool kEgNt = false>
+template <int NB, bool DOT, bool kEgNt = false, typename XT = double>
 __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
     int nrows, int nslices, int gw, const int* __restrict__ cols1, const double* __restrict__ w1,
     const int* __restrict__ e12, const double* __restrict__ coef, const int* __restrict__ off2,
-    const int* __restrict__ cols2, const double* __restrict__ vals2, const double* __restrict__ x1,
-    const double* __restrict__ x2, double* __restrict__ y, const double* __restrict__ dot_with,
-    double* __restrict__ partial, int ld) {
+    const int* __restrict__ cols2, const double* __restrict__ vals2, const XT* __restrict__ x1,
+    const typename ident<XT>::type* __restrict__ x2, double* __restrict__ y,
+    const typename ident<XT>::type* __restrict__ dot_with, double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int LD = row_ld<NB>(ld);
     {
@@ -1120,8 +1146,8 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
 #pragma unroll 1
         for (int rs0 = 0; rs0 < T; rs0 += TH) {
             double acc[TH][C];
-            eg_row_product<NB, false, kEgNt, TH>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, LD, rs0, acc);
-            sell_row_part<NB, false, false, kEgNt, TH>(cols2, vals2, x2, nullptr, o2, w2, lane, LD, rs0, acc);
+            eg_row_product<NB, false, kEgNt, TH, XT>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, LD, rs0, acc);
+            sell_row_part<NB, false, false, kEgNt, TH, XT>(cols2, vals2, x2, nullptr, o2, w2, lane, LD, rs0, acc);
 #pragma unroll
             for (int q = 0; q < TH; ++q) {
                 const int row = slice * kWave + (rs0 + q) * G + g;
@@ -1130,7 +1156,7 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
                 store_c_stream<kEgNt, C>(y + at, acc[q]);
                 if constexpr (DOT) {
                     double wv[C];
-                    load_c<C>(dot_with + at, wv);
+                    load_v<C>(dot_with + at, wv);
 #pragma unroll
                     for (int c = 0; c < C; ++c) p[c] = fma(wv[c], acc[q][c], p[c]);
                 }
@@ -1140,12 +1166,12 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
     if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
-template <int NB, bool DOT, bool kEgNt = false>
+template <int NB, bool DOT, bool kEgNt = false, typename OT = double>
 __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices, int gw, const int* __restrict__ cols,
                                                           const double* __restrict__ w, const int* __restrict__ e12,
                                                           const double* __restrict__ coef,
                                                           const double* __restrict__ dinv, const double* __restrict__ r,
-                                                          double* __restrict__ xout, double c0, double c1,
+                                                          OT* __restrict__ xout, double c0, double c1,
                                                           double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int LD = row_ld<NB>(ld);
@@ -1175,11 +1201,13 @@ __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices
                 load_c<C>(r + at, rv);
                 load_c<C>(dinv + at, di);
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    xv[c] = di[c] * (c0 * rv[c] - c1 * acc[q][c]);
-                    if constexpr (DOT) p[c] = fma(rv[c], xv[c], p[c]);
+                for (int c = 0; c < C; ++c) xv[c] = di[c] * (c0 * rv[c] - c1 * acc[q][c]);
+                round_to<OT>(xv);
+                if constexpr (DOT) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) p[c] = fma(rv[c], xv[c], p[c]);
                 }
-                store_c_stream<kEgNt, C>(xout + at, xv);
+                store_v_stream<kEgNt, C>(xout + at, xv);
             }
         }
     }
@@ -1235,7 +1263,7 @@ __global__ __launch_bounds__(kBlock) void scale_cols_bv32_kernel(size_t nflat, c
 // MINRES w / x update restricted to an index list of rows: w, x are compact [nsel][NB], u is full
 template <int NB>
 __global__ __launch_bounds__(kBlock) void minres_wx_idx_kernel(size_t nflat, const int* __restrict__ rows,
-                                                               const double* __restrict__ c0, const double* __restrict__ u,
+                                                               const double* __restrict__ c0, const zreal* __restrict__ u,
                                                                const double* __restrict__ c1, double* __restrict__ w0,
                                                                const double* __restrict__ c2, const double* __restrict__ w1,
                                                                const double* __restrict__ c3, double* __restrict__ x, int ld) {
@@ -1247,7 +1275,7 @@ __global__ __launch_bounds__(kBlock) void minres_wx_idx_kernel(size_t nflat, con
     const size_t sel = e / W;
     const int k0 = (int)(e % W);
     double uv[C], w0v[C], w1v[C], xv[C];
-    load_c<C>(u + (size_t)rows[sel] * W + k0, uv);
+    load_v<C>(u + (size_t)rows[sel] * W + k0, uv);
     load_c<C>(w0 + e, w0v);
     load_c<C>(w1 + e, w1v);
     load_c<C>(x + e, xv);
@@ -1295,9 +1323,9 @@ __global__ __launch_bounds__(kBlock) void cheb_first_kernel(size_t nflat, const 
     if constexpr (DOT) reduce_flat_store<NB>(p, partial, W);
 }
 
-template <int NB>
+template <int NB, typename BT = double>
 __global__ __launch_bounds__(kBlock) void dot_kernel(size_t nflat, const double* __restrict__ a,
-                                                     const double* __restrict__ b, double* __restrict__ partial, int ld) {
+                                                     const BT* __restrict__ b, double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C;
     double p[C];
 #pragma unroll
@@ -1306,11 +1334,36 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(size_t nflat, const double*
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nflat; i += (size_t)gridDim.x * kBlock) {
         double av[C], bv[C];
         load_c<C>(a + i * C, av);
-        load_c<C>(b + i * C, bv);
+        load_v<C>(b + i * C, bv);
 #pragma unroll
         for (int c = 0; c < C; ++c) p[c] = fma(av[c], bv[c], p[c]);
     }
     reduce_flat_store<NB>(p, partial, row_ld<NB>(ld));
+}
+
+// z = storage-rounded copy of a preconditioner result that a kernel without a typed output left in fp64, with the fused
+// <r, z> of the rounded values (the paths off the hot configurations: higher-degree smoothers, algebraic transfers)
+template <int NB, bool DOT>
+__global__ __launch_bounds__(kBlock) void convert_dot_kernel(size_t nflat, const double* __restrict__ in,
+                                                             zreal* __restrict__ out, const double* __restrict__ r,
+                                                             double* __restrict__ partial, int ld) {
+    constexpr int C = Lay<NB>::C;
+    double p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nflat; i += (size_t)gridDim.x * kBlock) {
+        double v[C];
+        load_c<C>(in + i * C, v);
+        round_to<zreal>(v);
+        if constexpr (DOT) {
+            double rv[C];
+            load_c<C>(r + i * C, rv);
+#pragma unroll
+            for (int c = 0; c < C; ++c) p[c] = fma(rv[c], v[c], p[c]);
+        }
+        store_v<C>(out + i * C, v);
+    }
+    if constexpr (DOT) reduce_flat_store<NB>(p, partial, row_ld<NB>(ld));
 }
 
 template <int NB, bool NT = false>
@@ -1334,7 +1387,7 @@ __global__ __launch_bounds__(kBlock) void lincomb3_kernel(size_t nflat, const do
 
 template <int NB, bool NT>
 __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const double* __restrict__ c0,
-                                                           const double* __restrict__ u, const double* __restrict__ c1,
+                                                           const zreal* __restrict__ u, const double* __restrict__ c1,
                                                            double* __restrict__ w0, const double* __restrict__ c2,
                                                            const double* __restrict__ w1, const double* __restrict__ c3,
                                                            double* __restrict__ x, int ld) {
@@ -1344,7 +1397,7 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const d
     const size_t e = i * C;
     const int k0 = (int)(e % row_ld<NB>(ld));
     double uv[C], w0v[C], w1v[C], xv[C];
-    load_c_nt<NT, C>(u + e, uv);
+    load_v_nt<NT, C>(u + e, uv);
     load_c_nt<NT, C>(w0 + e, w0v);
     load_c_nt<NT, C>(w1 + e, w1v);
     load_c_nt<NT, C>(x + e, xv);
@@ -1372,7 +1425,7 @@ __global__ __launch_bounds__(kBlock) void minres_wx_deferred_kernel(size_t nflat
     double uv[k::kWxDefer][C], a[C], b[C], xv[C];
 #pragma unroll
     for (int j = 0; j < k::kWxDefer; ++j)
-        if (j < B.cnt) load_c_nt<NT, C>(B.u[j] + e, uv[j]);
+        if (j < B.cnt) load_v_nt<NT, C>(B.u[j] + e, uv[j]);
     load_c_nt<NT, C>(w0 + e, a);
     load_c_nt<NT, C>(w1 + e, b);
     load_c_nt<NT, C>(x + e, xv);
@@ -2179,9 +2232,10 @@ PMC_TAIL_INLINE void tail_vcycle_lds(const TailParams& P, int nb, int k, double*
     }
 }
 
+// out32: xout points at fp32 storage (the preconditioned Krylov vectors, zreal)
 __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(const TailParams* __restrict__ pp, int nb,
                                                                const double* __restrict__ rin, double* __restrict__ xout,
-                                                               double* __restrict__ partial) {
+                                                               double* __restrict__ partial, int out32) {
     extern __shared__ __align__(16) double lds[];
     __shared__ double red[kTailThreads / kWave];
     const TailParams& P = *pp;
@@ -2197,8 +2251,15 @@ __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(const TailParams*
     const double* x0 = r0 + L0.n;
     double p = 0.0;
     for (int i = threadIdx.x; i < L0.n; i += kTailThreads) {
-        xout[(size_t)i * nb + k] = x0[i];
-        p = fma(r0[i], x0[i], p);
+        double xi = x0[i];
+        if (out32) {
+            const float xf = (float)xi;
+            reinterpret_cast<float*>(xout)[(size_t)i * nb + k] = xf;
+            xi = (double)xf;
+        } else {
+            xout[(size_t)i * nb + k] = xi;
+        }
+        p = fma(r0[i], xi, p);
     }
     if (partial) {
 #pragma unroll
@@ -2430,11 +2491,32 @@ static inline bool nt_poly(const SellView& A, int nb) {
     return limit > 0.0 && bytes > limit;
 }
 
-template <int NB, int TAG>
-static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const double* x, double* y, bool accumulate,
-                        double* dot_partial, const double* dot_with) {
+template <int NB, int TAG, typename XT>
+static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const XT* x, double* y, bool accumulate,
+                        double* dot_partial, const XT* dot_with) {
     // <x, Ax> with a diagonal-last matrix: x_i is what the row's last slice column gathers
     const bool dl = TAG == 1 && Lay<NB>::T > 1 && A.diag_last && dot_with == x;
+    if constexpr (!std::is_same<XT, double>::value) {
+        // fp32-stored input (the preconditioned Krylov vectors): the operator products of the solver loop only
+        if (A.bv || accumulate) throw Error(PMC_ERR_INTERNAL, "spmm: fp32 input with per-realization values / accumulation");
+        const bool nt = TAG != 0 && nt_streams(A, NB, dot_partial != nullptr);
+        if (nt) {
+            if (dot_partial && dl)
+                sell_spmm_kernel<NB, false, 0, true, TAG, true, false, (Lay<NB>::T > 1), XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+            else if (dot_partial)
+                sell_spmm_kernel<NB, false, 0, true, TAG, true, false, false, XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+            else
+                sell_spmm_kernel<NB, false, 0, false, TAG, true, false, false, XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+        } else {
+            if (dot_partial && dl)
+                sell_spmm_kernel<NB, false, 0, true, TAG, false, false, (Lay<NB>::T > 1), XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+            else if (dot_partial)
+                sell_spmm_kernel<NB, false, 0, true, TAG, false, false, false, XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+            else
+                sell_spmm_kernel<NB, false, 0, false, TAG, false, false, false, XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+        }
+        return;
+    } else
     if (A.bv && A.f32) {
         if (dot_partial)
             sell_spmm_kernel<NB, 2, 0, true, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
@@ -2476,8 +2558,9 @@ static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const
     }
 }
 
-int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate, double* dot_partial,
-         const double* dot_with) {
+template <typename XT>
+static int spmm_t(hipStream_t st, int nb, const SellView& A, const XT* x, double* y, bool accumulate, double* dot_partial,
+                  const XT* dot_with) {
     if (A.nrows == 0) return 0;
     if (dot_partial && !dot_with) throw Error(PMC_ERR_INTERNAL, "spmm: fused dot without its second vector");
     dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
@@ -2491,9 +2574,9 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
         kernel_partial = dot_partial + (size_t)kCompressBlocks * nb;
     }
     PMC_DISPATCH_NB(nb, {
-        if (A.tag == 1) spmm_launch<NB, 1>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
-        else if (A.tag == 2) spmm_launch<NB, 2>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
-        else spmm_launch<NB, 0>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
+        if (A.tag == 1) spmm_launch<NB, 1, XT>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
+        else if (A.tag == 2) spmm_launch<NB, 2, XT>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
+        else spmm_launch<NB, 0, XT>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
     });
     check_launch();
     if (two_stage) {
@@ -2502,6 +2585,13 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
         return kCompressBlocks;
     }
     return dot_partial ? (int)g.x : 0;
+}
+int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate, double* dot_partial,
+         const double* dot_with) {
+    return spmm_t<double>(st, nb, A, x, y, accumulate, dot_partial, dot_with);
+}
+int spmm_z(hipStream_t st, int nb, const SellView& A, const zreal* x, double* y, double* dot_partial, const zreal* dot_with) {
+    return spmm_t<zreal>(st, nb, A, x, y, false, dot_partial, dot_with);
 }
 
 void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out,
@@ -2594,6 +2684,38 @@ int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool d
     return dot_partial ? (int)g.x : 0;
 }
 
+int poly2_z(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, zreal* xout,
+            double c0, double c1, double* dot_partial) {
+    if (As.nrows == 0) return 0;
+    if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
+    const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
+    PMC_DISPATCH_NB(nb, {
+        if (As.bv && As.f32) {
+            if (dot_partial)
+                sell_poly2_kernel<NB, 2, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, nullptr, nullptr, nullptr, nullptr, nb);
+            else
+                sell_poly2_kernel<NB, 2, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+        } else if (As.bv) {
+            if (dot_partial)
+                sell_poly2_kernel<NB, 1, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, nullptr, nullptr, nullptr, nullptr, nb);
+            else
+                sell_poly2_kernel<NB, 1, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+        } else if (nt_poly(As, NB)) {
+            if (dot_partial)
+                sell_poly2_kernel<NB, 0, true, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, nullptr, nullptr, nullptr, nullptr, nb);
+            else
+                sell_poly2_kernel<NB, 0, false, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+        } else {
+            if (dot_partial)
+                sell_poly2_kernel<NB, 0, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, nullptr, nullptr, nullptr, nullptr, nb);
+            else
+                sell_poly2_kernel<NB, 0, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+        }
+    });
+    check_launch();
+    return dot_partial ? (int)g.x : 0;
+}
+
 void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, float* xout, double c0,
                     double c1) {
     if (As.nrows == 0) return;
@@ -2629,24 +2751,35 @@ void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res
     check_launch();
 }
 
-int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
-                    double* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial) {
+template <typename OT>
+static int vc_postsmooth32_t(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
+                             OT* xout, double c0, double c1, const double* r, const int* parent, const double* xc,
+                             double* dot_partial) {
     if (As.nrows == 0) return 0;
     if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_postsmooth32: shared values expected");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (nt_poly(As, NB)) {
             if (dot_partial)
-                vc_poly2_kernel<NB, float, double, float, true, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
+                vc_poly2_kernel<NB, float, OT, float, true, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
             else
-                vc_poly2_kernel<NB, float, double, float, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
+                vc_poly2_kernel<NB, float, OT, float, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
         } else if (dot_partial)
-            vc_poly2_kernel<NB, float, double, float, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
+            vc_poly2_kernel<NB, float, OT, float, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
         else
-            vc_poly2_kernel<NB, float, double, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
+            vc_poly2_kernel<NB, float, OT, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;
+}
+
+int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
+                    double* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial) {
+    return vc_postsmooth32_t<double>(st, nb, As, dinv, res, x, xout, c0, c1, r, parent, xc, dot_partial);
+}
+int vc_postsmooth32_z(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
+                      zreal* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial) {
+    return vc_postsmooth32_t<zreal>(st, nb, As, dinv, res, x, xout, c0, c1, r, parent, xc, dot_partial);
 }
 
 // ---- the same level with per-realization fp32 values (Darcy; SellView::f32) and per-realization diagonals
@@ -2687,23 +2820,34 @@ void vc_residual32_bv(hipStream_t st, int nb, const SellView& A, const double* r
     check_launch();
 }
 
-int vc_postsmooth32_bv(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
-                       double* xout, double c0, double c1, const double* r, double* dot_partial) {
+template <typename OT>
+static int vc_postsmooth32_bv_t(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
+                                OT* xout, double c0, double c1, const double* r, double* dot_partial) {
     if (As.nrows == 0) return 0;
     if (!(As.bv && As.f32)) throw Error(PMC_ERR_INTERNAL, "vc_postsmooth32_bv: per-realization fp32 values expected");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (dot_partial)
-            vc_poly2_kernel<NB, float, double, float, true, false, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, nullptr, nullptr, nb);
+            vc_poly2_kernel<NB, float, OT, float, true, false, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, nullptr, nullptr, nb);
         else
-            vc_poly2_kernel<NB, float, double, float, false, false, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, nullptr, nullptr, nb);
+            vc_poly2_kernel<NB, float, OT, float, false, false, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, nullptr, nullptr, nb);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;
 }
 
-int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, const double* x1, const SellView& A2,
-                 const double* x2, double* y, double* dot_partial, const double* dot_with) {
+int vc_postsmooth32_bv(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
+                       double* xout, double c0, double c1, const double* r, double* dot_partial) {
+    return vc_postsmooth32_bv_t<double>(st, nb, As, dinv, res, x, xout, c0, c1, r, dot_partial);
+}
+int vc_postsmooth32_bv_z(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
+                         zreal* xout, double c0, double c1, const double* r, double* dot_partial) {
+    return vc_postsmooth32_bv_t<zreal>(st, nb, As, dinv, res, x, xout, c0, c1, r, dot_partial);
+}
+
+template <typename XT>
+static int eg_pair_spmm_t(hipStream_t st, int nb, const EgView& M, const double* coef, const XT* x1, const SellView& A2,
+                          const XT* x2, double* y, double* dot_partial, const XT* dot_with) {
     if (M.nrows == 0) return 0;
     if (A2.bv || A2.nrows != M.nrows || A2.nslices != M.nslices)
         throw Error(PMC_ERR_INTERNAL, "eg_pair_spmm: second operator must share the rows and carry shared values");
@@ -2711,13 +2855,42 @@ int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, co
     PMC_DISPATCH_NB(nb, {
         if (nt_flat((size_t)M.nrows * NB * 2)) {   // from 4 MiB per vector on
             if (dot_partial)
-                eg_pair_spmm_kernel<NB, true, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
+                eg_pair_spmm_kernel<NB, true, true, XT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
             else
-                eg_pair_spmm_kernel<NB, false, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
+                eg_pair_spmm_kernel<NB, false, true, XT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
         } else if (dot_partial)
-            eg_pair_spmm_kernel<NB, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
+            eg_pair_spmm_kernel<NB, true, false, XT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
         else
-            eg_pair_spmm_kernel<NB, false><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
+            eg_pair_spmm_kernel<NB, false, false, XT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
+    });
+    check_launch();
+    return dot_partial ? (int)g.x : 0;
+}
+
+int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, const double* x1, const SellView& A2,
+                 const double* x2, double* y, double* dot_partial, const double* dot_with) {
+    return eg_pair_spmm_t<double>(st, nb, M, coef, x1, A2, x2, y, dot_partial, dot_with);
+}
+int eg_pair_spmm_z(hipStream_t st, int nb, const EgView& M, const double* coef, const zreal* x1, const SellView& A2,
+                   const zreal* x2, double* y, double* dot_partial, const zreal* dot_with) {
+    return eg_pair_spmm_t<zreal>(st, nb, M, coef, x1, A2, x2, y, dot_partial, dot_with);
+}
+
+template <typename OT>
+static int eg_poly2_t(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, OT* xout,
+                      double c0, double c1, double* dot_partial) {
+    if (M.nrows == 0) return 0;
+    const dim3 g = grid_bounded(grid_slices(M.nslices), dot_partial != nullptr);
+    PMC_DISPATCH_NB(nb, {
+        if (nt_flat((size_t)M.nrows * NB * 2)) {
+            if (dot_partial)
+                eg_poly2_kernel<NB, true, true, OT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
+            else
+                eg_poly2_kernel<NB, false, true, OT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
+        } else if (dot_partial)
+            eg_poly2_kernel<NB, true, false, OT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
+        else
+            eg_poly2_kernel<NB, false, false, OT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;
@@ -2725,18 +2898,25 @@ int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, co
 
 int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, double* xout,
              double c0, double c1, double* dot_partial) {
-    if (M.nrows == 0) return 0;
-    const dim3 g = grid_bounded(grid_slices(M.nslices), dot_partial != nullptr);
+    return eg_poly2_t<double>(st, nb, M, coef, dinv, r, xout, c0, c1, dot_partial);
+}
+int eg_poly2_z(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, zreal* xout,
+               double c0, double c1, double* dot_partial) {
+    return eg_poly2_t<zreal>(st, nb, M, coef, dinv, r, xout, c0, c1, dot_partial);
+}
+
+template <typename XT>
+static int pair_spmm_t(hipStream_t st, int nb, const SellView& A1, const XT* x1, const SellView& A2, const XT* x2, double* y,
+                       double* dot_partial, const XT* dot_with) {
+    if (A1.nrows == 0) return 0;
+    if (!A1.bv || A2.bv || A1.nrows != A2.nrows || A1.nslices != A2.nslices)
+        throw Error(PMC_ERR_INTERNAL, "pair_spmm: operand mismatch");
+    const dim3 g = grid_bounded(grid_slices(A1.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
-        if (nt_flat((size_t)M.nrows * NB * 2)) {
-            if (dot_partial)
-                eg_poly2_kernel<NB, true, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
-            else
-                eg_poly2_kernel<NB, false, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
-        } else if (dot_partial)
-            eg_poly2_kernel<NB, true><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
+        if (dot_partial)
+            sell_pair_spmm_kernel<NB, true, XT><<<groups(g, nb), kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
         else
-            eg_poly2_kernel<NB, false><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
+            sell_pair_spmm_kernel<NB, false, XT><<<groups(g, nb), kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;
@@ -2744,18 +2924,11 @@ int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const 
 
 int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, const SellView& A2, const double* x2, double* y,
               double* dot_partial, const double* dot_with) {
-    if (A1.nrows == 0) return 0;
-    if (!A1.bv || A2.bv || A1.nrows != A2.nrows || A1.nslices != A2.nslices)
-        throw Error(PMC_ERR_INTERNAL, "pair_spmm: operand mismatch");
-    const dim3 g = grid_bounded(grid_slices(A1.nslices), dot_partial != nullptr);
-    PMC_DISPATCH_NB(nb, {
-        if (dot_partial)
-            sell_pair_spmm_kernel<NB, true><<<groups(g, nb), kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
-        else
-            sell_pair_spmm_kernel<NB, false><<<groups(g, nb), kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
-    });
-    check_launch();
-    return dot_partial ? (int)g.x : 0;
+    return pair_spmm_t<double>(st, nb, A1, x1, A2, x2, y, dot_partial, dot_with);
+}
+int pair_spmm_z(hipStream_t st, int nb, const SellView& A1, const zreal* x1, const SellView& A2, const zreal* x2, double* y,
+                double* dot_partial, const zreal* dot_with) {
+    return pair_spmm_t<zreal>(st, nb, A1, x1, A2, x2, y, dot_partial, dot_with);
 }
 
 void scale_cols_bv(hipStream_t st, int nb, int64_t nslots, const int* cols, const double* vals, const double* colscale,
@@ -2776,7 +2949,7 @@ void scale_cols_bv32(hipStream_t st, int nb, int64_t nslots, const int* cols, co
     check_launch();
 }
 
-void minres_wx_idx(hipStream_t st, int nb, int nsel, const int* rows, const double* c0, const double* u, const double* c1,
+void minres_wx_idx(hipStream_t st, int nb, int nsel, const int* rows, const double* c0, const zreal* u, const double* c1,
                    double* w0, const double* c2, const double* w1, const double* c3, double* x) {
     if (nsel == 0) return;
     PMC_DISPATCH_NB(nb, { minres_wx_idx_kernel<NB><<<grid_flat(nsel, nb), kBlock, 0, st>>>(flat_count(nsel, nb), rows, c0, u, c1, w0, c2, w1, c3, x, nb); });
@@ -2810,6 +2983,24 @@ int dot(hipStream_t st, int nb, int n, const double* a, const double* b, double*
     return (int)g.x;
 }
 
+int dot_z(hipStream_t st, int nb, int n, const double* a, const zreal* b, double* partial) {
+    const dim3 g = grid_dot(n, nb);
+    PMC_DISPATCH_NB(nb, { dot_kernel<NB, zreal><<<g, kBlock, 0, st>>>(flat_count(n, nb), a, b, partial, nb); });
+    check_launch();
+    return (int)g.x;
+}
+
+int convert_z(hipStream_t st, int nb, int n, const double* in, zreal* out, const double* r, double* dot_partial) {
+    if (n == 0) return 0;
+    const dim3 g = grid_dot(n, nb);
+    PMC_DISPATCH_NB(nb, {
+        if (dot_partial) convert_dot_kernel<NB, true><<<g, kBlock, 0, st>>>(flat_count(n, nb), in, out, r, dot_partial, nb);
+        else convert_dot_kernel<NB, false><<<g, kBlock, 0, st>>>(flat_count(n, nb), in, out, nullptr, nullptr, nb);
+    });
+    check_launch();
+    return dot_partial ? (int)g.x : 0;
+}
+
 int wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial) {
     const dim3 g = grid_dot(n, nb);
     PMC_DISPATCH_NB(nb, { wdot_kernel<NB><<<g, kBlock, 0, st>>>(flat_count(n, nb), w, x, partial, nb); });
@@ -2834,7 +3025,7 @@ void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, 
     check_launch();
 }
 
-void minres_wx(hipStream_t st, int nb, int n, const double* c0, const double* u, const double* c1, double* w0,
+void minres_wx(hipStream_t st, int nb, int n, const double* c0, const zreal* u, const double* c1, double* w0,
                const double* c2, const double* w1, const double* c3, double* x) {
     const bool nt = nt_flat((size_t)n * nb);
     PMC_DISPATCH_NB(nb, {
@@ -3013,7 +3204,7 @@ void transpose_bv(hipStream_t st, int nb, size_t count, const double* in, double
 }
 
 int mg_tail(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_doubles, const double* r, double* xout,
-            double* dot_partial) {
+            double* dot_partial, bool out32) {
     const size_t bytes = lds_doubles * sizeof(double);
     if (bytes > kTailLdsBytes) throw Error(PMC_ERR_INTERNAL, "mg_tail: LDS request too large");
     // the dynamic-LDS limit is a per-device function attribute: raise it once per device (idempotent if two lanes race)
@@ -3025,7 +3216,7 @@ int mg_tail(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_dou
                                     (int)kTailLdsBytes));
         attr_mask.fetch_or(1ull << (dev & 63));
     }
-    mg_tail_kernel<<<nb, kTailThreads, bytes, st>>>(dev_params, nb, r, xout, dot_partial);
+    mg_tail_kernel<<<nb, kTailThreads, bytes, st>>>(dev_params, nb, r, xout, dot_partial, out32 ? 1 : 0);
     check_launch();
     return dot_partial ? 1 : 0;
 }

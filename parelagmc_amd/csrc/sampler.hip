@@ -381,32 +381,33 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     A.apply = [Av](const Lanes& L, int nb_, const double* x, double* y, double* partial, double*) {
         return k::DotParts{partial, k::spmm(L.main, nb_, Av, x, y, false, partial, x)};
     };
+    A.apply_z = [Av](const Lanes& L, int nb_, const zreal* x, double* y, double* partial, double*) {
+        return k::DotParts{partial, k::spmm_z(L.main, nb_, Av, x, y, partial, x)};
+    };
     const SellView Mv = view(d.M);
     const double* dinvM = d.dinvM.p;
     ChebParams cpM{degM, 1.0, d.ratio_M, d.M_scaled.p};
+    if (!cheb_fused(cpM, true)) cx2.ensure((size_t)n_u * nb);   // higher degrees iterate in fp64 scratch (cheb_apply_z)
     double* cxp = cx.p;
+    double* cx2p = cx2.p;
     double* cdp = cd.p;
-    PrecFn prec = [=](const Lanes& L, int nb_, const double* r, double* z, double* dot_partial, double* dot_partial2) {
-        const int flips = cheb_flips(cpM, true);
-        double* start = (flips % 2 == 0) ? z : cxp;
-        double* other = (flips % 2 == 0) ? cxp : z;
+    PrecFn prec = [=](const Lanes& L, int nb_, const double* r, zreal* z, double* dot_partial, double* dot_partial2) {
         // The two diagonal blocks are independent.  The V-cycle of the S-block runs on the main stream; once its
         // bandwidth-bound finest-level kernels are enqueued, the one-pass polynomial of the M-block starts on the second
         // stream and fills the chip while the V-cycle's coarse levels (short kernels, a few workgroups each) run.
         int nblk_u = 0;
         auto m_block = [&]() {
             L.fork();
-            double* res = cheb_apply(L.side(), nb_, Mv, dinvM, false, cpM, r, start, other, cdp, true, dot_partial2, &nblk_u);
-            if (res != z) throw Error(PMC_ERR_INTERNAL, "M-block smoother landed in the wrong buffer");
+            nblk_u = cheb_apply_z(L.side(), nb_, Mv, dinvM, false, cpM, r, z, cxp, cx2p, cdp, dot_partial2);
         };
-        const int nblk_s = mgp->vcycle(L.main, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_, dot_partial, m_block);
+        const int nblk_s = mgp->vcycle_z(L.main, nb_, mg_l0, r + (size_t)n_u * nb_, z + (size_t)n_u * nb_, dot_partial, m_block);
         L.join();
         return k::DotParts{dot_partial, nblk_s, dot_partial2, nblk_u};   // <r, z> = s-block partials + u-block partials
     };
     // only the s-block of the solution is ever read (PDESampler.cpp:526): update only those rows
     GraphHint hint;
     hint.key = hash_mix(hash_mix(0x5a, (uint64_t)level + 1), (uint64_t)nb);
-    hint.sig = hash_ptr(hash_ptr(mgp->signature(mg_l0), cx.p), cd.p);
+    hint.sig = hash_ptr(hash_ptr(hash_ptr(mgp->signature(mg_l0), cx.p), cd.p), cx2.p);
     MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work, n_u, n_s, nullptr, hint);
     if (stats) {
         ctx.phase_mark(2);

@@ -58,6 +58,20 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
     return cur;
 }
 
+int cheb_apply_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
+                 const double* r, zreal* z, double* xa, double* xb, double* d, double* dot_partial) {
+    if (cheb_fused(cp, true)) {
+        double c0, c1;
+        cheb2_coefficients(cp.lmax, cp.ratio, &c0, &c1);
+        SellView As = A;
+        As.vals = cp.scaled_vals;
+        return k::poly2_z(st, nb, As, dinv, dinv_bv, r, z, c0, c1, dot_partial);
+    }
+    if (!xa || !xb || !d) throw Error(PMC_ERR_INTERNAL, "cheb_apply_z: scratch vectors missing");
+    const double* res = cheb_apply(st, nb, A, dinv, dinv_bv, cp, r, xa, xb, d, true);
+    return k::convert_z(st, nb, A.nrows, res, z, r, dot_partial);
+}
+
 int cheb_post_from_residual(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv,
                             const ChebParams& cp, const double* r, const double* res, double* x, const int* parent,
                             const double* xc, double* dot_partial) {
@@ -175,25 +189,40 @@ static bool vcycle_f32() {
     return v;
 }
 
-double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, double* dot_partial,
-                         int* dot_blocks, const std::function<void()>* side) {
+double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, zreal* ztarget,
+                         double* dot_partial, int* dot_blocks, const std::function<void()>* side) {
     MgLevel& lv = L[l];
     lv.ensure(nb);
-    const bool ends_here = (use_tail && l < (int)tail.size() && tail[l].p) || l == (int)L.size() - 1 || lv.is_last;
+    const bool tail_here = use_tail && l < (int)tail.size() && tail[l].p;
+    const bool last = (l == (int)L.size() - 1) || lv.is_last;
+    const bool f32_shared = !last && !lv.bv && lv.has_sp && lv.p_oct && smooth_degree == 2 && lv.vals_scaled.p && vcycle_f32();
+    const bool f32_bv = !last && lv.bv && lv.f32 && lv.p_oct && smooth_degree == 2 && lv.scaled32.p && vcycle_f32();
+    if (ztarget && !(tail_here || f32_shared || f32_bv)) {
+        // no kernel with a typed output ends this cycle: fp64 result, then one rounding pass with the fused <r, z>
+        const double* res = cycle(st, nb, l, l0, r, nullptr, nullptr, nullptr, nullptr, side);
+        const int nblk = k::convert_z(st, nb, lv.n, res, ztarget, r, dot_partial);
+        if (dot_blocks) *dot_blocks = nblk;
+        return nullptr;
+    }
+    const bool ends_here = tail_here || last;
     if (side && *side && ends_here) (*side)();   // beside the bottom of the V: the least parallel kernels of the cycle
-    if (use_tail && l < (int)tail.size() && tail[l].p) {
+    if (tail_here) {
+        if (ztarget) {
+            const int nblk = k::mg_tail_z(st, nb, tail[l].p, tail_lds[l], r, ztarget, dot_partial);
+            if (dot_blocks) *dot_blocks = nblk;
+            return nullptr;
+        }
         double* out = target ? target : lv.xa.p;
         const int nblk = k::mg_tail(st, nb, tail[l].p, tail_lds[l], r, out, dot_partial);
         if (dot_blocks) *dot_blocks = nblk;
         return out;
     }
     const SellView A = lv.sview();
-    const bool last = (l == (int)L.size() - 1) || lv.is_last;
     // Shared-value level with an injection prolongator over groups of 8 (uniform refinement) and the one-pass degree-2
     // smoothers: the iterate and the residuals of the level - vectors that live only inside this application of the
     // preconditioner - are kept in fp32 (k::vc_* kernels; the buffers xb / res hold them).  Input, output, coarse vectors and
     // all arithmetic stay fp64.
-    if (!last && !lv.bv && lv.has_sp && lv.p_oct && smooth_degree == 2 && lv.vals_scaled.p && vcycle_f32()) {
+    if (f32_shared) {
         double c0, c1;
         cheb2_coefficients(lv.lmax, smooth_ratio, &c0, &c1);
         SellView As = A;
@@ -205,16 +234,17 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         MgLevel& lc = L[l + 1];
         lc.ensure(nb);
         k::vc_residual_restrict8_32(st, nb, A, r, xf, resf, lc.r.p);
-        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, side);
+        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, nullptr, side);
         k::vc_residual_coarse32(st, nb, view(lv.SP), resf, xc);
-        const int nblk = k::vc_postsmooth32(st, nb, As, lv.dinv.p, resf, xf, out, c0, c1, r, lv.parent.p, xc, dot_partial);
+        const int nblk = ztarget ? k::vc_postsmooth32_z(st, nb, As, lv.dinv.p, resf, xf, ztarget, c0, c1, r, lv.parent.p, xc, dot_partial)
+                                 : k::vc_postsmooth32(st, nb, As, lv.dinv.p, resf, xf, out, c0, c1, r, lv.parent.p, xc, dot_partial);
         if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
-        return out;
+        return ztarget ? nullptr : out;
     }
     // The same for a per-realization level with fp32 values (Darcy): pre-smoothing into an fp32 iterate, restriction of its
     // residual without storing the fine residual (nothing reads it: there is no S P for per-realization values), the coarse
     // correction added to the fp32 iterate, residual (fp32) and post-smoothing from it.
-    if (!last && lv.bv && lv.f32 && lv.p_oct && smooth_degree == 2 && lv.scaled32.p && vcycle_f32()) {
+    if (f32_bv) {
         double c0, c1;
         cheb2_coefficients(lv.lmax, smooth_ratio, &c0, &c1);
         SellView As = A;
@@ -226,12 +256,13 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         MgLevel& lc = L[l + 1];
         lc.ensure(nb);
         k::vc_restrict8_32_bv(st, nb, A, r, xf, lc.r.p);
-        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, side);
+        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, nullptr, side);
         k::vc_prolong8_32(st, nb, lv.n, xf, xc);
         k::vc_residual32_bv(st, nb, A, r, xf, df);
-        const int nblk = k::vc_postsmooth32_bv(st, nb, As, lv.dinv.p, df, xf, out, c0, c1, r, dot_partial);
+        const int nblk = ztarget ? k::vc_postsmooth32_bv_z(st, nb, As, lv.dinv.p, df, xf, ztarget, c0, c1, r, dot_partial)
+                                 : k::vc_postsmooth32_bv(st, nb, As, lv.dinv.p, df, xf, out, c0, c1, r, dot_partial);
         if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
-        return out;
+        return ztarget ? nullptr : out;
     }
     const int last_deg = lv.is_last ? lv.last_degree : coarse_degree;
     const double last_rat = lv.is_last ? lv.last_ratio : coarse_ratio;
@@ -259,7 +290,7 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         k::residual(st, nb, A, r, x, lv.res.p);
         k::spmm(st, nb, view(lv.Pt), lv.res.p, lc.r.p, false, nullptr, nullptr);
     }
-    double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, side);
+    double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, nullptr, side);
     if (lv.has_sp && !lv.bv && cheb_fused(cp, false)) {
         // r - S (x + P xc) = res - (S P) xc, in place; then x <- x + P xc + p2(that residual) in one pass
         k::residual(st, nb, view(lv.SP), lv.res.p, xc, lv.res.p);
@@ -275,8 +306,15 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
 int Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial,
                       const std::function<void()>& side) {
     int nblk = 0;
-    double* res = cycle(st, nb, l0, l0, r, xout, dot_partial, &nblk, side ? &side : nullptr);
+    double* res = cycle(st, nb, l0, l0, r, xout, nullptr, dot_partial, &nblk, side ? &side : nullptr);
     if (res != xout) throw Error(PMC_ERR_INTERNAL, "V-cycle result landed in the wrong buffer");
+    return nblk;
+}
+
+int Multigrid::vcycle_z(hipStream_t st, int nb, int l0, const double* r, zreal* zout, double* dot_partial,
+                        const std::function<void()>& side) {
+    int nblk = 0;
+    cycle(st, nb, l0, l0, r, nullptr, zout, dot_partial, &nblk, side ? &side : nullptr);
     return nblk;
 }
 
@@ -385,11 +423,12 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     const Lanes L = ctx.lanes(split);
     w.ensure(n, nb);
     k::MinresState* S = w.state.p;
-    double* v0 = w.v0.p; double* v1 = w.v1.p; double* u0 = w.u0.p; double* u1 = w.u1.p;
+    double* v0 = w.v0.p; double* v1 = w.v1.p; zreal* u0 = w.u0.p; zreal* u1 = w.u1.p;
     double* w0 = w.w0.p; double* w1 = w.w1.p; double* q = w.q.p;
 
     // v1 = b - A x0
     if (x_rows && !zero_guess) throw Error(PMC_ERR_INTERNAL, "minres: compact solution needs a zero initial guess");
+    if (!A.apply_z || (!zero_guess && !A.apply)) throw Error(PMC_ERR_INTERNAL, "minres: operator closures missing");
     if (zero_guess) {
         k::fill(st, x_rows ? (size_t)x_nrows * nb : len, x, 0.0);
         k::copy(st, len, b, v1);
@@ -402,7 +441,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     const size_t xoff = (size_t)x_row0 * nb;
     const size_t seg2 = (size_t)dot_capacity(n, nb) * nb;
     k::DotParts dp = prec(L, nb, v1, u1, w.partial.p, w.partial.p + seg2);
-    if (dp.total() == 0) dp = k::DotParts{w.partial.p, k::dot(st, nb, n, v1, u1, w.partial.p)};
+    if (dp.total() == 0) dp = k::DotParts{w.partial.p, k::dot_z(st, nb, n, v1, u1, w.partial.p)};
     const int every = o.check_every > 0 ? o.check_every : 1;
     const bool graphs = hint.key != 0 && o.use_graph != 0 && every == 2;
     const bool late = L.split && !graphs && A.n0 > 0 && A.n0 < n && late_wx();
@@ -432,7 +471,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     };
 
     MinresResult out;
-    double* u2 = nullptr;
+    zreal* u2 = nullptr;
     if (late) {
         w.u2.ensure(len);
         u2 = w.u2.p;
@@ -442,9 +481,9 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     // written u (both blocks of u are then the most recently written data on the chip), before the scalar recurrences
     // and the w / x update of iteration i, which do not depend on it.
     k::DotParts dp_op;
-    auto apply_op = [&](const double* u) {
+    auto apply_op = [&](const zreal* u) {
         if (timing) w.op_timer.begin(st);
-        dp_op = A.apply(L, nb, u, q, w.partial_op.p, w.partial_op.p + seg2);
+        dp_op = A.apply_z(L, nb, u, q, w.partial_op.p, w.partial_op.p + seg2);
         if (timing) w.op_timer.end(st);   // + an empty bracket: what one event record costs on this stream
     };
     // one MINRES iteration with explicit roles of the ping-pong vectors; on entry q = A u1_ and its dot are in place
@@ -456,8 +495,8 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     // of the next Lanczos update and ahead of the M-block of the preconditioner; the first stream carries the s-rows of
     // the update and the V-cycle, whose coarse levels leave most of the chip idle.  Same kernels, same arguments, same
     // results; the preconditioned vector the update reads must survive one more iteration, hence three of them.
-    struct PendingWx { const double* u = nullptr; double *w0 = nullptr, *w1 = nullptr; } pend;
-    auto wx = [&](hipStream_t s, const double* u_, double* w0_, double* w1_) {
+    struct PendingWx { const zreal* u = nullptr; double *w0 = nullptr, *w1 = nullptr; } pend;
+    auto wx = [&](hipStream_t s, const zreal* u_, double* w0_, double* w1_) {
         if (x_rows) k::minres_wx_idx(s, nb, x_nrows, x_rows, cW0, u_, cW1, w0_, cW2, w1_, cW3, x);
         else k::minres_wx(s, nb, x_nrows, cW0, u_ + xoff, cW1, w0_, cW2, w1_, cW3, x + xoff);
     };
@@ -465,7 +504,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         if (pend.u) wx(s, pend.u, pend.w0, pend.w1);
         pend.u = nullptr;
     };
-    auto iteration = [&](double* u0_, double* u1_, double* v0_, double* v1_, double* w0_, double* w1_, bool last) {
+    auto iteration = [&](zreal* u0_, zreal* u1_, double* v0_, double* v1_, double* w0_, double* w1_, bool last) {
         if (late) {
             const size_t off = (size_t)A.n0 * nb;
             L.fork();
@@ -476,7 +515,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             k::lincomb3(st, nb, n, cV0, q, cV1, v1_, cV2, v0_);
         }
         k::DotParts d2 = prec(L, nb, v0_, u0_, w.partial.p, w.partial.p + seg2);   // joins the second stream
-        if (d2.total() == 0) d2 = k::DotParts{w.partial.p, k::dot(st, nb, n, v0_, u0_, w.partial.p)};
+        if (d2.total() == 0) d2 = k::DotParts{w.partial.p, k::dot_z(st, nb, n, v0_, u0_, w.partial.p)};
         if (!last) {
             apply_op(u0_);
             k::minres_scal21(st, nb, S, d2, dp_op, stage_on() ? w.stage.p : nullptr);
@@ -565,7 +604,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         w.u2.ensure(len);
         w.u3.ensure(len);
         w.u4.ensure(len);
-        double* ub[R] = {u1, u0, w.u2.p, w.u3.p, w.u4.p};
+        zreal* ub[R] = {u1, u0, w.u2.p, w.u3.p, w.u4.p};
         static_assert(R == 5, "ring buffers of the deferred w / x update");
         int c = 0;                                   // ub[c] holds the preconditioned vector of the current Lanczos vector
         k::WxDeferred pending{};
@@ -589,7 +628,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             ++it;
             iteration(u0, u1, v0, v1, w0, w1, it == o.max_iter);
             if (late) {                      // u1 (read by the pending update) stays untouched for one more iteration
-                double* t = u1;
+                zreal* t = u1;
                 u1 = u0;
                 u0 = u2;
                 u2 = t;

@@ -35,6 +35,11 @@ inline bool cheb_fused(const ChebParams& cp, bool /*zero_guess*/) { return cp.de
 double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
                    const double* r, double* xa, double* xb, double* d, bool zero_guess,
                    double* dot_partial = nullptr, int* dot_blocks = nullptr);
+// The same from a zero guess with the result in zreal storage (a preconditioner block of a MINRES solve): the one-pass
+// degree-2 kernel writes z itself; other degrees iterate in the fp64 scratch xa / xb and round at the end.  Returns the
+// partial-block count of <r, z> (dot_partial != nullptr).
+int cheb_apply_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
+                 const double* r, zreal* z, double* xa, double* xb, double* d, double* dot_partial);
 // Post-smoothing of a V-cycle level from an already formed residual `res` = r - A (x + P xc) without x + P xc in memory:
 // x <- x + xc[parent] + p2(res); degree 2 with scaled values only.  Returns the partial-block count of <r, x>.
 int cheb_post_from_residual(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv,
@@ -117,9 +122,13 @@ struct Multigrid {
     // the intermediate ones (measured: a 9 us level-1 residual takes 37 us next to the M-block polynomial).
     int vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial = nullptr,
                const std::function<void()>& side = nullptr);
+    // the same with the result in zreal storage (S-block of a MINRES preconditioner): the last kernel of the cycle writes it
+    int vcycle_z(hipStream_t st, int nb, int l0, const double* r, zreal* zout, double* dot_partial = nullptr,
+                 const std::function<void()>& side = nullptr);
 
   private:
-    double* cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, double* dot_partial,
+    // ztarget != nullptr (top level of vcycle_z only): the result goes there and the return value is null
+    double* cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, zreal* ztarget, double* dot_partial,
                   int* dot_blocks, const std::function<void()>* side);
 };
 
@@ -134,6 +143,9 @@ struct LinOp {
     // (independent row blocks may run between L.fork() and L.join(); ordered on L.main again on return)
     std::function<k::DotParts(const Lanes& L, int nb, const double* x, double* y, double* dot_partial,
                               double* dot_partial2)> apply;
+    // the same product from a preconditioned vector (zreal storage): every product inside the MINRES loop
+    std::function<k::DotParts(const Lanes& L, int nb, const zreal* x, double* y, double* dot_partial,
+                              double* dot_partial2)> apply_z;
 };
 // z = B^-1 r.  When dot_partial != nullptr the preconditioner may fuse <r, z> into its last kernels and
 // return the number of partial blocks it wrote (0 = not computed, the solver then runs a separate dot).
@@ -141,7 +153,8 @@ struct LinOp {
 // return everything must be ordered on L.main again.
 // dot_partial / dot_partial2 (each dot_capacity(n) blocks) receive the fused <r, z>: return where the partials are
 // (total() == 0: not computed, the solver then runs a separate dot).
-using PrecFn = std::function<k::DotParts(const Lanes& L, int nb, const double* r, double* z, double* dot_partial,
+// z is stored as zreal (see kernels.hpp); <r, z> is the inner product with the STORED values.
+using PrecFn = std::function<k::DotParts(const Lanes& L, int nb, const double* r, zreal* z, double* dot_partial,
                                          double* dot_partial2)>;
 
 // Caller-side identity of one solver configuration for hipGraph reuse: `key` names the configuration (handle, level,
@@ -199,10 +212,11 @@ struct OpTimer {
 };
 
 struct MinresWork {
-    DevBuf<double> v0, v1, u0, u1, w0, w1, q, partial;
+    DevBuf<double> v0, v1, w0, w1, q, partial;
+    DevBuf<zreal> u0, u1;                    // preconditioned vectors
     DevBuf<double> stage;                    // first-stage sums of the scalar kernel (k::minres_scal21)
-    DevBuf<double> u2;                       // third preconditioned vector: only when the w / x update runs one iteration late
-    DevBuf<double> u3, u4;                   // ring of the deferred w / x update (with u0, u1, u2: kWxDefer + 1 vectors)
+    DevBuf<zreal> u2;                        // third preconditioned vector: only when the w / x update runs one iteration late
+    DevBuf<zreal> u3, u4;                    // ring of the deferred w / x update (with u0, u1, u2: kWxDefer + 1 vectors)
     DevBuf<double> partial_op;               // partials of the operator's fused <u, Au> (the preconditioner's live in `partial`)
     std::map<uint64_t, int> iter_hint;       // per solver configuration: iterations its previous solve needed
     DevBuf<k::MinresState> state;
