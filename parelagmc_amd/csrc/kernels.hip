@@ -621,7 +621,9 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
 }
 
 // Chebyshev / Jacobi step: d = a d + b dinv (r - A xin); xout = xin + d ; DOT: partials of <r, xout>
-template <int NB, int BV, bool DOT>
+// OT != double: the LAST step of a polynomial whose result is a preconditioned Krylov vector (zreal storage): d is not
+// written back, the iterate is rounded to its storage before the fused dot
+template <int NB, int BV, bool DOT, typename OT = double>
 __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
                                                            const double* __restrict__ dinv,
                                                            const double* __restrict__ r,
                                                            const double* __restrict__ xin, double* __restrict__ d,
-                                                           double* __restrict__ xout, double a, double b,
+                                                           OT* __restrict__ xout, double a, double b,
                                                            double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int LD = row_ld<NB>(ld);
@@ -674,10 +676,14 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
             for (int c = 0; c < C; ++c) {
                 dv[c] = a * dv[c] + b * di[c] * (rv[c] - acc[rs][c]);
                 xv[c] += dv[c];
-                if constexpr (DOT) p[c] = fma(rv[c], xv[c], p[c]);
             }
-            store_c<C>(d + at, dv);
-            store_c<C>(xout + at, xv);
+            round_to<OT>(xv);
+            if constexpr (DOT) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) p[c] = fma(rv[c], xv[c], p[c]);
+            }
+            if constexpr (std::is_same<OT, double>::value) store_c<C>(d + at, dv);
+            store_v<C>(xout + at, xv);
         }
     }
     if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
@@ -2651,6 +2657,33 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
     return dot_partial ? (int)g.x : 0;
 }
 
+int cheb_step_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
+                const double* xin, double* d, zreal* zout, double a, double b, double* dot_partial) {
+    if (A.nrows == 0) return 0;
+    if (A.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "cheb_step: value/diagonal batching mismatch");
+    const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
+    PMC_DISPATCH_NB(nb, {
+        if (A.bv && A.f32) {
+            if (dot_partial)
+                sell_cheb_kernel<NB, 2, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, dot_partial, nb);
+            else
+                sell_cheb_kernel<NB, 2, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, nullptr, nb);
+        } else if (A.bv) {
+            if (dot_partial)
+                sell_cheb_kernel<NB, 1, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, dot_partial, nb);
+            else
+                sell_cheb_kernel<NB, 1, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, nullptr, nb);
+        } else {
+            if (dot_partial)
+                sell_cheb_kernel<NB, 0, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, dot_partial, nb);
+            else
+                sell_cheb_kernel<NB, 0, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, nullptr, nb);
+        }
+    });
+    check_launch();
+    return dot_partial ? (int)g.x : 0;
+}
+
 int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
           double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with, const int* padd_idx,
           const double* padd_x) {
@@ -2685,31 +2718,32 @@ int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool d
 }
 
 int poly2_z(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, zreal* xout,
-            double c0, double c1, double* dot_partial) {
+            double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with, const int* padd_idx,
+            const double* padd_x) {
     if (As.nrows == 0) return 0;
     if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (As.bv && As.f32) {
             if (dot_partial)
-                sell_poly2_kernel<NB, 2, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, nullptr, nullptr, nullptr, nullptr, nb);
+                sell_poly2_kernel<NB, 2, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, 2, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+                sell_poly2_kernel<NB, 2, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         } else if (As.bv) {
             if (dot_partial)
-                sell_poly2_kernel<NB, 1, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, nullptr, nullptr, nullptr, nullptr, nb);
+                sell_poly2_kernel<NB, 1, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, 1, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+                sell_poly2_kernel<NB, 1, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         } else if (nt_poly(As, NB)) {
             if (dot_partial)
-                sell_poly2_kernel<NB, 0, true, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, nullptr, nullptr, nullptr, nullptr, nb);
+                sell_poly2_kernel<NB, 0, true, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, 0, false, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+                sell_poly2_kernel<NB, 0, false, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         } else {
             if (dot_partial)
-                sell_poly2_kernel<NB, 0, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, nullptr, nullptr, nullptr, nullptr, nb);
+                sell_poly2_kernel<NB, 0, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, 0, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+                sell_poly2_kernel<NB, 0, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         }
     });
     check_launch();

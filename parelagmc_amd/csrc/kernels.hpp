@@ -103,13 +103,18 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
 // dot_partial != nullptr: also per-block partials of <r, xout>; returns the number of blocks written.
 int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
               const double* xin, double* d, double* xout, double a, double b, double* dot_partial = nullptr);
+// the LAST step of a polynomial whose result is a preconditioned Krylov vector: as cheb_step, the iterate goes to zreal
+// storage (rounded before the fused dot), d is left as it was
+int cheb_step_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
+                const double* xin, double* d, zreal* zout, double a, double b, double* dot_partial = nullptr);
 // one-pass degree-2 polynomial from a zero guess: xout = dinv.*(c0 r - c1 As r), As = A D^-1 (shared values)
 int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
           double c0, double c1, double* dot_partial = nullptr, const double* xadd = nullptr,
           const double* dot_with = nullptr, const int* padd_idx = nullptr, const double* padd_x = nullptr);
 // ... into zreal storage (the value stored is the one the fused <r, xout> uses)
 int poly2_z(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, zreal* xout,
-            double c0, double c1, double* dot_partial = nullptr);
+            double c0, double c1, double* dot_partial = nullptr, const double* xadd = nullptr,
+            const double* dot_with = nullptr, const int* padd_idx = nullptr, const double* padd_x = nullptr);
 // V-cycle level with fp32 intermediates (shared values; see vc_poly2_kernel): pre-smoothing from zero into an fp32 iterate,
 // residual + restriction over groups of 8 rows from it (fp32 residual, fp64 coarse right-hand side), res -= (S P) xc, and the
 // post-smoothing x + xc[parent] + p2(res) -> fp64 result with the fused <r, result>

@@ -11,7 +11,7 @@ namespace pmc {
 
 double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
                    const double* r, double* xa, double* xb, double* d, bool zero_guess, double* dot_partial,
-                   int* dot_blocks) {
+                   int* dot_blocks, zreal* zlast) {
     if (cp.degree < 1) throw Error(PMC_ERR_INVALID, "Chebyshev degree must be >= 1");
     const double lmax = cp.lmax, lmin = cp.lmax / cp.ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
@@ -25,20 +25,23 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
         As.vals = cp.scaled_vals;
         int nblk;
         if (zero_guess) {
-            nblk = k::poly2(st, nb, As, dinv, dinv_bv, r, xa, c0, c1, dot_partial);
+            nblk = zlast ? k::poly2_z(st, nb, As, dinv, dinv_bv, r, zlast, c0, c1, dot_partial)
+                         : k::poly2(st, nb, As, dinv, dinv_bv, r, xa, c0, c1, dot_partial);
         } else {
-            // x2 = x0 + p2(r - A x0): residual into the work vector, polynomial of it accumulated onto x0 in place
+            // x2 = x0 + p2(r - A x0): residual into the work vector, polynomial of it accumulated onto x0 (in place, or
+            // into the typed result)
             k::residual(st, nb, A, r, xa, d);
-            nblk = k::poly2(st, nb, As, dinv, dinv_bv, d, xa, c0, c1, dot_partial, xa, r);
+            nblk = zlast ? k::poly2_z(st, nb, As, dinv, dinv_bv, d, zlast, c0, c1, dot_partial, xa, r)
+                         : k::poly2(st, nb, As, dinv, dinv_bv, d, xa, c0, c1, dot_partial, xa, r);
         }
         if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
-        return xa;
+        return zlast ? nullptr : xa;
     }
     double* cur = xa;
     double* oth = xb;
     int step = 0;
     int nblk = 0;
-    double* dp = (cp.degree == 1) ? dot_partial : nullptr;
+    double* dp = (cp.degree == 1 && !zlast) ? dot_partial : nullptr;
     if (zero_guess) {
         nblk = k::cheb_first(st, nb, A.nrows, dinv, dinv_bv, r, d, cur, 1.0 / theta, dp);
         step = 1;
@@ -50,9 +53,18 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
     for (; step < cp.degree; ++step) {
         const double rho = 1.0 / (2.0 * sigma - rho_old);
         dp = (step == cp.degree - 1) ? dot_partial : nullptr;
+        if (zlast && step == cp.degree - 1) {
+            nblk = k::cheb_step_z(st, nb, A, dinv, dinv_bv, r, cur, d, zlast, rho * rho_old, 2.0 * rho / delta, dp);
+            cur = nullptr;                      // the result is in zlast
+            break;
+        }
         nblk = k::cheb_step(st, nb, A, dinv, dinv_bv, r, cur, d, oth, rho * rho_old, 2.0 * rho / delta, dp);
         std::swap(cur, oth);
         rho_old = rho;
+    }
+    if (zlast && cur) {                         // degree 1: no typed kernel, one rounding pass with the fused dot
+        nblk = k::convert_z(st, nb, A.nrows, cur, zlast, r, dot_partial);
+        cur = nullptr;
     }
     if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
     return cur;
@@ -60,21 +72,15 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
 
 int cheb_apply_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
                  const double* r, zreal* z, double* xa, double* xb, double* d, double* dot_partial) {
-    if (cheb_fused(cp, true)) {
-        double c0, c1;
-        cheb2_coefficients(cp.lmax, cp.ratio, &c0, &c1);
-        SellView As = A;
-        As.vals = cp.scaled_vals;
-        return k::poly2_z(st, nb, As, dinv, dinv_bv, r, z, c0, c1, dot_partial);
-    }
-    if (!xa || !xb || !d) throw Error(PMC_ERR_INTERNAL, "cheb_apply_z: scratch vectors missing");
-    const double* res = cheb_apply(st, nb, A, dinv, dinv_bv, cp, r, xa, xb, d, true);
-    return k::convert_z(st, nb, A.nrows, res, z, r, dot_partial);
+    if (!cheb_fused(cp, true) && (!xa || !xb || !d)) throw Error(PMC_ERR_INTERNAL, "cheb_apply_z: scratch vectors missing");
+    int nblk = 0;
+    cheb_apply(st, nb, A, dinv, dinv_bv, cp, r, xa, xb, d, true, dot_partial, &nblk, z);
+    return nblk;
 }
 
 int cheb_post_from_residual(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv,
                             const ChebParams& cp, const double* r, const double* res, double* x, const int* parent,
-                            const double* xc, double* dot_partial) {
+                            const double* xc, double* dot_partial, zreal* zout) {
     if (!(cp.degree == 2 && cp.scaled_vals)) throw Error(PMC_ERR_INTERNAL, "fused post-smoothing needs degree 2");
     const double lmax = cp.lmax, lmin = cp.lmax / cp.ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
@@ -85,6 +91,7 @@ int cheb_post_from_residual(hipStream_t st, int nb, const SellView& A, const dou
     const double c1 = 2.0 * rho1 / (delta * theta);
     SellView As = A;
     As.vals = cp.scaled_vals;
+    if (zout) return k::poly2_z(st, nb, As, dinv, dinv_bv, res, zout, c0, c1, dot_partial, x, r, parent, xc);
     return k::poly2(st, nb, As, dinv, dinv_bv, res, x, c0, c1, dot_partial, x, r, parent, xc);
 }
 
@@ -197,13 +204,7 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
     const bool f32_shared = !last && !lv.bv && lv.has_sp && lv.p_oct && smooth_degree == 2 && lv.vals_scaled.p && vcycle_f32();
     const bool f32_bv = !last && lv.bv && lv.f32 && lv.p_oct && smooth_degree == 2 && lv.scaled32.p && vcycle_f32();
-    if (ztarget && !(tail_here || f32_shared || f32_bv)) {
-        // no kernel with a typed output ends this cycle: fp64 result, then one rounding pass with the fused <r, z>
-        const double* res = cycle(st, nb, l, l0, r, nullptr, nullptr, nullptr, nullptr, side);
-        const int nblk = k::convert_z(st, nb, lv.n, res, ztarget, r, dot_partial);
-        if (dot_blocks) *dot_blocks = nblk;
-        return nullptr;
-    }
+    if (ztarget && target) throw Error(PMC_ERR_INTERNAL, "V-cycle: two result buffers");
     const bool ends_here = tail_here || last;
     if (side && *side && ends_here) (*side)();   // beside the bottom of the V: the least parallel kernels of the cycle
     if (tail_here) {
@@ -277,7 +278,7 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     }
     if (last) {
         const ChebParams& cp = cp_last;
-        return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true, dot_partial, dot_blocks);
+        return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true, dot_partial, dot_blocks, ztarget);
     }
     const ChebParams& cp = cp_smooth;
     double* x = cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, start, other, lv.d.p, true);
@@ -295,12 +296,12 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         // r - S (x + P xc) = res - (S P) xc, in place; then x <- x + P xc + p2(that residual) in one pass
         k::residual(st, nb, view(lv.SP), lv.res.p, xc, lv.res.p);
         const int nblk = cheb_post_from_residual(st, nb, A, lv.dinv.p, lv.bv, cp, r, lv.res.p, x, lv.parent.p, xc,
-                                                 dot_partial);
+                                                 dot_partial, ztarget);
         if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
-        return x;
+        return ztarget ? nullptr : x;
     }
     k::spmm(st, nb, view(lv.P), xc, x, true, nullptr, nullptr);
-    return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, x, oth, lv.d.p, false, dot_partial, dot_blocks);
+    return cheb_apply(st, nb, A, lv.dinv.p, lv.bv, cp, r, x, oth, lv.d.p, false, dot_partial, dot_blocks, ztarget);
 }
 
 int Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial,

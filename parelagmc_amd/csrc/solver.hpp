@@ -34,17 +34,19 @@ inline bool cheb_fused(const ChebParams& cp, bool /*zero_guess*/) { return cp.de
 // dot_partial != nullptr: the last step also writes per-block partials of <r, result>; *dot_blocks gets their count.
 double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
                    const double* r, double* xa, double* xb, double* d, bool zero_guess,
-                   double* dot_partial = nullptr, int* dot_blocks = nullptr);
-// The same from a zero guess with the result in zreal storage (a preconditioner block of a MINRES solve): the one-pass
-// degree-2 kernel writes z itself; other degrees iterate in the fp64 scratch xa / xb and round at the end.  Returns the
-// partial-block count of <r, z> (dot_partial != nullptr).
+                   double* dot_partial = nullptr, int* dot_blocks = nullptr, zreal* zlast = nullptr);
+// zlast != nullptr: the last kernel writes the result there in zreal storage (rounded before the fused dot) and null is
+// returned (degree 1 has no typed kernel: one extra rounding pass)
+// The same from a zero guess with the result in zreal storage (a preconditioner block of a MINRES solve): the last kernel
+// writes z itself; earlier steps of an unfused polynomial iterate in the fp64 scratch xa / xb.  Returns the partial-block
+// count of <r, z> (dot_partial != nullptr).
 int cheb_apply_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
                  const double* r, zreal* z, double* xa, double* xb, double* d, double* dot_partial);
 // Post-smoothing of a V-cycle level from an already formed residual `res` = r - A (x + P xc) without x + P xc in memory:
 // x <- x + xc[parent] + p2(res); degree 2 with scaled values only.  Returns the partial-block count of <r, x>.
 int cheb_post_from_residual(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv,
                             const ChebParams& cp, const double* r, const double* res, double* x, const int* parent,
-                            const double* xc, double* dot_partial);
+                            const double* xc, double* dot_partial, zreal* zout = nullptr);
 // number of buffer flips cheb_apply performs
 inline int cheb_flips(const ChebParams& cp, bool zero_guess) {
     if (cheb_fused(cp, zero_guess)) return 0;

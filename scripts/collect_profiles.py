@@ -80,10 +80,12 @@ try:
             f.write("kernel,launches,mean_counter_value_KB\n")
             for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
                 f.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.3f}\n")
-    kern = "eg_pair_spmm_kernel<16, true, true>"
+    kern = "eg_pair_spmm_kernel<16, true, true,"
     fr, n = mean(fetch, kern)
     wr, _ = mean(write, kern)
-    out["c3_eg_nb16_inloop"] = {"kernel": f"pmc::{kern} (u-rows of the Darcy operator, level 0 of config 3)",
+    if fr is None or wr is None:
+        raise FileNotFoundError(f"no rows of {kern} in the config-3 counter passes")
+    out["c3_eg_nb16_inloop"] = {"kernel": f"pmc::{kern} ...> (u-rows of the Darcy operator, level 0 of config 3)",
                                 "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB_raw": wr,
                                 "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
 except FileNotFoundError as e:

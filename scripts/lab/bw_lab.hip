@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(r_)); exit(1); } } while (0)
@@ -64,6 +65,36 @@ __global__ __launch_bounds__(256) void write_kernel(size_t n, d2* __restrict__ b
     }
 }
 
+// y = c0 a + c1 b + c2 y on interleaved batches of 16 columns (the Lanczos update of the MINRES loop: three streams in, one
+// out, in place): U 16-byte pieces per thread, loads / store optionally non-temporal
+template <int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void lincomb_kernel(size_t n, const double* __restrict__ c, const d2* __restrict__ a,
+                                                      const d2* __restrict__ b, d2* __restrict__ y) {
+    const size_t base = (size_t)blockIdx.x * 256 * U;
+    d2 av[U], bv[U], yv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * 256 + threadIdx.x;
+        if (i < n) {
+            av[u] = NTL ? __builtin_nontemporal_load(a + i) : a[i];
+            bv[u] = NTL ? __builtin_nontemporal_load(b + i) : b[i];
+            yv[u] = NTL ? __builtin_nontemporal_load(y + i) : y[i];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * 256 + threadIdx.x;
+        if (i < n) {
+            const int k0 = (int)((2 * i) % 16);
+            d2 r;
+            r.x = c[k0] * av[u].x + c[256 + k0] * bv[u].x + c[512 + k0] * yv[u].x;
+            r.y = c[k0 + 1] * av[u].y + c[256 + k0 + 1] * bv[u].y + c[512 + k0 + 1] * yv[u].y;
+            if (NTS) __builtin_nontemporal_store(r, y + i);
+            else y[i] = r;
+        }
+    }
+}
+
 template <class F>
 static double timeit(hipStream_t st, int rep, F f) {
     hipEvent_t e0, e1;
@@ -95,7 +126,50 @@ static void run(hipStream_t st, size_t n, const d2* a, d2* b, double* out) {
     }
 }
 
+template <int U, bool NTL, bool NTS>
+static void run_lincomb(hipStream_t st, size_t n, const double* c, const d2* a, const d2* b, d2* y) {
+    const unsigned g = (unsigned)((n + 256 * U - 1) / (256 * U));
+    const double t = timeit(st, 10, [&] { lincomb_kernel<U, NTL, NTS><<<g, 256, 0, st>>>(n, c, a, b, y); });
+    printf("  lincomb U=%d nt_load=%d nt_store=%d grid=%8u : %7.1f us  %6.2f TB/s (3 r + 1 w)\n", U, (int)NTL, (int)NTS, g,
+           t * 1e3, 4.0 * n * 16.0 / (t * 1e-3) / 1e12);
+}
+
+static int lincomb_lab(int argc, char** argv) {
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    for (int i = 2; i < argc; ++i) {
+        const size_t mb = (size_t)atol(argv[i]);
+        const size_t n = mb * 1024 * 1024 / 16;
+        d2 *a, *b, *y;
+        double* c;
+        CK(hipMalloc(&a, n * 16));
+        CK(hipMalloc(&b, n * 16));
+        CK(hipMalloc(&y, n * 16));
+        CK(hipMalloc(&c, 768 * 8));
+        CK(hipMemsetAsync(a, 0, n * 16, st));
+        CK(hipMemsetAsync(b, 0, n * 16, st));
+        CK(hipMemsetAsync(y, 0, n * 16, st));
+        CK(hipMemsetAsync(c, 0, 768 * 8, st));
+        printf("== lincomb, %zu MiB per vector\n", mb);
+        run_lincomb<1, false, false>(st, n, c, a, b, y);
+        run_lincomb<1, true, false>(st, n, c, a, b, y);
+        run_lincomb<1, true, true>(st, n, c, a, b, y);
+        run_lincomb<2, false, false>(st, n, c, a, b, y);
+        run_lincomb<2, true, false>(st, n, c, a, b, y);
+        run_lincomb<2, true, true>(st, n, c, a, b, y);
+        run_lincomb<4, false, false>(st, n, c, a, b, y);
+        run_lincomb<4, true, false>(st, n, c, a, b, y);
+        run_lincomb<4, true, true>(st, n, c, a, b, y);
+        CK(hipFree(a));
+        CK(hipFree(b));
+        CK(hipFree(y));
+        CK(hipFree(c));
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "lincomb") return lincomb_lab(argc, argv);
     hipStream_t st;
     CK(hipStreamCreate(&st));
     std::vector<size_t> mbs;

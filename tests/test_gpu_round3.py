@@ -301,3 +301,45 @@ def test_super_batch_edges_projections_and_observation_operator(gpu_ctx, hex_hie
     for i in (0, 64, 69):
         assert np.allclose(G[i], compute_G(do, Gobs, 0, k[i])[0], rtol=1e-8, atol=1e-10)
     ds.close()
+
+
+def test_fp32_krylov_vectors_on_every_preconditioner_path(gpu_ctx, hex_hierarchy, seeded_rng):
+    """The preconditioned MINRES vectors z are stored in fp32 (zreal, csrc/kernels.hpp; pmc_krylov_z_bytes): the last kernel
+    of each preconditioner block writes them, the operator products and the w / x updates read them.  Solver configurations
+    other than the default one end in other kernels: M-block degree 3 / 4 (typed last Chebyshev step, cheb_step_z; on Darcy
+    any degree but 2 also leaves the element-grouped form: pair_spmm_z), V-cycle smoothing degree 3 (the general cycle),
+    degree 1 (no typed kernel: fp64 scratch + k::convert_z), the hipGraph replay and the two-stream schedule.  Every one of them must still reproduce the oracle's
+    direct solves at a 1e-12 solver tolerance - the stored precision of z only perturbs the preconditioner
+    (src/PDESampler.cpp:279-333 and src/DarcySolver.cpp:472-649 are the solves being restated)."""
+    from oracle.darcy_oracle import DarcyOracle
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    assert gpu_ctx.lib.pmc_krylov_z_bytes() in (4, 8)
+    sp_ = build_sampler_problem(hex_hierarchy, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    so, do = SamplerOracle(sp_), DarcyOracle(dp)
+    nreal = 16
+    xi = seeded_rng.standard_normal((nreal, sp_.levels[0].n_s))
+    ref_s = {lvl: [so.eval(lvl, 0, xi[b])[0] for b in (0, 7, 15)] for lvl in (0, 1)}
+    tight = dict(rel_tol=1e-12, abs_tol=1e-14, mini_max_rows=0)
+    variants = [dict(), dict(cheb_degree_M=4), dict(cheb_degree_M=3), dict(mg_smooth_degree=3), dict(use_graph=1),
+                dict(two_streams=1), dict(two_streams=2, check_every=1), dict(mg_smooth_degree=1, cheb_degree_M=1, max_iter=900)]
+    base_iters = None
+    for kw in variants:
+        o = capi.solver_opts(**tight, **kw)
+        smp, ds = capi.PDESampler(gpu_ctx, sp_, o), capi.DarcySolver(gpu_ctx, dp, o)
+        for lvl in (0, 1):
+            s, st = smp.Eval(lvl, xi, xi_level=0, return_stats=True)
+            assert all(t[1] == 1 for t in st), (kw, lvl, st[:3])
+            for j, b in enumerate((0, 7, 15)):
+                assert rel(s[b], ref_s[lvl][j]) <= 1e-8, (kw, lvl, b)
+            Q, C, stq = ds.SolveFwd(lvl, s, return_stats=True)
+            assert all(t[1] == 1 for t in stq), (kw, lvl, stq[:3])
+            for b in (0, 15):
+                assert abs(Q[b] - do.solve_fwd(lvl, s[b])[0]) <= 1e-8 * abs(Q[b]), (kw, lvl, b)
+            if not kw and lvl == 0:
+                base_iters = max(t[0] for t in st)
+        ds.close()
+        smp.close()
+    assert base_iters is not None and base_iters > 0
