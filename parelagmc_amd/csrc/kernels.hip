@@ -27,6 +27,18 @@ static constexpr int kWave = 64;
 #ifndef PMC_K5_TWO_COLUMNS
 #define PMC_K5_TWO_COLUMNS 0
 #endif
+#ifndef PMC_LEAN_GATHER
+#define PMC_LEAN_GATHER 1
+#endif
+static constexpr bool kLeanGather = PMC_LEAN_GATHER != 0;   // see sell_row_part: fp32 gathers without column scaling
+#ifndef PMC_LEAN_CS
+#define PMC_LEAN_CS 1
+#endif
+static constexpr bool kLeanCs = PMC_LEAN_CS != 0;           // ... fp64 gathers / column scaling (eg_poly2_kernel)
+#ifndef PMC_EG_LATE_COEF
+#define PMC_EG_LATE_COEF 1
+#endif
+static constexpr bool kEgLateCoef = PMC_EG_LATE_COEF != 0;  // see eg_row_product
 static constexpr bool kK5TwoColumns = PMC_K5_TWO_COLUMNS != 0;   // tuning build: K5 steps two slice columns at a time (see sell_row_range); measured slower, off
 
 static unsigned dot_grid_bound();
@@ -150,6 +162,34 @@ __device__ __forceinline__ void round_to(double (&v)[C]) {
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int i = 0; i < C; ++i) v[i] = (double)(float)v[i];
+    }
+}
+
+// What a gather leaves in registers until its FMA: fp32-stored vectors stay fp32 (half the registers per gather in flight)
+// and are widened only when they are consumed.
+template <typename XT, int C>
+struct RawVec {
+    XT v[C];
+};
+template <int C>
+__device__ __forceinline__ void load_raw(const double* __restrict__ p, RawVec<double, C>& r) { load_c<C>(p, r.v); }
+template <int C>
+__device__ __forceinline__ void load_raw(const float* __restrict__ p, RawVec<float, C>& r) {
+    if constexpr (C == 1) {
+        r.v[0] = p[0];
+    } else if constexpr (C == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        r.v[0] = t.x;
+        r.v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i) {
+            const float4 t = reinterpret_cast<const float4*>(p)[i];
+            r.v[4 * i] = t.x;
+            r.v[4 * i + 1] = t.y;
+            r.v[4 * i + 2] = t.z;
+            r.v[4 * i + 3] = t.w;
+        }
     }
 }
 
@@ -1031,6 +1071,10 @@ __global__ __launch_bounds__(kBlock) void sell_pair_spmm_kernel(
 // T / TH such passes keeps TH instead of T rows' accumulators, gathers and shuffled slot data alive - the element-grouped
 // kernels below, which carry two accumulators and up to three gathered vectors per row, drop from 206-246 VGPRs (two waves per
 // SIMD) to four waves per SIMD; the (index, value) pairs of the later passes come from L1.
+template <int NB, bool CS, typename XT>
+__device__ __forceinline__ constexpr bool lean_part() {
+    return Lay<NB>::T > 1 && ((!CS && sizeof(XT) == 4) ? kLeanGather : kLeanCs);
+}
 template <int NB, bool CS, bool ZERO, bool NT, int TH, typename XT = double>
 __device__ __forceinline__ void sell_row_part(const int* __restrict__ cols, const double* __restrict__ vals,
                                               const XT* __restrict__ x, const double* __restrict__ cs, int off, int width,
@@ -1049,6 +1093,48 @@ __device__ __forceinline__ void sell_row_part(const int* __restrict__ cols, cons
     if (width > 0) {
         cj = load_stream<NT>(cols + slot);
         vj = load_stream<NT>(vals + slot);
+    }
+    if constexpr (lean_part<NB, CS, XT>()) {
+        // Lean loop: 32-bit element offsets address the gathers, gathered rows stay in their storage type until their FMA
+        // (fp32 rows of the preconditioned Krylov vectors: half the registers), and the matrix values are fetched across
+        // lanes only AFTER the gathers have been issued - fewer registers live while the loads are in flight, and the
+        // cross-lane traffic overlaps the gather latency.  Hex 64^3 x 16, rocprofv3 averages: Darcy operator u-rows
+        // 96.9 -> 85.1 us, M-block polynomial 119.5 -> 114.8 us (compiled for three waves per SIMD instead the operator
+        // spills and takes 90.5 us; the same loop in the block operator K5 - 92 instead of 114 registers, five waves - changed
+        // nothing measurable).
+        for (int j = 0; j < width; ++j, slot += kWave) {
+            int cn = cj;
+            double vn = vj;
+            if (j + 1 < width) {
+                cn = load_stream<NT>(cols + slot + kWave);
+                vn = load_stream<NT>(vals + slot + kWave);
+            }
+            unsigned at[TH];
+#pragma unroll
+            for (int q = 0; q < TH; ++q) at[q] = (unsigned)__shfl(cj, (rs0 + q) * G + g, kWave) * (unsigned)LD + (unsigned)(t * C);
+            RawVec<XT, C> xr[TH];
+            double sv[CS ? TH : 1][C];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < TH; ++q) {
+                load_raw<C>(x + at[q], xr[q]);
+                if constexpr (CS) load_c<C>(cs + at[q], sv[q]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < TH; ++q) {
+                const double a = __shfl(vj, (rs0 + q) * G + g, kWave);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    double xv = (double)xr[q].v[c];
+                    if constexpr (CS) xv *= sv[q][c];
+                    acc[q][c] = fma(a, xv, acc[q][c]);
+                }
+            }
+            cj = cn;
+            vj = vn;
+        }
+        return;
     }
     for (int j = 0; j < width; ++j, slot += kWave) {
         int cn = cj;
@@ -1103,12 +1189,21 @@ __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, con
     const int g = lane / T, t = lane % T;
     const int off = slice * 2 * gw * kWave;
     double a[TH][C], c1[TH][C];
+    // lean variant (fp32 x, three waves per SIMD instead of two): only the coefficient-row INDICES are fetched ahead of a
+    // sweep, the rows themselves after it - 2 TH C registers fewer live while the gathers are in flight
+    constexpr bool LATE = lean_part<NB, CS, XT>() && kEgLateCoef;
+    int e1[TH];
 #pragma unroll
     for (int q = 0; q < TH; ++q) {
         const int row = min(slice * kWave + (rs0 + q) * G + g, nrows - 1);
-        load_c<C>(coef + (size_t)e12[2 * row] * LD + t * C, c1[q]);
+        if constexpr (LATE) e1[q] = e12[2 * row];
+        else load_c<C>(coef + (size_t)e12[2 * row] * LD + t * C, c1[q]);
     }
     sell_row_part<NB, CS, true, kEgNt, TH, XT>(cols, w, x, cs, off, gw, lane, LD, rs0, a);
+    if constexpr (LATE) {
+#pragma unroll
+        for (int q = 0; q < TH; ++q) load_c<C>(coef + (size_t)e1[q] * LD + t * C, c1[q]);
+    }
 #pragma unroll
     for (int q = 0; q < TH; ++q)
 #pragma unroll
@@ -1116,9 +1211,14 @@ __device__ __forceinline__ void eg_row_product(const int* __restrict__ cols, con
 #pragma unroll
     for (int q = 0; q < TH; ++q) {
         const int row = min(slice * kWave + (rs0 + q) * G + g, nrows - 1);
-        load_c<C>(coef + (size_t)e12[2 * row + 1] * LD + t * C, c1[q]);
+        if constexpr (LATE) e1[q] = e12[2 * row + 1];
+        else load_c<C>(coef + (size_t)e12[2 * row + 1] * LD + t * C, c1[q]);
     }
     sell_row_part<NB, CS, true, kEgNt, TH, XT>(cols, w, x, cs, off + gw * kWave, gw, lane, LD, rs0, a);
+    if constexpr (LATE) {
+#pragma unroll
+        for (int q = 0; q < TH; ++q) load_c<C>(coef + (size_t)e1[q] * LD + t * C, c1[q]);
+    }
 #pragma unroll
     for (int q = 0; q < TH; ++q)
 #pragma unroll
@@ -2885,6 +2985,9 @@ static int eg_pair_spmm_t(hipStream_t st, int nb, const EgView& M, const double*
     if (M.nrows == 0) return 0;
     if (A2.bv || A2.nrows != M.nrows || A2.nslices != M.nslices)
         throw Error(PMC_ERR_INTERNAL, "eg_pair_spmm: second operator must share the rows and carry shared values");
+    // the kernels address their gathers with 32-bit element offsets (sell_row_part)
+    if ((uint64_t)std::max(M.nrows, A2.ncols_hint) * (uint64_t)nb >= (1ull << 32))
+        throw Error(PMC_ERR_INVALID, "eg_pair_spmm: rows x batch width exceed 32-bit gather offsets");
     const dim3 g = grid_bounded(grid_slices(M.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (nt_flat((size_t)M.nrows * NB * 2)) {   // from 4 MiB per vector on
@@ -2914,6 +3017,8 @@ template <typename OT>
 static int eg_poly2_t(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, OT* xout,
                       double c0, double c1, double* dot_partial) {
     if (M.nrows == 0) return 0;
+    if ((uint64_t)M.nrows * (uint64_t)nb >= (1ull << 32))
+        throw Error(PMC_ERR_INVALID, "eg_poly2: rows x batch width exceed 32-bit gather offsets");
     const dim3 g = grid_bounded(grid_slices(M.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (nt_flat((size_t)M.nrows * NB * 2)) {
