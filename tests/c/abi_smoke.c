@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
     t_problem p = t_load(argv[1]);
     printf("pmc version %d, ABI %d\n", pmc_version(), pmc_abi_version());
     if (pmc_abi_version() != PMC_ABI_VERSION) { fprintf(stderr, "header / library ABI mismatch\n"); return 1; }
+    if (pmc_krylov_z_bytes() != 4 && pmc_krylov_z_bytes() != 8) { fprintf(stderr, "bad z storage width\n"); return 1; }
     pmc_ctx* ctx = NULL;
     CHECK(pmc_ctx_create(0, &ctx));
     pmc_solver_opts opts;
