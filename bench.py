@@ -481,7 +481,7 @@ def config4(seed, lanes=4, cpu=True):
     return out
 
 
-def config5(seed, lanes=2, cpu=True):
+def config5(seed, lanes=4, cpu=True):
     """BASELINE config 5 at full size on ONE GPU: SPE10-shaped box 1200 x 2200 x 170, 7 x 27 x 10 coarse cells refined 3 x
     (56 x 216 x 80 = 967 680 elements, 3.9 M Darcy DoF), L2ProjectionPDESampler on the box enlarged by one coarse cell per side,
     correlation length 100, 4 levels, k_ref == 1 (spe_perm.dat is not shipped)."""
