@@ -325,7 +325,7 @@ def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=256, roofline=False)
     dt = time.perf_counter() - t0
     launches = int(ctxs[0].lib.pmc_kernel_launches() - l0)
     ph1 = [mgr.phase_times(l) for l in range(3)]
-    widths = [sm[0].BatchWidth(l) for l in range(3)]
+    widths = [min(sm[0].BatchWidth(l), dr[0].BatchWidth(l)) for l in range(3)]   # what the manager hands over: the smaller
     out = {"workload": "MLMC Darcy + SPDE sampler, cube_hex 64^3/32^3/16^3 (1 060 864 / 134 144 / 17 152 DoF), lognormal, "
                        f"eff_perm QoI, InitRun {ns}, {lanes} lanes, realizations per launch per level {widths}"
                        + (f", sharded over {world} ranks" if farm else ""),
@@ -570,7 +570,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=32,
+                    help="realizations per plugin call and lane (sampler levels up to 8 M rows run 32 per launch)")
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batches in flight per GPU (one context + host thread each): the launch-latency-"
                          "bound coarse-level kernels of one batch overlap the bandwidth-bound kernels of the other")

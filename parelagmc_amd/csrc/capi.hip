@@ -437,7 +437,7 @@ int pmc_darcy_operator_bytes(const pmc_darcy* d, int level, int nbatch, double* 
 }
 int pmc_darcy_batch_width(const pmc_darcy* d, int level) {
     if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
-    return batch_width((size_t)d->impl.lv[level].n_u + d->impl.lv[level].n_p);
+    return batch_width((size_t)d->impl.lv[level].n_u + d->impl.lv[level].n_p, true);
 }
 int64_t pmc_darcy_nnz(const pmc_darcy* d, int level) {
     if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;

@@ -39,6 +39,12 @@ static constexpr bool kLeanCs = PMC_LEAN_CS != 0;           // ... fp64 gathers 
 #define PMC_EG_LATE_COEF 1
 #endif
 static constexpr bool kEgLateCoef = PMC_EG_LATE_COEF != 0;  // see eg_row_product
+#ifndef PMC_LEAN_RANGE_MIN_NB
+#define PMC_LEAN_RANGE_MIN_NB 32
+#endif
+// sell_row_range takes the lean gather loop (see sell_row_part) from this batch width on: at NB = 32 the one-column loop
+// needs 170-184 registers (two waves per SIMD), the lean one fits three; at NB = 16 (four waves either way) it changed nothing
+static constexpr int kLeanRangeMinNb = PMC_LEAN_RANGE_MIN_NB;
 static constexpr bool kK5TwoColumns = PMC_K5_TWO_COLUMNS != 0;   // tuning build: K5 steps two slice columns at a time (see sell_row_range); measured slower, off
 
 static unsigned dot_grid_bound();
@@ -355,11 +361,15 @@ __device__ __forceinline__ void reduce_flat_store(double (&p)[Lay<NB>::C], doubl
 // every row ends with its diagonal entry and is padded with zero-weight copies of it) gathers x[row] there, so a fused
 // <x, Ax> needs no second read of x - which by the end of a slice has long left the L2 (measured at 0.6 M rows: 25 MB of
 // 280 MB per launch).
+template <int NB>
+__device__ __forceinline__ constexpr bool lean_range() {
+    return Lay<NB>::T > 1 && NB >= kLeanRangeMinNb;
+}
 template <int NB, int BV, bool CS, bool ZERO, int JC = 1, bool NT = false, typename XT = double>
 __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
                                                const XT* __restrict__ x, const double* __restrict__ cs, int off,
                                                int width, int lane, int LD, double (&acc)[Lay<NB>::T][Lay<NB>::C],
-                                               double (*xlast)[Lay<NB>::C] = nullptr) {
+                                               double (*xlast)[Lay<NB>::C] = nullptr, double* pdot = nullptr) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int g = lane / T, t = lane % T;
     if constexpr (ZERO) {
@@ -474,6 +484,66 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         cj = load_stream<NT>(cols + slot);
         if constexpr (!BV) vj = load_stream<NT>(vals + slot);
     }
+    if constexpr (lean_range<NB>()) {
+        // lean loop (as sell_row_part): 32-bit element offsets, gathered rows and fp32 per-realization values stay in their
+        // storage type until the FMA, shared values are fetched across lanes after the gathers have been issued; with pdot
+        // the fused <x, A x> of a diagonal-last matrix is taken right at the row's last column (rows past the end carry
+        // zero values)
+        for (int j = 0; j < width; ++j, slot += kWave) {
+            int cn = cj;
+            double vn = vj;
+            if (j + 1 < width) {
+                cn = load_stream<NT>(cols + slot + kWave);
+                if constexpr (!BV) vn = load_stream<NT>(vals + slot + kWave);
+            }
+            unsigned at[T];
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs) at[rs] = (unsigned)__shfl(cj, rs * G + g, kWave) * (unsigned)LD + (unsigned)(t * C);
+            RawVec<XT, C> xr[T];
+            RawVec<float, C> avf[BV == 2 ? T : 1];
+            double avd[BV == 1 ? T : 1][C];
+            double sv[CS ? T : 1][C];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs) {
+                load_raw<C>(x + at[rs], xr[rs]);
+                if constexpr (CS) load_c<C>(cs + at[rs], sv[rs]);
+                if constexpr (BV == 2)
+                    load_raw<C>(reinterpret_cast<const float*>(vals) + ((size_t)(slot - lane + rs * G + g) * LD + t * C), avf[rs]);
+                if constexpr (BV == 1) load_c<C>(vals + ((size_t)(slot - lane + rs * G + g) * LD + t * C), avd[rs]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs) {
+                double a = 0.0;
+                if constexpr (!BV) a = __shfl(vj, rs * G + g, kWave);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    double xv = (double)xr[rs].v[c];
+                    if constexpr (CS) xv *= sv[rs][c];
+                    if constexpr (BV == 2) acc[rs][c] = fma((double)avf[rs].v[c], xv, acc[rs][c]);
+                    else if constexpr (BV == 1) acc[rs][c] = fma(avd[rs][c], xv, acc[rs][c]);
+                    else acc[rs][c] = fma(a, xv, acc[rs][c]);
+                }
+            }
+            if (j + 1 == width) {
+                if (pdot) {
+#pragma unroll
+                    for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) pdot[c] = fma((double)xr[rs].v[c], acc[rs][c], pdot[c]);
+                } else if (xlast) {
+#pragma unroll
+                    for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) xlast[rs][c] = (double)xr[rs].v[c];
+                }
+            }
+            cj = cn;
+            vj = vn;
+        }
+        return;
+    }
     for (int j = 0; j < width; ++j, slot += kWave) {
         // software pipeline: the next slice column's (value, index) pair is requested before this
         // column's gathers, so its latency overlaps them
@@ -568,7 +638,7 @@ __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
 // few MB) disappears from the V-cycle.
 // XT: storage type of x and dot_with (fp32 for the preconditioned Krylov vectors, zreal)
 template <int NB, int BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false, bool DL = false, typename XT = double>
-__global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+__global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? 3 : 1)) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
                                                            const double* __restrict__ vals,
@@ -598,8 +668,13 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
     for (int si = sw.begin; si < sw.end; si += sw.stride) {
         const int slice = sched ? sched[si] : si;   // optional processing order (locality), see Sell::sched
         double acc[T][C];
-        double xd[DL ? T : 1][C];
-        if constexpr (DL) {
+        constexpr bool LEAN_DL = DL && lean_range<NB>();   // the dot is taken inside the gather loop
+        double xd[DL && !LEAN_DL ? T : 1][C];
+        if constexpr (LEAN_DL) {
+            const int off = slice_off[slice];
+            sell_row_range<NB, false, false, true, 1, NT, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6,
+                                                             lane, LD, acc, nullptr, p);
+        } else if constexpr (DL) {
             const int off = slice_off[slice];
             sell_row_range<NB, false, false, true, 1, NT, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6,
                                                              lane, LD, acc, xd);
@@ -629,7 +704,8 @@ __global__ __launch_bounds__(kBlock) void sell_spmm_kernel(int nrows, int nslice
                     for (int c = 0; c < C; ++c) acc[rs][c] = rv[c] - acc[rs][c];
                 }
                 store_c_stream<NT, C>(y + at, acc[rs]);
-                if constexpr (DL) {
+                if constexpr (LEAN_DL) {
+                } else if constexpr (DL) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) p[c] = fma(xd[rs][c], acc[rs][c], p[c]);
                 } else if constexpr (DOT) {
@@ -737,7 +813,7 @@ __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslice
 // From a NONZERO guess x0 the same polynomial acts on the residual: x2 = x0 + p2(r - A x0); then r is that residual,
 // xadd = x0 (may alias xout: no gathers on it) and the dot is taken with dot_with (the right-hand side).
 template <int NB, int BV, bool DOT, bool NT = false, typename OT = double>
-__global__ __launch_bounds__(kBlock) void sell_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+__global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 ? 3 : 1)) void sell_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                             const int* __restrict__ sched,
                                                             const int* __restrict__ cols,
                                                             const double* __restrict__ vals_scaled,
@@ -829,52 +905,7 @@ template <int NB, typename XT, bool NT = false, int BV = 0>
 __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, const double* __restrict__ vals,
                                                  const XT* __restrict__ x, int off, int width, int lane, int LD,
                                                  double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
-    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
-    const int g = lane / T, t = lane % T;
-#pragma unroll
-    for (int rs = 0; rs < T; ++rs)
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
-    int slot = off + lane;
-    int cj = 0;
-    double vj = 0.0;
-    if (width > 0) {
-        cj = load_stream<NT>(cols + slot);
-        if constexpr (BV == 0) vj = load_stream<NT>(vals + slot);
-    }
-    for (int j = 0; j < width; ++j, slot += kWave) {
-        int cn = cj;
-        double vn = vj;
-        if (j + 1 < width) {
-            cn = load_stream<NT>(cols + slot + kWave);
-            if constexpr (BV == 0) vn = load_stream<NT>(vals + slot + kWave);
-        }
-        int cc[T];
-        double aa[T];
-#pragma unroll
-        for (int rs = 0; rs < T; ++rs) {
-            const int src = rs * G + g;
-            cc[rs] = (T == 1) ? cj : __shfl(cj, src, kWave);
-            if constexpr (BV == 0) aa[rs] = (T == 1) ? vj : __shfl(vj, src, kWave);
-        }
-        double xv[T][C], av[T][C];
-        if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rs = 0; rs < T; ++rs) {
-            load_v<C>(x + (size_t)cc[rs] * LD + t * C, xv[rs]);
-            if constexpr (BV != 0) load_bv<BV, C>(vals, (size_t)(slot - lane + rs * G + g) * LD + t * C, av[rs]);
-        }
-        if constexpr (T > 1) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rs = 0; rs < T; ++rs)
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                if constexpr (BV != 0) acc[rs][c] = fma(av[rs][c], xv[rs][c], acc[rs][c]);
-                else acc[rs][c] = fma(aa[rs], xv[rs][c], acc[rs][c]);
-            }
-        cj = cn;
-        vj = vn;
-    }
+    sell_row_range<NB, BV, false, true, 1, NT, XT>(cols, vals, x, nullptr, off, width, lane, LD, acc);
 }
 
 // out = dinv (c0 r - c1 As r) (+ xadd) (+ padd_x[padd_idx]) with r of type XT (gathered and read at the own row), out of
@@ -2547,6 +2578,11 @@ static inline void check_launch(int n = 1) {
     PMC_HIP(hipGetLastError());
     count_kernel_launches(n);
 }
+// the lean gather loops address rows with 32-bit element offsets: rows x row stride of every gathered vector must fit
+static inline void check_offsets32(const SellView& A, int nb) {
+    if ((uint64_t)std::max(A.nrows, A.ncols_hint) * (uint64_t)nb >= (1ull << 32))
+        throw Error(PMC_ERR_INVALID, "operand exceeds the 32-bit gather offsets of the SpMM kernels (rows x batch width >= 2^32)");
+}
 // flat vector kernels stream non-temporally once one vector exceeds PMC_NT_FLAT_MB MiB (default 8; 0 = never)
 static inline bool nt_flat(size_t doubles) {
     static const double limit = [] {
@@ -2667,6 +2703,7 @@ static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const
 template <typename XT>
 static int spmm_t(hipStream_t st, int nb, const SellView& A, const XT* x, double* y, bool accumulate, double* dot_partial,
                   const XT* dot_with) {
+    check_offsets32(A, nb);
     if (A.nrows == 0) return 0;
     if (dot_partial && !dot_with) throw Error(PMC_ERR_INTERNAL, "spmm: fused dot without its second vector");
     dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
@@ -2702,6 +2739,7 @@ int spmm_z(hipStream_t st, int nb, const SellView& A, const zreal* x, double* y,
 
 void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out,
                         double* coarse) {
+    check_offsets32(A, nb);
     if (A.nrows == 0) return;
     if (A.nrows % 8 != 0) throw Error(PMC_ERR_INTERNAL, "residual_restrict8: rows are not groups of 8");
     const dim3 g = grid_slices(A.nslices);
@@ -2717,6 +2755,7 @@ void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double*
 }
 
 void residual(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out) {
+    check_offsets32(A, nb);
     if (A.nrows == 0) return;
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
@@ -2732,6 +2771,7 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
 
 int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
               const double* xin, double* d, double* xout, double a, double b, double* dot_partial) {
+    check_offsets32(A, nb);
     if (A.nrows == 0) return 0;
     if (A.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "cheb_step: value/diagonal batching mismatch");
     const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
@@ -2759,6 +2799,7 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
 
 int cheb_step_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
                 const double* xin, double* d, zreal* zout, double a, double b, double* dot_partial) {
+    check_offsets32(A, nb);
     if (A.nrows == 0) return 0;
     if (A.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "cheb_step: value/diagonal batching mismatch");
     const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
@@ -2787,6 +2828,7 @@ int cheb_step_z(hipStream_t st, int nb, const SellView& A, const double* dinv, b
 int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
           double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with, const int* padd_idx,
           const double* padd_x) {
+    check_offsets32(As, nb);
     if (As.nrows == 0) return 0;
     if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
@@ -2820,6 +2862,7 @@ int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool d
 int poly2_z(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, zreal* xout,
             double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with, const int* padd_idx,
             const double* padd_x) {
+    check_offsets32(As, nb);
     if (As.nrows == 0) return 0;
     if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
@@ -2852,6 +2895,7 @@ int poly2_z(hipStream_t st, int nb, const SellView& As, const double* dinv, bool
 
 void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, float* xout, double c0,
                     double c1) {
+    check_offsets32(As, nb);
     if (As.nrows == 0) return;
     if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_presmooth32: shared values expected");
     const dim3 g = grid_slices(As.nslices);
@@ -2866,6 +2910,7 @@ void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* di
 
 void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out,
                               double* coarse) {
+    check_offsets32(A, nb);
     if (A.nrows == 0) return;
     if (A.bv || A.nrows % 8 != 0) throw Error(PMC_ERR_INTERNAL, "vc_residual_restrict8_32: shared values and groups of 8 rows expected");
     const dim3 g = grid_slices(A.nslices);
@@ -2876,6 +2921,7 @@ void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const d
 }
 
 void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res, const double* xc) {
+    check_offsets32(SP, nb);
     if (SP.nrows == 0) return;
     if (SP.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual_coarse32: shared values expected");
     const dim3 g = grid_slices(SP.nslices);
@@ -2889,6 +2935,7 @@ template <typename OT>
 static int vc_postsmooth32_t(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
                              OT* xout, double c0, double c1, const double* r, const int* parent, const double* xc,
                              double* dot_partial) {
+    check_offsets32(As, nb);
     if (As.nrows == 0) return 0;
     if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_postsmooth32: shared values expected");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
@@ -2919,6 +2966,7 @@ int vc_postsmooth32_z(hipStream_t st, int nb, const SellView& As, const double* 
 // ---- the same level with per-realization fp32 values (Darcy; SellView::f32) and per-realization diagonals
 void vc_presmooth32_bv(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, float* xout, double c0,
                        double c1) {
+    check_offsets32(As, nb);
     if (As.nrows == 0) return;
     if (!(As.bv && As.f32)) throw Error(PMC_ERR_INTERNAL, "vc_presmooth32_bv: per-realization fp32 values expected");
     const dim3 g = grid_slices(As.nslices);
@@ -2929,6 +2977,7 @@ void vc_presmooth32_bv(hipStream_t st, int nb, const SellView& As, const double*
 }
 
 void vc_restrict8_32_bv(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, double* coarse) {
+    check_offsets32(A, nb);
     if (A.nrows == 0) return;
     if (!(A.bv && A.f32) || A.nrows % 8 != 0) throw Error(PMC_ERR_INTERNAL, "vc_restrict8_32_bv: operand mismatch");
     const dim3 g = grid_slices(A.nslices);
@@ -2945,6 +2994,7 @@ void vc_prolong8_32(hipStream_t st, int nb, int n, float* x, const double* xc) {
 }
 
 void vc_residual32_bv(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out) {
+    check_offsets32(A, nb);
     if (A.nrows == 0) return;
     if (!(A.bv && A.f32)) throw Error(PMC_ERR_INTERNAL, "vc_residual32_bv: per-realization fp32 values expected");
     const dim3 g = grid_slices(A.nslices);
@@ -2957,6 +3007,7 @@ void vc_residual32_bv(hipStream_t st, int nb, const SellView& A, const double* r
 template <typename OT>
 static int vc_postsmooth32_bv_t(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
                                 OT* xout, double c0, double c1, const double* r, double* dot_partial) {
+    check_offsets32(As, nb);
     if (As.nrows == 0) return 0;
     if (!(As.bv && As.f32)) throw Error(PMC_ERR_INTERNAL, "vc_postsmooth32_bv: per-realization fp32 values expected");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
@@ -3047,6 +3098,7 @@ int eg_poly2_z(hipStream_t st, int nb, const EgView& M, const double* coef, cons
 template <typename XT>
 static int pair_spmm_t(hipStream_t st, int nb, const SellView& A1, const XT* x1, const SellView& A2, const XT* x2, double* y,
                        double* dot_partial, const XT* dot_with) {
+    check_offsets32(A1, nb);
     if (A1.nrows == 0) return 0;
     if (!A1.bv || A2.bv || A1.nrows != A2.nrows || A1.nslices != A2.nslices)
         throw Error(PMC_ERR_INTERNAL, "pair_spmm: operand mismatch");

@@ -56,12 +56,14 @@ for refine, nvec in ((5, 595968), (6, 4743168)):
             for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
                 f.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.3f}\n")
     # one lane alone on the GPU splits the Lanczos update into a u-row and an s-row launch (two streams): compare totals
-    lv = [x for k, vals in fetch.items() if "lincomb3_kernel<16" in k for x in vals]
+    # (the bench runs the large levels 32 realizations per launch; older passes 16)
+    nbw = 32 if any("lincomb3_kernel<32" in k for k in fetch) else 16
+    lv = [x for k, vals in fetch.items() if f"lincomb3_kernel<{nbw}" in k for x in vals]
     split = len(set(round(x / 1024.0) for x in lv)) > 1 and max(lv) > 1.5 * min(lv)
     lf = sum(lv) / len(lv) * (2 if split else 1)
-    read_kb = 3 * nvec * 16 * 8 / 1024.0
-    for key, kern in ((f"r{refine}_nb16_inloop", "sell_spmm_kernel<16, 0, 0, true, 1,"),
-                      (f"r{refine}_nb16", "sell_spmm_kernel<16, 0, 0, false, 2,"),
+    read_kb = 3 * nvec * nbw * 8 / 1024.0
+    for key, kern in ((f"r{refine}_nb{nbw}_inloop", f"sell_spmm_kernel<{nbw}, 0, 0, true, 1,"),
+                      (f"r{refine}_nb{nbw}", f"sell_spmm_kernel<{nbw}, 0, 0, false, 2,"),
                       (f"r{refine}_nb1", "sell_spmm_kernel<1, 0, 0, false, 2,")):
         fr, n = mean(fetch, kern)
         wr, _ = mean(write, kern)
@@ -69,7 +71,7 @@ for refine, nvec in ((5, 595968), (6, 4743168)):
             continue
         out[key] = {"kernel": f"pmc::{kern} ...> on A", "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB_raw": wr,
                     "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
-    out[f"r{refine}_correction"] = ("FETCH_SIZE x2 on gfx950; cross-check in the same pass on the flat lincomb3_kernel<16>: raw "
+    out[f"r{refine}_correction"] = ("FETCH_SIZE x2 on gfx950; cross-check in the same pass on the flat lincomb3_kernel: raw "
                                     f"{lf:.0f} KB for {read_kb:.0f} KB actually read (ratio {read_kb / lf:.3f})")
 # Darcy operator of config 3 (u-rows [M(k) | B^T] x with the fused dot, in the MINRES loop)
 try:
