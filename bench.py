@@ -571,7 +571,7 @@ def main():
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32,
-                    help="realizations per plugin call and lane (sampler levels up to 8 M rows run 32 per launch)")
+                    help="realizations per plugin call and lane (sampler levels up to 5 M rows run 32 per launch)")
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batches in flight per GPU (one context + host thread each): the launch-latency-"
                          "bound coarse-level kernels of one batch overlap the bandwidth-bound kernels of the other")

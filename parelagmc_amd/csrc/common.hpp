@@ -193,7 +193,7 @@ struct Ctx {
 };
 
 // Interleaved batch width of a level with `rows` unknowns (saddle-point system).  Large levels are bandwidth-bound at 16
-// realizations per launch; sampler levels up to 8 M rows (PMC_S_WIDE_ROWS) and Darcy levels small enough to be bound by
+// realizations per launch; sampler levels up to 5 M rows (PMC_S_WIDE_ROWS) and Darcy levels small enough to be bound by
 // launch latency take 32 (PMC_WIDE_ROWS: limit, default 300 000 rows; set, it applies to both kinds, 0 = always 16), and the smaller the level the more column groups of 32 one launch carries - 64, 128 or 256
 // realizations (PMC_W64_ROWS / PMC_W128_ROWS / PMC_W256_ROWS: limits, 0 = never) - until a launch fills the chip.
 int batch_width(size_t rows, bool darcy = false);

@@ -384,13 +384,13 @@ int batch_width(size_t rows, bool darcy) {
         return e ? (size_t)atoll(e) : dflt;
     };
     // Large levels: the sampler's kernels move more per gather at 32 realizations per launch (config 2, four lanes: 1 741 ->
-    // 1 794 samples/s, one lane 1 237 -> 1 358; beyond 8 M rows the vectors of four lanes no longer pay for it); the
+    // 1 794 samples/s, one lane 1 237 -> 1 358; beyond 5 M rows the vectors of four lanes beside a Darcy solver no longer fit comfortably: config 5); the
     // element-grouped Darcy kernels sweep a slice in two passes at that width and gain nothing, and a Darcy level takes
     // several times the memory per realization
     // PMC_WIDE_ROWS: limit of the 32-wide launches for Darcy levels, and for sampler levels too when it is set (0 = always
     // 16); PMC_S_WIDE_ROWS: the sampler's own limit
     static const size_t l32 = lim("PMC_WIDE_ROWS", 300000),
-                        l32s = lim("PMC_S_WIDE_ROWS", getenv("PMC_WIDE_ROWS") ? l32 : (size_t)8000000),
+                        l32s = lim("PMC_S_WIDE_ROWS", getenv("PMC_WIDE_ROWS") ? l32 : (size_t)5000000),
                         l64 = lim("PMC_W64_ROWS", 150000), l128 = lim("PMC_W128_ROWS", 40000), l256 = lim("PMC_W256_ROWS", 20000);
     if (rows > (darcy ? l32 : l32s)) return 16;
     if (rows <= l256) return 256;
