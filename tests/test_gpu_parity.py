@@ -437,6 +437,14 @@ def test_full_size_config2_properties(gpu_ctx):
     assert info == 0
     s_red = (1.0 / a) * winv * (L.B @ u) + (g / a) * winv * r
     assert rel(s[0], s_red) < 1e-6
+    # (iv) a level of this size runs 32 realizations per launch (batch_width, csrc/solver.hip: the lean gather loop of the
+    # NB = 32 kernels): every column of a full launch equals its single evaluation, on both sides of the half-way column
+    assert smp.BatchWidth(0) == 32
+    xi32 = smp.Sample(0, first_id=100, nbatch=32)
+    s32, st32 = smp.Eval(0, xi32, return_stats=True)
+    assert all(t[1] == 1 for t in st32)
+    for b in (0, 15, 16, 31):
+        assert rel(smp.Eval(0, xi32[b:b + 1])[0], s32[b]) < 1e-7, b
     smp.close()
 
 
@@ -896,6 +904,7 @@ def test_full_size_config3_darcy_properties(gpu_ctx):
     dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], n_mc_levels=3)
     assert [L.ndofs for L in dp.levels[:3]] == [1060864, 134144, 17152]
     ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(rel_tol=1e-10, abs_tol=1e-30))
+    assert [ds.BatchWidth(lvl) for lvl in range(3)] == [16, 64, 256]   # Darcy levels above 300 k unknowns keep 16 per launch
     for lvl in range(3):
         Q, C = ds.SolveFwd(lvl, np.ones((1, dp.levels[lvl].n_p)))
         assert abs(Q[0] - 2.0) < 1e-8 and C[0] == dp.levels[lvl].ndofs
