@@ -9,6 +9,10 @@
                          - SELF-GENERATED oracle outputs (sparse direct solves) for seeded
                            inputs; they guard the oracle against drift, they are not
                            reference outputs (the reference cannot be built here).
+                           The two hex fixtures are computed by oracle/fe_ref.py - closed-form
+                           RT0/P0 operators that import nothing of parelagmc_amd.fe - and stored in
+                           the product's cell order (cells matched by centroid); the oracle on the
+                           product's builders must reproduce them to 1e-10 or this script stops.
 """
 import json
 import os
@@ -22,8 +26,10 @@ sys.path.insert(0, ROOT)
 
 from parelagmc_amd.fe import (box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem,  # noqa: E402
                               read_mfem_mesh)
+from oracle import fe_ref  # noqa: E402
 from oracle.darcy_oracle import DarcyOracle  # noqa: E402
 from oracle.sampler_oracle import SamplerOracle  # noqa: E402
+from parelagmc_amd.fe.mesh import element_centroids  # noqa: E402
 
 REF_MESHES = "/root/reference/meshes"
 
@@ -34,6 +40,23 @@ def mesh_to_json(name):
              bdr=m.bdr.tolist(), bdr_attr=m.bdr_attr.tolist(), source=f"meshes/{name}.mesh")
     with open(os.path.join(HERE, "meshes", name + ".json"), "w") as f:
         json.dump(d, f)
+
+
+def cell_perm(space, ref):
+    """perm with: product cell i == reference cell perm[i] (matched by centroid)"""
+    def order(x):
+        return np.lexsort(np.round(x * 1e9).astype(np.int64).T[::-1])
+    a, b = element_centroids(space.mesh), ref.cell_centroids()
+    ia, ib = order(a), order(b)
+    assert np.allclose(a[ia], b[ib])
+    perm = np.empty(len(a), np.int64)
+    perm[ia] = ib
+    return perm
+
+
+def agree(a, b, what):
+    if not np.allclose(a, b, rtol=0, atol=1e-10 * np.abs(b).max()):
+        raise SystemExit(f"{what}: oracle on the product's builders and oracle/fe_ref.py disagree")
 
 
 def main():
@@ -59,11 +82,23 @@ def main():
     h = build_hierarchy(box_mesh([4, 4, 4], [2, 2, 2], "hex"), 1)
     sp = build_sampler_problem(h, corlen=0.1)
     so = SamplerOracle(sp)
+    ref_levels = fe_ref.hex_hierarchy([4, 4, 4], [2.0, 2.0, 2.0], 1)
+    rs = fe_ref.RefSampler(ref_levels, 0.1)
+    perm = [cell_perm(h.spaces[l], ref_levels[l]) for l in range(2)]
+
+    def to_ref(v, l):
+        out = np.empty_like(v)
+        out[perm[l]] = v
+        return out
+
     xi = rng.standard_normal((2, sp.levels[0].n_s))
-    s00 = np.stack([so.eval(0, 0, x)[0] for x in xi])
-    s10 = np.stack([so.eval(1, 0, x)[0] for x in xi])      # coarse field from fine xi (Ps^T coupling)
+    s00 = np.stack([rs.eval(0, 0, to_ref(x, 0))[perm[0]] for x in xi])
+    s10 = np.stack([rs.eval(1, 0, to_ref(x, 0))[perm[1]] for x in xi])      # coarse field from fine xi (Ps^T coupling)
     xi1 = rng.standard_normal((2, sp.levels[1].n_s))
-    s11 = np.stack([so.eval(1, 1, x)[0] for x in xi1])
+    s11 = np.stack([rs.eval(1, 1, to_ref(x, 1))[perm[1]] for x in xi1])
+    agree(np.stack([so.eval(0, 0, x)[0] for x in xi]), s00, "s00")
+    agree(np.stack([so.eval(1, 0, x)[0] for x in xi]), s10, "s10")
+    agree(np.stack([so.eval(1, 1, x)[0] for x in xi1]), s11, "s11")
     np.savez_compressed(os.path.join(HERE, "gold_sampler_hex.npz"), xi0=xi, s00=s00, s10=s10, xi1=xi1, s11=s11)
     # GOLD-1: inline_quad, 1 level, d=2
     hq = build_hierarchy(box_mesh([2, 2], [1.0, 1.0], "quad"), 0)
@@ -81,7 +116,10 @@ def main():
         for lvl in range(2):
             k = np.stack([sol.eval(lvl, 0, x)[0] for x in xi])
             out[f"k_L{lvl}"] = k
-            out[f"Q_L{lvl}_{'div' if kd else 'mul'}"] = np.array([do.solve_fwd(lvl, kk)[0] for kk in k])
+            rd = fe_ref.RefDarcy(ref_levels[lvl], [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], k_divides=kd)
+            Q = np.array([rd.solve_fwd(to_ref(kk, lvl))[0] for kk in k])
+            agree(np.array([do.solve_fwd(lvl, kk)[0] for kk in k]), Q, f"Q level {lvl}")
+            out[f"Q_L{lvl}_{'div' if kd else 'mul'}"] = Q
     np.savez_compressed(os.path.join(HERE, "gold_darcy_hex.npz"), **out)
     print("fixtures written")
 

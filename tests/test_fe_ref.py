@@ -1,0 +1,153 @@
+"""oracle/fe_ref.py (closed-form Cartesian-hex RT0/P0 operators, no import of parelagmc_amd.fe) against the product's
+builders, entry by entry, and against the golden fixtures.
+
+The two builders number cells and faces differently and orient faces differently; both are matched GEOMETRICALLY (cell and
+face centroids), the orientation signs are read off the divergence matrices and must then explain the mass matrices as
+well.  Spec: /root/reference/src/PDESampler.cpp:232-258 (M, W, D, boundary elimination), SURVEY.md Appendix A.5."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import fe_ref
+from oracle.darcy_oracle import DarcyOracle
+from oracle.sampler_oracle import SamplerOracle
+from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem
+from parelagmc_amd.fe.mesh import element_centroids
+from parelagmc_amd.fe.rt0 import mass_matrix
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _match(a, b, tol=1e-9):
+    """perm with a[i] == b[perm[i]] for two point clouds holding the same points"""
+    def key(x):
+        return np.lexsort(np.round(x / tol).astype(np.int64).T[::-1])
+    ia, ib = key(a), key(b)
+    assert np.allclose(a[ia], b[ib], atol=10 * tol)
+    perm = np.empty(len(a), np.int64)
+    perm[ia] = ib
+    return perm
+
+
+def _maps(space, ref):
+    """(cell permutation, face permutation, face signs): product index -> reference index, s_f = +-1 so that a product
+    u-dof equals s_f times the reference u-dof of the same face"""
+    cperm = _match(element_centroids(space.mesh), ref.cell_centroids())
+    fc = space.mesh.verts[space.faces.face_verts].mean(axis=1)
+    fperm = _match(fc, ref.face_centroids())
+    Bp = space.B.tocsr()
+    Br = ref.divergence()[cperm][:, fperm].tocsr()
+    assert (Bp != 0).multiply(Br != 0).nnz == Bp.nnz == Br.nnz          # same pattern
+    ratio = sp.csr_matrix(Bp.multiply(Br))                                # entries +-1: product of the two signs
+    s = np.zeros(space.n_u)
+    coo = ratio.tocoo()
+    s[coo.col] = coo.data
+    # both cells of an interior face must agree on the sign
+    assert abs(ratio - sp.csr_matrix(abs(Br) @ sp.diags(s))).max() == 0.0
+    assert set(np.unique(s)) <= {-1.0, 1.0}
+    return cperm, fperm, s
+
+
+@pytest.mark.parametrize("n0,nref", [(4, 0), (4, 1), (4, 2)])
+def test_hex_operators_equal_the_closed_forms_entry_by_entry(n0, nref):
+    h = build_hierarchy(box_mesh([n0] * 3, [2.0, 2.0, 2.0], "hex"), nref)
+    levels = fe_ref.hex_hierarchy([n0] * 3, [2.0, 2.0, 2.0], nref)
+    maps = []
+    for space, ref in zip(h.spaces, levels):
+        cperm, fperm, s = _maps(space, ref)
+        maps.append(cperm)
+        S = sp.diags(s)
+        assert space.n_u == ref.n_u and space.n_s == ref.n_s
+        np.testing.assert_allclose(space.vol, ref.w_diag()[cperm], rtol=1e-14)
+        # unconstrained mass matrix and M(c) for a random coefficient (the Darcy M(k))
+        rng = np.random.default_rng(5)
+        c = np.exp(rng.standard_normal(space.n_s))
+        for coeff_p, coeff_r in ((None, None), (c, None)):
+            Mp = mass_matrix(space.emass, coeff_p)
+            cr = None
+            if coeff_p is not None:
+                cr = np.empty(ref.n_s)
+                cr[cperm] = c
+            Mr = (S @ ref.mass(cr)[fperm][:, fperm] @ S).tocsr()
+            d = abs(Mp - Mr)
+            assert d.max() <= 1e-14 * abs(Mr).max()
+            assert (Mp != 0).nnz == (Mr != 0).nnz                         # no extra stored couplings either way
+        # boundary attributes (the Darcy BC arrays index them)
+        np.testing.assert_array_equal(space.faces.face_bdr_attr, ref.boundary_attribute()[fperm])
+    # P0 prolongators
+    for l in range(nref):
+        Pr = levels[l].prolongation(levels[l + 1])[maps[l]][:, maps[l + 1]]
+        assert abs(h.P[l] - Pr).max() == 0.0
+
+
+def test_sampler_operators_and_fields_from_the_independent_builder():
+    """the arrays the HIP path receives (build_sampler_problem) == the closed forms after boundary elimination, the two
+    direct solves give the same field for the same white noise (ids matched geometrically), and the golden fixture holds
+    for the independent builder"""
+    h = build_hierarchy(box_mesh([4, 4, 4], [2.0, 2.0, 2.0], "hex"), 1)
+    spb = build_sampler_problem(h, corlen=0.1)
+    levels = fe_ref.hex_hierarchy([4, 4, 4], [2.0, 2.0, 2.0], 1)
+    ref = fe_ref.RefSampler(levels, 0.1)
+    assert abs(spb.matern_g - ref.g) <= 1e-13 * ref.g and spb.alpha == ref.alpha
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))["matern_g"]["cases"]
+    for case in kat:
+        assert abs(fe_ref.matern_g(case["corlen"], case["dim"]) - case["g"]) <= 1e-12 * case["g"]
+    cperms = []
+    for l, (space, L) in enumerate(zip(h.spaces, spb.levels)):
+        cperm, fperm, s = _maps(space, levels[l])
+        cperms.append(cperm)
+        S = sp.diags(s)
+        M, B, w = ref.operators(l)
+        assert abs(L.M - S @ M[fperm][:, fperm] @ S).max() <= 1e-14 * abs(M).max()
+        assert abs(L.B - B[cperm][:, fperm] @ S).max() == 0.0
+        np.testing.assert_allclose(L.w_diag, w[cperm], rtol=1e-14)
+    gold = np.load(os.path.join(GOLD, "gold_sampler_hex.npz"))
+    so = SamplerOracle(spb)
+
+    def to_ref(v, l):                 # product cell order -> reference cell order
+        out = np.empty_like(v)
+        out[cperms[l]] = v
+        return out
+
+    for xi, s00, s10 in zip(gold["xi0"], gold["s00"], gold["s10"]):
+        f0 = ref.eval(0, 0, to_ref(xi, 0))
+        f1 = ref.eval(1, 0, to_ref(xi, 0))
+        np.testing.assert_allclose(f0[cperms[0]], s00, rtol=0, atol=1e-10 * np.abs(s00).max())
+        np.testing.assert_allclose(f1[cperms[1]], s10, rtol=0, atol=1e-10 * np.abs(s10).max())
+        np.testing.assert_allclose(f0[cperms[0]], so.eval(0, 0, xi)[0], rtol=0, atol=1e-10 * np.abs(s00).max())
+    for xi, s11 in zip(gold["xi1"], gold["s11"]):
+        np.testing.assert_allclose(ref.eval(1, 1, to_ref(xi, 1))[cperms[1]], s11, rtol=0, atol=1e-10 * np.abs(s11).max())
+
+
+def test_darcy_known_answer_and_goldens_from_the_independent_builder():
+    """DarcyDeterministicTest (/root/reference/examples/CMakeLists.txt:62-66): Q = 2 and 17152 / 2240 / 304 dofs from the
+    closed-form operators alone; for log-normal k the independent solve reproduces the golden QoIs and the oracle's"""
+    ess, obs, inflow = [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1]
+    levels = fe_ref.hex_hierarchy([4, 4, 4], [2.0, 2.0, 2.0], 2)
+    for L, dofs in zip(levels, (17152, 2240, 304)):
+        Q, C, _ = fe_ref.RefDarcy(L, ess, obs, inflow).solve_fwd(np.ones(L.n_s))
+        assert abs(Q - 2.0) < 1e-11 and int(C) == dofs
+    h = build_hierarchy(box_mesh([4, 4, 4], [2.0, 2.0, 2.0], "hex"), 1)
+    gold = np.load(os.path.join(GOLD, "gold_darcy_hex.npz"))
+    lv = fe_ref.hex_hierarchy([4, 4, 4], [2.0, 2.0, 2.0], 1)
+    for kd, tag in ((True, "div"), (False, "mul")):
+        dp = build_darcy_problem(h, ess, obs, inflow, k_divides=kd)
+        do = DarcyOracle(dp)
+        for l in range(2):
+            cperm, fperm, s = _maps(h.spaces[l], lv[l])
+            rd = fe_ref.RefDarcy(lv[l], ess, obs, inflow, k_divides=kd)
+            # rhs / observation functional / essential mask of the product == the closed forms (up to the face signs)
+            np.testing.assert_array_equal(dp.levels[l].ess_mask.astype(bool), rd.ess[fperm])
+            np.testing.assert_allclose(dp.levels[l].rhs[:lv[l].n_u], s * rd.rhs_u[fperm], atol=0)
+            np.testing.assert_allclose(dp.levels[l].obs[:lv[l].n_u], s * rd.obs_u[fperm], atol=0)
+            for k, Qg in zip(gold[f"k_L{l}"], gold[f"Q_L{l}_{tag}"]):
+                kr = np.empty_like(k)
+                kr[cperm] = k
+                Q, _, sol = rd.solve_fwd(kr)
+                assert abs(Q - Qg) <= 1e-10 * abs(Qg)
+                Qo, _, solo = do.solve_fwd(l, k, return_solution=True)
+                assert abs(Q - Qo) <= 1e-10 * abs(Qo)
+                np.testing.assert_allclose(solo[:lv[l].n_u], s * sol[:lv[l].n_u][fperm], atol=1e-10 * np.abs(sol).max())
