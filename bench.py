@@ -6,7 +6,11 @@ A step = Sample + Eval of `--streams` batches of `--batch` realizations, white n
 all inputs are resident in HBM when the timed region starts.  Contract: W untimed warm-up steps,
 then exactly K steps bracketed by barrier + torch.cuda.synchronize(); MAX over ranks; rank 0
 prints ONE JSON line.  The timed region carries no instrumentation; the roofline figures are taken in
-separate short passes after it.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL),
+separate short passes after it.  Behind the headline the default run (N = 1) also measures, under "extra", every other
+BASELINE configuration on this GPU with bounded work: config 3 (MLMC Darcy + SPDE), the 1 060 864-DoF hex sampler point,
+the HBM-bound r = 6 point, configs 4 and 5 (GPU legs), the all-fp64 storage option and the drop-in one-realization-per-call
+path; the finite-element SETUP of those configurations (numpy, no GPU) is built by background worker processes while the
+GPU works on the earlier ones.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL),
 every rank owns a full replica of the operators and its own realizations (weak scaling, no data-path
 collective); the one exchange of a sample farm - the SUM all-reduce of the MLMC accumulators - is exercised
 through the library's own communicator (pmc_comm_* / pmc_allreduce_sum_f64, RCCL) under extra.mlmc_farm.
@@ -34,6 +38,121 @@ def build_problem(nref, extra_coarse=True):
     return build_sampler_problem(h, corlen=0.1, lognormal=False, n_mc_levels=1)
 
 
+def build_config3():
+    from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem
+    h = build_hierarchy(box_mesh([4, 4, 4], [2, 2, 2], "hex"), 4)
+    sp = build_sampler_problem(h, corlen=0.1, lognormal=True, n_mc_levels=3)
+    dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], n_mc_levels=3)
+    return sp, dp
+
+
+def build_config4():
+    from parelagmc_amd.fe import build_hierarchy, build_sampler_problem, mesh_from_json
+    h = build_hierarchy(mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet_embed.json")), 4)
+    return build_sampler_problem(h, corlen=0.1, embedded=True, lognormal=True, n_mc_levels=3)
+
+
+def build_config5():
+    from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem, l2_projection_hierarchy
+    nx, ny, nz = 7, 27, 10
+    hx, hy, hz = 1200.0 / nx, 2200.0 / ny, 170.0 / nz
+    ho = build_hierarchy(box_mesh([nx, ny, nz], [1200.0, 2200.0, 170.0], "hex"), 3)
+    he = build_hierarchy(box_mesh([nx + 2, ny + 2, nz + 2], [1200.0 + 2 * hx, 2200.0 + 2 * hy, 170.0 + 2 * hz], "hex",
+                                  origin=[-hx, -hy, -hz]), 3)
+    sp = build_sampler_problem(he, corlen=100.0, lognormal=True)
+    ops = l2_projection_hierarchy(ho, he)
+    dp = build_darcy_problem(ho, [1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0])
+    return sp, ops, dp
+
+
+def _setup_worker(kind):
+    """runs in a worker PROCESS (numpy / scipy only, never touches the GPU): the one-time finite-element setup of a
+    configuration - what the reference does once in BuildHierarchy (/root/reference/src/PDESampler.cpp:177-334,
+    src/DarcySolver.cpp:60-244), outside every timed region"""
+    t0 = time.perf_counter()
+    out = {"r6": lambda: build_problem(6), "c3": build_config3, "c4": build_config4, "c5": build_config5}[kind]()
+    return out, time.perf_counter() - t0
+
+
+def _worker_init(cpus):
+    try:
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        os.nice(5)
+    except Exception:   # noqa: BLE001
+        pass
+
+
+class SetupPool:
+    """Background builders of the configurations' operators.  Started BEFORE this process touches the GPU (fresh `spawn`
+    children that import numpy / scipy only), kept off the first CPUs so that the lanes' launch threads are not disturbed."""
+
+    def __init__(self, kinds):
+        import concurrent.futures as cf
+        import multiprocessing as mp
+        self.fut, self.seconds = {}, {}
+        self.pool = None
+        if not kinds:
+            return
+        allowed = sorted(os.sched_getaffinity(0))
+        cpus = allowed[6:] if len(allowed) >= 12 else None
+        self.pool = cf.ProcessPoolExecutor(max_workers=len(kinds), mp_context=mp.get_context("spawn"),
+                                           initializer=_worker_init, initargs=(cpus,))
+        for k in kinds:
+            self.fut[k] = self.pool.submit(_setup_worker, k)
+
+    def get(self, kind):
+        """the configuration's problem objects (blocks until the worker has them; built inline without a pool)"""
+        if kind not in self.fut:
+            out, dt = _setup_worker(kind)
+        else:
+            out, dt = self.fut.pop(kind).result()
+        self.seconds[kind] = dt
+        return out
+
+    def close(self):
+        if self.pool:
+            self.pool.shutdown(wait=False, cancel_futures=True)
+            self.pool = None
+
+
+def gpu_numa_cpus(local_rank):
+    """CPUs of the NUMA node the rank's GPU hangs off (KFD topology -> DRM render node -> numa_node), restricted to the
+    CPUs this process may use; None when the box does not say.  Read from sysfs only: usable before any HIP call."""
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    gpus = []
+    for node in sorted(os.listdir(top), key=int):
+        props = dict(line.split()[:2] for line in open(os.path.join(top, node, "properties")) if len(line.split()) >= 2)
+        if int(props.get("simd_count", "0")) > 0:
+            gpus.append(int(props["drm_render_minor"]))
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    order = [int(x) for x in vis.split(",")] if vis and all(x.strip().isdigit() for x in vis.split(",")) else list(range(len(gpus)))
+    minor = gpus[order[local_rank % len(order)]]
+    numa = int(open(f"/sys/class/drm/renderD{minor}/device/numa_node").read())
+    if numa < 0:
+        return None
+    cpus = set()
+    for part in open(f"/sys/devices/system/node/node{numa}/cpulist").read().strip().split(","):
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    cpus &= os.sched_getaffinity(0)
+    return {"numa_node": numa, "cpus": sorted(cpus)} if len(cpus) >= 2 else None
+
+
+def pin_rank_to_gpu_numa(local_rank):
+    """Called by a rank BEFORE it imports torch or creates a pmc_ctx: 8 ranks x 4 lane threads issue ~57 k launches/s each,
+    and a launch thread on the other socket pays the inter-socket hop on every doorbell.  Returns what was done (for the
+    rank's record in the JSON line); never fatal."""
+    try:
+        info = gpu_numa_cpus(local_rank)
+        if info is None:
+            return {"pinned": False, "why": "no NUMA information for the GPU"}
+        os.sched_setaffinity(0, info["cpus"])
+        return {"pinned": True, "numa_node": info["numa_node"], "ncpus": len(info["cpus"])}
+    except Exception as e:   # noqa: BLE001
+        return {"pinned": False, "why": repr(e)}
+
+
 def host_cores():
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota and by
     PMC_CPU_CORES; a 1-GPU box grants a 16-core share of the host, so that is the default cap."""
@@ -58,7 +177,8 @@ def cpu_baseline(problem, seed, nsamples_per_core=12):
     n = problem.levels[0].n_s
     xi = np.stack([normal_fill(n, seed, i, 0) for i in range(ns)])
     rhs = cp.rhs(0, 0, xi)
-    cp.solve(0, rhs[:cores], nthreads=cores)          # warm-up (page in, thread pool)
+    if nsamples_per_core >= 4:
+        cp.solve(0, rhs[:cores], nthreads=cores)      # warm-up (page in, thread pool); not for the one-per-core samples
     t0 = time.perf_counter()
     _, iters = cp.solve(0, rhs, nthreads=cores)
     dt = time.perf_counter() - t0
@@ -67,14 +187,14 @@ def cpu_baseline(problem, seed, nsamples_per_core=12):
                       f"mean {float(np.mean(np.abs(iters))):.1f} iterations, {dt:.1f} s wall"}
 
 
-def solver_bytes_per_iteration(problem, nb):
+def solver_bytes_per_iteration(problem, nb, zb=4):
     """ALGORITHMIC bytes one MINRES iteration of a batch of nb realizations moves on level 0 (every
     operand once; matrices 12 B per stored nonzero + 4 B per row, vectors 8 nb B per row touched)."""
     import scipy.sparse as sp
     L = problem.levels
     V = 8.0 * nb
-    Z = float(z_bytes()) * nb      # a preconditioned vector z (fp32 storage unless the library is a -DPMC_Z64 build)
-    F = 4.0 * nb                   # an fp32 intermediate of the V-cycle (iterate, residual)
+    Z = float(zb) * nb             # a preconditioned vector z: fp32 storage by default, fp64 with PMC_STORAGE_FP64
+    F = float(zb) * nb             # an intermediate of the V-cycle (iterate, residual): the same storage option
 
     def mat(nnz, nrows):
         return 12.0 * nnz + 4.0 * nrows
@@ -102,11 +222,6 @@ def solver_bytes_per_iteration(problem, nb):
         total += mat(nnzS, ns_l) + 2 * F * ns_l + V * nc                       # res - (S P) xc   (S P has the pattern of S)
         total += mat(nnzS, ns_l) + 12.0 * ns_l + (2 * F + V + out) * ns_l + V * nc   # post-smoothing + coarse correction + dot
     return total
-
-
-def z_bytes():
-    from parelagmc_amd import capi
-    return int(capi.load_library().pmc_krylov_z_bytes())
 
 
 def lib_sha256():
@@ -157,18 +272,42 @@ def traffic_provenance():
             "head": _TRAFFIC.get("head")}
 
 
+def in_threads(fn, n):
+    """fn(0) ... fn(n - 1) on n host threads (ctypes releases the GIL inside the library); re-raises the first failure"""
+    err = [None] * n
+
+    def run(i):
+        try:
+            fn(i)
+        except BaseException as e:   # noqa: BLE001
+            err[i] = e
+    if n == 1:
+        run(0)
+    else:
+        th = [threading.Thread(target=run, args=(i,)) for i in range(n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    for e in err:
+        if e is not None:
+            raise e
+
+
 class SamplerFarm:
     """`streams` independent batches in flight on one GPU: one context + sampler + buffers each."""
 
-    def __init__(self, problem, dev, seed, nb, streams, world=1, rank=0):
+    def __init__(self, problem, dev, seed, nb, streams, world=1, rank=0, opts=None):
         from parelagmc_amd import capi
         self.nb, self.ns, self.world, self.rank = nb, streams, world, rank
         self.n = problem.levels[0].n_s
-        self.lanes = []
-        for _ in range(streams):
+        self.lanes = [None] * streams
+
+        def make(i):    # the lanes' handles are set up side by side (host-side re-layout of the operators, one copy each)
             c = capi.Context(dev, seed=seed)
             c.seed(seed, nparts=world, mypart=rank)
-            self.lanes.append((c, capi.PDESampler(c, problem), c.empty(nb * self.n), c.empty(nb * self.n)))
+            self.lanes[i] = (c, capi.PDESampler(c, problem, opts), c.empty(nb * self.n), c.empty(nb * self.n))
+        in_threads(make, streams)
 
     def one_batch(self, lane, batch_index):
         c, sm, xi_d, s_d = self.lanes[lane]
@@ -208,7 +347,7 @@ def check_stats(stats, what):
         sys.exit(3)
 
 
-def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters_total, dt):
+def operator_roofline(farm, problem, nb, tag, next_batch, solver_bytes, iters_total, dt):
     """Roofline block of the dominant kernel, the block saddle-point SpMM K5, measured after the timed region:
     `achieved` is the instantiation the MINRES loop launches (fused <u, Au>), every launch of three solo batches of lane 0
     bracketed by HIP events on the lane's stream; `isolated` = the plain product launched back to back (operator and
@@ -233,20 +372,21 @@ def operator_roofline(farm, problem, nb, refine, next_batch, solver_bytes, iters
     # profiles/rNN_bench_s1_kernel_stats.csv) and is reported beside the headline, never as it.
     raw_ms = solo_ms / solo_launches if solo_launches > 0 else k_ms
     gap = gap_ms / solo_launches if solo_launches > 0 else 0.0
-    # the in-loop launches read their input - a preconditioned vector - in its storage width (fp32), the isolated ones fp64
-    loop_bytes = k_bytes - nb * (8.0 - z_bytes()) * (L.n_u + L.n_s)
+    # the in-loop launches read their input - a preconditioned vector - in its storage width (fp32 by default), the
+    # isolated ones fp64
+    loop_bytes = k_bytes - nb * (8.0 - smp.z_bytes()) * (L.n_u + L.n_s)
     ach = loop_bytes / (raw_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, 0, 0, true, 1, ...> (tag 1 = block operator K5 as launched "
                                      "by the MINRES loop: fused <u, Au>, diagonal-last, non-temporal streams by size; one lane "
                                      "alone on the GPU; profile rows with this prefix)",
            "achieved": ach, "peak": PEAK_GBS, "unit": "GB/s", "frac": ach / PEAK_GBS,
-           "traffic": traffic_entry(f"r{refine}_nb{nb}_inloop"), "traffic_provenance": traffic_provenance(),
+           "traffic": traffic_entry(f"{tag}_nb{nb}_inloop"), "traffic_provenance": traffic_provenance(),
            "bytes_per_launch": loop_bytes, "avg_kernel_ms": raw_ms, "launches": solo_launches,
            "timing": "raw HIP-event bracket around every in-loop launch",
            "event_overhead_ms": gap, "frac_net_of_event_overhead": loop_bytes / (max(raw_ms - gap, 1e-9) * 1e-3) / 1e9 / PEAK_GBS,
            "isolated": {"kernel": f"pmc::sell_spmm_kernel<{nb}, 0, 0, false, 2, ...> launched back to back",
                         "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "frac": k_bytes / (k_ms * 1e-3) / 1e9 / PEAK_GBS,
-                        "avg_kernel_ms": k_ms, "traffic": traffic_entry(f"r{refine}_nb{nb}")},
+                        "avg_kernel_ms": k_ms, "traffic": traffic_entry(f"{tag}_nb{nb}")},
            "spmv_nb1": {"achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "bytes_per_launch": k1_bytes, "avg_kernel_ms": k1_ms,
                         "frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / PEAK_GBS},
            # the whole solver: algorithmic bytes of every kernel of a MINRES iteration x batch-iterations executed in
@@ -275,11 +415,21 @@ def darcy_operator_roofline(ctx, smp, ds, level=0, nb=16):
         check_stats(st, "the in-loop Darcy operator pass")
         its.append(max(t[0] for t in st))
     ms, n, gap = ds.operator_time()
+    pms, pn, pgap = ds.poly_time()
     ds.set_operator_timing(False)
     nbytes = ds.operator_bytes(level, nb)
     raw = ms / max(n, 1)
     ach = nbytes / (raw * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": f"pmc::eg_pair_spmm_kernel<{nb}, true, ...> (u-rows [M(k) | B^T] x of the Darcy operator as "
+    pbytes = ds.poly_bytes(level, nb)
+    praw = pms / max(pn, 1)
+    poly = {"kernel": f"pmc::eg_poly2_kernel<{nb}, true, ...> (M-block polynomial of the preconditioner, z_u = D^-1 (c0 r - c1 M(k) "
+                      "D^-1 r), element-grouped M(k), per-realization l1 diagonal gathered beside r, fused <r, z>; timed on the "
+                      "solve's main stream)",
+            "achieved": pbytes / (praw * 1e-3) / 1e9 if pn else None, "peak": PEAK_GBS, "unit": "GB/s",
+            "frac": pbytes / (praw * 1e-3) / 1e9 / PEAK_GBS if pn else None, "bytes_per_launch": pbytes, "avg_kernel_ms": praw,
+            "launches": pn, "event_overhead_ms": pgap / max(pn, 1), "traffic": traffic_entry(f"c3_egpoly_nb{nb}_inloop")}
+    return {"bound": "hbm", "m_block_polynomial": poly,
+            "kernel": f"pmc::eg_pair_spmm_kernel<{nb}, true, ...> (u-rows [M(k) | B^T] x of the Darcy operator as "
                                       f"launched by the MINRES loop on level {level}: element-grouped M(k), fused <x, Ax>; one lane "
                                       "alone on the GPU, p-rows B x_u behind it on the same stream while timed)",
             "achieved": ach, "peak": PEAK_GBS, "unit": "GB/s", "frac": ach / PEAK_GBS,
@@ -290,21 +440,23 @@ def darcy_operator_roofline(ctx, smp, ds, level=0, nb=16):
             "minres_iterations": its}
 
 
-def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=256, roofline=False):
+def mlmc_config3(seed, probs, lanes=4, opts=None, farm=None, batch=256, roofline=False, reduce=None):
     """Secondary figure (BASELINE config 3): MLMC_Manager::InitRun with the SPDE sampler + Darcy QoI on cube_hex
     64^3 / 32^3 / 16^3, fixed sample counts, `lanes` concurrent streams.  Reported under "extra", never as `value`.
     farm = (world, rank, comm_ctx, device): the realizations of every level are sharded over the ranks and the accumulators
-    are all-reduced through the library's own RCCL communicator of comm_ctx (MLMC_Manager::SetFarm with reduce == NULL)."""
+    are all-reduced through the library's own RCCL communicator of comm_ctx (MLMC_Manager::SetFarm with reduce == NULL), or
+    through `reduce` (a rehearsal over gloo on a box with fewer GPUs than ranks).  probs = (sampler problem, Darcy problem)."""
     from parelagmc_amd import capi, host_api
-    from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem
-    h = build_hierarchy(box_mesh([4, 4, 4], [2, 2, 2], "hex"), 4)
-    sp = build_sampler_problem(h, corlen=0.1, lognormal=True, n_mc_levels=3)
-    dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], n_mc_levels=3)
+    sp, dp = probs
     dev = farm[3] if farm else 0
     # farm: the manager's primary context is the one that carries the RCCL communicator
     ctxs = ([farm[2]] if farm else []) + [capi.Context(dev, seed=seed) for _ in range(lanes - (1 if farm else 0))]
-    sm = [capi.PDESampler(c, sp, opts) for c in ctxs]
-    dr = [capi.DarcySolver(c, dp, opts) for c in ctxs]
+    sm, dr = [None] * lanes, [None] * lanes
+
+    def make(i):
+        sm[i] = capi.PDESampler(ctxs[i], sp, opts)
+        dr[i] = capi.DarcySolver(ctxs[i], dp, opts)
+    in_threads(make, lanes)
     # batch = upper limit of realizations per plugin call; per level the manager hands over what the plugins prefer
     # (pmc_sampler_batch_width: 16 at a time on the bandwidth-bound 64^3 level, 64 on 32^3, 256 - eight column groups of 32
     # in one launch - on 16^3), cut so that every lane gets a share
@@ -314,10 +466,11 @@ def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=256, roofline=False)
     world = 1
     if farm:
         world, rank = farm[0], farm[1]
-        mgr.set_farm(world, rank, None)              # reduce == NULL -> pmc_allreduce_sum_f64 (RCCL) of ctxs[0]
+        mgr.set_farm(world, rank, reduce)            # reduce == None -> pmc_allreduce_sum_f64 (RCCL) of ctxs[0]
     ns = [64 * world, 256 * world, 1024 * world]
     mgr.InitRun(ns)                                  # warm-up: allocations at the widths of the timed round
     mgr.Reset()
+    red0 = mgr.farm_times()
     ph0 = [mgr.phase_times(l) for l in range(3)]
     l0 = ctxs[0].lib.pmc_kernel_launches()
     t0 = time.perf_counter()
@@ -325,6 +478,7 @@ def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=256, roofline=False)
     dt = time.perf_counter() - t0
     launches = int(ctxs[0].lib.pmc_kernel_launches() - l0)
     ph1 = [mgr.phase_times(l) for l in range(3)]
+    red1 = mgr.farm_times()
     widths = [min(sm[0].BatchWidth(l), dr[0].BatchWidth(l)) for l in range(3)]   # what the manager hands over: the smaller
     out = {"workload": "MLMC Darcy + SPDE sampler, cube_hex 64^3/32^3/16^3 (1 060 864 / 134 144 / 17 152 DoF), lognormal, "
                        f"eff_perm QoI, InitRun {ns}, {lanes} lanes, realizations per launch per level {widths}"
@@ -337,6 +491,11 @@ def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=256, roofline=False)
            # the reference's per-level TimeManager entries (src/PDESampler.cpp:328-333, src/DarcySolver.cpp:231-243): device ms
            # of the timed round, summed over the lanes of this rank (HIP events, pmc_stats.solve_ms / setup_ms)
            "phase_timers_ms": [{k: ph1[l][k] - ph0[l][k] for k in ph1[l]} for l in range(3)]}
+    if farm:
+        # the farm's one collective (MLMC_Manager::InitRun, before computeNSamplesMSE): wall time of this rank inside it -
+        # waiting for the slowest rank included - and how many there were in the timed round (must be ONE)
+        out["allreduce_ms"] = red1[0] - red0[0]
+        out["allreduces_in_round"] = int(red1[1] - red0[1])
     if roofline:
         try:
             out["roofline"] = darcy_operator_roofline(ctxs[0], sm[0], dr[0], 0, 16)
@@ -347,7 +506,7 @@ def mlmc_config3(seed, lanes=4, opts=None, farm=None, batch=256, roofline=False)
         x.close()
     for c in ctxs:
         c.close()
-    return out, (sp, dp)
+    return out
 
 
 def darcy_cpu_baseline(sp, dp, seed, per_core=(1, 2, 8)):
@@ -456,20 +615,19 @@ def cpu_level_rates(sp, dp, seed, levels, per_core):
                       "is not available to the C restatement, on stretched cells its geometric V-cycle needs more iterations"}
 
 
-def config4(seed, lanes=4, cpu=True):
+def config4(seed, sp, lanes=4, cpu=True, nrep=4):
     """BASELINE config 4 at full size on ONE GPU: EmbeddedPDESampler on cube_tet_embed refined 4 x (831 488 tets, 2.5 M DoF
-    on the finest level), 3 Monte Carlo levels, lognormal."""
+    on the finest level), 3 Monte Carlo levels, lognormal.  sp: build_config4()."""
     from parelagmc_amd import capi
-    from parelagmc_amd.fe import build_hierarchy, build_sampler_problem, mesh_from_json
-    h = build_hierarchy(mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet_embed.json")), 4)
-    sp = build_sampler_problem(h, corlen=0.1, embedded=True, lognormal=True, n_mc_levels=3)
-    L = []
-    for _ in range(lanes):
+    L = [None] * lanes
+
+    def make(i):
         c = capi.Context(0, seed=seed)
-        L.append((c, capi.PDESampler(c, sp, projection="gather"), None))
+        L[i] = (c, capi.PDESampler(c, sp, projection="gather"), None)
+    in_threads(make, lanes)
     out = {"workload": "EmbeddedPDESampler cube_tet_embed r=4, DoF " + str([lv.n_u + lv.n_s for lv in sp.levels[:3]]) +
                        f", original elements {[len(i) for i in sp.orig_index[:3]]}, per level nsamples x (Sample + Eval), {lanes} lanes",
-           "levels": level_rates(L, (0, 1, 2), nrep=4, darcy=False)}
+           "levels": level_rates(L, (0, 1, 2), nrep=nrep, darcy=False)}
     for c, sm, _ in L:
         sm.close()
         c.close()
@@ -481,28 +639,22 @@ def config4(seed, lanes=4, cpu=True):
     return out
 
 
-def config5(seed, lanes=4, cpu=True):
+def config5(seed, probs, lanes=4, cpu=True, nrep=2):
     """BASELINE config 5 at full size on ONE GPU: SPE10-shaped box 1200 x 2200 x 170, 7 x 27 x 10 coarse cells refined 3 x
     (56 x 216 x 80 = 967 680 elements, 3.9 M Darcy DoF), L2ProjectionPDESampler on the box enlarged by one coarse cell per side,
-    correlation length 100, 4 levels, k_ref == 1 (spe_perm.dat is not shipped)."""
+    correlation length 100, 4 levels, k_ref == 1 (spe_perm.dat is not shipped).  probs: build_config5()."""
     from parelagmc_amd import capi, host_api
-    from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem, l2_projection_hierarchy
-    nx, ny, nz = 7, 27, 10
-    hx, hy, hz = 1200.0 / nx, 2200.0 / ny, 170.0 / nz
-    ho = build_hierarchy(box_mesh([nx, ny, nz], [1200.0, 2200.0, 170.0], "hex"), 3)
-    he = build_hierarchy(box_mesh([nx + 2, ny + 2, nz + 2], [1200.0 + 2 * hx, 2200.0 + 2 * hy, 170.0 + 2 * hz], "hex",
-                                  origin=[-hx, -hy, -hz]), 3)
-    sp = build_sampler_problem(he, corlen=100.0, lognormal=True)
-    ops = l2_projection_hierarchy(ho, he)
-    dp = build_darcy_problem(ho, [1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0])
-    L = []
-    for _ in range(lanes):
+    sp, ops, dp = probs
+    L = [None] * lanes
+
+    def make(i):
         c = capi.Context(0, seed=seed)
-        L.append((c, capi.PDESampler(c, sp, projection="l2", l2_ops=ops), capi.DarcySolver(c, dp)))
+        L[i] = (c, capi.PDESampler(c, sp, projection="l2", l2_ops=ops), capi.DarcySolver(c, dp))
+    in_threads(make, lanes)
     out = {"workload": "SPE10-shaped box 56 x 216 x 80, L2ProjectionPDESampler (sampler DoF " + str([lv.n_u + lv.n_s for lv in sp.levels]) +
                        ") + DarcySolver (DoF " + str([lv.ndofs for lv in dp.levels]) + f"), 4 levels, algebraic Schur hierarchies "
                        f"on the stretched cells, per level nsamples x (Sample + Eval + SolveFwd), {lanes} lanes",
-           "levels": level_rates(L, (0, 1, 2, 3), nrep=2, darcy=True)}
+           "levels": level_rates(L, (0, 1, 2, 3), nrep=nrep, darcy=True)}
     mgr = host_api.MLMCManager(4, sampler=L[0][1], solver=L[0][2], wall_time=True)
     for c, sm, ds in L[1:]:
         mgr.add_lane(sm, ds)
@@ -565,6 +717,128 @@ def spawn_ranks(n):
     return rc
 
 
+def timed_farm(farm, steps, first_step, warmup=2):
+    """`warmup` untimed + `steps` timed steps of a SamplerFarm (device-synchronised on both sides);
+    returns (seconds, stats of the timed steps)"""
+    for i in range(warmup):
+        farm.step(first_step + i)
+    for lane in farm.lanes:
+        lane[0].synchronize()
+    t0 = time.perf_counter()
+    st = []
+    for i in range(steps):
+        st += farm.step(first_step + warmup + i)
+    for lane in farm.lanes:
+        lane[0].synchronize()
+    return time.perf_counter() - t0, st
+
+
+def sampler_point(problem, dev, seed, nb, ns, steps, tag, what, cpu_per_core=None, opts=None, roofline=True):
+    """One sampler-only figure on level 0 of `problem` (the harness shape of the headline: `ns` lanes x `nb` realizations per
+    step): value, iterations, K5 roofline of the in-loop launches, and - cpu_per_core - the CPU column beside it."""
+    farm = SamplerFarm(problem, dev, seed, nb, ns, opts=opts)
+    dt, st = timed_farm(farm, steps, 0)
+    check_stats(st, what)
+    it = [t[0] for t in st]
+    bi = float(sum(max(it[b:b + nb]) for b in range(0, len(it), nb)))
+    L = problem.levels[0]
+    zb = farm.lanes[0][1].z_bytes()
+    out = {"workload": what, "value": steps * nb * ns / dt, "unit": "samples/s", "steps": steps, "batch": nb, "streams": ns,
+           "mean_minres_iterations": float(np.mean(it)), "precond_storage": "fp32" if zb == 4 else "fp64"}
+    if roofline:
+        out["roofline"] = operator_roofline(farm, problem, nb, tag, (2 + steps + 1) * ns,
+                                            solver_bytes_per_iteration(problem, nb, zb), bi, dt)
+    farm.close()
+    if cpu_per_core:
+        try:
+            out["cpu_baseline"] = cpu_baseline(problem, seed, cpu_per_core)
+        except Exception as e:   # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+def dropin_sampler(problem, dev, seed, n=16, use_graph=0):
+    """The case the reference's UNCHANGED serial manager produces (/root/reference/src/MLMC_Manager.cpp:119-121): one
+    Sample + one Eval per call, nbatch = 1, HOST pointers - exactly what INTEGRATION.md section 2 binds.  One handle."""
+    from parelagmc_amd import capi
+    c = capi.Context(dev, seed=seed)
+    smp = capi.PDESampler(c, problem, capi.solver_opts(use_graph=use_graph, check_every=2))
+    xi = smp.Sample(0, first_id=0, nbatch=1)
+    for _ in range(2):
+        smp.Eval(0, xi)
+    t_s = t_e = 0.0
+    its = []
+    for i in range(n):
+        t0 = time.perf_counter()
+        xi = smp.Sample(0, first_id=100 + i, nbatch=1)
+        t1 = time.perf_counter()
+        _, st = smp.Eval(0, xi, return_stats=True)
+        t2 = time.perf_counter()
+        t_s += t1 - t0
+        t_e += t2 - t1
+        check_stats(st, "the one-realization-per-call path")
+        its.append(st[0][0])
+    smp.close()
+    c.close()
+    return {"samples_per_s": n / (t_s + t_e), "ms_per_Sample": 1e3 * t_s / n, "ms_per_Eval": 1e3 * t_e / n, "calls": n,
+            "mean_minres_iterations": float(np.mean(its)), "use_graph": use_graph}
+
+
+def dropin_mlmc(probs, dev, seed, ns=(2, 8, 32), use_graph=0):
+    """Config 3 driven the way the reference's serial MLMC_Manager::InitRun drives its plugins
+    (/root/reference/src/MLMC_Manager.cpp:113-173): per realization of a level pair Sample(l), Eval(l+1), SolveFwd(l+1),
+    Eval(l, warm start), SolveFwd(l), one realization per call, host pointers."""
+    from parelagmc_amd import capi
+    sp, dp = probs
+    c = capi.Context(dev, seed=seed)
+    o = capi.solver_opts(use_graph=use_graph, check_every=2)
+    smp, ds = capi.PDESampler(c, sp, o), capi.DarcySolver(c, dp, o)
+    nl = 3
+
+    def realization(l, rid):
+        t = {}
+        t0 = time.perf_counter()
+        xi = smp.Sample(l, first_id=rid, nbatch=1)
+        t["Sample"] = time.perf_counter() - t0
+        qc = 0.0
+        emb = None
+        if l + 1 < nl:
+            t0 = time.perf_counter()
+            s, emb = smp.Eval(l + 1, xi, xi_level=l, want_embed=True)
+            t["Eval_coarse"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            qc = ds.SolveFwd(l + 1, s)[0][0]
+            t["SolveFwd_coarse"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        s = smp.Eval(l, xi, xi_level=l, init_s=emb, init_level=l + 1 if emb is not None else None, use_init=emb is not None)
+        t["Eval"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        q = ds.SolveFwd(l, s)[0][0]
+        t["SolveFwd"] = time.perf_counter() - t0
+        return q - qc, t
+    levels = []
+    total_t = 0.0
+    for l in (2, 1, 0):
+        realization(l, 10 ** 6 + l)                      # warm-up: allocations
+        acc = {}
+        t0 = time.perf_counter()
+        for i in range(ns[l]):
+            _, t = realization(l, i)
+            for k_, v in t.items():
+                acc[k_] = acc.get(k_, 0.0) + v
+        dt = time.perf_counter() - t0
+        total_t += dt
+        levels.append({"level": l, "realizations": ns[l], "realizations_per_s": ns[l] / dt,
+                       "ms_per_call": {k_: 1e3 * v / ns[l] for k_, v in acc.items()}})
+    ds.close()
+    smp.close()
+    c.close()
+    cost = {e["level"]: 1.0 / e["realizations_per_s"] for e in levels}
+    w = np.array([64.0, 256.0, 1024.0])
+    return {"levels": levels, "use_graph": use_graph,
+            "round_64_256_1024_realizations_per_s": float(w.sum() / sum(w[l] * cost[l] for l in range(3)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -579,11 +853,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mlmc", action="store_true", help="skip the secondary config-3 (MLMC Darcy+SPDE) figure")
     ap.add_argument("--no-r6", action="store_true", help="skip the HBM-bound point (cube_tet r=6, 4.74 M DoF) under extra.r6")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline only: no extra.* at all (neither configs 3 / 4 / 5, r = 6, the hex point, the fp64 storage "
+                         "run nor the drop-in path)")
     ap.add_argument("--all-configs", action="store_true",
-                    help="also run BASELINE configs 4 (EmbeddedPDESampler, 2.5 M DoF) and 5 (SPE10-shaped Darcy MLMC, 3.9 M DoF) "
-                         "at full size on this GPU with a bounded CPU sample beside each: extra.c4 / extra.c5 (minutes)")
+                    help="configs 4 and 5 with their CPU columns as well (the default run measures their GPU legs only)")
     ap.add_argument("--only-config", type=int, choices=(4, 5), default=None,
-                    help="with --all-configs: run only this one of the two (each takes minutes; a GPU call has a time limit)")
+                    help="of configs 4 and 5 run only this one")
     ap.add_argument("--seed", type=int, default=20261003)
     args = ap.parse_args()
 
@@ -591,12 +867,30 @@ def main():
         # `python bench.py --gpus N` without a launcher: this process starts the N ranks itself and never touches the GPU
         sys.exit(spawn_ranks(args.gpus))
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # a rank of a farm binds itself to the CPUs next to its GPU BEFORE torch / HIP start their threads
+    affinity = pin_rank_to_gpu_numa(local_rank) if world > 1 else {"pinned": False, "why": "single rank"}
+
+    # one-time finite-element setup of the configurations behind the headline: in worker processes, started before this
+    # process initialises the GPU (they never touch it)
+    extras = world == 1 and not args.no_extras
+    kinds = []
+    if extras or (world > 1 and not args.no_mlmc and not args.no_extras):
+        if not args.no_mlmc:
+            kinds.append("c3")
+    if extras:
+        if not args.no_r6 and args.refine != 6:
+            kinds.append("r6")
+        for k in (4, 5):
+            if args.only_config in (None, k):
+                kinds.append(f"c{k}")
+    pool = SetupPool(kinds)
+
+    import torch
+    import torch.distributed as dist
+
     if args.gpus != world:
         print(f"bench: --gpus {args.gpus} but WORLD_SIZE {world}: the launcher must start exactly --gpus ranks", file=sys.stderr)
         sys.exit(2)
@@ -652,15 +946,16 @@ def main():
     # mypart = rank, i.e. the global ids first * world + rank, ..., last * world + rank - disjoint by construction
     mine = {"rank": rank, "device": dev, "samples": args.steps * nb * ns, "seconds": dt_local,
             "global_ids": [args.warmup * ns * nb * world + rank, ((args.warmup + args.steps) * ns * nb - 1) * world + rank],
-            "id_stride": world}
+            "id_stride": world, "cpu_affinity": affinity}
     per_rank = [mine]
     if world > 1:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
     out = None
+    zb = farm.lanes[0][1].z_bytes()
     if rank == 0:
-        sbytes = solver_bytes_per_iteration(problem, nb)
+        sbytes = solver_bytes_per_iteration(problem, nb, zb)
         next_batch = (args.warmup + args.steps + 1) * ns
         out = {
             "metric": "MC samples/sec (SPDE field + Darcy QoI) at stated DoF; SpMV HBM GB/s vs roofline",
@@ -672,28 +967,65 @@ def main():
                                    f"BASELINE config 2 is (the Darcy QoI leg is measured on config 3 under extra.mlmc_config3), "
                                    f"MINRES 300/1e-6/1e-12, {ns} x {nb} realizations per step, all converged",
                        "mean_minres_iterations": acc[0] / max(acc[1], 1.0), "batch": nb, "streams": ns,
-                       "parallelism": f"sample-farm x{world}"},
+                       "parallelism": f"sample-farm x{world}",
+                       # pmc_solver_opts.precond_storage of this run: operators, Krylov vectors, products, recurrences and
+                       # ALL arithmetic are fp64 (`dtype`); fp32 is only how data INSIDE one application of the
+                       # preconditioner is stored (extra.fp64_storage: the same run with everything stored fp64)
+                       "precond_storage": "fp32" if zb == 4 else "fp64"},
             "devices": min(world, ndev), "ranks": per_rank,
-            "roofline": operator_roofline(farm, problem, nb, args.refine, next_batch, sbytes, acc[2], dt),
+            "roofline": operator_roofline(farm, problem, nb, f"r{args.refine}", next_batch, sbytes, acc[2], dt),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, args.seed)
     farm.close()
     extra = {}
-    if not args.no_mlmc:
+
+    def attempt(name, fn):
+        """a secondary figure must never cost the headline line"""
+        t_ = time.perf_counter()
         try:
-            if world == 1:
-                m, probs = mlmc_config3(args.seed, roofline=True)
-                if not args.no_cpu_baseline:
+            extra[name] = fn()
+        except Exception as e:   # noqa: BLE001
+            extra[name] = {"error": repr(e)}
+        if isinstance(extra.get(name), dict):
+            extra[name]["wall_s"] = time.perf_counter() - t_
+
+    cpu = not args.no_cpu_baseline
+    if extras:
+        # everything fp64 (pmc_solver_opts.precond_storage = PMC_STORAGE_FP64): the same harness, a third of the steps
+        attempt("fp64_storage", lambda: sampler_point(
+            problem, dev, args.seed, nb, ns, max(4, args.steps // 3), f"r{args.refine}_fp64",
+            f"the headline workload with precond_storage = fp64 (everything stored fp64, as the reference is: "
+            f"/root/reference/src/PDESampler.cpp:279-333)", opts=capi.solver_opts(precond_storage=capi.PMC_STORAGE_FP64)))
+        # the drop-in path of INTEGRATION.md section 2: one realization per call, host pointers
+        attempt("dropin_nb1", lambda: {
+            "what": "one Sample + one Eval (+ SolveFwd) per call with nbatch = 1 and HOST pointers, one handle: what the "
+                    "reference's unchanged serial manager would drive (src/MLMC_Manager.cpp:113-173)",
+            "config2": dropin_sampler(problem, dev, args.seed, 16, 0),
+            "config2_hipgraph": dropin_sampler(problem, dev, args.seed, 16, 1)})
+    if not args.no_mlmc and not args.no_extras:
+        probs3 = pool.get("c3")
+        if world == 1:
+            def c3():
+                m = mlmc_config3(args.seed, probs3, lanes=min(4, max(1, ns)), roofline=True)
+                if cpu:
                     try:
-                        m["cpu_baseline"] = darcy_cpu_baseline(probs[0], probs[1], args.seed)
+                        m["cpu_baseline"] = darcy_cpu_baseline(probs3[0], probs3[1], args.seed)
                     except Exception as e:   # noqa: BLE001
                         m["cpu_baseline"] = {"error": repr(e)}
-                extra["mlmc_config3"] = m
-            else:
-                # every rank takes part: sharded InitRun, accumulators summed by pmc_allreduce_sum_f64 (RCCL).  The
-                # communicator is set up and tried FIRST, and the ranks agree (torch.distributed) on whether it works, so
-                # that no rank enters the farm alone
+                return m
+            attempt("mlmc_config3", c3)
+            attempt("dropin_nb1_config3", lambda: dropin_mlmc(probs3, dev, args.seed))
+            # the north star's "~1 M DoF 3D SPDE sampler": level 0 of config 3's hierarchy on its own, 1 060 864 DoF
+            attempt("hex64", lambda: sampler_point(
+                probs3[0], dev, args.seed, nb, ns, 6, "hex64",
+                f"PDESampler cube_hex 64^3, {probs3[0].levels[0].n_u + probs3[0].levels[0].n_s} DoF, lognormal, level 0 of "
+                f"config 3's hierarchy on its own: {ns} x {nb} realizations per step", cpu_per_core=2 if cpu else None))
+        else:
+            # every rank takes part: sharded InitRun, accumulators summed by pmc_allreduce_sum_f64 (RCCL).  The
+            # communicator is set up and tried FIRST, and the ranks agree (torch.distributed) on whether it works, so
+            # that no rank enters the farm alone
+            try:
                 uid = [None]
                 c0 = capi.Context(dev, seed=args.seed)
                 if rank == 0:
@@ -708,52 +1040,43 @@ def main():
                     ok, why = 0, repr(e)
                 flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                lanes3 = min(4, max(1, ns))
                 if int(flag.item()) == 1:
-                    m, _ = mlmc_config3(args.seed, farm=(world, rank, c0, dev))
+                    m = mlmc_config3(args.seed, probs3, lanes=lanes3, farm=(world, rank, c0, dev))
+                    m["collective"] = "rccl (pmc_allreduce_sum_f64 of the library's communicator)"
                     m["ranks_in_rccl_communicator"] = world
-                    if rank == 0:
-                        extra["mlmc_farm"] = m
+                elif dist.get_backend() == "gloo":
+                    # rehearsal on a box with fewer GPUs than ranks: the same farm, the accumulators summed over gloo
+                    def gloo_sum(buf):
+                        tt = torch.from_numpy(buf)
+                        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+                    m = mlmc_config3(args.seed, probs3, lanes=lanes3, farm=(world, rank, c0, dev), reduce=gloo_sum)
+                    m["collective"] = "gloo (rehearsal: the ranks share a GPU, RCCL refused: " + why + ")"
                 else:
                     c0.close()
-                    if rank == 0:
-                        extra["mlmc_farm"] = {"error": "RCCL communicator of the library not available on every rank: " + why}
-        except Exception as e:   # noqa: BLE001 - the secondary figure must never cost the headline line
-            extra["mlmc_config3" if world == 1 else "mlmc_farm"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_r6 and args.refine != 6:
-        try:
-            p6 = build_problem(6)
-            f6 = SamplerFarm(p6, dev, args.seed, nb, ns)
-            for i in range(2):
-                f6.step(i)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            st6 = []
-            steps6 = 8
-            for i in range(steps6):
-                st6 += f6.step(2 + i)
-            torch.cuda.synchronize()
-            dt6 = time.perf_counter() - t0
-            check_stats(st6, "the r=6 run")
-            it6 = [t[0] for t in st6]
-            bi6 = float(sum(max(it6[b:b + nb]) for b in range(0, len(it6), nb)))
-            L6 = p6.levels[0]
-            extra["r6"] = {"workload": f"PDESampler cube_tet r=6, {L6.n_u + L6.n_s} DoF (nnz(A)={L6.nnz}): operator + vectors "
-                                       "exceed the 256 MiB Infinity Cache, every kernel is HBM-bound",
-                           "value": steps6 * nb * ns / dt6, "unit": "samples/s", "steps": steps6,
-                           "mean_minres_iterations": float(np.mean(it6)),
-                           "roofline": operator_roofline(f6, p6, nb, 6, (2 + steps6 + 1) * ns, solver_bytes_per_iteration(p6, nb),
-                                                         bi6, dt6)}
-            f6.close()
-        except Exception as e:   # noqa: BLE001
-            extra["r6"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and args.all_configs:
-        for name, fn in (("c4", config4), ("c5", config5)):
-            if args.only_config is not None and name != f"c{args.only_config}":
-                continue
-            try:
-                extra[name] = fn(args.seed, cpu=not args.no_cpu_baseline)
-            except Exception as e:   # noqa: BLE001
-                extra[name] = {"error": repr(e)}
+                    m = {"error": "RCCL communicator of the library not available on every rank: " + why}
+                if "allreduce_ms" in m:
+                    # every rank's time inside the round's one all-reduce (the slowest rank's wait is the others' cost)
+                    ar = [None] * world
+                    dist.all_gather_object(ar, m["allreduce_ms"])
+                    m["allreduce_ms_per_rank"] = ar
+                if rank == 0:
+                    extra["mlmc_farm"] = m
+            except Exception as e:   # noqa: BLE001 - the secondary figure must never cost the headline line
+                if rank == 0:
+                    extra["mlmc_farm"] = {"error": repr(e)}
+    if extras:
+        for k, fn in ((4, config4), (5, config5)):
+            if args.only_config in (None, k):
+                attempt(f"c{k}", lambda k=k, fn=fn: fn(args.seed, pool.get(f"c{k}"), cpu=args.all_configs and cpu,
+                                                      nrep=2 if k == 4 else 1))
+        if not args.no_r6 and args.refine != 6:
+            attempt("r6", lambda: sampler_point(
+                pool.get("r6"), dev, args.seed, nb, ns, 8, "r6",
+                "PDESampler cube_tet r=6, 4743168 DoF: operator + vectors exceed the 256 MiB Infinity Cache, every kernel is "
+                "HBM-bound", cpu_per_core=1 if cpu else None))
+        extra["setup_seconds_in_worker_processes"] = dict(pool.seconds)
+    pool.close()
     if rank == 0 and extra:
         out["extra"] = extra
     if world > 1:

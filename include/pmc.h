@@ -38,6 +38,13 @@ extern "C" {
 
 enum pmc_memspace { PMC_MEM_HOST = 0, PMC_MEM_DEVICE = 1 };
 enum pmc_projection { PMC_PROJ_NONE = 0, PMC_PROJ_GATHER = 1, PMC_PROJ_L2 = 2 };
+/* pmc_solver_opts.precond_storage: how data that lives INSIDE one application of the preconditioner z = B^-1 v is stored -
+ * the preconditioned vectors z themselves, the V-cycle's iterates / residuals on a level, the per-realization values of the
+ * Darcy Schur-complement hierarchy.  Operators, Lanczos vectors, products A z, directions, solution, every inner product and
+ * ALL arithmetic are fp64 either way (the reference is fp64 end to end, src/PDESampler.cpp:279-333); with FP32 the solver is
+ * MINRES with the fixed symmetric preconditioner fl32(B^-1 .), converges to the same solution at the same tolerance and
+ * moves a quarter fewer bytes per iteration. */
+enum pmc_storage { PMC_STORAGE_FP32 = 0, PMC_STORAGE_FP64 = 1 };
 
 typedef struct pmc_ctx pmc_ctx;
 typedef struct pmc_sampler pmc_sampler;
@@ -87,6 +94,7 @@ typedef struct pmc_solver_opts {
                                  (default: only when the handle is the only one on its device and the level has at least
                                  ~1.5 M rows x realizations; with several handles per GPU their kernels already fill the
                                  gaps), 1 = always, 2 = never.  Results do not depend on it.                                 */
+    int32_t precond_storage;  /* enum pmc_storage (ABI 3): PMC_STORAGE_FP32 (default) or PMC_STORAGE_FP64 = everything fp64    */
 } pmc_solver_opts;
 
 /* Per-realization solver report; the reference returns -1 for iteration counts
@@ -136,18 +144,28 @@ typedef struct pmc_darcy_level {
 
 /* ---- library / context ---------------------------------------------------------------- */
 int pmc_version(void);
-#define PMC_ABI_VERSION 2 /* layout of pmc_solver_opts / pmc_stats; 2: abi_version field, solve_ms / setup_ms */
+#define PMC_ABI_VERSION 3 /* layout of pmc_solver_opts / pmc_stats; 2: abi_version field, solve_ms / setup_ms; 3: precond_storage */
 int pmc_abi_version(void); /* the library's PMC_ABI_VERSION */
-/* bytes per entry of the PRECONDITIONED Krylov vectors inside the MINRES solves (4: fp32 storage, fp64 arithmetic; 8 in a
- * -DPMC_Z64 build).  The byte counts pmc_sampler_apply_operator reports are for fp64 input; the launches inside the solver loop
- * read their input vector at this width. */
+/* bytes per entry of the PRECONDITIONED Krylov vectors inside the MINRES solves of a handle (4: PMC_STORAGE_FP32, 8:
+ * PMC_STORAGE_FP64; pmc_krylov_z_bytes: of the default options).  The byte counts pmc_sampler_apply_operator reports are for
+ * fp64 input; the launches inside the solver loop read their input vector at this width. */
 int pmc_krylov_z_bytes(void);
+int pmc_sampler_krylov_z_bytes(const pmc_sampler* s);
+int pmc_darcy_krylov_z_bytes(const pmc_darcy* d);
 /* kernels launched by this process through the library so far (all handles, all host threads): launch-rate diagnostics */
 uint64_t pmc_kernel_launches(void);
 const char* pmc_last_error(void);
 void pmc_solver_opts_default(pmc_solver_opts* opts);
 
+/* pmc_ctx_create_abi refuses a caller compiled against another PMC_ABI_VERSION (another layout of pmc_solver_opts /
+ * pmc_stats) before any handle exists - also callers that pass opts == NULL (defaults) and a pmc_stats array later.  C and
+ * C++ callers get it through the macro below; binders that cannot use macros (ctypes, cgo) call it directly.  The plain
+ * pmc_ctx_create symbol stays exported and performs no such check: the create functions then check pmc_solver_opts only. */
 int pmc_ctx_create(int device_id, pmc_ctx** out);
+int pmc_ctx_create_abi(int device_id, int abi_version, pmc_ctx** out);
+#ifndef PMC_NO_ABI_CHECK_MACRO
+#define pmc_ctx_create(device_id, out) pmc_ctx_create_abi((device_id), PMC_ABI_VERSION, (out))
+#endif
 void pmc_ctx_destroy(pmc_ctx* ctx);
 int pmc_ctx_synchronize(pmc_ctx* ctx);
 /* hipStream_t all work of this ctx is enqueued on (for callers that record their own events) */
@@ -211,6 +229,20 @@ int pmc_sampler_eval(pmc_sampler* s, int level, int xi_level, int nbatch, const 
                      const double* init_s, int init_level, int use_init, double* embed_s_out, int memspace,
                      pmc_stats* stats);
 
+/* invA[level]->Mult(rhs, sol) (src/PDESampler.cpp:397,521), the narrowest seam of the reference: the whole linear solve
+ * A [u; s] = rhs on FULL vectors of n_u + n_s entries per realization (sample-major), every row of the solution maintained.
+ * use_sol_as_guess != 0 = mfem::Solver::iterative_mode (:510): sol holds the initial guess on entry.  pmc_sampler_eval is this
+ * solve with the right-hand side, warm start and output maps of Eval around it (and only the s-rows maintained); this entry
+ * exists for callers that keep the reference's Eval and replace just the solver, and for true-residual checks. */
+int pmc_sampler_mult(pmc_sampler* s, int level, int nbatch, const double* rhs, double* sol, int use_sol_as_guess,
+                     int memspace, pmc_stats* stats);
+
+/* z = B^-1 r: ONE application of the block-diagonal preconditioner the MINRES solves of `level` use (the reference's
+ * "BJ-GS" block, examples/example_helpers/CreateSamplerParameterList.hpp:68-113), fp64 in and out, full vectors, nbatch one
+ * of the level's launch widths.  Diagnostics: sqrt(<r, B^-1 r>) of a TRUE residual r = b - A x is the quantity whose
+ * recurrence estimate pmc_stats.final_norm reports. */
+int pmc_sampler_apply_preconditioner(pmc_sampler* s, int level, int nbatch, const double* r, double* z, int memspace);
+
 /* y = A x with A = [M B^T; B -alpha W] of `level` (src/PDESampler.cpp:279-284; the oper->Mult inside the
  * Krylov loop, kernel K5) for nbatch in {1,2,4,8,16,32,64,128,256} vectors of n_u+n_s entries each.  The SpMM kernel is
  * launched `repeat` >= 1 times between two HIP events on the ctx stream; avg_ms (may be NULL) receives the
@@ -247,6 +279,14 @@ int pmc_darcy_batch_width(const pmc_darcy* d, int level);  /* as pmc_sampler_bat
 int pmc_darcy_set_operator_timing(pmc_darcy* d, int on);
 int pmc_darcy_operator_time(pmc_darcy* d, double* total_ms, int64_t* launches, double* event_overhead_ms);
 int pmc_darcy_operator_bytes(const pmc_darcy* d, int level, int nbatch, double* bytes);
+/* The same for the other large gather kernel of a Darcy iteration, the M-block polynomial of the preconditioner
+ * z_u = D^-1 (c0 r - c1 M(k) D^-1 r) (eg_poly2_kernel; the reference's A00^-1 block, three l1-Gauss-Seidel sweeps on M(k),
+ * CreateSamplerParameterList.hpp:80-93): timed by the same pmc_darcy_set_operator_timing switch (the launch then runs on
+ * the solve's main stream instead of beside the V-cycle's bottom).  Algorithmic bytes: 12 B per stored slot of the
+ * element-grouped matrix + 12 B per dof + the coefficient table + nbatch ((8 + 8 + z) n_u): r and the per-realization l1
+ * diagonal read, z written. */
+int pmc_darcy_poly_time(pmc_darcy* d, double* total_ms, int64_t* launches, double* event_overhead_ms);
+int pmc_darcy_poly_bytes(const pmc_darcy* d, int level, int nbatch, double* bytes);
 /* SolveFwd(level, k, Q, C) (src/DarcySolver.cpp:416-437).  k: nbatch x n_p(level) in
  * `memspace`; Q, C: host arrays of nbatch; sol_out (may be NULL): nbatch x (n_u+n_p) in
  * `memspace` (SolveFwd_RtnPressure, :439-470, reads its p-block). */

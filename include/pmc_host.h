@@ -88,6 +88,10 @@ int pmc_mlmc_reset(pmc_mlmc* m);                             /* zero sums and co
 int pmc_mlmc_replay_log(pmc_mlmc* m, const char* path, int64_t* nread);
 int pmc_mlmc_init_run(pmc_mlmc* m, const int32_t* nsamples); /* MLMC_Manager::InitRun  */
 int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* out);
+/* the farm's one collective: wall milliseconds this rank has spent inside the SUM all-reduce of the accumulators (waiting
+ * for the slowest rank included) and the number of reductions so far - one per InitRun round (the place the serial
+ * reference would need it: src/MLMC_Manager.cpp:178, before computeNSamplesMSE) */
+int pmc_mlmc_farm_times(pmc_mlmc* m, double* allreduce_ms, int64_t* reductions);
 /* the table MLMC_Manager::ShowMe prints after every InitRun (src/MLMC_Manager.cpp:216-297), same labels / widths /
  * precision, into buf (NUL-terminated, truncated to cap); *needed (may be NULL) receives the full size incl. the NUL */
 int pmc_mlmc_show_me(pmc_mlmc* m, char* buf, size_t cap, size_t* needed);

@@ -35,7 +35,11 @@ class pmc_solver_opts(C.Structure):
                 ("mg_smooth_degree", C.c_int32), ("mg_smooth_ratio", C.c_double),
                 ("mg_coarse_degree", C.c_int32), ("mg_coarse_ratio", C.c_double), ("check_every", C.c_int32),
                 ("use_graph", C.c_int32), ("schur_scale", C.c_double), ("mg_coarsening", C.c_int32), ("mini_max_rows", C.c_int32),
-                ("two_streams", C.c_int32)]
+                ("two_streams", C.c_int32), ("precond_storage", C.c_int32)]
+
+
+PMC_ABI_VERSION = 3          # include/pmc.h: layout of pmc_solver_opts / pmc_stats these classes restate
+PMC_STORAGE_FP32, PMC_STORAGE_FP64 = 0, 1
 
 
 class pmc_stats(C.Structure):
@@ -64,8 +68,11 @@ SYMBOLS = {
     "pmc_solver_opts_default": (None, [C.POINTER(pmc_solver_opts)]),
     "pmc_abi_version": (C.c_int, []),
     "pmc_krylov_z_bytes": (C.c_int, []),
+    "pmc_sampler_krylov_z_bytes": (C.c_int, [_VP]),
+    "pmc_darcy_krylov_z_bytes": (C.c_int, [_VP]),
     "pmc_kernel_launches": (C.c_uint64, []),
     "pmc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
+    "pmc_ctx_create_abi": (C.c_int, [C.c_int, C.c_int, C.POINTER(_VP)]),
     "pmc_ctx_destroy": (None, [_VP]),
     "pmc_ctx_synchronize": (C.c_int, [_VP]),
     "pmc_ctx_stream": (_VP, [_VP]),
@@ -90,11 +97,15 @@ SYMBOLS = {
     "pmc_darcy_set_operator_timing": (C.c_int, [_VP, C.c_int]),
     "pmc_darcy_operator_time": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pmc_darcy_operator_bytes": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "pmc_darcy_poly_time": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "pmc_darcy_poly_bytes": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pmc_sampler_nnz": (C.c_int64, [_VP, C.c_int]),
     "pmc_sampler_true_p": (C.c_int, [_VP, C.c_int, C.POINTER(pmc_csr)]),
     "pmc_sampler_sample": (C.c_int, [_VP, C.c_int, C.c_uint64, C.c_int, _DP, C.c_int]),
     "pmc_sampler_eval": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _DP, _DP, _DP, C.c_int, C.c_int, _DP, C.c_int,
                                    C.POINTER(pmc_stats)]),
+    "pmc_sampler_mult": (C.c_int, [_VP, C.c_int, C.c_int, _DP, _DP, C.c_int, C.c_int, C.POINTER(pmc_stats)]),
+    "pmc_sampler_apply_preconditioner": (C.c_int, [_VP, C.c_int, C.c_int, _DP, _DP, C.c_int]),
     "pmc_sampler_apply_operator": (C.c_int, [_VP, C.c_int, C.c_int, _DP, _DP, C.c_int, C.c_int, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double)]),
     "pmc_sampler_set_operator_timing": (C.c_int, [_VP, C.c_int]),
@@ -250,7 +261,8 @@ class Context:
     def __init__(self, device_id: int = 0, seed: int = 0):
         self.lib = load_library()
         h = _VP()
-        _check(self.lib.pmc_ctx_create(int(device_id), C.byref(h)))
+        # the versioned entry point: a library with another pmc_solver_opts / pmc_stats layout refuses this binding
+        _check(self.lib.pmc_ctx_create_abi(int(device_id), PMC_ABI_VERSION, C.byref(h)))
         self.h = h
         self.device_id = device_id
         self._children = []     # weakrefs to handles that must die before the context does
@@ -366,6 +378,10 @@ class PDESampler:
         """realizations of `level` one launch of the solver kernels carries (pmc_sampler_batch_width)"""
         return self.ctx.lib.pmc_sampler_batch_width(self.h, level)
 
+    def z_bytes(self):
+        """bytes per entry of the preconditioned Krylov vectors of this handle (4: PMC_STORAGE_FP32, 8: PMC_STORAGE_FP64)"""
+        return self.ctx.lib.pmc_sampler_krylov_z_bytes(self.h)
+
     def GetNNZ(self, level):
         return self.ctx.lib.pmc_sampler_nnz(self.h, level)
 
@@ -459,6 +475,36 @@ class PDESampler:
         _check(self.ctx.lib.pmc_sampler_apply_operator(self.h, level, nb, px, py, ms, repeat, C.byref(t), C.byref(b)))
         return y, t.value, b.value
 
+    def ApplyPreconditioner(self, level, r):
+        """z = B^-1 r, one application of the MINRES preconditioner of `level` (pmc_sampler_apply_preconditioner); r: (nbatch,
+        n_u+n_s) numpy, nbatch one of 1, 2, 4, ... up to the level's launch width"""
+        r = _f64(np.atleast_2d(r))
+        z = np.empty_like(r)
+        pr, ms = _addr(r)
+        pz, _ = _addr(z)
+        _check(self.ctx.lib.pmc_sampler_apply_preconditioner(self.h, level, r.shape[0], pr, pz, ms))
+        return z
+
+    def Solve(self, level, rhs, guess=None, return_stats=False):
+        """invA[level]->Mult(rhs, sol) (pmc_sampler_mult): the full solution [u; s] of A x = rhs.  rhs: (nbatch, n_u+n_s)
+        numpy or a DeviceArray; guess (same kind): initial guess (iterative_mode)."""
+        L = self.problem.levels[level]
+        n = L.n_u + L.n_s
+        if isinstance(rhs, np.ndarray):
+            rhs = _f64(np.atleast_2d(rhs))
+            nb = rhs.shape[0]
+            sol = np.empty_like(rhs) if guess is None else _f64(np.atleast_2d(guess)).copy()
+        else:
+            nb = rhs.n // n
+            sol = self.ctx.empty(rhs.n) if guess is None else guess
+        pr, ms = _addr(rhs)
+        px, _ = _addr(sol)
+        st = (pmc_stats * nb)()
+        _check(self.ctx.lib.pmc_sampler_mult(self.h, level, nb, pr, px, 0 if guess is None else 1, ms, st))
+        if return_stats:
+            return sol, [(t.iterations, t.converged, t.initial_norm, t.final_norm) for t in st]
+        return sol
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.pmc_sampler_destroy(self.h)
@@ -502,6 +548,9 @@ class DarcySolver:
     def BatchWidth(self, level):
         return self.ctx.lib.pmc_darcy_batch_width(self.h, level)
 
+    def z_bytes(self):
+        return self.ctx.lib.pmc_darcy_krylov_z_bytes(self.h)
+
     def set_operator_timing(self, on: bool):
         """Bracket every in-loop launch of the u-rows [M(k) | B^T] x (eg_pair_spmm) with HIP events."""
         _check(self.ctx.lib.pmc_darcy_set_operator_timing(self.h, 1 if on else 0))
@@ -515,6 +564,17 @@ class DarcySolver:
     def operator_bytes(self, level, nbatch):
         b = C.c_double(0.0)
         _check(self.ctx.lib.pmc_darcy_operator_bytes(self.h, level, nbatch, C.byref(b)))
+        return b.value
+
+    def poly_time(self):
+        """the same for the M-block polynomial of the preconditioner (eg_poly2): (bracket ms, launches, empty-bracket ms)"""
+        ms, n, gap = C.c_double(0.0), C.c_int64(0), C.c_double(0.0)
+        _check(self.ctx.lib.pmc_darcy_poly_time(self.h, C.byref(ms), C.byref(n), C.byref(gap)))
+        return ms.value, n.value, gap.value
+
+    def poly_bytes(self, level, nbatch):
+        b = C.c_double(0.0)
+        _check(self.ctx.lib.pmc_darcy_poly_bytes(self.h, level, nbatch, C.byref(b)))
         return b.value
 
     def SolveFwd(self, level, k, nbatch=None, want_solution=False, sol_out=None, return_stats=False):

@@ -103,7 +103,7 @@ extern "C" {
 
 int pmc_version(void) { return 100; }
 int pmc_abi_version(void) { return PMC_ABI_VERSION; }
-int pmc_krylov_z_bytes(void) { return (int)sizeof(pmc::zreal); }
+int pmc_krylov_z_bytes(void) { return 4; }   // of the default options (PMC_STORAGE_FP32)
 uint64_t pmc_kernel_launches(void) { return kernel_launch_count(); }
 const char* pmc_last_error(void) { return g_last_error.c_str(); }
 
@@ -134,8 +134,20 @@ void pmc_solver_opts_default(pmc_solver_opts* o) {
     o->mini_max_rows = 6000;
     o->two_streams = 0;
     o->use_graph = 0;   // measured: no gain single-stream (kernels are latency-, not launch-bound), slower with 4 lanes
+    o->precond_storage = PMC_STORAGE_FP32;
 }
 
+#undef pmc_ctx_create   // the header redirects the name to pmc_ctx_create_abi for C / C++ callers
+int pmc_ctx_create(int device_id, pmc_ctx** out);
+int pmc_ctx_create_abi(int device_id, int abi_version, pmc_ctx** out) {
+    if (abi_version != PMC_ABI_VERSION) {
+        if (out) *out = nullptr;
+        set_last_error("caller was compiled against PMC_ABI_VERSION " + std::to_string(abi_version) + ", this library has " +
+                       std::to_string(PMC_ABI_VERSION) + " (layout of pmc_solver_opts / pmc_stats): rebuild against include/pmc.h");
+        return PMC_ERR_INVALID;
+    }
+    return pmc_ctx_create(device_id, out);
+}
 int pmc_ctx_create(int device_id, pmc_ctx** out) {
     return guarded([&] {
         PMC_REQUIRE(out != nullptr, "pmc_ctx_create: out is NULL");
@@ -288,7 +300,8 @@ int pmc_sampler_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_sampl
             o = *opts;
         }
         PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 0 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
-                        (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
+                        (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0 &&
+                        (o.precond_storage == PMC_STORAGE_FP32 || o.precond_storage == PMC_STORAGE_FP64),
                     "solver options out of range");
         *out = new pmc_sampler(*c, nlevels, n_mc_levels, levels, alpha, matern_g, lognormal != 0, o);
         for (int l = 0; l < (*out)->impl.nlevels; ++l) (*out)->impl.lv[l].out_size = (*out)->impl.lv[l].n_s;
@@ -315,6 +328,27 @@ int pmc_sampler_xi_size(const pmc_sampler* s, int level) {
 int pmc_sampler_sample_size(const pmc_sampler* s, int level) {
     if (!s || level < 0 || level >= s->impl.nlevels) return PMC_ERR_INVALID;
     return s->impl.lv[level].out_size;
+}
+int pmc_sampler_krylov_z_bytes(const pmc_sampler* s) {
+    return s ? (s->impl.opts.precond_storage == PMC_STORAGE_FP64 ? 8 : 4) : PMC_ERR_INVALID;
+}
+int pmc_darcy_krylov_z_bytes(const pmc_darcy* d) {
+    return d ? (d->impl.opts.precond_storage == PMC_STORAGE_FP64 ? 8 : 4) : PMC_ERR_INVALID;
+}
+int pmc_sampler_mult(pmc_sampler* s, int level, int nbatch, const double* rhs, double* sol, int use_sol_as_guess,
+                     int memspace, pmc_stats* stats) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr, "sampler is NULL");
+        PMC_REQUIRE(memspace == PMC_MEM_HOST || memspace == PMC_MEM_DEVICE, "bad memspace");
+        s->impl.mult(level, nbatch, rhs, sol, use_sol_as_guess != 0, memspace, stats);
+    });
+}
+int pmc_sampler_apply_preconditioner(pmc_sampler* s, int level, int nbatch, const double* r, double* z, int memspace) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr, "sampler is NULL");
+        PMC_REQUIRE(memspace == PMC_MEM_HOST || memspace == PMC_MEM_DEVICE, "bad memspace");
+        s->impl.apply_preconditioner(level, nbatch, r, z, memspace);
+    });
 }
 int pmc_sampler_batch_width(const pmc_sampler* s, int level) {
     if (!s || level < 0 || level >= s->impl.nlevels) return PMC_ERR_INVALID;
@@ -394,7 +428,8 @@ int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_l
             o = *opts;
         }
         PMC_REQUIRE(o.max_iter >= 1 && o.cheb_degree_M >= 0 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 &&
-                        (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0,
+                        (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0 &&
+                        (o.precond_storage == PMC_STORAGE_FP32 || o.precond_storage == PMC_STORAGE_FP64),
                     "solver options out of range");
         *out = new pmc_darcy(*c, nlevels, n_mc_levels, levels, k_divides != 0, o);
     });
@@ -417,6 +452,7 @@ int pmc_darcy_set_operator_timing(pmc_darcy* d, int on) {
     return guarded([&] {
         PMC_REQUIRE(d != nullptr, "darcy handle is NULL");
         d->impl.op_timer.on = on != 0;
+        d->impl.poly_timer.on = on != 0;
     });
 }
 int pmc_darcy_operator_time(pmc_darcy* d, double* total_ms, int64_t* launches, double* event_overhead_ms) {
@@ -433,6 +469,22 @@ int pmc_darcy_operator_bytes(const pmc_darcy* d, int level, int nbatch, double* 
         PMC_REQUIRE(d != nullptr && bytes != nullptr && level >= 0 && level < d->impl.nlevels && valid_batch(nbatch),
                     "pmc_darcy_operator_bytes: bad arguments");
         *bytes = d->impl.operator_bytes(level, nbatch);
+    });
+}
+int pmc_darcy_poly_time(pmc_darcy* d, double* total_ms, int64_t* launches, double* event_overhead_ms) {
+    return guarded([&] {
+        PMC_REQUIRE(d != nullptr, "darcy handle is NULL");
+        if (total_ms) *total_ms = d->impl.poly_timer.ms;
+        if (launches) *launches = d->impl.poly_timer.launches;
+        if (event_overhead_ms) *event_overhead_ms = d->impl.poly_timer.gap_ms;
+        d->impl.poly_timer.clear();
+    });
+}
+int pmc_darcy_poly_bytes(const pmc_darcy* d, int level, int nbatch, double* bytes) {
+    return guarded([&] {
+        PMC_REQUIRE(d != nullptr && bytes != nullptr && level >= 0 && level < d->impl.nlevels && valid_batch(nbatch),
+                    "pmc_darcy_poly_bytes: bad arguments");
+        *bytes = d->impl.poly_bytes(level, nbatch);
     });
 }
 int pmc_darcy_batch_width(const pmc_darcy* d, int level) {

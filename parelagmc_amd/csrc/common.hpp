@@ -192,6 +192,18 @@ struct Ctx {
     void activate() const;
 };
 
+// Tuning overrides from the environment exist only in LABORATORY builds of the library (make lab-lib: -DPMC_LAB,
+// scripts/lab/): the product library reads no PMC_* variable except PMC_VERBOSE (setup report on stderr), and every default
+// below is what the product runs with.  What a caller may legitimately choose is in pmc_solver_opts.
+inline const char* lab_env(const char* name) {
+#ifdef PMC_LAB
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // Interleaved batch width of a level with `rows` unknowns (saddle-point system).  Large levels are bandwidth-bound at 16
 // realizations per launch; sampler levels up to 5 M rows (PMC_S_WIDE_ROWS) and Darcy levels small enough to be bound by
 // launch latency take 32 (PMC_WIDE_ROWS: limit, default 300 000 rows; set, it applies to both kinds, 0 = always 16), and the smaller the level the more column groups of 32 one launch carries - 64, 128 or 256

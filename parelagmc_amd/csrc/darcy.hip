@@ -17,16 +17,6 @@ namespace pmc {
 
 namespace {
 
-// PMC_DARCY_F32=0: keep the per-realization values of the Schur-complement hierarchy in fp64 also for the V-cycle kernels
-// (A/B switch; default: fp32 copies, see MgLevel::f32)
-bool precond_f32() {
-    static const bool v = [] {
-        const char* e = getenv("PMC_DARCY_F32");
-        return !e || atoi(e) != 0;
-    }();
-    return v;
-}
-
 struct Triple { int r, c, idx; double w; };
 
 // pattern + contribution lists from a bag of (row, col, idx, w) tuples; `extra` pattern entries
@@ -133,6 +123,7 @@ std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, 
     mg.smooth_ratio = o.mg_smooth_ratio;
     mg.coarse_degree = o.mg_coarse_degree;
     mg.coarse_ratio = o.mg_coarse_ratio;
+    mg.f32_intermediates = o.precond_storage != PMC_STORAGE_FP64;
     const int nl = (int)lvh.size();
     mg.L.resize(nl);
     ch->cl.resize(nl);
@@ -143,7 +134,7 @@ std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, 
         const HostCsr& pat = sym.pat;
         m.n = pat.nrows;
         m.bv = true;
-        m.f32 = precond_f32();
+        m.f32 = o.precond_storage != PMC_STORAGE_FP64;   // fp32 copies of the per-realization values for the V-cycle kernels
         m.lmax = 1.0;                        // dinv carries the per-realization Gershgorin bound (k::gersh_scale_bv)
         sell_build(m.S, pat, false, true, st);   // per-realization values: sized by Darcy::ensure for the width in use
         {
@@ -206,6 +197,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
     mg.smooth_ratio = o.mg_smooth_ratio;
     mg.coarse_degree = o.mg_coarse_degree;
     mg.coarse_ratio = o.mg_coarse_ratio;
+    mg.f32_intermediates = o.precond_storage != PMC_STORAGE_FP64;
 
     std::vector<Symbolic> schur(nlevels);          // own (rediscretised) Schur lists per level
     std::vector<HostCsr> Pl(nlevels);
@@ -410,7 +402,7 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         MgLevel& m = mg.L[l];
         m.n = d.n_p;
         m.bv = true;
-        m.f32 = precond_f32();
+        m.f32 = o.precond_storage != PMC_STORAGE_FP64;
         m.lmax = 2.0 * 1.0001;   // weakly diagonally dominant M-matrix: spec(D^-1 S) in (0, 2]
         sell_build(m.S, pattern[l], false, true, st);   // per-realization values: sized by Darcy::ensure for the width in use
         // own Schur lists mapped onto the (possibly larger) level pattern
@@ -484,16 +476,26 @@ double Darcy::operator_bytes(int level, int nb) const {
     // (8 B), the coefficient table once ((n_p + 1) x nb doubles); otherwise 4 B per column index + 8 nb B per value.  B^T: 12 B
     // per nonzero.  4 B per row of slice offsets.  Vectors: x_u and x_p read, y_u written (the dot takes x_u from the same read).
     const DarcyLevel& d = lv[level];
-    // the input is a preconditioned vector (zreal storage), the result fp64
-    const double V = 8.0 * nb, Z = (double)sizeof(zreal) * nb;
+    // the input is a preconditioned vector (fp32 or fp64 storage), the result fp64
+    const double V = 8.0 * nb, Z = (opts.precond_storage == PMC_STORAGE_FP64 ? 8.0 : 4.0) * nb;
     double b = 12.0 * (double)d.Bt.nnz + 4.0 * d.n_u + Z * ((double)d.n_u + d.n_p) + V * d.n_u;
     if (use_eg(d)) b += 12.0 * (double)d.Meg.nslots + 8.0 * d.n_u + V * (d.n_p + 1.0);
     else b += (4.0 + V) * (double)d.M.nnz;
     return b;
 }
 
+double Darcy::poly_bytes(int level, int nb) const {
+    // one launch of z_u = D^-1 (c0 r - c1 M(k) D^-1 r) on the element-grouped matrix: 12 B per stored slot, the two
+    // coefficient rows per dof (8 B), 4 B per row, the coefficient table once; vectors: r and the per-realization l1
+    // diagonal are gathered (each row once algorithmically), z is written in its storage
+    const DarcyLevel& d = lv[level];
+    const double V = 8.0 * nb, Z = (opts.precond_storage == PMC_STORAGE_FP64 ? 8.0 : 4.0) * nb;
+    if (!use_eg(d)) return (4.0 + V) * (double)d.M.nnz + 4.0 * d.n_u + (2.0 * V + Z) * d.n_u;
+    return 12.0 * (double)d.Meg.nslots + 12.0 * d.n_u + V * (d.n_p + 1.0) + (2.0 * V + Z) * d.n_u;
+}
+
 bool Darcy::use_eg(const DarcyLevel& d) const {
-    static const bool off = getenv("PMC_DARCY_NO_EG") != nullptr;   // tuning / A-B switch
+    static const bool off = lab_env("PMC_DARCY_NO_EG") != nullptr;   // laboratory A/B switch: materialise M(k)
     return d.has_eg && (opts.cheb_degree_M == 2 || opts.cheb_degree_M == 0) && !off;   // 0 (automatic) = 2 here: the element-grouped form is degree 2
 }
 
@@ -661,10 +663,11 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     A.n = n;
     A.n0 = n_u;
     OpTimer* tm = &op_timer;
+    OpTimer* tp = &poly_timer;
     // (the Darcy solves start from zero: only the product from a preconditioned vector is ever needed)
-    A.apply_z = [=](const Lanes& L, int nb_, const zreal* x, double* y, double* partial, double* partial2) {
+    A.apply_z = [=](const Lanes& L, int nb_, zvec x, double* y, double* partial, double* partial2) {
         // u-rows: M(k) x_u + B^T x_p in one pass; p-rows: B x_u (beside it on the second stream); <x, Ax> fused into both
-        const zreal* xp = x + (size_t)n_u * nb_;
+        const zvec xp = x + (size_t)n_u * nb_;
         const bool timed = tm->on && partial != nullptr;      // the in-loop launches (fused dot) only
         if (timed) tm->begin(L.main);                          // timed: the p-rows follow on the same stream, not beside it
         else L.fork();
@@ -683,11 +686,20 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     double* cdp = cd.p;
     Multigrid* mgp = chain ? &chain->mg : &mg;
     const int mg_l0 = chain ? 0 : level;
-    PrecFn prec = [=](const Lanes& L, int nb_, const double* r, zreal* z, double* dot_partial, double* dot_partial2) {
+    PrecFn prec = [=](const Lanes& L, int nb_, const double* r, zvec z, double* dot_partial, double* dot_partial2) {
         // independent diagonal blocks: V-cycle of the S-block on the main stream, the M-block polynomial on the second
         // stream beside the V-cycle's coarse levels (see the sampler's preconditioner)
         int nblk_u = 0;
         auto m_block = [&]() {
+            if (eg && tp->on) {
+                // timed: on the main stream, bracketed by events (an empty bracket behind it), not beside the tail
+                double c0, c1;
+                cheb2_coefficients(cpM.lmax, cpM.ratio, &c0, &c1);
+                tp->begin(L.main);
+                nblk_u = k::eg_poly2_z(L.main, nb_, Mg, coefp, l1, r, z, c0, c1, dot_partial2);
+                tp->end(L.main);
+                return;
+            }
             L.fork();
             if (eg) {
                 double c0, c1;
@@ -724,6 +736,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
         ctx.phase_report(stats, nb);
     }
     if (op_timer.on) op_timer.harvest();   // minres_solve has synchronised the stream
+    if (poly_timer.on) poly_timer.harvest();
     // K15: Q = <obs, sol>
     const int qblocks = compact ? k::wdot(st, nb, ncomp, comp_w, sol_compact.p, qpartial.p)
                                 : k::wdot(st, nb, n, d.obs.p, sol.p, qpartial.p);

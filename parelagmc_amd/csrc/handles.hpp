@@ -48,9 +48,15 @@ struct Sampler {
               bool use_init, double* emb_out, int memspace, pmc_stats* stats);
     void apply_operator(int level, int nb, const double* x, double* y, int memspace, int repeat, double* avg_ms,
                         double* bytes);
+    // invA[level]->Mult(rhs, sol) on full vectors of n_u + n_s entries per realization (sample-major)
+    void mult(int level, int nbatch, const double* rhs, double* sol, bool use_guess, int memspace, pmc_stats* stats);
+    // z = B^-1 r: one application of the MINRES preconditioner (diagnostics: true preconditioned residual norms)
+    void apply_preconditioner(int level, int nbatch, const double* r, double* z, int memspace);
 
   private:
     void ensure(int level, int nb);
+    void solve_system(int level, int nb, bool zero_guess, int x_row0, int x_nrows, pmc_stats* stats);
+    PrecFn preconditioner(int level, int nb, int degM, Multigrid* mgp, int mg_l0);
     void eval_chunk(int level, int xi_level, int nb, const double* xi_d, double* s_d, const double* init_d,
                     int init_level, bool use_init, double* emb_d, pmc_stats* stats);
 };
@@ -120,6 +126,10 @@ struct Darcy {
     // <x, Ax>; k::pair_spmm when the element-grouped form is not available)
     OpTimer op_timer;
     double operator_bytes(int level, int nb) const;   // algorithmic bytes of ONE such launch
+    // ... and of the M-block polynomial of the preconditioner (k::eg_poly2, the other large gather kernel of an iteration):
+    // timed on the same switch, on the main stream instead of beside the V-cycle's bottom
+    OpTimer poly_timer;
+    double poly_bytes(int level, int nb) const;
     DevBuf<double> sol, sol_compact, cx, cd, cx2, stage_k, stage_sol, qpartial, qout, gtmp, gout;
     bool use_eg(const DarcyLevel& d) const;
     void set_observations(int level, const pmc_csr* Gobs);

@@ -24,9 +24,6 @@ namespace pmc {
 #endif
 static constexpr int kBlock = PMC_KBLOCK;   // workgroup size of the streaming / SpMM kernels (tuning builds may override)
 static constexpr int kWave = 64;
-#ifndef PMC_K5_TWO_COLUMNS
-#define PMC_K5_TWO_COLUMNS 0
-#endif
 #ifndef PMC_LEAN_GATHER
 #define PMC_LEAN_GATHER 1
 #endif
@@ -45,7 +42,6 @@ static constexpr bool kEgLateCoef = PMC_EG_LATE_COEF != 0;  // see eg_row_produc
 // sell_row_range takes the lean gather loop (see sell_row_part) from this batch width on: at NB = 32 the one-column loop
 // needs 170-184 registers (two waves per SIMD), the lean one fits three; at NB = 16 (four waves either way) it changed nothing
 static constexpr int kLeanRangeMinNb = PMC_LEAN_RANGE_MIN_NB;
-static constexpr bool kK5TwoColumns = PMC_K5_TWO_COLUMNS != 0;   // tuning build: K5 steps two slice columns at a time (see sell_row_range); measured slower, off
 
 static unsigned dot_grid_bound();
 int dot_capacity(int nrows, int nb) {
@@ -365,7 +361,7 @@ template <int NB>
 __device__ __forceinline__ constexpr bool lean_range() {
     return Lay<NB>::T > 1 && NB >= kLeanRangeMinNb;
 }
-template <int NB, int BV, bool CS, bool ZERO, int JC = 1, bool NT = false, typename XT = double>
+template <int NB, int BV, bool CS, bool ZERO, bool NT = false, typename XT = double>
 __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, const double* __restrict__ vals,
                                                const XT* __restrict__ x, const double* __restrict__ cs, int off,
                                                int width, int lane, int LD, double (&acc)[Lay<NB>::T][Lay<NB>::C],
@@ -416,68 +412,6 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         return;
     }
 
-    if constexpr (JC == 2) {
-        // TWO slice columns per step: 2 T gathers in flight per wavefront.  The extra registers halve the resident
-        // workgroups per CU - on purpose: fewer slices in flight shrink the set of x rows the XCD's L2 has to keep alive
-        // (measured with an occupancy-limited launch: FETCH_SIZE 182 -> 156 MB) and the doubled memory-level parallelism per
-        // wave was meant to keep the latency hidden.  Measured: FETCH_SIZE 182 -> 168 MB but 41 -> 48 us (3 instead of 4
-        // waves per SIMD cost more than the 16 gathers in flight return), so the build default is the one-column loop.
-        // Shared values, no column scaling (the block operator K5).
-        static_assert(!BV && !CS, "two-column stepping is written for shared values without column scaling");
-        int ca = 0, cb = 0;
-        double va = 0.0, vb = 0.0;
-        if (width > 0) {
-            ca = load_stream<NT>(cols + slot);
-            va = load_stream<NT>(vals + slot);
-            cb = ca;
-            if (width > 1) {
-                cb = load_stream<NT>(cols + slot + kWave);
-                vb = load_stream<NT>(vals + slot + kWave);
-            }
-        }
-        for (int j = 0; j < width; j += 2, slot += 2 * kWave) {
-            int na = ca, nb_ = cb;
-            double wa = 0.0, wb = 0.0;
-            if (j + 2 < width) {
-                na = load_stream<NT>(cols + slot + 2 * kWave);
-                wa = load_stream<NT>(vals + slot + 2 * kWave);
-                nb_ = na;
-                if (j + 3 < width) {
-                    nb_ = load_stream<NT>(cols + slot + 3 * kWave);
-                    wb = load_stream<NT>(vals + slot + 3 * kWave);
-                }
-            }
-            int cc0[T], cc1[T];
-            double aa0[T], aa1[T];
-#pragma unroll
-            for (int rs = 0; rs < T; ++rs) {
-                const int src = rs * G + g;
-                cc0[rs] = __shfl(ca, src, kWave);
-                aa0[rs] = __shfl(va, src, kWave);
-                cc1[rs] = __shfl(cb, src, kWave);
-                aa1[rs] = __shfl(vb, src, kWave);
-            }
-            double x0[T][C], x1[T][C];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rs = 0; rs < T; ++rs) {
-                load_v<C>(x + (size_t)cc0[rs] * LD + t * C, x0[rs]);
-                load_v<C>(x + (size_t)cc1[rs] * LD + t * C, x1[rs]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rs = 0; rs < T; ++rs) {
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    acc[rs][c] = fma(aa0[rs], x0[rs][c], acc[rs][c]);
-                    acc[rs][c] = fma(aa1[rs], x1[rs][c], acc[rs][c]);
-                }
-            }
-            ca = na; va = wa;
-            cb = nb_; vb = wb;
-        }
-        return;
-    }
     int cj = 0;
     double vj = 0.0;
     if (width > 0) {
@@ -600,7 +534,7 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
                                                  int slice, int lane, int LD, double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
     const int off = slice_off[slice];
     const int width = (slice_off[slice + 1] - off) >> 6;
-    sell_row_range<NB, BV, false, true, 1, false, XT>(cols, vals, x, nullptr, off, width, lane, LD, acc);
+    sell_row_range<NB, BV, false, true, false, XT>(cols, vals, x, nullptr, off, width, lane, LD, acc);
 }
 
 // XCD-aware slice assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (block b runs on XCD b % 8),
@@ -636,7 +570,7 @@ __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
 // 8 i .. 8 i + 7 with unit weights (uniformly refined tetrahedra / hexahedra): a slice holds 8 whole groups, the sum is
 // a fixed xor tree over the lanes of a row step, and the separate restriction kernel (13 us of dependent latency for a
 // few MB) disappears from the V-cycle.
-// XT: storage type of x and dot_with (fp32 for the preconditioned Krylov vectors, zreal)
+// XT: storage type of x and dot_with (fp32 or fp64 for the preconditioned Krylov vectors, zvec)
 template <int NB, int BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false, bool DL = false, typename XT = double>
 __global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? 3 : 1)) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
@@ -672,18 +606,15 @@ __global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? 3
         double xd[DL && !LEAN_DL ? T : 1][C];
         if constexpr (LEAN_DL) {
             const int off = slice_off[slice];
-            sell_row_range<NB, false, false, true, 1, NT, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6,
+            sell_row_range<NB, false, false, true, NT, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6,
                                                              lane, LD, acc, nullptr, p);
         } else if constexpr (DL) {
             const int off = slice_off[slice];
-            sell_row_range<NB, false, false, true, 1, NT, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6,
+            sell_row_range<NB, false, false, true, NT, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6,
                                                              lane, LD, acc, xd);
-        } else if constexpr (TAG != 0 && !BV && T > 1 && kK5TwoColumns) {
-            const int off = slice_off[slice];
-            sell_row_range<NB, false, false, true, 2, false, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
         } else if constexpr (NT) {
             const int off = slice_off[slice];
-            sell_row_range<NB, BV, false, true, 1, true, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+            sell_row_range<NB, BV, false, true, true, XT>(cols, vals, x, nullptr, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
         } else {
             sell_row_product<NB, BV, XT>(slice_off, cols, vals, x, slice, lane, LD, acc);
         }
@@ -737,7 +668,7 @@ __global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? 3
 }
 
 // Chebyshev / Jacobi step: d = a d + b dinv (r - A xin); xout = xin + d ; DOT: partials of <r, xout>
-// OT != double: the LAST step of a polynomial whose result is a preconditioned Krylov vector (zreal storage): d is not
+// OT != double: the LAST step of a polynomial whose result is a preconditioned Krylov vector (zvec storage): d is not
 // written back, the iterate is rounded to its storage before the fused dot
 template <int NB, int BV, bool DOT, typename OT = double>
 __global__ __launch_bounds__(kBlock) void sell_cheb_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
@@ -845,7 +776,7 @@ __global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 ? 3 : 1)) void sell_po
         double acc[T][C];
         if constexpr (NT) {
             const int off = slice_off[slice];
-            sell_row_range<NB, BV, false, true, 1, true>(cols, vals_scaled, r, nullptr, off, (slice_off[slice + 1] - off) >> 6,
+            sell_row_range<NB, BV, false, true, true>(cols, vals_scaled, r, nullptr, off, (slice_off[slice + 1] - off) >> 6,
                                                         lane, LD, acc);
         } else {
             sell_row_product<NB, BV>(slice_off, cols, vals_scaled, r, slice, lane, LD, acc);
@@ -905,7 +836,7 @@ template <int NB, typename XT, bool NT = false, int BV = 0>
 __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, const double* __restrict__ vals,
                                                  const XT* __restrict__ x, int off, int width, int lane, int LD,
                                                  double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
-    sell_row_range<NB, BV, false, true, 1, NT, XT>(cols, vals, x, nullptr, off, width, lane, LD, acc);
+    sell_row_range<NB, BV, false, true, NT, XT>(cols, vals, x, nullptr, off, width, lane, LD, acc);
 }
 
 // out = dinv (c0 r - c1 As r) (+ xadd) (+ padd_x[padd_idx]) with r of type XT (gathered and read at the own row), out of
@@ -1398,9 +1329,9 @@ __global__ __launch_bounds__(kBlock) void scale_cols_bv32_kernel(size_t nflat, c
 }
 
 // MINRES w / x update restricted to an index list of rows: w, x are compact [nsel][NB], u is full
-template <int NB>
+template <int NB, typename UT>
 __global__ __launch_bounds__(kBlock) void minres_wx_idx_kernel(size_t nflat, const int* __restrict__ rows,
-                                                               const double* __restrict__ c0, const zreal* __restrict__ u,
+                                                               const double* __restrict__ c0, const UT* __restrict__ u,
                                                                const double* __restrict__ c1, double* __restrict__ w0,
                                                                const double* __restrict__ c2, const double* __restrict__ w1,
                                                                const double* __restrict__ c3, double* __restrict__ x, int ld) {
@@ -1480,9 +1411,9 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(size_t nflat, const double*
 
 // z = storage-rounded copy of a preconditioner result that a kernel without a typed output left in fp64, with the fused
 // <r, z> of the rounded values (the paths off the hot configurations: higher-degree smoothers, algebraic transfers)
-template <int NB, bool DOT>
+template <int NB, bool DOT, typename OT>
 __global__ __launch_bounds__(kBlock) void convert_dot_kernel(size_t nflat, const double* __restrict__ in,
-                                                             zreal* __restrict__ out, const double* __restrict__ r,
+                                                             OT* __restrict__ out, const double* __restrict__ r,
                                                              double* __restrict__ partial, int ld) {
     constexpr int C = Lay<NB>::C;
     double p[C];
@@ -1491,7 +1422,7 @@ __global__ __launch_bounds__(kBlock) void convert_dot_kernel(size_t nflat, const
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nflat; i += (size_t)gridDim.x * kBlock) {
         double v[C];
         load_c<C>(in + i * C, v);
-        round_to<zreal>(v);
+        round_to<OT>(v);
         if constexpr (DOT) {
             double rv[C];
             load_c<C>(r + i * C, rv);
@@ -1522,9 +1453,9 @@ __global__ __launch_bounds__(kBlock) void lincomb3_kernel(size_t nflat, const do
     store_c<C>(y + e, yv);
 }
 
-template <int NB, bool NT>
+template <int NB, bool NT, typename UT>
 __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const double* __restrict__ c0,
-                                                           const zreal* __restrict__ u, const double* __restrict__ c1,
+                                                           const UT* __restrict__ u, const double* __restrict__ c1,
                                                            double* __restrict__ w0, const double* __restrict__ c2,
                                                            const double* __restrict__ w1, const double* __restrict__ c3,
                                                            double* __restrict__ x, int ld) {
@@ -1550,7 +1481,7 @@ __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const d
 // The w / x updates of B.cnt <= kWxDefer iterations in one pass (see kWxDefer): the u vectors of all pending iterations are
 // requested first, the recurrences then run in registers in iteration order - the same operations in the same order as
 // cnt successive minres_wx launches.
-template <int NB, bool NT>
+template <int NB, bool NT, typename UT>
 __global__ __launch_bounds__(kBlock) void minres_wx_deferred_kernel(size_t nflat, k::WxDeferred B,
                                                                     const double* __restrict__ cW, double* __restrict__ w0,
                                                                     double* __restrict__ w1, double* __restrict__ x, int ld) {
@@ -1562,7 +1493,7 @@ __global__ __launch_bounds__(kBlock) void minres_wx_deferred_kernel(size_t nflat
     double uv[k::kWxDefer][C], a[C], b[C], xv[C];
 #pragma unroll
     for (int j = 0; j < k::kWxDefer; ++j)
-        if (j < B.cnt) load_v_nt<NT, C>(B.u[j] + e, uv[j]);
+        if (j < B.cnt) load_v_nt<NT, C>(static_cast<const UT*>(B.u[j]) + e, uv[j]);
     load_c_nt<NT, C>(w0 + e, a);
     load_c_nt<NT, C>(w1 + e, b);
     load_c_nt<NT, C>(x + e, xv);
@@ -2369,7 +2300,7 @@ PMC_TAIL_INLINE void tail_vcycle_lds(const TailParams& P, int nb, int k, double*
     }
 }
 
-// out32: xout points at fp32 storage (the preconditioned Krylov vectors, zreal)
+// out32: xout points at fp32 storage (the preconditioned Krylov vectors in fp32 storage)
 __global__ __launch_bounds__(kTailThreads) void mg_tail_kernel(const TailParams* __restrict__ pp, int nb,
                                                                const double* __restrict__ rin, double* __restrict__ xout,
                                                                double* __restrict__ partial, int out32) {
@@ -2586,7 +2517,7 @@ static inline void check_offsets32(const SellView& A, int nb) {
 // flat vector kernels stream non-temporally once one vector exceeds PMC_NT_FLAT_MB MiB (default 8; 0 = never)
 static inline bool nt_flat(size_t doubles) {
     static const double limit = [] {
-        const char* e = getenv("PMC_NT_FLAT_MB");
+        const char* e = lab_env("PMC_NT_FLAT_MB");
         return (e ? atof(e) : 8.0) * 1024.0 * 1024.0;
     }();
     return limit > 0.0 && (double)doubles * 8.0 > limit;
@@ -2596,7 +2527,7 @@ static inline bool nt_flat(size_t doubles) {
 // the single-block final reduction (PMC_DOT_GRID overrides it for tuning runs)
 static unsigned dot_grid_bound() {
     static const unsigned v = [] {
-        const char* e = getenv("PMC_DOT_GRID");
+        const char* e = lab_env("PMC_DOT_GRID");
         const long x = e ? atol(e) : 0;
         return x >= 8 ? (unsigned)x : 4096u;
     }();
@@ -2614,7 +2545,7 @@ static inline dim3 grid_bounded(dim3 g, bool bounded) { return bounded ? dim3(st
 static inline bool nt_streams(const SellView& A, int nb, bool in_loop) {
     const double bytes = 12.0 * (double)A.nslices * 64.0 * 6.0 + 16.0 * nb * (double)A.nrows;   // ~6 entries per row
     static const double loop_limit = [] {
-        const char* e = getenv("PMC_NT_MIN_MB");
+        const char* e = lab_env("PMC_NT_MIN_MB");
         return (e ? atof(e) : 128.0) * 1024.0 * 1024.0;
     }();
     return bytes > (in_loop ? loop_limit : 256.0 * 1024.0 * 1024.0);
@@ -2626,7 +2557,7 @@ static inline bool nt_streams(const SellView& A, int nb, bool in_loop) {
 // PMC_NT_POLY_MB: threshold in MiB of operands, 0 = never.
 static inline bool nt_poly(const SellView& A, int nb) {
     static const double limit = [] {
-        const char* e = getenv("PMC_NT_POLY_MB");
+        const char* e = lab_env("PMC_NT_POLY_MB");
         return (e ? atof(e) : 32.0) * 1024.0 * 1024.0;
     }();
     const double bytes = 12.0 * (double)A.nslices * 64.0 * 6.0 + 16.0 * nb * (double)A.nrows;
@@ -2689,14 +2620,8 @@ static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const
             sell_spmm_kernel<NB, false, 0, true, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (accumulate)
             sell_spmm_kernel<NB, false, 1, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
-        else {
-            // tuning probe: unused dynamic LDS limits the workgroups per CU (occupancy experiment on the isolated launches)
-            static const size_t probe_lds = [] {
-                const char* e = getenv("PMC_K5_LDS");
-                return e ? (size_t)atol(e) : (size_t)0;
-            }();
-            sell_spmm_kernel<NB, false, 0, false, TAG><<<groups(g, nb), kBlock, TAG == 2 ? probe_lds : 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
-        }
+        else
+            sell_spmm_kernel<NB, false, 0, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
     }
 }
 
@@ -2733,8 +2658,9 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
          const double* dot_with) {
     return spmm_t<double>(st, nb, A, x, y, accumulate, dot_partial, dot_with);
 }
-int spmm_z(hipStream_t st, int nb, const SellView& A, const zreal* x, double* y, double* dot_partial, const zreal* dot_with) {
-    return spmm_t<zreal>(st, nb, A, x, y, false, dot_partial, dot_with);
+int spmm_z(hipStream_t st, int nb, const SellView& A, zvec x, double* y, double* dot_partial, zvec dot_with) {
+    if (x.f32) return spmm_t<float>(st, nb, A, x.as<float>(), y, false, dot_partial, dot_with.as<float>());
+    return spmm_t<double>(st, nb, A, x.as<double>(), y, false, dot_partial, dot_with.as<double>());
 }
 
 void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out,
@@ -2769,8 +2695,9 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
     check_launch();
 }
 
-int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
-              const double* xin, double* d, double* xout, double a, double b, double* dot_partial) {
+template <typename OT>
+static int cheb_step_t(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
+                       const double* xin, double* d, OT* xout, double a, double b, double* dot_partial) {
     check_offsets32(A, nb);
     if (A.nrows == 0) return 0;
     if (A.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "cheb_step: value/diagonal batching mismatch");
@@ -2778,47 +2705,66 @@ int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, boo
     PMC_DISPATCH_NB(nb, {
         if (A.bv && A.f32) {
             if (dot_partial)
-                sell_cheb_kernel<NB, 2, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
+                sell_cheb_kernel<NB, 2, true, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
             else
-                sell_cheb_kernel<NB, 2, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
+                sell_cheb_kernel<NB, 2, false, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
         } else if (A.bv) {
             if (dot_partial)
-                sell_cheb_kernel<NB, true, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
+                sell_cheb_kernel<NB, 1, true, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
             else
-                sell_cheb_kernel<NB, true, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
+                sell_cheb_kernel<NB, 1, false, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
         } else {
             if (dot_partial)
-                sell_cheb_kernel<NB, false, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
+                sell_cheb_kernel<NB, 0, true, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
             else
-                sell_cheb_kernel<NB, false, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
+                sell_cheb_kernel<NB, 0, false, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
         }
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;
 }
 
+int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
+              const double* xin, double* d, double* xout, double a, double b, double* dot_partial) {
+    return cheb_step_t<double>(st, nb, A, dinv, dinv_bv, r, xin, d, xout, a, b, dot_partial);
+}
+
+// fp64 storage: the iterate of the last step goes straight to zout, d is left as it was (as the typed kernel does)
 int cheb_step_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
-                const double* xin, double* d, zreal* zout, double a, double b, double* dot_partial) {
-    check_offsets32(A, nb);
-    if (A.nrows == 0) return 0;
-    if (A.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "cheb_step: value/diagonal batching mismatch");
-    const dim3 g = grid_bounded(grid_slices(A.nslices), dot_partial != nullptr);
+                const double* xin, double* d, zvec zout, double a, double b, double* dot_partial) {
+    if (zout.f32) return cheb_step_t<float>(st, nb, A, dinv, dinv_bv, r, xin, d, zout.as<float>(), a, b, dot_partial);
+    return cheb_step_t<double>(st, nb, A, dinv, dinv_bv, r, xin, d, zout.as<double>(), a, b, dot_partial);
+}
+
+template <typename OT>
+static int poly2_t(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, OT* xout,
+                   double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with, const int* padd_idx,
+                   const double* padd_x) {
+    check_offsets32(As, nb);
+    if (As.nrows == 0) return 0;
+    if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
+    const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
-        if (A.bv && A.f32) {
+        if (As.bv && As.f32) {
             if (dot_partial)
-                sell_cheb_kernel<NB, 2, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, dot_partial, nb);
+                sell_poly2_kernel<NB, 2, true, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_cheb_kernel<NB, 2, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, nullptr, nb);
-        } else if (A.bv) {
+                sell_poly2_kernel<NB, 2, false, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
+        } else if (As.bv) {
             if (dot_partial)
-                sell_cheb_kernel<NB, 1, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, dot_partial, nb);
+                sell_poly2_kernel<NB, 1, true, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_cheb_kernel<NB, 1, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, nullptr, nb);
+                sell_poly2_kernel<NB, 1, false, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
+        } else if (nt_poly(As, NB)) {
+            if (dot_partial)
+                sell_poly2_kernel<NB, 0, true, true, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
+            else
+                sell_poly2_kernel<NB, 0, false, true, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         } else {
             if (dot_partial)
-                sell_cheb_kernel<NB, 0, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, dot_partial, nb);
+                sell_poly2_kernel<NB, 0, true, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_cheb_kernel<NB, 0, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, zout, a, b, nullptr, nb);
+                sell_poly2_kernel<NB, 0, false, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         }
     });
     check_launch();
@@ -2828,69 +2774,15 @@ int cheb_step_z(hipStream_t st, int nb, const SellView& A, const double* dinv, b
 int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
           double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with, const int* padd_idx,
           const double* padd_x) {
-    check_offsets32(As, nb);
-    if (As.nrows == 0) return 0;
-    if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
-    const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
-    PMC_DISPATCH_NB(nb, {
-        if (As.bv && As.f32) {
-            if (dot_partial)
-                sell_poly2_kernel<NB, 2, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
-            else
-                sell_poly2_kernel<NB, 2, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
-        } else if (As.bv) {
-            if (dot_partial)
-                sell_poly2_kernel<NB, true, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
-            else
-                sell_poly2_kernel<NB, true, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
-        } else if (nt_poly(As, NB)) {
-            if (dot_partial)
-                sell_poly2_kernel<NB, false, true, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
-            else
-                sell_poly2_kernel<NB, false, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
-        } else {
-            if (dot_partial)
-                sell_poly2_kernel<NB, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
-            else
-                sell_poly2_kernel<NB, false, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
-        }
-    });
-    check_launch();
-    return dot_partial ? (int)g.x : 0;
+    return poly2_t<double>(st, nb, As, dinv, dinv_bv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
 }
 
-int poly2_z(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, zreal* xout,
+int poly2_z(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, zvec xout,
             double c0, double c1, double* dot_partial, const double* xadd, const double* dot_with, const int* padd_idx,
             const double* padd_x) {
-    check_offsets32(As, nb);
-    if (As.nrows == 0) return 0;
-    if (As.bv != dinv_bv) throw Error(PMC_ERR_INTERNAL, "poly2: value/diagonal batching mismatch");
-    const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
-    PMC_DISPATCH_NB(nb, {
-        if (As.bv && As.f32) {
-            if (dot_partial)
-                sell_poly2_kernel<NB, 2, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
-            else
-                sell_poly2_kernel<NB, 2, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
-        } else if (As.bv) {
-            if (dot_partial)
-                sell_poly2_kernel<NB, 1, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
-            else
-                sell_poly2_kernel<NB, 1, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
-        } else if (nt_poly(As, NB)) {
-            if (dot_partial)
-                sell_poly2_kernel<NB, 0, true, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
-            else
-                sell_poly2_kernel<NB, 0, false, true, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
-        } else {
-            if (dot_partial)
-                sell_poly2_kernel<NB, 0, true, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
-            else
-                sell_poly2_kernel<NB, 0, false, false, zreal><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
-        }
-    });
-    check_launch();
-    return dot_partial ? (int)g.x : 0;
+    if (xout.f32)
+        return poly2_t<float>(st, nb, As, dinv, dinv_bv, r, xout.as<float>(), c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
+    return poly2_t<double>(st, nb, As, dinv, dinv_bv, r, xout.as<double>(), c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
 }
 
 void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, float* xout, double c0,
@@ -2959,8 +2851,9 @@ int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* di
     return vc_postsmooth32_t<double>(st, nb, As, dinv, res, x, xout, c0, c1, r, parent, xc, dot_partial);
 }
 int vc_postsmooth32_z(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
-                      zreal* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial) {
-    return vc_postsmooth32_t<zreal>(st, nb, As, dinv, res, x, xout, c0, c1, r, parent, xc, dot_partial);
+                      zvec xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial) {
+    if (xout.f32) return vc_postsmooth32_t<float>(st, nb, As, dinv, res, x, xout.as<float>(), c0, c1, r, parent, xc, dot_partial);
+    return vc_postsmooth32_t<double>(st, nb, As, dinv, res, x, xout.as<double>(), c0, c1, r, parent, xc, dot_partial);
 }
 
 // ---- the same level with per-realization fp32 values (Darcy; SellView::f32) and per-realization diagonals
@@ -3026,8 +2919,9 @@ int vc_postsmooth32_bv(hipStream_t st, int nb, const SellView& As, const double*
     return vc_postsmooth32_bv_t<double>(st, nb, As, dinv, res, x, xout, c0, c1, r, dot_partial);
 }
 int vc_postsmooth32_bv_z(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
-                         zreal* xout, double c0, double c1, const double* r, double* dot_partial) {
-    return vc_postsmooth32_bv_t<zreal>(st, nb, As, dinv, res, x, xout, c0, c1, r, dot_partial);
+                         zvec xout, double c0, double c1, const double* r, double* dot_partial) {
+    if (xout.f32) return vc_postsmooth32_bv_t<float>(st, nb, As, dinv, res, x, xout.as<float>(), c0, c1, r, dot_partial);
+    return vc_postsmooth32_bv_t<double>(st, nb, As, dinv, res, x, xout.as<double>(), c0, c1, r, dot_partial);
 }
 
 template <typename XT>
@@ -3059,9 +2953,11 @@ int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, co
                  const double* x2, double* y, double* dot_partial, const double* dot_with) {
     return eg_pair_spmm_t<double>(st, nb, M, coef, x1, A2, x2, y, dot_partial, dot_with);
 }
-int eg_pair_spmm_z(hipStream_t st, int nb, const EgView& M, const double* coef, const zreal* x1, const SellView& A2,
-                   const zreal* x2, double* y, double* dot_partial, const zreal* dot_with) {
-    return eg_pair_spmm_t<zreal>(st, nb, M, coef, x1, A2, x2, y, dot_partial, dot_with);
+int eg_pair_spmm_z(hipStream_t st, int nb, const EgView& M, const double* coef, zvec x1, const SellView& A2,
+                   zvec x2, double* y, double* dot_partial, zvec dot_with) {
+    if (x1.f32)
+        return eg_pair_spmm_t<float>(st, nb, M, coef, x1.as<float>(), A2, x2.as<float>(), y, dot_partial, dot_with.as<float>());
+    return eg_pair_spmm_t<double>(st, nb, M, coef, x1.as<double>(), A2, x2.as<double>(), y, dot_partial, dot_with.as<double>());
 }
 
 template <typename OT>
@@ -3090,9 +2986,10 @@ int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const 
              double c0, double c1, double* dot_partial) {
     return eg_poly2_t<double>(st, nb, M, coef, dinv, r, xout, c0, c1, dot_partial);
 }
-int eg_poly2_z(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, zreal* xout,
+int eg_poly2_z(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, zvec xout,
                double c0, double c1, double* dot_partial) {
-    return eg_poly2_t<zreal>(st, nb, M, coef, dinv, r, xout, c0, c1, dot_partial);
+    if (xout.f32) return eg_poly2_t<float>(st, nb, M, coef, dinv, r, xout.as<float>(), c0, c1, dot_partial);
+    return eg_poly2_t<double>(st, nb, M, coef, dinv, r, xout.as<double>(), c0, c1, dot_partial);
 }
 
 template <typename XT>
@@ -3117,9 +3014,10 @@ int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, cons
               double* dot_partial, const double* dot_with) {
     return pair_spmm_t<double>(st, nb, A1, x1, A2, x2, y, dot_partial, dot_with);
 }
-int pair_spmm_z(hipStream_t st, int nb, const SellView& A1, const zreal* x1, const SellView& A2, const zreal* x2, double* y,
-                double* dot_partial, const zreal* dot_with) {
-    return pair_spmm_t<zreal>(st, nb, A1, x1, A2, x2, y, dot_partial, dot_with);
+int pair_spmm_z(hipStream_t st, int nb, const SellView& A1, zvec x1, const SellView& A2, zvec x2, double* y,
+                double* dot_partial, zvec dot_with) {
+    if (x1.f32) return pair_spmm_t<float>(st, nb, A1, x1.as<float>(), A2, x2.as<float>(), y, dot_partial, dot_with.as<float>());
+    return pair_spmm_t<double>(st, nb, A1, x1.as<double>(), A2, x2.as<double>(), y, dot_partial, dot_with.as<double>());
 }
 
 void scale_cols_bv(hipStream_t st, int nb, int64_t nslots, const int* cols, const double* vals, const double* colscale,
@@ -3140,10 +3038,13 @@ void scale_cols_bv32(hipStream_t st, int nb, int64_t nslots, const int* cols, co
     check_launch();
 }
 
-void minres_wx_idx(hipStream_t st, int nb, int nsel, const int* rows, const double* c0, const zreal* u, const double* c1,
+void minres_wx_idx(hipStream_t st, int nb, int nsel, const int* rows, const double* c0, zvec u, const double* c1,
                    double* w0, const double* c2, const double* w1, const double* c3, double* x) {
     if (nsel == 0) return;
-    PMC_DISPATCH_NB(nb, { minres_wx_idx_kernel<NB><<<grid_flat(nsel, nb), kBlock, 0, st>>>(flat_count(nsel, nb), rows, c0, u, c1, w0, c2, w1, c3, x, nb); });
+    PMC_DISPATCH_NB(nb, {
+        if (u.f32) minres_wx_idx_kernel<NB, float><<<grid_flat(nsel, nb), kBlock, 0, st>>>(flat_count(nsel, nb), rows, c0, u.as<float>(), c1, w0, c2, w1, c3, x, nb);
+        else minres_wx_idx_kernel<NB, double><<<grid_flat(nsel, nb), kBlock, 0, st>>>(flat_count(nsel, nb), rows, c0, u.as<double>(), c1, w0, c2, w1, c3, x, nb);
+    });
     check_launch();
 }
 
@@ -3174,19 +3075,27 @@ int dot(hipStream_t st, int nb, int n, const double* a, const double* b, double*
     return (int)g.x;
 }
 
-int dot_z(hipStream_t st, int nb, int n, const double* a, const zreal* b, double* partial) {
+int dot_z(hipStream_t st, int nb, int n, const double* a, zvec b, double* partial) {
     const dim3 g = grid_dot(n, nb);
-    PMC_DISPATCH_NB(nb, { dot_kernel<NB, zreal><<<g, kBlock, 0, st>>>(flat_count(n, nb), a, b, partial, nb); });
+    PMC_DISPATCH_NB(nb, {
+        if (b.f32) dot_kernel<NB, float><<<g, kBlock, 0, st>>>(flat_count(n, nb), a, b.as<float>(), partial, nb);
+        else dot_kernel<NB, double><<<g, kBlock, 0, st>>>(flat_count(n, nb), a, b.as<double>(), partial, nb);
+    });
     check_launch();
     return (int)g.x;
 }
 
-int convert_z(hipStream_t st, int nb, int n, const double* in, zreal* out, const double* r, double* dot_partial) {
+int convert_z(hipStream_t st, int nb, int n, const double* in, zvec out, const double* r, double* dot_partial) {
     if (n == 0) return 0;
     const dim3 g = grid_dot(n, nb);
     PMC_DISPATCH_NB(nb, {
-        if (dot_partial) convert_dot_kernel<NB, true><<<g, kBlock, 0, st>>>(flat_count(n, nb), in, out, r, dot_partial, nb);
-        else convert_dot_kernel<NB, false><<<g, kBlock, 0, st>>>(flat_count(n, nb), in, out, nullptr, nullptr, nb);
+        if (out.f32) {
+            if (dot_partial) convert_dot_kernel<NB, true, float><<<g, kBlock, 0, st>>>(flat_count(n, nb), in, out.as<float>(), r, dot_partial, nb);
+            else convert_dot_kernel<NB, false, float><<<g, kBlock, 0, st>>>(flat_count(n, nb), in, out.as<float>(), nullptr, nullptr, nb);
+        } else {
+            if (dot_partial) convert_dot_kernel<NB, true, double><<<g, kBlock, 0, st>>>(flat_count(n, nb), in, out.as<double>(), r, dot_partial, nb);
+            else convert_dot_kernel<NB, false, double><<<g, kBlock, 0, st>>>(flat_count(n, nb), in, out.as<double>(), nullptr, nullptr, nb);
+        }
     });
     check_launch();
     return dot_partial ? (int)g.x : 0;
@@ -3207,7 +3116,7 @@ void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, do
 void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b,
               const double* c2, double* y) {
     // non-temporal loads on large levels (one lane 1104 -> 1129, four lanes 1400 -> 1412 samples/s); PMC_NT_LINCOMB=0: off
-    static const bool nt_on = [] { const char* e = getenv("PMC_NT_LINCOMB"); return !e || atoi(e) != 0; }();
+    static const bool nt_on = [] { const char* e = lab_env("PMC_NT_LINCOMB"); return !e || atoi(e) != 0; }();
     const bool nt = nt_on && nt_flat((size_t)n * nb);
     PMC_DISPATCH_NB(nb, {
         if (nt) lincomb3_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y, nb);
@@ -3216,13 +3125,19 @@ void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, 
     check_launch();
 }
 
-void minres_wx(hipStream_t st, int nb, int n, const double* c0, const zreal* u, const double* c1, double* w0,
-               const double* c2, const double* w1, const double* c3, double* x) {
+template <typename UT>
+static void minres_wx_t(hipStream_t st, int nb, int n, const double* c0, const UT* u, const double* c1, double* w0,
+                        const double* c2, const double* w1, const double* c3, double* x) {
     const bool nt = nt_flat((size_t)n * nb);
     PMC_DISPATCH_NB(nb, {
-        if (nt) minres_wx_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x, nb);
-        else minres_wx_kernel<NB, false><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x, nb);
+        if (nt) minres_wx_kernel<NB, true, UT><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x, nb);
+        else minres_wx_kernel<NB, false, UT><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, u, c1, w0, c2, w1, c3, x, nb);
     });
+}
+void minres_wx(hipStream_t st, int nb, int n, const double* c0, zvec u, const double* c1, double* w0,
+               const double* c2, const double* w1, const double* c3, double* x) {
+    if (u.f32) minres_wx_t<float>(st, nb, n, c0, u.as<float>(), c1, w0, c2, w1, c3, x);
+    else minres_wx_t<double>(st, nb, n, c0, u.as<double>(), c1, w0, c2, w1, c3, x);
     check_launch();
 }
 
@@ -3233,8 +3148,13 @@ void minres_wx_deferred(hipStream_t st, int nb, int n, const MinresState* s, con
     const double* cW = reinterpret_cast<const double*>(reinterpret_cast<const char*>(s) + offsetof(MinresState, cW));
     const bool nt = nt_flat((size_t)n * nb);
     PMC_DISPATCH_NB(nb, {
-        if (nt) minres_wx_deferred_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), B, cW, w0, w1, x, nb);
-        else minres_wx_deferred_kernel<NB, false><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), B, cW, w0, w1, x, nb);
+        if (B.f32) {
+            if (nt) minres_wx_deferred_kernel<NB, true, float><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), B, cW, w0, w1, x, nb);
+            else minres_wx_deferred_kernel<NB, false, float><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), B, cW, w0, w1, x, nb);
+        } else {
+            if (nt) minres_wx_deferred_kernel<NB, true, double><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), B, cW, w0, w1, x, nb);
+            else minres_wx_deferred_kernel<NB, false, double><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), B, cW, w0, w1, x, nb);
+        }
     });
     check_launch();
 }

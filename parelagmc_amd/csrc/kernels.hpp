@@ -6,16 +6,30 @@
 
 namespace pmc {
 
-// Storage type of the PRECONDITIONED Krylov vectors z = B^-1 v of the MINRES solves.  They are the method's search
-// directions: whatever is stored IS the direction, every inner product and recurrence uses the stored values, so rounding
-// them to fp32 perturbs the preconditioner by 6e-8 relative and nothing else (iteration counts and converged fields
-// unchanged to 1e-12 in the probes); each z is written once and read three times per iteration.
-// Lanczos vectors, operator products, w, x and every scalar stay fp64.  -DPMC_Z64 builds the fp64 variant (A/B).
-#ifdef PMC_Z64
-typedef double zreal;
-#else
-typedef float zreal;
-#endif
+// The PRECONDITIONED Krylov vectors z = B^-1 v of the MINRES solves, in the storage pmc_solver_opts.precond_storage asks
+// for: fp32 (default) or fp64.  They are the method's search directions: whatever is stored IS the direction, every inner
+// product and recurrence uses the stored values, so rounding them to fp32 perturbs the preconditioner by 6e-8 relative and
+// nothing else (iteration counts and converged fields unchanged to 1e-12, true residuals at full size:
+// tests/test_gpu_round4.py); each z is written once and read three times per iteration.  Lanczos vectors, operator products,
+// w, x and every scalar are fp64 whatever the option says.  The launchers below take the vector with its storage type at
+// run time and pick the kernel instantiation (the fp64 ones are the kernels every other caller uses anyway).
+struct zvec {
+    void* p = nullptr;
+    bool f32 = true;
+    zvec() = default;
+    zvec(void* p_, bool f32_) : p(p_), f32(f32_) {}
+    size_t elem_bytes() const { return f32 ? 4 : 8; }
+    zvec operator+(size_t elems) const { return zvec(static_cast<char*>(p) + elems * elem_bytes(), f32); }
+    explicit operator bool() const { return p != nullptr; }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+// device buffer behind a zvec: `count` entries in either storage
+struct ZBuf {
+    DevBuf<float> b;
+    void ensure(size_t count, bool f32) { b.ensure(f32 ? count : 2 * count); }
+    zvec v(bool f32) const { return zvec(b.p, f32); }
+};
 
 // Device view of a SELL-64 matrix.  vals == shared values (nslots) or, when bv, per-realization
 // values (nslots*NB, interleaved like vectors).
@@ -69,9 +83,10 @@ namespace k {
 // coefficients and preconditioned vector.  One pass costs (kWxDefer + 5) vector streams instead of 6 kWxDefer.
 static constexpr int kWxDefer = 4;
 struct WxDeferred {
-    const zreal* u[kWxDefer];   // preconditioned vectors of the pending iterations (rows of the maintained block), oldest first
+    const void* u[kWxDefer];    // preconditioned vectors of the pending iterations (rows of the maintained block), oldest first
     int slot[kWxDefer];          // coefficient set (MinresState::cW ring) of each
     int cnt;
+    bool f32;                    // storage of the u vectors
 };
 
 // Device-resident MINRES scalars, one entry per batch column.
@@ -91,8 +106,8 @@ struct MinresState {
 // writes per-block partial sums of <dot_with, A x>; returns the number of partial blocks written.
 int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate,
           double* dot_partial, const double* dot_with);
-// the same product from a vector in zreal storage (shared values, no accumulation): the operator products of the solver loop
-int spmm_z(hipStream_t st, int nb, const SellView& A, const zreal* x, double* y, double* dot_partial, const zreal* dot_with);
+// the same product from a vector in zvec storage (shared values, no accumulation): the operator products of the solver loop
+int spmm_z(hipStream_t st, int nb, const SellView& A, zvec x, double* y, double* dot_partial, zvec dot_with);
 // out = r - A x and coarse[i] = sum of out over the rows 8 i .. 8 i + 7 (restriction with the transpose of an
 // "8 consecutive children, unit weights" prolongator); A.nrows must be a multiple of 8
 void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out,
@@ -103,16 +118,16 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
 // dot_partial != nullptr: also per-block partials of <r, xout>; returns the number of blocks written.
 int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
               const double* xin, double* d, double* xout, double a, double b, double* dot_partial = nullptr);
-// the LAST step of a polynomial whose result is a preconditioned Krylov vector: as cheb_step, the iterate goes to zreal
+// the LAST step of a polynomial whose result is a preconditioned Krylov vector: as cheb_step, the iterate goes to zvec
 // storage (rounded before the fused dot), d is left as it was
 int cheb_step_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
-                const double* xin, double* d, zreal* zout, double a, double b, double* dot_partial = nullptr);
+                const double* xin, double* d, zvec zout, double a, double b, double* dot_partial = nullptr);
 // one-pass degree-2 polynomial from a zero guess: xout = dinv.*(c0 r - c1 As r), As = A D^-1 (shared values)
 int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
           double c0, double c1, double* dot_partial = nullptr, const double* xadd = nullptr,
           const double* dot_with = nullptr, const int* padd_idx = nullptr, const double* padd_x = nullptr);
-// ... into zreal storage (the value stored is the one the fused <r, xout> uses)
-int poly2_z(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, zreal* xout,
+// ... into zvec storage (the value stored is the one the fused <r, xout> uses)
+int poly2_z(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, zvec xout,
             double c0, double c1, double* dot_partial = nullptr, const double* xadd = nullptr,
             const double* dot_with = nullptr, const int* padd_idx = nullptr, const double* padd_x = nullptr);
 // V-cycle level with fp32 intermediates (shared values; see vc_poly2_kernel): pre-smoothing from zero into an fp32 iterate,
@@ -126,7 +141,7 @@ void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res
 int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
                     double* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial);
 int vc_postsmooth32_z(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
-                      zreal* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial);
+                      zvec xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial);
 // ... and for a level with per-realization fp32 values and diagonals (Darcy; no S P: the coarse correction is added to the
 // fp32 iterate, then residual and post-smoothing): the fine residual of the restriction is never stored
 void vc_presmooth32_bv(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, float* xout, double c0,
@@ -137,12 +152,12 @@ void vc_residual32_bv(hipStream_t st, int nb, const SellView& A, const double* r
 int vc_postsmooth32_bv(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
                        double* xout, double c0, double c1, const double* r, double* dot_partial);
 int vc_postsmooth32_bv_z(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
-                         zreal* xout, double c0, double c1, const double* r, double* dot_partial);
+                         zvec xout, double c0, double c1, const double* r, double* dot_partial);
 // y = A1 x1 + A2 x2 (A1 per-realization values, A2 shared values, same rows); optional fused dot
 int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, const SellView& A2, const double* x2, double* y,
               double* dot_partial, const double* dot_with);
-int pair_spmm_z(hipStream_t st, int nb, const SellView& A1, const zreal* x1, const SellView& A2, const zreal* x2, double* y,
-                double* dot_partial, const zreal* dot_with);
+int pair_spmm_z(hipStream_t st, int nb, const SellView& A1, zvec x1, const SellView& A2, zvec x2, double* y,
+                double* dot_partial, zvec dot_with);
 // out[slot][k] = vals[slot][k] * colscale[cols[slot]][k]
 void scale_cols_bv(hipStream_t st, int nb, int64_t nslots, const int* cols, const double* vals, const double* colscale,
                    double* out);
@@ -150,7 +165,7 @@ void scale_cols_bv(hipStream_t st, int nb, int64_t nslots, const int* cols, cons
 void scale_cols_bv32(hipStream_t st, int nb, int64_t nslots, const int* cols, const double* vals, const double* colscale,
                      float* out_scaled, float* out_vals);
 // MINRES w/x update on an index list of rows (w0, w1, x compact [nsel][nb]; u full)
-void minres_wx_idx(hipStream_t st, int nb, int nsel, const int* rows, const double* c0, const zreal* u, const double* c1,
+void minres_wx_idx(hipStream_t st, int nb, int nsel, const int* rows, const double* c0, zvec u, const double* c1,
                    double* w0, const double* c2, const double* w1, const double* c3, double* x);
 // first step from a zero guess: d = b*dinv.*r; x = d
 int cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, const double* r, double* d,
@@ -158,13 +173,13 @@ int cheb_first(hipStream_t st, int nb, int n, const double* dinv, bool dinv_bv, 
 // both return the number of partial blocks written
 int dot(hipStream_t st, int nb, int n, const double* a, const double* b, double* partial);
 int wdot(hipStream_t st, int nb, int n, const double* w, const double* x, double* partial);
-int dot_z(hipStream_t st, int nb, int n, const double* a, const zreal* b, double* partial);
-// out = in rounded to zreal storage; dot_partial != nullptr: partials of <r, out>.  Returns the partial-block count.
-int convert_z(hipStream_t st, int nb, int n, const double* in, zreal* out, const double* r, double* dot_partial);
+int dot_z(hipStream_t st, int nb, int n, const double* a, zvec b, double* partial);
+// out = in rounded to zvec storage; dot_partial != nullptr: partials of <r, out>.  Returns the partial-block count.
+int convert_z(hipStream_t st, int nb, int n, const double* in, zvec out, const double* r, double* dot_partial);
 void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, double* out);
 void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b,
               const double* c2, double* y);
-void minres_wx(hipStream_t st, int nb, int n, const double* c0, const zreal* u, const double* c1, double* w0,
+void minres_wx(hipStream_t st, int nb, int n, const double* c0, zvec u, const double* c1, double* w0,
                const double* c2, const double* w1, const double* c3, double* x);
 void fill(hipStream_t st, size_t n, double* x, double v);
 void copy(hipStream_t st, size_t n, const double* src, double* dst);
@@ -208,13 +223,13 @@ void darcy_assemble(hipStream_t st, int nb, const SellView& Mp, const int* slot_
 // dot_partial != nullptr: partials of <dot_with, y>.  Returns the partial-block count.
 int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, const double* x1, const SellView& A2,
                  const double* x2, double* y, double* dot_partial, const double* dot_with);
-int eg_pair_spmm_z(hipStream_t st, int nb, const EgView& M, const double* coef, const zreal* x1, const SellView& A2,
-                   const zreal* x2, double* y, double* dot_partial, const zreal* dot_with);
+int eg_pair_spmm_z(hipStream_t st, int nb, const EgView& M, const double* coef, zvec x1, const SellView& A2,
+                   zvec x2, double* y, double* dot_partial, zvec dot_with);
 // one-pass degree-2 Chebyshev polynomial of D^-1 M(k) from a zero guess (see sell_poly2_kernel) on the element-grouped
 // matrix: xout = dinv (c0 r - c1 M(k) (dinv r)); dot_partial != nullptr: partials of <r, xout>
 int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, double* xout,
              double c0, double c1, double* dot_partial);
-int eg_poly2_z(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, zreal* xout,
+int eg_poly2_z(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, zvec xout,
                double c0, double c1, double* dot_partial);
 
 // per-realization Gershgorin scaling of dinv (batched values): afterwards spec(diag(dinv) S) lies in (0, 1] for every
@@ -274,9 +289,9 @@ void mini_sampler_solve(hipStream_t st, int nb, const MiniSamplerParams& P, size
 // vectors of the first tail level.  dot_partial != nullptr: writes <r, xout> per column as ONE partial block.
 int mg_tail(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_doubles, const double* r, double* xout,
             double* dot_partial, bool out32 = false);
-inline int mg_tail_z(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_doubles, const double* r, zreal* xout,
+inline int mg_tail_z(hipStream_t st, int nb, const TailParams* dev_params, size_t lds_doubles, const double* r, zvec xout,
                      double* dot_partial) {
-    return mg_tail(st, nb, dev_params, lds_doubles, r, reinterpret_cast<double*>(xout), dot_partial, sizeof(zreal) == 4);
+    return mg_tail(st, nb, dev_params, lds_doubles, r, xout.as<double>(), dot_partial, xout.f32);
 }
 // out[k][i] = in[i][k]: per-realization values of a small level re-laid column-major for the tail kernel, whose
 // workgroup k then streams only its own realization's values

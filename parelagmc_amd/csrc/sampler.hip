@@ -14,7 +14,7 @@ namespace pmc {
 // PMC_DIAG_LAST=0 builds the block operator in plain CSR order (A/B switch for the diagonal-last fused dot)
 static bool diag_last_on() {
     static const bool v = [] {
-        const char* e = getenv("PMC_DIAG_LAST");
+        const char* e = lab_env("PMC_DIAG_LAST");
         return !e || atoi(e) != 0;
     }();
     return v;
@@ -55,6 +55,7 @@ std::unique_ptr<Multigrid> build_sa_chain(const HostCsr& K, const std::vector<do
     mg->smooth_ratio = o.mg_smooth_ratio;
     mg->coarse_degree = o.mg_coarse_degree;
     mg->coarse_ratio = o.mg_coarse_ratio;
+    mg->f32_intermediates = o.precond_storage != PMC_STORAGE_FP64;
     mg->L.resize(lv.size());
     for (size_t l = 0; l < lv.size(); ++l) {
         MgLevel& m = mg->L[l];
@@ -113,6 +114,7 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
     mg.smooth_ratio = o.mg_smooth_ratio;
     mg.coarse_degree = o.mg_coarse_degree;
     mg.coarse_ratio = o.mg_coarse_ratio;
+    mg.f32_intermediates = o.precond_storage != PMC_STORAGE_FP64;
     for (int l = 0; l < nlevels; ++l) {
         const pmc_sampler_level& L = in[l];
         SamplerLevel& d = lv[l];
@@ -294,7 +296,7 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
                          int init_level, bool use_init, double* emb_d, pmc_stats* stats) {
     hipStream_t st = ctx.stream;
     SamplerLevel& d = lv[level];
-    const int n_u = d.n_u, n_s = d.n_s, n = n_u + n_s;
+    const int n_u = d.n_u, n_s = d.n_s;
     ensure(level, nb);
     if (stats) ctx.phase_mark(0);
     // rhs_s = -g W^{1/2} xi on xi_level, restricted with Ps^T (PDESampler.cpp:423-438); rhs_u = 0 (:441-442)
@@ -332,13 +334,34 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
         zero_guess = false;
     }
     if (stats) ctx.phase_mark(1);
+    // only the s-block of the solution is ever read (PDESampler.cpp:526): maintain only those rows
+    solve_system(level, nb, zero_guess, n_u, n_s, stats);
+    // outputs (:526-533 and the embedded variants' maps)
+    const double* sol_s = sol.p + (size_t)n_u * nb;
+    if (d.proj == PMC_PROJ_NONE) {
+        k::deinterleave(st, nb, n_s, sol_s, nullptr, nullptr, lognormal, s_d);
+    } else if (d.proj == PMC_PROJ_GATHER) {
+        k::deinterleave(st, nb, d.out_size, sol_s, d.gather.p, nullptr, lognormal, s_d);
+    } else {
+        k::spmm(st, nb, view(d.Gt), sol_s, tA.p, false, nullptr, nullptr);
+        k::deinterleave(st, nb, d.out_size, tA.p, nullptr, d.inv_w.p, lognormal, s_d);
+    }
+    if (emb_d) k::deinterleave(st, nb, n_s, sol_s, nullptr, nullptr, false, emb_d);
+}
+
+// invA[level]->Mult(rhs, sol) (PDESampler.cpp:397,521): preconditioned MINRES on the interleaved member vectors rhs -> sol
+// for nb realizations; rows [x_row0, x_row0 + x_nrows) of the solution are maintained.  The caller has marked phase 1.
+void Sampler::solve_system(int level, int nb, bool zero_guess, int x_row0, int x_nrows, pmc_stats* stats) {
+    hipStream_t st = ctx.stream;
+    SamplerLevel& d = lv[level];
+    const int n_u = d.n_u, n_s = d.n_s, n = n_u + n_s;
     const bool use_amg = level < (int)amg.size() && amg[level];
     Multigrid* mgp = use_amg ? amg[level].get() : &mg;
     const int mg_l0 = use_amg ? 0 : level;
     // small level whose whole Schur V-cycle fits the LDS tail: one persistent workgroup per realization runs the entire
     // MINRES solve (k::mini_sampler_solve) instead of ~7 kernel launches per iteration
     static const int mini_env = [] {      // tuning override of opts.mini_max_rows
-        const char* e = getenv("PMC_MINI_MAX_ROWS");
+        const char* e = lab_env("PMC_MINI_MAX_ROWS");
         return e ? atoi(e) : -1;
     }();
     const int mini_max_rows = mini_env >= 0 ? mini_env : opts.mini_max_rows;
@@ -359,9 +382,9 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
         mp.max_iter = opts.max_iter;
         mp.rel_tol = opts.rel_tol;
         mp.abs_tol = opts.abs_tol;
-        mp.x_row0 = n_u;
-        mp.x_nrows = n_s;
-        mp.scratch_per_col = (size_t)5 * n + (size_t)3 * n_s;
+        mp.x_row0 = x_row0;
+        mp.x_nrows = x_nrows;
+        mp.scratch_per_col = (size_t)5 * n + (size_t)3 * x_nrows;
         mini_scratch.ensure(mp.scratch_per_col * nb);
         mini_stats.ensure(kMaxBatch);
         k::mini_sampler_solve(st, nb, mp, mgp->tail_lds[mg_l0], rhs.p, sol.p, zero_guess, mini_scratch.p, mini_stats.p);
@@ -381,9 +404,26 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     A.apply = [Av](const Lanes& L, int nb_, const double* x, double* y, double* partial, double*) {
         return k::DotParts{partial, k::spmm(L.main, nb_, Av, x, y, false, partial, x)};
     };
-    A.apply_z = [Av](const Lanes& L, int nb_, const zreal* x, double* y, double* partial, double*) {
+    A.apply_z = [Av](const Lanes& L, int nb_, zvec x, double* y, double* partial, double*) {
         return k::DotParts{partial, k::spmm_z(L.main, nb_, Av, x, y, partial, x)};
     };
+    PrecFn prec = preconditioner(level, nb, degM, mgp, mg_l0);
+    GraphHint hint;
+    hint.key = hash_mix(hash_mix(hash_mix(0x5a, (uint64_t)level + 1), (uint64_t)nb), (uint64_t)x_row0);
+    hint.sig = hash_ptr(hash_ptr(hash_ptr(mgp->signature(mg_l0), cx.p), cd.p), cx2.p);
+    MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work, x_row0, x_nrows, nullptr, hint);
+    if (stats) {
+        ctx.phase_mark(2);
+        for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
+        ctx.phase_report(stats, nb);
+    }
+    }
+}
+
+// z = B^-1 r of `level`: the block-diagonal preconditioner of the MINRES solve (M-block polynomial | V-cycle on the Schur block)
+PrecFn Sampler::preconditioner(int level, int nb, int degM, Multigrid* mgp, int mg_l0) {
+    SamplerLevel& d = lv[level];
+    const int n_u = d.n_u;
     const SellView Mv = view(d.M);
     const double* dinvM = d.dinvM.p;
     ChebParams cpM{degM, 1.0, d.ratio_M, d.M_scaled.p};
@@ -391,7 +431,7 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     double* cxp = cx.p;
     double* cx2p = cx2.p;
     double* cdp = cd.p;
-    PrecFn prec = [=](const Lanes& L, int nb_, const double* r, zreal* z, double* dot_partial, double* dot_partial2) {
+    return [=](const Lanes& L, int nb_, const double* r, zvec z, double* dot_partial, double* dot_partial2) {
         // The two diagonal blocks are independent.  The V-cycle of the S-block runs on the main stream; once its
         // bandwidth-bound finest-level kernels are enqueued, the one-pass polynomial of the M-block starts on the second
         // stream and fills the chip while the V-cycle's coarse levels (short kernels, a few workgroups each) run.
@@ -404,28 +444,70 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
         L.join();
         return k::DotParts{dot_partial, nblk_s, dot_partial2, nblk_u};   // <r, z> = s-block partials + u-block partials
     };
-    // only the s-block of the solution is ever read (PDESampler.cpp:526): update only those rows
-    GraphHint hint;
-    hint.key = hash_mix(hash_mix(0x5a, (uint64_t)level + 1), (uint64_t)nb);
-    hint.sig = hash_ptr(hash_ptr(hash_ptr(mgp->signature(mg_l0), cx.p), cd.p), cx2.p);
-    MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work, n_u, n_s, nullptr, hint);
-    if (stats) {
-        ctx.phase_mark(2);
-        for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
-        ctx.phase_report(stats, nb);
+}
+
+void Sampler::apply_preconditioner(int level, int nbatch, const double* r_in, double* z_out, int memspace) {
+    PMC_REQUIRE(level >= 0 && level < n_mc, "apply_preconditioner: level out of range");
+    PMC_REQUIRE(valid_batch(nbatch) && nbatch <= batch_width((size_t)lv[level].n_u + lv[level].n_s) && r_in != nullptr && z_out != nullptr,
+                "apply_preconditioner: nbatch must be a launch width of the level");
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    SamplerLevel& d = lv[level];
+    const size_t n = (size_t)d.n_u + d.n_s;
+    const int nb = nbatch;
+    ensure(level, nb);
+    DevBuf<double> stage, zi(n * nb), part((size_t)2 * dot_capacity((int)n, nb) * nb);
+    const double* r_d = r_in;
+    if (memspace == PMC_MEM_HOST) {
+        stage.alloc(n * nb);
+        PMC_HIP(hipMemcpyAsync(stage.p, r_in, sizeof(double) * n * nb, hipMemcpyHostToDevice, st));
+        r_d = stage.p;
     }
+    k::interleave(st, nb, (int)n, r_d, nullptr, 1.0, rhs.p);
+    const bool use_amg = level < (int)amg.size() && amg[level];
+    Multigrid* mgp = use_amg ? amg[level].get() : &mg;
+    const int degM = opts.cheb_degree_M > 0 ? opts.cheb_degree_M : (d.ratio_M > 16.0 ? 4 : 2);
+    PrecFn prec = preconditioner(level, nb, degM, mgp, use_amg ? 0 : level);
+    // the result is taken in fp64: with PMC_STORAGE_FP32 the solver additionally rounds it to fp32 (6e-8 relative)
+    prec(ctx.lanes(false), nb, rhs.p, zvec(zi.p, false), part.p, part.p + (size_t)dot_capacity((int)n, nb) * nb);
+    double* out_d = memspace == PMC_MEM_HOST ? stage.p : z_out;
+    k::deinterleave(st, nb, (int)n, zi.p, nullptr, nullptr, false, out_d);
+    if (memspace == PMC_MEM_HOST) PMC_HIP(hipMemcpyAsync(z_out, stage.p, sizeof(double) * n * nb, hipMemcpyDeviceToHost, st));
+    PMC_HIP(hipStreamSynchronize(st));
+}
+
+void Sampler::mult(int level, int nbatch, const double* rhs_in, double* sol_io, bool use_guess, int memspace, pmc_stats* stats) {
+    PMC_REQUIRE(level >= 0 && level < n_mc, "Mult: level out of range");
+    PMC_REQUIRE(nbatch >= 1 && rhs_in != nullptr && sol_io != nullptr, "Mult: bad arguments");
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    const size_t n = (size_t)lv[level].n_u + lv[level].n_s;
+    DevBuf<double> stage_r, stage_x;
+    int done = 0;
+    while (done < nbatch) {
+        int nb = batch_width(n);
+        while (nb > nbatch - done) nb >>= 1;
+        ensure(level, nb);
+        const double* r_d = rhs_in + (size_t)done * n;
+        double* x_d = sol_io + (size_t)done * n;
+        if (memspace == PMC_MEM_HOST) {
+            stage_r.ensure(n * nb);
+            stage_x.ensure(n * nb);
+            PMC_HIP(hipMemcpyAsync(stage_r.p, r_d, sizeof(double) * n * nb, hipMemcpyHostToDevice, st));
+            if (use_guess) PMC_HIP(hipMemcpyAsync(stage_x.p, x_d, sizeof(double) * n * nb, hipMemcpyHostToDevice, st));
+            r_d = stage_r.p;
+        }
+        double* xdev = memspace == PMC_MEM_HOST ? stage_x.p : x_d;
+        if (stats) ctx.phase_mark(0);
+        k::interleave(st, nb, (int)n, r_d, nullptr, 1.0, rhs.p);
+        if (use_guess) k::interleave(st, nb, (int)n, xdev, nullptr, 1.0, sol.p);
+        if (stats) ctx.phase_mark(1);
+        solve_system(level, nb, !use_guess, 0, (int)n, stats ? stats + done : nullptr);
+        k::deinterleave(st, nb, (int)n, sol.p, nullptr, nullptr, false, xdev);
+        if (memspace == PMC_MEM_HOST) PMC_HIP(hipMemcpyAsync(x_d, stage_x.p, sizeof(double) * n * nb, hipMemcpyDeviceToHost, st));
+        PMC_HIP(hipStreamSynchronize(st));
+        done += nb;
     }
-    // outputs (:526-533 and the embedded variants' maps)
-    const double* sol_s = sol.p + (size_t)n_u * nb;
-    if (d.proj == PMC_PROJ_NONE) {
-        k::deinterleave(st, nb, n_s, sol_s, nullptr, nullptr, lognormal, s_d);
-    } else if (d.proj == PMC_PROJ_GATHER) {
-        k::deinterleave(st, nb, d.out_size, sol_s, d.gather.p, nullptr, lognormal, s_d);
-    } else {
-        k::spmm(st, nb, view(d.Gt), sol_s, tA.p, false, nullptr, nullptr);
-        k::deinterleave(st, nb, d.out_size, tA.p, nullptr, d.inv_w.p, lognormal, s_d);
-    }
-    if (emb_d) k::deinterleave(st, nb, n_s, sol_s, nullptr, nullptr, false, emb_d);
 }
 
 void Sampler::apply_operator(int level, int nb, const double* x, double* y, int memspace, int repeat, double* avg_ms,
@@ -449,10 +531,10 @@ void Sampler::apply_operator(int level, int nb, const double* x, double* y, int 
     SellView Av = view(d.A);
     Av.tag = 2;   // own kernel instantiation: the profile row of these launches holds nothing else
     k::spmm(st, nb, Av, xi.p, yi.p, false, nullptr, nullptr);   // untimed first touch
-    // tuning probes: PMC_PROBE_FLUSH_MB = bytes overwritten between launches (evicts the operator from L2 / Infinity
-    // Cache, i.e. the state in which MINRES finds it), PMC_PROBE_DOT = time the fused <x, Ax> variant
-    const char* e_flush = getenv("PMC_PROBE_FLUSH_MB");
-    const char* e_dot = getenv("PMC_PROBE_DOT");
+    // laboratory probes (lab builds only): PMC_PROBE_FLUSH_MB = bytes overwritten between launches (evicts the operator
+    // from L2 / Infinity Cache, i.e. the state in which MINRES finds it), PMC_PROBE_DOT = time the fused <x, Ax> variant
+    const char* e_flush = lab_env("PMC_PROBE_FLUSH_MB");
+    const char* e_dot = lab_env("PMC_PROBE_DOT");
     const size_t flush_bytes = e_flush ? (size_t)atol(e_flush) << 20 : 0;
     DevBuf<double> flush, part;
     if (flush_bytes) flush.alloc(flush_bytes / sizeof(double));
@@ -505,8 +587,9 @@ void Sampler::eval(int level, int xi_level, int nbatch, const double* xi, double
     // init_level a chunk's embed rows (n_s each) would overwrite init rows (n_init < n_s each) of later chunks before
     // they are read: keep a private copy of init_s for the whole call then.
     DevBuf<double> init_copy;
-    if (use_init && memspace == PMC_MEM_DEVICE && emb_out == init_s && n_init != n_s &&
-        nbatch > std::min(16, batch_width((size_t)lv[level].n_u + lv[level].n_s))) {
+    const int width = batch_width((size_t)lv[level].n_u + lv[level].n_s);
+    const bool several_chunks = !valid_batch(nbatch) || nbatch > width;   // exactly when the loop below cuts the call
+    if (use_init && memspace == PMC_MEM_DEVICE && emb_out == init_s && n_init != n_s && several_chunks) {
         init_copy.alloc((size_t)n_init * nbatch);
         PMC_HIP(hipMemcpyAsync(init_copy.p, init_s, sizeof(double) * n_init * nbatch, hipMemcpyDeviceToDevice, st));
         init_s = init_copy.p;

@@ -11,7 +11,7 @@ namespace pmc {
 
 double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
                    const double* r, double* xa, double* xb, double* d, bool zero_guess, double* dot_partial,
-                   int* dot_blocks, zreal* zlast) {
+                   int* dot_blocks, zvec zlast) {
     if (cp.degree < 1) throw Error(PMC_ERR_INVALID, "Chebyshev degree must be >= 1");
     const double lmax = cp.lmax, lmin = cp.lmax / cp.ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
@@ -71,7 +71,7 @@ double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv
 }
 
 int cheb_apply_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
-                 const double* r, zreal* z, double* xa, double* xb, double* d, double* dot_partial) {
+                 const double* r, zvec z, double* xa, double* xb, double* d, double* dot_partial) {
     if (!cheb_fused(cp, true) && (!xa || !xb || !d)) throw Error(PMC_ERR_INTERNAL, "cheb_apply_z: scratch vectors missing");
     int nblk = 0;
     cheb_apply(st, nb, A, dinv, dinv_bv, cp, r, xa, xb, d, true, dot_partial, &nblk, z);
@@ -80,7 +80,7 @@ int cheb_apply_z(hipStream_t st, int nb, const SellView& A, const double* dinv, 
 
 int cheb_post_from_residual(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv,
                             const ChebParams& cp, const double* r, const double* res, double* x, const int* parent,
-                            const double* xc, double* dot_partial, zreal* zout) {
+                            const double* xc, double* dot_partial, zvec zout) {
     if (!(cp.degree == 2 && cp.scaled_vals)) throw Error(PMC_ERR_INTERNAL, "fused post-smoothing needs degree 2");
     const double lmax = cp.lmax, lmin = cp.lmax / cp.ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
@@ -187,23 +187,14 @@ void Multigrid::build_tails(hipStream_t st) {
     }
 }
 
-// PMC_VCYCLE_F32=0: fp64 intermediates in the V-cycle of shared-value hierarchies (A/B switch for the k::vc_* kernels)
-static bool vcycle_f32() {
-    static const bool v = [] {
-        const char* e = getenv("PMC_VCYCLE_F32");
-        return !e || atoi(e) != 0;
-    }();
-    return v;
-}
-
-double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, zreal* ztarget,
+double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, zvec ztarget,
                          double* dot_partial, int* dot_blocks, const std::function<void()>* side) {
     MgLevel& lv = L[l];
     lv.ensure(nb);
     const bool tail_here = use_tail && l < (int)tail.size() && tail[l].p;
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
-    const bool f32_shared = !last && !lv.bv && lv.has_sp && lv.p_oct && smooth_degree == 2 && lv.vals_scaled.p && vcycle_f32();
-    const bool f32_bv = !last && lv.bv && lv.f32 && lv.p_oct && smooth_degree == 2 && lv.scaled32.p && vcycle_f32();
+    const bool f32_shared = !last && !lv.bv && lv.has_sp && lv.p_oct && smooth_degree == 2 && lv.vals_scaled.p && f32_intermediates;
+    const bool f32_bv = !last && lv.bv && lv.f32 && lv.p_oct && smooth_degree == 2 && lv.scaled32.p && f32_intermediates;
     if (ztarget && target) throw Error(PMC_ERR_INTERNAL, "V-cycle: two result buffers");
     const bool ends_here = tail_here || last;
     if (side && *side && ends_here) (*side)();   // beside the bottom of the V: the least parallel kernels of the cycle
@@ -235,7 +226,7 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         MgLevel& lc = L[l + 1];
         lc.ensure(nb);
         k::vc_residual_restrict8_32(st, nb, A, r, xf, resf, lc.r.p);
-        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, nullptr, side);
+        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, zvec(), nullptr, nullptr, side);
         k::vc_residual_coarse32(st, nb, view(lv.SP), resf, xc);
         const int nblk = ztarget ? k::vc_postsmooth32_z(st, nb, As, lv.dinv.p, resf, xf, ztarget, c0, c1, r, lv.parent.p, xc, dot_partial)
                                  : k::vc_postsmooth32(st, nb, As, lv.dinv.p, resf, xf, out, c0, c1, r, lv.parent.p, xc, dot_partial);
@@ -257,7 +248,7 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         MgLevel& lc = L[l + 1];
         lc.ensure(nb);
         k::vc_restrict8_32_bv(st, nb, A, r, xf, lc.r.p);
-        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, nullptr, side);
+        double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, zvec(), nullptr, nullptr, side);
         k::vc_prolong8_32(st, nb, lv.n, xf, xc);
         k::vc_residual32_bv(st, nb, A, r, xf, df);
         const int nblk = ztarget ? k::vc_postsmooth32_bv_z(st, nb, As, lv.dinv.p, df, xf, ztarget, c0, c1, r, dot_partial)
@@ -291,7 +282,7 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         k::residual(st, nb, A, r, x, lv.res.p);
         k::spmm(st, nb, view(lv.Pt), lv.res.p, lc.r.p, false, nullptr, nullptr);
     }
-    double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, nullptr, nullptr, nullptr, side);
+    double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, zvec(), nullptr, nullptr, side);
     if (lv.has_sp && !lv.bv && cheb_fused(cp, false)) {
         // r - S (x + P xc) = res - (S P) xc, in place; then x <- x + P xc + p2(that residual) in one pass
         k::residual(st, nb, view(lv.SP), lv.res.p, xc, lv.res.p);
@@ -307,12 +298,12 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
 int Multigrid::vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial,
                       const std::function<void()>& side) {
     int nblk = 0;
-    double* res = cycle(st, nb, l0, l0, r, xout, nullptr, dot_partial, &nblk, side ? &side : nullptr);
+    double* res = cycle(st, nb, l0, l0, r, xout, zvec(), dot_partial, &nblk, side ? &side : nullptr);
     if (res != xout) throw Error(PMC_ERR_INTERNAL, "V-cycle result landed in the wrong buffer");
     return nblk;
 }
 
-int Multigrid::vcycle_z(hipStream_t st, int nb, int l0, const double* r, zreal* zout, double* dot_partial,
+int Multigrid::vcycle_z(hipStream_t st, int nb, int l0, const double* r, zvec zout, double* dot_partial,
                         const std::function<void()>& side) {
     int nblk = 0;
     cycle(st, nb, l0, l0, r, nullptr, zout, dot_partial, &nblk, side ? &side : nullptr);
@@ -332,13 +323,17 @@ uint64_t Multigrid::signature(int l0) const {
         h = hash_ptr(h, m.SP.vals.p); h = hash_ptr(h, m.parent.p);
         h = hash_ptr(h, m.res.p); h = hash_ptr(h, m.vals_bv.p); h = hash_ptr(h, m.vals_scaled.p); h = hash_ptr(h, m.dinv.p);
         h = hash_ptr(h, m.vals32.p); h = hash_ptr(h, m.scaled32.p);
+        // the LDS tail descriptors and the transposed copies they point at are re-allocated when a wider batch arrives
+        // (ensure_bv_tail_width): a graph captured before that must not be replayed
+        h = hash_ptr(h, m.vals_t.p); h = hash_ptr(h, m.scaled_t.p); h = hash_ptr(h, m.dinv_t.p);
+        if (l < (int)tail.size()) h = hash_ptr(h, tail[l].p);
     }
     return h;
 }
 
-void MinresWork::ensure(int n, int nb) {
+void MinresWork::ensure(int n, int nb, bool z32) {
     const size_t need = (size_t)n * nb;
-    v0.ensure(need); v1.ensure(need); u0.ensure(need); u1.ensure(need);
+    v0.ensure(need); v1.ensure(need); u0.ensure(need, z32); u1.ensure(need, z32);
     w0.ensure(need); w1.ensure(need); q.ensure(need);
     // two segments each (see k::DotParts): [0, cap) and [cap, 2 cap)
     partial.ensure((size_t)2 * dot_capacity(n, nb) * nb);
@@ -365,7 +360,7 @@ static void axpby(hipStream_t st, size_t n, double a, const double* x, double b,
 // Rows x batch width from which a solve uses both streams of its handle (PMC_SPLIT_MIN overrides; 0 = never split)
 static size_t split_threshold() {
     static const size_t v = [] {
-        const char* e = getenv("PMC_SPLIT_MIN");
+        const char* e = lab_env("PMC_SPLIT_MIN");
         return e ? (size_t)atoll(e) : (size_t)1500000;
     }();
     return v;
@@ -373,14 +368,29 @@ static size_t split_threshold() {
 
 static bool stage_on() {
     static const bool v = [] {
-        const char* e = getenv("PMC_SCAL_STAGE");
+        const char* e = lab_env("PMC_SCAL_STAGE");
         return !e || atoi(e) != 0;
     }();
     return v;
 }
+// Rows up to which a SAMPLER level is solved 32 realizations per launch, from the memory of the device: a solve keeps
+// ~110 bytes per row and realization (five fp64 Krylov vectors, the ring of preconditioned vectors, right-hand side,
+// solution, the V-cycle's level vectors, staging), and a GPU is expected to carry up to eight handles at once (four manager
+// lanes, each with a sampler and a Darcy solver); half the memory is left to the operators and the other plugin.  288 GB:
+// 5.1 M rows (config 5's 6.46 M-row level therefore runs 16 wide, as measured necessary in round 3).  Deterministic: the
+// TOTAL memory is asked, not what happens to be free, so every lane and every rank of a farm picks the same width.
+static size_t sampler_wide_rows() {
+    static const size_t v = [] {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return (size_t)5000000;
+        return (size_t)((double)total_b * 0.5 / (110.0 * 32.0 * 8.0));
+    }();
+    return v;
+}
+
 int batch_width(size_t rows, bool darcy) {
     static const auto lim = [](const char* name, size_t dflt) {
-        const char* e = getenv(name);
+        const char* e = lab_env(name);
         return e ? (size_t)atoll(e) : dflt;
     };
     // Large levels: the sampler's kernels move more per gather at 32 realizations per launch (config 2, four lanes: 1 741 ->
@@ -390,7 +400,7 @@ int batch_width(size_t rows, bool darcy) {
     // PMC_WIDE_ROWS: limit of the 32-wide launches for Darcy levels, and for sampler levels too when it is set (0 = always
     // 16); PMC_S_WIDE_ROWS: the sampler's own limit
     static const size_t l32 = lim("PMC_WIDE_ROWS", 300000),
-                        l32s = lim("PMC_S_WIDE_ROWS", getenv("PMC_WIDE_ROWS") ? l32 : (size_t)5000000),
+                        l32s = lim("PMC_S_WIDE_ROWS", lab_env("PMC_WIDE_ROWS") ? l32 : sampler_wide_rows()),
                         l64 = lim("PMC_W64_ROWS", 150000), l128 = lim("PMC_W128_ROWS", 40000), l256 = lim("PMC_W256_ROWS", 20000);
     if (rows > (darcy ? l32 : l32s)) return 16;
     if (rows <= l256) return 256;
@@ -402,7 +412,7 @@ int batch_width(size_t rows, bool darcy) {
 // PMC_WX_DEFER=0: one w / x update launch per iteration (A/B switch for k::minres_wx_deferred)
 static bool wx_defer_on() {
     static const bool v = [] {
-        const char* e = getenv("PMC_WX_DEFER");
+        const char* e = lab_env("PMC_WX_DEFER");
         return !e || atoi(e) != 0;
     }();
     return v;
@@ -411,7 +421,7 @@ static bool wx_defer_on() {
 // PMC_LATE_WX=0 keeps the w / x update inside its own iteration also on two streams (A/B switch)
 static bool late_wx() {
     static const bool v = [] {
-        const char* e = getenv("PMC_LATE_WX");
+        const char* e = lab_env("PMC_LATE_WX");
         return !e || atoi(e) != 0;
     }();
     return v;
@@ -429,9 +439,10 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     const bool split = o.two_streams == 1 || (o.two_streams == 0 && split_threshold() > 0 && len >= split_threshold() &&
                                               Ctx::contexts_on_device(ctx.device) == 1);
     const Lanes L = ctx.lanes(split);
-    w.ensure(n, nb);
+    const bool z32 = o.precond_storage != PMC_STORAGE_FP64;
+    w.ensure(n, nb, z32);
     k::MinresState* S = w.state.p;
-    double* v0 = w.v0.p; double* v1 = w.v1.p; zreal* u0 = w.u0.p; zreal* u1 = w.u1.p;
+    double* v0 = w.v0.p; double* v1 = w.v1.p; zvec u0 = w.u0.v(z32); zvec u1 = w.u1.v(z32);
     double* w0 = w.w0.p; double* w1 = w.w1.p; double* q = w.q.p;
 
     // v1 = b - A x0
@@ -479,17 +490,17 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     };
 
     MinresResult out;
-    zreal* u2 = nullptr;
+    zvec u2;
     if (late) {
-        w.u2.ensure(len);
-        u2 = w.u2.p;
+        w.u2.ensure(len, z32);
+        u2 = w.u2.v(z32);
     }
     const bool timing = w.op_timer.on && !(hint.key != 0 && o.use_graph != 0);
     // q = A u, d1 = <u, A u>.  The product for iteration i+1 is issued right after the preconditioner of iteration i has
     // written u (both blocks of u are then the most recently written data on the chip), before the scalar recurrences
     // and the w / x update of iteration i, which do not depend on it.
     k::DotParts dp_op;
-    auto apply_op = [&](const zreal* u) {
+    auto apply_op = [&](zvec u) {
         if (timing) w.op_timer.begin(st);
         dp_op = A.apply_z(L, nb, u, q, w.partial_op.p, w.partial_op.p + seg2);
         if (timing) w.op_timer.end(st);   // + an empty bracket: what one event record costs on this stream
@@ -503,16 +514,16 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     // of the next Lanczos update and ahead of the M-block of the preconditioner; the first stream carries the s-rows of
     // the update and the V-cycle, whose coarse levels leave most of the chip idle.  Same kernels, same arguments, same
     // results; the preconditioned vector the update reads must survive one more iteration, hence three of them.
-    struct PendingWx { const zreal* u = nullptr; double *w0 = nullptr, *w1 = nullptr; } pend;
-    auto wx = [&](hipStream_t s, const zreal* u_, double* w0_, double* w1_) {
+    struct PendingWx { zvec u; double *w0 = nullptr, *w1 = nullptr; } pend;
+    auto wx = [&](hipStream_t s, zvec u_, double* w0_, double* w1_) {
         if (x_rows) k::minres_wx_idx(s, nb, x_nrows, x_rows, cW0, u_, cW1, w0_, cW2, w1_, cW3, x);
         else k::minres_wx(s, nb, x_nrows, cW0, u_ + xoff, cW1, w0_, cW2, w1_, cW3, x + xoff);
     };
     auto flush_wx = [&](hipStream_t s) {
         if (pend.u) wx(s, pend.u, pend.w0, pend.w1);
-        pend.u = nullptr;
+        pend.u = zvec();
     };
-    auto iteration = [&](zreal* u0_, zreal* u1_, double* v0_, double* v1_, double* w0_, double* w1_, bool last) {
+    auto iteration = [&](zvec u0_, zvec u1_, double* v0_, double* v1_, double* w0_, double* w1_, bool last) {
         if (late) {
             const size_t off = (size_t)A.n0 * nb;
             L.fork();
@@ -568,8 +579,8 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         if (n_active > 0 && it + 2 <= o.max_iter) {
             uint64_t sig = hash_mix(hint.sig, (uint64_t)nb);
             sig = hash_mix(sig, (uint64_t)n);
-            for (const void* p : {(const void*)b, (const void*)x, (const void*)v0, (const void*)v1, (const void*)u0,
-                                  (const void*)u1, (const void*)w0, (const void*)w1, (const void*)q,
+            for (const void* p : {(const void*)b, (const void*)x, (const void*)v0, (const void*)v1, (const void*)u0.p,
+                                  (const void*)u1.p, (const void*)w0, (const void*)w1, (const void*)q,
                                   (const void*)w.partial.p, (const void*)w.partial_op.p, (const void*)S, (const void*)w.stage.p,
                                   (const void*)x_rows})
                 sig = hash_ptr(sig, p);
@@ -609,13 +620,14 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     } else if (defer) {
         // ring of kWxDefer + 1 preconditioned vectors: the pending iterations' z stay alive until their updates are flushed
         constexpr int R = k::kWxDefer + 1;
-        w.u2.ensure(len);
-        w.u3.ensure(len);
-        w.u4.ensure(len);
-        zreal* ub[R] = {u1, u0, w.u2.p, w.u3.p, w.u4.p};
+        w.u2.ensure(len, z32);
+        w.u3.ensure(len, z32);
+        w.u4.ensure(len, z32);
+        zvec ub[R] = {u1, u0, w.u2.v(z32), w.u3.v(z32), w.u4.v(z32)};
         static_assert(R == 5, "ring buffers of the deferred w / x update");
         int c = 0;                                   // ub[c] holds the preconditioned vector of the current Lanczos vector
         k::WxDeferred pending{};
+        pending.f32 = z32;
         auto flush = [&]() {
             k::minres_wx_deferred(st, nb, x_nrows, S, pending, w0, w1, x + xoff);
             pending.cnt = 0;
@@ -623,7 +635,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         while (n_active > 0 && it < o.max_iter) {
             ++it;
             iteration(ub[(c + 1) % R], ub[c], v0, v1, w0, w1, it == o.max_iter);
-            pending.u[pending.cnt] = ub[c] + xoff;
+            pending.u[pending.cnt] = (ub[c] + xoff).p;
             pending.slot[pending.cnt] = (it - 1) % k::kWxDefer;
             if (++pending.cnt == k::kWxDefer) flush();
             c = (c + 1) % R;
@@ -636,7 +648,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             ++it;
             iteration(u0, u1, v0, v1, w0, w1, it == o.max_iter);
             if (late) {                      // u1 (read by the pending update) stays untouched for one more iteration
-                zreal* t = u1;
+                zvec t = u1;
                 u1 = u0;
                 u0 = u2;
                 u2 = t;

@@ -34,19 +34,19 @@ inline bool cheb_fused(const ChebParams& cp, bool /*zero_guess*/) { return cp.de
 // dot_partial != nullptr: the last step also writes per-block partials of <r, result>; *dot_blocks gets their count.
 double* cheb_apply(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
                    const double* r, double* xa, double* xb, double* d, bool zero_guess,
-                   double* dot_partial = nullptr, int* dot_blocks = nullptr, zreal* zlast = nullptr);
-// zlast != nullptr: the last kernel writes the result there in zreal storage (rounded before the fused dot) and null is
+                   double* dot_partial = nullptr, int* dot_blocks = nullptr, zvec zlast = zvec());
+// zlast non-null: the last kernel writes the result there in zvec storage (rounded before the fused dot) and null is
 // returned (degree 1 has no typed kernel: one extra rounding pass)
-// The same from a zero guess with the result in zreal storage (a preconditioner block of a MINRES solve): the last kernel
+// The same from a zero guess with the result in zvec storage (a preconditioner block of a MINRES solve): the last kernel
 // writes z itself; earlier steps of an unfused polynomial iterate in the fp64 scratch xa / xb.  Returns the partial-block
 // count of <r, z> (dot_partial != nullptr).
 int cheb_apply_z(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const ChebParams& cp,
-                 const double* r, zreal* z, double* xa, double* xb, double* d, double* dot_partial);
+                 const double* r, zvec z, double* xa, double* xb, double* d, double* dot_partial);
 // Post-smoothing of a V-cycle level from an already formed residual `res` = r - A (x + P xc) without x + P xc in memory:
 // x <- x + xc[parent] + p2(res); degree 2 with scaled values only.  Returns the partial-block count of <r, x>.
 int cheb_post_from_residual(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv,
                             const ChebParams& cp, const double* r, const double* res, double* x, const int* parent,
-                            const double* xc, double* dot_partial, zreal* zout = nullptr);
+                            const double* xc, double* dot_partial, zvec zout = zvec());
 // number of buffer flips cheb_apply performs
 inline int cheb_flips(const ChebParams& cp, bool zero_guess) {
     if (cheb_fused(cp, zero_guess)) return 0;
@@ -105,6 +105,9 @@ struct Multigrid {
     std::vector<DevBuf<TailParams>> tail;
     std::vector<size_t> tail_lds;
     bool use_tail = true;
+    // pmc_solver_opts.precond_storage: the intermediates of a level (iterate, residuals) of the structured hierarchies live
+    // in fp32 (k::vc_* kernels) or - false - in fp64 like everything else
+    bool f32_intermediates = true;
     void build_tails(hipStream_t st);
     // per-realization hierarchies: give every level of at most max_rows rows transposed value copies so that
     // build_tails can include them; refresh_bv_tail(nb) re-fills the copies (call after every numeric refresh)
@@ -124,13 +127,13 @@ struct Multigrid {
     // the intermediate ones (measured: a 9 us level-1 residual takes 37 us next to the M-block polynomial).
     int vcycle(hipStream_t st, int nb, int l0, const double* r, double* xout, double* dot_partial = nullptr,
                const std::function<void()>& side = nullptr);
-    // the same with the result in zreal storage (S-block of a MINRES preconditioner): the last kernel of the cycle writes it
-    int vcycle_z(hipStream_t st, int nb, int l0, const double* r, zreal* zout, double* dot_partial = nullptr,
+    // the same with the result in zvec storage (S-block of a MINRES preconditioner): the last kernel of the cycle writes it
+    int vcycle_z(hipStream_t st, int nb, int l0, const double* r, zvec zout, double* dot_partial = nullptr,
                  const std::function<void()>& side = nullptr);
 
   private:
-    // ztarget != nullptr (top level of vcycle_z only): the result goes there and the return value is null
-    double* cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, zreal* ztarget, double* dot_partial,
+    // ztarget non-null (top level of vcycle_z only): the result goes there and the return value is null
+    double* cycle(hipStream_t st, int nb, int l, int l0, const double* r, double* target, zvec ztarget, double* dot_partial,
                   int* dot_blocks, const std::function<void()>* side);
 };
 
@@ -145,8 +148,8 @@ struct LinOp {
     // (independent row blocks may run between L.fork() and L.join(); ordered on L.main again on return)
     std::function<k::DotParts(const Lanes& L, int nb, const double* x, double* y, double* dot_partial,
                               double* dot_partial2)> apply;
-    // the same product from a preconditioned vector (zreal storage): every product inside the MINRES loop
-    std::function<k::DotParts(const Lanes& L, int nb, const zreal* x, double* y, double* dot_partial,
+    // the same product from a preconditioned vector (zvec storage): every product inside the MINRES loop
+    std::function<k::DotParts(const Lanes& L, int nb, zvec x, double* y, double* dot_partial,
                               double* dot_partial2)> apply_z;
 };
 // z = B^-1 r.  When dot_partial != nullptr the preconditioner may fuse <r, z> into its last kernels and
@@ -155,8 +158,8 @@ struct LinOp {
 // return everything must be ordered on L.main again.
 // dot_partial / dot_partial2 (each dot_capacity(n) blocks) receive the fused <r, z>: return where the partials are
 // (total() == 0: not computed, the solver then runs a separate dot).
-// z is stored as zreal (see kernels.hpp); <r, z> is the inner product with the STORED values.
-using PrecFn = std::function<k::DotParts(const Lanes& L, int nb, const double* r, zreal* z, double* dot_partial,
+// z is a zvec (see kernels.hpp); <r, z> is the inner product with the STORED values.
+using PrecFn = std::function<k::DotParts(const Lanes& L, int nb, const double* r, zvec z, double* dot_partial,
                                          double* dot_partial2)>;
 
 // Caller-side identity of one solver configuration for hipGraph reuse: `key` names the configuration (handle, level,
@@ -215,10 +218,10 @@ struct OpTimer {
 
 struct MinresWork {
     DevBuf<double> v0, v1, w0, w1, q, partial;
-    DevBuf<zreal> u0, u1;                    // preconditioned vectors
+    ZBuf u0, u1;                             // preconditioned vectors (storage: pmc_solver_opts.precond_storage)
     DevBuf<double> stage;                    // first-stage sums of the scalar kernel (k::minres_scal21)
-    DevBuf<zreal> u2;                        // third preconditioned vector: only when the w / x update runs one iteration late
-    DevBuf<zreal> u3, u4;                    // ring of the deferred w / x update (with u0, u1, u2: kWxDefer + 1 vectors)
+    ZBuf u2;                                 // third preconditioned vector: only when the w / x update runs one iteration late
+    ZBuf u3, u4;                             // ring of the deferred w / x update (with u0, u1, u2: kWxDefer + 1 vectors)
     DevBuf<double> partial_op;               // partials of the operator's fused <u, Au> (the preconditioner's live in `partial`)
     std::map<uint64_t, int> iter_hint;       // per solver configuration: iterations its previous solve needed
     DevBuf<k::MinresState> state;
@@ -233,7 +236,7 @@ struct MinresWork {
     MinresWork(const MinresWork&) = delete;
     MinresWork& operator=(const MinresWork&) = delete;
     ~MinresWork();
-    void ensure(int n, int nb);
+    void ensure(int n, int nb, bool z32);
 };
 
 struct MinresResult {

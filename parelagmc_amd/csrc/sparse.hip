@@ -424,8 +424,8 @@ std::vector<AmgLevelHost> sa_hierarchy(const HostCsr& K0, const std::vector<doub
         if (lvl == 0) iso0 = csr_anisotropy(K) <= 10.0;
         bool weak = iso0;
         if (iso0) {   // tuning overrides (isotropic problems only)
-            if (const char* e = getenv(lvl == 0 ? "PMC_SA_ISO_PASSES0" : "PMC_SA_ISO_PASSES1")) extra = atoi(e) - passes;
-            if (const char* e = getenv("PMC_SA_ISO_WEAK")) weak = atoi(e) != 0;
+            if (const char* e = lab_env(lvl == 0 ? "PMC_SA_ISO_PASSES0" : "PMC_SA_ISO_PASSES1")) extra = atoi(e) - passes;
+            if (const char* e = lab_env("PMC_SA_ISO_WEAK")) weak = atoi(e) != 0;
         }
         const int nc = aggregate_rows(K, passes + extra, theta, agg, weak);
         if (getenv("PMC_VERBOSE"))

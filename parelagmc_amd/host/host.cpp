@@ -580,7 +580,12 @@ void MLMC_Manager::InitRun(std::vector<int>& level_nsamples_init) {
             if (ns > 0) run_level(ilevel, ns);
         }
     }
-    if (nranks_ > 1) reduce_(pending_.data(), (int)pending_.size());
+    if (nranks_ > 1) {
+        const double t0 = now_s();
+        reduce_(pending_.data(), (int)pending_.size());
+        reduce_seconds_ += now_s() - t0;
+        ++reduce_count_;
+    }
     for (size_t i = 0; i < (size_t)nlevels * NVAR; ++i) sums[i] += pending_[i];
     for (int l = 0; l < nlevels; ++l) {
         level_seconds[l] += pending_[(size_t)nlevels * NVAR + l];
@@ -764,16 +769,26 @@ void ML_BayesRatio_Manager::Reset() {
 
 // One level of InitRun (ML_BayesRatio_Manager.hpp:323-372 coarsest, :375-430 level pairs).  Realization i of the level
 // uses prior draw 2i for Z and 2i+1 for R (two independent samples, :334-341).
+int ML_BayesRatio_Manager::level_batch(int ilevel, int nsamples) const {
+    // a level pair evaluates both levels of the pair in one plugin call each: the finer level's width decides
+    int b = batch_;
+    const int pref = problem.PreferredBatch(ilevel);
+    if (pref > 0) b = std::min(b, pref);
+    const int share = (nsamples + nranks_ - 1) / nranks_;
+    return std::max(1, std::min(b, share));
+}
+
 void ML_BayesRatio_Manager::run_level(int ilevel, int nsamples) {
     const uint64_t base = (uint64_t)level_nsamples[ilevel];
     double* psum = pending_.data() + (size_t)ilevel * NVAR;
-    std::vector<double> z(batch_), r(batch_), zc(batch_), rc(batch_), c(batch_), ctot(batch_), tmp(batch_);
-    const int nblocks = (nsamples + batch_ - 1) / batch_;
+    const int lb = level_batch(ilevel, nsamples);
+    std::vector<double> z(lb), r(lb), zc(lb), rc(lb), c(lb), ctot(lb), tmp(lb);
+    const int nblocks = (nsamples + lb - 1) / lb;
     const bool coarsest = (ilevel == nlevels - 1);
     const double t0 = now_s();
     for (int blk = rank_; blk < nblocks; blk += nranks_) {
-        const int first = blk * batch_;
-        const int m = std::min(batch_, nsamples - first);
+        const int first = blk * lb;
+        const int m = std::min(lb, nsamples - first);
         std::fill(ctot.begin(), ctot.end(), 0.0);
         std::fill(zc.begin(), zc.end(), 0.0);
         std::fill(rc.begin(), rc.end(), 0.0);
@@ -954,6 +969,9 @@ class DeviceBayesRatioProblem : public BayesRatioProblem {
         for (int b = 0; b < s.Batch(); ++b) R[b] = q[b] * like[b];
     }
     int GetGlobalNumberOfDofs(int level) const override { return pmc_darcy_num_dofs(solver_, level); }
+    int PreferredBatch(int level) const override {
+        return std::min(sampler_.PreferredBatch(level), pmc_darcy_batch_width(solver_, level));
+    }
 
   private:
     PDESampler sampler_;
@@ -1154,6 +1172,14 @@ int pmc_mlmc_phase_times(pmc_mlmc* m, int level, double* sampler_mult_ms, double
         if (!m) throw std::invalid_argument("manager is NULL");
         m->mgr->PhaseTimesOfLevel(level, sampler_mult_ms, darcy_setup_ms, darcy_mult_ms, sampler_realizations,
                                   darcy_realizations);
+    });
+}
+int pmc_mlmc_farm_times(pmc_mlmc* m, double* allreduce_ms, int64_t* reductions) {
+    return hguard([&] {
+        if (!m) throw std::invalid_argument("manager is NULL");
+        double sec = 0.0;
+        m->mgr->FarmTimes(&sec, reductions);
+        if (allreduce_ms) *allreduce_ms = 1e3 * sec;
     });
 }
 int pmc_mlmc_result_get(pmc_mlmc* m, pmc_mlmc_result* r) {

@@ -256,6 +256,12 @@ class MLMC_Manager {
     /// Additional plugin pair (own context / HIP stream) working on this rank's realizations concurrently:
     /// the launch-latency-bound kernels of the small levels of one lane overlap the other lanes' work.
     void AddLane(pmc_ctx* ctx, PhysicalMLSolver& solver, MLSampler& sampler);
+    /// the farm's collective: seconds this rank spent in the SUM all-reduce of the accumulators and the number of
+    /// reductions (one per InitRun round, src/MLMC_Manager.cpp:178 is where the serial reference would need it)
+    void FarmTimes(double* allreduce_seconds, int64_t* reductions) const {
+        if (allreduce_seconds) *allreduce_seconds = reduce_seconds_;
+        if (reductions) *reductions = reduce_count_;
+    }
     /// Run ML simulation by sampling v_init_nsamples then the missing samples until the estimator variance target is met
     void Run();
     /// Run ML simulation using level_nsamples_init[i] samples on level i
@@ -302,6 +308,8 @@ class MLMC_Manager {
     int batch_, max_rounds_;
     int nranks_ = 1, rank_ = 0;
     std::function<void(double*, int)> reduce_;
+    double reduce_seconds_ = 0.0;          // wall time this rank spent inside the farm's all-reduce (incl. waiting for the
+    int64_t reduce_count_ = 0;             // slowest rank), and how many there were: one per InitRun round
     std::vector<double> pending_;          // this round's local contributions (sums + counts + seconds)
     struct Lane {
         MLSampler* sampler;
@@ -326,6 +334,8 @@ class BayesRatioProblem {
     /// likelihood[b] and R[b] = Q[b] * likelihood[b]; C[b] = cost (dofs)
     virtual void ComputeLikelihoodAndR(int level, Vector& s, double* likelihood, double* R, double* C) = 0;
     virtual int GetGlobalNumberOfDofs(int level) const = 0;
+    /// realizations of `level` one launch of the device plugins carries (0: no preference), see MLSampler::PreferredBatch
+    virtual int PreferredBatch(int /*level*/) const { return 0; }
 };
 
 /// Multilevel (nlevels > 1) / single-level (nlevels == 1) ratio estimator, src/ML_BayesRatio_Manager.hpp.
@@ -361,6 +371,8 @@ class ML_BayesRatio_Manager {
   private:
     void computeNSamplesMSE();
     void run_level(int ilevel, int nsamples);
+    /// plugin-call size of a level: min(batch, what the plugins prefer there, a rank's share) - as MLMC_Manager::level_batch
+    int level_batch(int ilevel, int nsamples) const;
     double& S(int l, int v) { return sums[(size_t)l * NVAR + v]; }
     BayesRatioProblem& problem;
     int auto_eps2, init_nsamples_, batch_, max_rounds_;

@@ -62,6 +62,7 @@ HOST_SYMBOLS = {
     "pmc_mlmc_result_get": (C.c_int, [_VP, C.POINTER(pmc_mlmc_result)]),
     "pmc_mlmc_show_me": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "pmc_mlmc_print_timers": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pmc_mlmc_farm_times": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pmc_mlmc_phase_times": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pmc_bayes_likelihood": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.c_int, _DPTR, C.c_int, C.c_double, _DPTR, _DPTR, _DPTR,
@@ -186,7 +187,7 @@ class RatioManager:
     ML_BayesRatio_Splitting_Manager / SL_BayesRatio_Splitting_Manager."""
 
     def __init__(self, nlevels, sampler=None, solver=None, G_obs=None, noise=None, callbacks=None, likelihood=None,
-                 eps2=0.001, ratio=0.5, init_nsamples=10, wall_time=True, batch=32, max_rounds=1000, splitting=False):
+                 eps2=0.001, ratio=0.5, init_nsamples=10, wall_time=True, batch=256, max_rounds=1000, splitting=False):
         self.lib = load_host_library()
         self.nlevels = nlevels
         p = pmc_mlmc_params()
@@ -443,6 +444,12 @@ class MLMCManager:
         _hcheck(self.lib.pmc_mlmc_phase_times(self.h, level, C.byref(a), C.byref(b), C.byref(c), C.byref(n1), C.byref(n2)))
         return {"sampler_mult_ms": a.value, "darcy_build_ms": b.value, "darcy_mult_ms": c.value,
                 "sampler_realizations": n1.value, "darcy_realizations": n2.value}
+
+    def farm_times(self):
+        """(milliseconds this rank spent in the farm's SUM all-reduce so far, number of reductions = InitRun rounds)"""
+        ms, n = C.c_double(0), C.c_int64(0)
+        _hcheck(self.lib.pmc_mlmc_farm_times(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def Reset(self):
         _hcheck(self.lib.pmc_mlmc_reset(self.h))

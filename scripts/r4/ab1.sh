@@ -9,7 +9,7 @@ run() {   # label, env assignments..., -- bench args
   envs=()
   while [ "$1" != "--" ]; do envs+=("$1"); shift; done
   shift
-  env "${envs[@]}" timeout -k 10 300 python $R/bench.py --no-cpu-baseline --no-mlmc --no-r6 "$@" 2>/dev/null | python -c "
+  env "${envs[@]}" timeout -k 10 300 python $R/bench.py --no-extras --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
 print('$label', 'value', round(d['value'], 1), 'ms/step', round(d['ms_per_step'], 2), 'it', round(d['config']['mean_minres_iterations'], 2), 'k5_us', round(r['avg_kernel_ms'] * 1e3, 2), 'frac', round(r['frac'], 3), 'solver', round(r['solver']['frac'], 3), flush=True)" >> $out || exit 1

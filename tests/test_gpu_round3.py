@@ -20,27 +20,38 @@ def rel(a, b):
 
 
 def test_bench_starts_its_own_ranks():
-    """`python bench.py --gpus 2` without a launcher (the driver's command) must run TWO ranks (the reference starts its
-    ranks under mpirun, examples/MLMC.cpp:43-50).  Rehearsed on one GPU: both ranks share device 0 and torch.distributed
-    falls back to gloo (RCCL refuses two ranks on one device, so extra.mlmc_farm may carry that error text)."""
+    """`python bench.py --gpus N` without a launcher (the driver's command) must run N ranks (the reference starts its
+    ranks under mpirun, examples/MLMC.cpp:43-50).  Rehearsed with FOUR ranks x one lane on one GPU (the box admits at most six
+    processes on its card, so eight cannot be rehearsed here; tests/test_farm_gloo.py runs eight ranks of the manager on the
+    CPU): the ranks share device 0, torch.distributed falls back to gloo, RCCL refuses several ranks on one device and the
+    farm's accumulators are summed over gloo instead - same manager, same sharding, same single reduction per round."""
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--refine", "3", "--steps", "2",
-                        "--warmup", "1", "--no-cpu-baseline", "--no-r6"], env=env, capture_output=True, text=True,
-                       timeout=900)
+    W = 4
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--streams", "1", "--refine", "3",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-r6"], env=env, capture_output=True,
+                       text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["n_gpus"] == W and out["scaling"] == "weak"
     ranks = out["ranks"]
-    assert [x["rank"] for x in ranks] == [0, 1]
-    # leap-frog split: rank r owns the global realization ids r, r + 2, ... - same count, disjoint ranges
-    assert ranks[0]["samples"] == ranks[1]["samples"] == 2 * out["config"]["batch"] * out["config"]["streams"]
-    assert ranks[0]["id_stride"] == 2 and ranks[0]["global_ids"][0] % 2 == 0 and ranks[1]["global_ids"][0] % 2 == 1
-    assert abs(out["value"] - 2 * ranks[0]["samples"] / (out["ms_per_step"] * 1e-3 * out["steps"])) < 1e-6 * out["value"]
-    assert "mlmc_farm" in out["extra"]
+    assert [x["rank"] for x in ranks] == list(range(W))
+    # leap-frog split: rank r owns the global realization ids r, r + W, ... - same count, disjoint ranges
+    per = 2 * out["config"]["batch"] * out["config"]["streams"]
+    assert all(x["samples"] == per and x["id_stride"] == W for x in ranks)
+    assert [x["global_ids"][0] % W for x in ranks] == list(range(W))
+    ids = [set(range(x["global_ids"][0], x["global_ids"][1] + 1, W)) for x in ranks]
+    assert all(len(s_) == per for s_ in ids) and len(set().union(*ids)) == W * per
+    assert all("pinned" in x["cpu_affinity"] for x in ranks)          # every rank tried to bind to its GPU's NUMA node
+    assert abs(out["value"] - W * per / (out["ms_per_step"] * 1e-3 * out["steps"])) < 1e-6 * out["value"]
+    farm = out["extra"]["mlmc_farm"]
+    assert "error" not in farm, farm
+    assert farm["nsamples_after_allreduce"] == [64 * W, 256 * W, 1024 * W]
+    assert farm["allreduces_in_round"] == 1 and farm["allreduce_ms"] >= 0.0 and len(farm["allreduce_ms_per_rank"]) == W
+    assert farm["collective"].startswith("gloo")
     assert "cpu_baseline" not in out and "r6" not in out["extra"]
 
 
@@ -138,7 +149,7 @@ def test_phase_timers_operator_timing_and_abi_version(gpu_ctx, hex_hierarchy_sma
     from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
     sp_ = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
     dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
-    assert gpu_ctx.lib.pmc_abi_version() == 2
+    assert gpu_ctx.lib.pmc_abi_version() == 3
     bad = capi.solver_opts()
     bad.abi_version = 1
     with pytest.raises(capi.PmcError):
