@@ -44,6 +44,13 @@ $(LABBIN): $(OBJDIR)/k5_lab.o $(OBJS)
 lab: $(LABBIN)
 .PHONY: lab
 
+# laboratory build of the library: the same sources with -DPMC_LAB, i.e. with the PMC_* tuning overrides of csrc/common.hpp
+# (lab_env) compiled in.  The product library (libpmc.so) reads none of them.  scripts/lab/*.sh copy it over libpmc.so on the
+# GPU box's scratch tree for same-box A/B runs.
+lab-lib:
+	$(MAKE) OBJDIR=build/obj_lab LIB=parelagmc_amd/lib/libpmc_lab.so EXTRA="-DPMC_LAB $(LABEXTRA)" parelagmc_amd/lib/libpmc_lab.so
+.PHONY: lab-lib
+
 # Boundary tests compiled from C and C++ (tests/test_abi_binaries.py runs them): the C program sees include/pmc.h only,
 # the C++ one the MFEM adapter (against tests/c/mfem_shim.hpp) and the mirror classes of parelagmc.hpp
 ABIBIN := tests/c/bin

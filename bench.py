@@ -106,7 +106,11 @@ class SetupPool:
         if kind not in self.fut:
             out, dt = _setup_worker(kind)
         else:
-            out, dt = self.fut.pop(kind).result()
+            try:
+                out, dt = self.fut.pop(kind).result()
+            except Exception as e:   # noqa: BLE001 - a lost worker must not cost the figure: build it here
+                print(f"bench: setup worker for {kind} failed ({e!r}); building inline", file=sys.stderr)
+                out, dt = _setup_worker(kind)
         self.seconds[kind] = dt
         return out
 
@@ -875,7 +879,8 @@ def main():
 
     # one-time finite-element setup of the configurations behind the headline: in worker processes, started before this
     # process initialises the GPU (they never touch it)
-    extras = world == 1 and not args.no_extras
+    # (--no-mlmc --no-r6 together: the headline-only command line of the older development scripts)
+    extras = world == 1 and not args.no_extras and not (args.no_mlmc and args.no_r6)
     kinds = []
     if extras or (world > 1 and not args.no_mlmc and not args.no_extras):
         if not args.no_mlmc:

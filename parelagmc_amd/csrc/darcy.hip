@@ -662,13 +662,15 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     LinOp A;
     A.n = n;
     A.n0 = n_u;
+    // in-loop event brackets are not recorded while the MINRES iterations may be captured into a hipGraph (as the sampler's)
+    const bool timing_ok = opts.use_graph == 0;
     OpTimer* tm = &op_timer;
     OpTimer* tp = &poly_timer;
     // (the Darcy solves start from zero: only the product from a preconditioned vector is ever needed)
     A.apply_z = [=](const Lanes& L, int nb_, zvec x, double* y, double* partial, double* partial2) {
         // u-rows: M(k) x_u + B^T x_p in one pass; p-rows: B x_u (beside it on the second stream); <x, Ax> fused into both
         const zvec xp = x + (size_t)n_u * nb_;
-        const bool timed = tm->on && partial != nullptr;      // the in-loop launches (fused dot) only
+        const bool timed = timing_ok && tm->on && partial != nullptr;      // the in-loop launches (fused dot) only
         if (timed) tm->begin(L.main);                          // timed: the p-rows follow on the same stream, not beside it
         else L.fork();
         const int nu_blk = eg ? k::eg_pair_spmm_z(L.main, nb_, Mg, coefp, x, Btv, xp, y, partial, x)
@@ -691,7 +693,7 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
         // stream beside the V-cycle's coarse levels (see the sampler's preconditioner)
         int nblk_u = 0;
         auto m_block = [&]() {
-            if (eg && tp->on) {
+            if (eg && tp->on && timing_ok) {
                 // timed: on the main stream, bracketed by events (an empty bracket behind it), not beside the tail
                 double c0, c1;
                 cheb2_coefficients(cpM.lmax, cpM.ratio, &c0, &c1);

@@ -42,6 +42,15 @@ static constexpr bool kEgLateCoef = PMC_EG_LATE_COEF != 0;  // see eg_row_produc
 // sell_row_range takes the lean gather loop (see sell_row_part) from this batch width on: at NB = 32 the one-column loop
 // needs 170-184 registers (two waves per SIMD), the lean one fits three; at NB = 16 (four waves either way) it changed nothing
 static constexpr int kLeanRangeMinNb = PMC_LEAN_RANGE_MIN_NB;
+#ifndef PMC_K5_DEEP
+#define PMC_K5_DEEP 0
+#endif
+// laboratory variant (LABEXTRA=-DPMC_K5_DEEP=1): the lean gather loop with TWO slice columns of gathers in flight per
+// wavefront, held as raw fp32 (see sell_row_range); measured in round 4, LAB_NOTES section 9
+static constexpr bool kK5Deep = PMC_K5_DEEP != 0;
+#ifndef PMC_K5_DEEP_WAVES
+#define PMC_K5_DEEP_WAVES 2
+#endif
 
 static unsigned dot_grid_bound();
 int dot_capacity(int nrows, int nb) {
@@ -418,6 +427,68 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         cj = load_stream<NT>(cols + slot);
         if constexpr (!BV) vj = load_stream<NT>(vals + slot);
     }
+    if constexpr (kK5Deep && lean_range<NB>() && !BV && !CS && sizeof(XT) == 4) {
+        // column j + 1's gathers are issued BEFORE column j's FMAs: 2 T gathers in flight per wavefront, both buffers raw fp32
+        RawVec<XT, C> xa[T], xb[T];
+        auto issue = [&](int cc, RawVec<XT, C>(&buf)[T]) {
+            unsigned at[T];
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs) at[rs] = (unsigned)__shfl(cc, rs * G + g, kWave) * (unsigned)LD + (unsigned)(t * C);
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs) load_raw<C>(x + at[rs], buf[rs]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto consume = [&](double vv, RawVec<XT, C>(&buf)[T], bool last) {
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs) {
+                const double a = __shfl(vv, rs * G + g, kWave);
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[rs][c] = fma(a, (double)buf[rs].v[c], acc[rs][c]);
+            }
+            if (last) {
+                if (pdot) {
+#pragma unroll
+                    for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) pdot[c] = fma((double)buf[rs].v[c], acc[rs][c], pdot[c]);
+                } else if (xlast) {
+#pragma unroll
+                    for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) xlast[rs][c] = (double)buf[rs].v[c];
+                }
+            }
+        };
+        if (width <= 0) return;
+        int c1 = cj;
+        double v1 = vj;
+        if (width > 1) {
+            c1 = load_stream<NT>(cols + slot + kWave);
+            v1 = load_stream<NT>(vals + slot + kWave);
+        }
+        issue(cj, xa);
+        int j = 0;
+        for (; j + 1 < width; j += 2, slot += 2 * kWave) {
+            int c2 = c1, c3 = c1;
+            double v2 = v1, v3 = v1;
+            if (j + 2 < width) {
+                c2 = load_stream<NT>(cols + slot + 2 * kWave);
+                v2 = load_stream<NT>(vals + slot + 2 * kWave);
+            }
+            issue(c1, xb);                         // column j + 1
+            consume(vj, xa, false);                // column j
+            if (j + 3 < width) {
+                c3 = load_stream<NT>(cols + slot + 3 * kWave);
+                v3 = load_stream<NT>(vals + slot + 3 * kWave);
+            }
+            if (j + 2 < width) issue(c2, xa);      // column j + 2
+            consume(v1, xb, j + 2 == width);       // column j + 1
+            cj = c2; vj = v2;
+            c1 = c3; v1 = v3;
+        }
+        if (j < width) consume(vj, xa, true);      // odd width: the last column is still in flight in xa
+        return;
+    }
     if constexpr (lean_range<NB>()) {
         // lean loop (as sell_row_part): 32-bit element offsets, gathered rows and fp32 per-realization values stay in their
         // storage type until the FMA, shared values are fetched across lanes after the gathers have been issued; with pdot
@@ -572,7 +643,7 @@ __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
 // few MB) disappears from the V-cycle.
 // XT: storage type of x and dot_with (fp32 or fp64 for the preconditioned Krylov vectors, zvec)
 template <int NB, int BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false, bool DL = false, typename XT = double>
-__global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? 3 : 1)) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+__global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? (kK5Deep ? PMC_K5_DEEP_WAVES : 3) : 1)) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
                                                            const double* __restrict__ vals,

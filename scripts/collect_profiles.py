@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def find(d, suffix):
@@ -22,11 +22,19 @@ def find(d, suffix):
     return max(hits, key=os.path.getmtime)
 
 
-for src, dst, what in (("prof_bench", "bench", "python bench.py"),
-                       ("prof_s1", "bench_s1", "python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-mlmc --no-r6"),
-                       ("prof_s1_r6", "bench_s1_r6", "python bench.py --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-mlmc"),
-                       ("prof_c3", "c3_darcy_op", "python scripts/c3_darcy_op.py")):
-    shutil.copy(find(src, "kernel_stats.csv"), os.path.join(P, f"{tag}_{dst}_kernel_stats.csv"))
+for src, dst, what in (("prof_bench", "bench", "python bench.py --steps 20 --warmup 5"),
+                       ("prof_s1", "bench_s1", "python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-extras"),
+                       ("prof_s1_r6", "bench_s1_r6", "python bench.py --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras"),
+                       ("prof_c3", "c3_darcy_op", "python scripts/c3_darcy_op.py"),
+                       ("prof_s1_onestream", "lab_s1_onestream",
+                        "LABORATORY library (libpmc_lab.so, PMC_SPLIT_MIN=0: one lane on ONE stream, every kernel alone on the chip) "
+                        "python bench.py --streams 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras")):
+    try:
+        stats = find(src, "kernel_stats.csv")
+    except FileNotFoundError:
+        print("no", src)
+        continue
+    shutil.copy(stats, os.path.join(P, f"{tag}_{dst}_kernel_stats.csv"))
     with open(os.path.join(G, f"{src}.log")) as f:
         lines = [ln for ln in f if ln.startswith("{")]
     with open(os.path.join(P, f"{tag}_{dst}_output.log"), "w") as f:
@@ -82,32 +90,34 @@ try:
             f.write("kernel,launches,mean_counter_value_KB\n")
             for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
                 f.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.3f}\n")
-    kern = "eg_pair_spmm_kernel<16, true, true,"
-    fr, n = mean(fetch, kern)
-    wr, _ = mean(write, kern)
-    if fr is None or wr is None:
-        raise FileNotFoundError(f"no rows of {kern} in the config-3 counter passes")
-    out["c3_eg_nb16_inloop"] = {"kernel": f"pmc::{kern} ...> (u-rows of the Darcy operator, level 0 of config 3)",
-                                "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB_raw": wr,
-                                "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
+    for key, kern, what in (("c3_eg_nb16_inloop", "eg_pair_spmm_kernel<16, true, true,", "u-rows of the Darcy operator, level 0 of config 3"),
+                            ("c3_egpoly_nb16_inloop", "eg_poly2_kernel<16, true, true,", "M-block polynomial of the Darcy preconditioner, level 0 of config 3")):
+        fr, n = mean(fetch, kern)
+        wr, _ = mean(write, kern)
+        if fr is None or wr is None:
+            raise FileNotFoundError(f"no rows of {kern} in the config-3 counter passes")
+        out[key] = {"kernel": f"pmc::{kern} ...> ({what})", "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB_raw": wr,
+                    "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
 except FileNotFoundError as e:
     print("no config-3 Darcy operator passes:", e)
-# provenance: the library the passes ran (the built .so travels to the GPU box with the snapshot) and the commit
+# provenance: the stamp scripts/make_profiles.sh wrote ON THE GPU BOX before its passes (the library and sources those
+# passes ran); the commit is named only when the tree's sources at HEAD hash to the same value
 import hashlib
 import subprocess
-with open(os.path.join(ROOT, "parelagmc_amd", "lib", "libpmc.so"), "rb") as f:
-    out["libpmc_sha256"] = hashlib.sha256(f.read()).hexdigest()
-import glob
-hs = hashlib.sha256()
-for fn in sorted(glob.glob(os.path.join(ROOT, "parelagmc_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "pmc.h")]):
-    with open(fn, "rb") as fh:
-        hs.update(os.path.basename(fn).encode() + b"\0" + fh.read())
-out["csrc_sha256"] = hs.hexdigest()    # the sources that library was built from (bench.py accepts either stamp)
+stamp = json.load(open(os.path.join(G, "profile_stamp.json")))
+out["libpmc_sha256"] = stamp["libpmc_sha256"]
+out["csrc_sha256"] = stamp["csrc_sha256"]
+out["stamp"] = stamp["where"]
 try:
+    sys.path.insert(0, ROOT)
+    import bench
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
     dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "parelagmc_amd/csrc", "include"],
                            capture_output=True, text=True).stdout.strip()
-    out["head"] = head + (" + uncommitted source changes" if dirty else "")
+    same = bench.csrc_sha256() == stamp["csrc_sha256"]
+    out["head"] = (head if same and not dirty else None)
+    out["head_note"] = ("sources at this commit hash to csrc_sha256" if same and not dirty else
+                        "the tree's sources differ from the ones the passes ran, or are uncommitted: no commit named")
 except Exception:   # noqa: BLE001
     out["head"] = None
 out["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py [--refine 6] --steps 2 --warmup 1 "

@@ -1,36 +1,59 @@
 #!/bin/bash
 # Regenerates the judged artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
-#   1. rocprofv3 --kernel-trace --stats of the DEFAULT bench command               -> gpurun_out/prof_bench/
-#   2. the same for one lane per GPU (--streams 1): per-kernel time without overlap -> gpurun_out/prof_s1/
-#   3. the same at the HBM-bound r = 6, one lane                                    -> gpurun_out/prof_s1_r6/
-#   4. the Darcy operator of config 3 in its MINRES loop, one lane (scripts/c3_darcy_op.py) -> gpurun_out/prof_c3/
+#   0. gpurun_out/profile_stamp.json: sha256 of the libpmc.so and of the sources the passes below RUN (written here, on the
+#      GPU box, at run time - scripts/collect_profiles.py copies it into profiles/pmc_traffic.json instead of hashing whatever
+#      sits in the tree when it is called)
+#   1. rocprofv3 --kernel-trace --stats of the DEFAULT bench command (the driver's)  -> gpurun_out/prof_bench/
+#   2. the same for one lane per GPU (--streams 1): per-kernel time without overlap   -> gpurun_out/prof_s1/
+#   3. the same at the HBM-bound r = 6, one lane                                      -> gpurun_out/prof_s1_r6/
+#   4. the Darcy operator + M-block polynomial of config 3 in the MINRES loop, one lane (scripts/c3_darcy_op.py) -> gpurun_out/prof_c3/
 #   5. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) on short single-lane runs at r = 5, at r = 6 and on the config-3 Darcy
-#      operator                                                         -> gpurun_out/pmc_{fetch,write}_{r5,r6,c3}/
-# scripts/collect_profiles.py then copies the summaries into profiles/ (tracked) and rebuilds profiles/pmc_traffic.json.
+#      kernels                                                            -> gpurun_out/pmc_{fetch,write}_{r5,r6,c3}/
+#   6. (laboratory library present) one lane on ONE stream, every kernel alone on the chip: standalone rows of the flat
+#      vector kernels (lincomb3, w / x update) against the streaming ceiling          -> gpurun_out/prof_s1_onestream/
+# scripts/collect_profiles.py rNN then copies the summaries into profiles/ (tracked) and rebuilds profiles/pmc_traffic.json.
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
+python3 - <<PY || exit 1
+import json, sys
+sys.path.insert(0, "$R")
+import bench
+json.dump({"libpmc_sha256": bench.lib_sha256(), "csrc_sha256": bench.csrc_sha256(), "where": "written on the GPU box by scripts/make_profiles.sh before its passes"},
+          open("$R/gpurun_out/profile_stamp.json", "w"))
+PY
 run() {   # name, then the bench arguments
   local name=$1; shift
-  timeout -k 10 500 rocprofv3 "${PROF[@]}" -d $R/gpurun_out/$name -o p --output-format csv -- python3 $R/bench.py "$@" > $R/gpurun_out/$name.log 2>&1 || return 1
+  rm -rf $R/gpurun_out/$name
+  timeout -k 10 700 rocprofv3 "${PROF[@]}" -d $R/gpurun_out/$name -o p --output-format csv -- python3 $R/bench.py "$@" > $R/gpurun_out/$name.log 2>&1 || return 1
   rm -f $R/gpurun_out/$name/*kernel_trace.csv $R/gpurun_out/$name/*/*kernel_trace.csv
   echo "$name done"
 }
 runpy() {   # name, script
   local name=$1; shift
+  rm -rf $R/gpurun_out/$name
   timeout -k 10 500 rocprofv3 "${PROF[@]}" -d $R/gpurun_out/$name -o p --output-format csv -- python3 $R/$1 > $R/gpurun_out/$name.log 2>&1 || return 1
   rm -f $R/gpurun_out/$name/*kernel_trace.csv $R/gpurun_out/$name/*/*kernel_trace.csv
   echo "$name done"
 }
 PROF=(--kernel-trace --stats)
-run prof_bench || exit 1
-run prof_s1 --streams 1 --steps 40 --no-cpu-baseline --no-mlmc --no-r6 || exit 1
-run prof_s1_r6 --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-mlmc || exit 1
+if [ -z "$SKIP_BENCH_PROFILE" ]; then run prof_bench --steps 20 --warmup 5 || exit 1; fi
+run prof_s1 --streams 1 --steps 40 --no-cpu-baseline --no-extras || exit 1
+run prof_s1_r6 --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras || exit 1
 runpy prof_c3 scripts/c3_darcy_op.py || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
   PROF=(--kernel-trace --pmc $c)
   n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
-  run pmc_${n}_r5 --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-mlmc --no-r6 || exit 1
-  run pmc_${n}_r6 --refine 6 --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-mlmc || exit 1
+  run pmc_${n}_r5 --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
+  run pmc_${n}_r6 --refine 6 --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
   runpy pmc_${n}_c3 scripts/c3_darcy_op.py || exit 1
 done
+if [ -f $R/parelagmc_amd/lib/libpmc_lab.so ]; then
+  PROF=(--kernel-trace --stats)
+  cp $R/parelagmc_amd/lib/libpmc.so /tmp/libpmc_product.so
+  cp $R/parelagmc_amd/lib/libpmc_lab.so $R/parelagmc_amd/lib/libpmc.so
+  PMC_SPLIT_MIN=0 run prof_s1_onestream --streams 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras
+  rc=$?
+  cp /tmp/libpmc_product.so $R/parelagmc_amd/lib/libpmc.so
+  [ $rc = 0 ] || exit 1
+fi

@@ -40,8 +40,8 @@ def test_true_residual_of_the_sampler_solve_at_full_size_both_storages(gpu_ctx, 
     """cube_tet r = 5 (595 968 DoF, BASELINE config 2) and r = 6 (4 743 168 DoF): for fp32 storage inside the preconditioner
     (the default) and for everything fp64, at the reference's tolerance 1e-6 and at 1e-12,
       * the TRUE preconditioned residual norm sqrt(<r, B^-1 r>), r = b - A x with the fp64 K5, agrees with the norm MINRES's
-        recurrence reports (pmc_stats.final_norm) within a factor 2 at 1e-6 (at 1e-12 the recurrence runs below what fp64
-        can attain: there the true norm must stay below 1e-9 of the initial one and the two storages within 2 x of each other);
+        recurrence reports (pmc_stats.final_norm) to 1e-4 relative at 1e-6 and to 1 % at 1e-12 (measured on MI355X: nine
+        digits at 1e-6, five at 1e-12, for both storages - the recurrence does not drift from the truth);
       * the two storages return the same field to the solver tolerance, with the same iteration counts."""
     from parelagmc_amd import capi
     sp = _tet_problem(nref)
@@ -69,18 +69,15 @@ def test_true_residual_of_the_sampler_solve_at_full_size_both_storages(gpu_ctx, 
             eta = np.array([t[3] for t in st])
             report[(storage, tol)] = dict(its=[t[0] for t in st], two=two, true=pnorm / eta0, reported=eta / eta0)
             fields[(storage, tol)] = x[:, L.n_u:].copy()
-            if tol == 1e-6:
-                ratio = pnorm / eta
-                assert np.all((ratio > 0.5) & (ratio < 2.0)), (storage, tol, ratio)
-                assert np.all(pnorm / eta0 <= 2.0e-6)
-            else:
-                assert np.all(pnorm / eta0 < 1e-9), (storage, pnorm / eta0)
+            ratio = pnorm / eta
+            assert np.all(np.abs(ratio - 1.0) < (1e-4 if tol == 1e-6 else 1e-2)), (storage, tol, ratio)
+            assert np.all(pnorm / eta0 <= tol)
             smp.close()
     print("true residuals r=%d:" % nref, {k: {a: np.asarray(b).tolist() for a, b in v.items()} for k, v in report.items()})
     for tol in (1e-6, 1e-12):
         a, b = report[(0, tol)], report[(1, tol)]
         assert a["its"] == b["its"]
-        assert np.all(a["true"] < 2.0 * b["true"] + 1e-300) and np.all(b["true"] < 2.0 * a["true"] + 1e-300)
+        assert np.all(np.abs(a["true"] / b["true"] - 1.0) < 1e-3)
         assert rel(fields[(0, tol)], fields[(1, tol)]) < (2e-6 if tol == 1e-6 else 1e-9)
 
 
@@ -114,7 +111,7 @@ def test_true_residual_of_the_darcy_solve_on_hex64_both_storages(gpu_ctx):
     for tol in (1e-6, 1e-12):
         a, b = out[(0, tol)], out[(1, tol)]
         assert a["its"] == b["its"]
-        assert np.all(a["two"] < 2.0 * b["two"]) and np.all(b["two"] < 2.0 * a["two"])
+        assert np.all(np.abs(a["two"] / b["two"] - 1.0) < 1e-2)
         assert np.all(np.abs(a["Q"] - b["Q"]) <= (1e-5 if tol == 1e-6 else 1e-9) * np.abs(b["Q"]))
         # 2-norm of the true residual against the preconditioned norm the recurrence reports: one order at most
         assert np.all(a["two"] < 10.0 * max(tol, 1e-10)) and np.all(b["two"] < 10.0 * max(tol, 1e-10))
