@@ -981,7 +981,7 @@ def main():
             "roofline": operator_roofline(farm, problem, nb, f"r{args.refine}", next_batch, sbytes, acc[2], dt),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(problem, args.seed)
+            out["cpu_baseline"] = cpu_baseline(problem, args.seed, 8)
     farm.close()
     extra = {}
 
@@ -1074,10 +1074,10 @@ def main():
         for k, fn in ((4, config4), (5, config5)):
             if args.only_config in (None, k):
                 attempt(f"c{k}", lambda k=k, fn=fn: fn(args.seed, pool.get(f"c{k}"), cpu=args.all_configs and cpu,
-                                                      nrep=2 if k == 4 else 1))
+                                                      nrep=3 if k == 4 else 2))
         if not args.no_r6 and args.refine != 6:
             attempt("r6", lambda: sampler_point(
-                pool.get("r6"), dev, args.seed, nb, ns, 8, "r6",
+                pool.get("r6"), dev, args.seed, nb, ns, 12, "r6",
                 "PDESampler cube_tet r=6, 4743168 DoF: operator + vectors exceed the 256 MiB Infinity Cache, every kernel is "
                 "HBM-bound", cpu_per_core=1 if cpu else None))
         extra["setup_seconds_in_worker_processes"] = dict(pool.seconds)

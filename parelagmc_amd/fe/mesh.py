@@ -69,6 +69,15 @@ def box_mesh(n, sizes, etype="hex", origin=None) -> Mesh:
     sizes = np.asarray(sizes, dtype=np.float64)
     dim = len(n)
     org = np.zeros(dim) if origin is None else np.asarray(origin, dtype=np.float64)
+    if etype == "tri":
+        # mfem::Mesh::Make2D with triangles: every cell of the quad grid split along the diagonal (i, j) - (i + 1, j + 1)
+        # [the order of the two triangles inside a cell is from memory of MFEM, not verified; nothing here depends on it]
+        q = box_mesh(n, sizes, "quad", origin)
+        e = q.elems
+        tri = np.stack([np.stack([e[:, 0], e[:, 1], e[:, 2]], axis=1), np.stack([e[:, 0], e[:, 2], e[:, 3]], axis=1)], axis=1)
+        m = Mesh("tri", q.verts, tri.reshape(-1, 3), np.ones(2 * len(e), np.int32), q.bdr, q.bdr_attr)
+        _orient_simplices(m)
+        return m
     if etype == "quad":
         nx, ny = n
         xs = org[0] + np.linspace(0.0, sizes[0], nx + 1)
@@ -171,6 +180,8 @@ def read_mfem_mesh(text_or_path) -> Mesh:
         if et == "hex":
             return box_mesh([int(kv["nx"]), int(kv["ny"]), int(kv["nz"])],
                             [float(kv["sx"]), float(kv["sy"]), float(kv["sz"])], "hex")
+        if et == "tri":
+            return box_mesh([int(kv["nx"]), int(kv["ny"])], [float(kv["sx"]), float(kv["sy"])], "tri")
         raise ValueError(f"INLINE mesh type {et!r} not supported")
     if not header.startswith("MFEM mesh v1.0"):
         raise ValueError(f"unsupported mesh header {header!r}")

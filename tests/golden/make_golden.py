@@ -2,6 +2,8 @@
 /root/reference exists).  Fixtures are DATA only:
   * meshes/*.json        - mesh data files the reference's tests/drivers read
                            (/root/reference/meshes/*.mesh), converted to JSON arrays;
+  * meshes/*.mesh        - six of those data files in their on-disk format (MFEM mesh v1.0 /
+                           INLINE, 68 B ... 4.6 KB each): fixtures of the mesh READER;
   * kat.json             - the reference's RNG-free known answers
                            (examples/CMakeLists.txt:62-66 DarcyDeterministicTest) and the
                            closed-form Matern coefficients of src/Utilities.hpp:188-200;
@@ -61,6 +63,12 @@ def agree(a, b, what):
 
 def main():
     if os.path.isdir(REF_MESHES):
+        # the mesh DATA files of the BASELINE configurations in their on-disk format (MFEM mesh v1.0 / INLINE), as fixtures of
+        # the reader: tests/test_fe.py reads them with fe/mesh.py::read_mfem_mesh and compares with the JSON arrays below
+        import shutil
+        for name in ("inline_quad", "inline_hex", "inline_tri", "cube_hex", "cube_tet", "cube_tet_embed"):
+            shutil.copy(os.path.join(REF_MESHES, name + ".mesh"), os.path.join(HERE, "meshes", name + ".mesh"))
+            os.chmod(os.path.join(HERE, "meshes", name + ".mesh"), 0o644)
         for name in ("inline_quad", "cube_hex", "cube_tet", "cube_tet_embed", "cube_hex_enlarge", "cube_tet_enlarge", "square",
                      "square_enlarge"):
             mesh_to_json(name)

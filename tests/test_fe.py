@@ -283,3 +283,33 @@ def test_rt0_p0_patch_test_without_the_oracle(name):
     bdr = s.faces.face_elem[:, 1] < 0
     assert np.abs(r[~bdr]).max() < 1e-12 * max(1.0, np.abs(pbar).max())
     assert np.allclose(r[bdr], -s_owner[bdr] * (xf[bdr] @ a + b), rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["inline_quad", "cube_hex", "cube_tet", "cube_tet_embed"])
+def test_mesh_reader_on_the_reference_mesh_files(name):
+    """fe/mesh.py::read_mfem_mesh on the reference's own mesh DATA files in their on-disk format (MFEM mesh v1.0 and the
+    INLINE generator format; /root/reference/meshes/*.mesh, committed as fixtures under tests/golden/meshes/): same
+    vertices, elements, attributes and boundary as the JSON arrays the rest of the suite uses (converted from the same files
+    by tests/golden/make_golden.py) - the reader is what a driver like /root/reference/examples/MLMC.cpp:163-201 starts from."""
+    from parelagmc_amd.fe import read_mfem_mesh
+    m = read_mfem_mesh(golden_path("meshes", name + ".mesh"))
+    j = mesh_from_json(golden_path("meshes", name + ".json"))
+    assert m.etype == j.etype and m.dim == j.dim
+    assert np.array_equal(m.elems, j.elems) and np.array_equal(m.elem_attr, j.elem_attr)
+    assert np.array_equal(m.bdr, j.bdr) and np.array_equal(m.bdr_attr, j.bdr_attr)
+    assert np.allclose(m.verts, j.verts, rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("name,etype,ne", [("inline_hex", "hex", None), ("inline_tri", "tri", None)])
+def test_inline_mesh_formats(name, etype, ne):
+    """the other two INLINE generator files of the reference (hexahedra, triangles): element type, counts from the header's
+    nx / ny / nz, unit-size bounding box"""
+    from parelagmc_amd.fe import read_mfem_mesh
+    txt = open(golden_path("meshes", name + ".mesh")).read()
+    hdr = dict(ln.split("=") for ln in txt.splitlines() if "=" in ln)
+    n = [int(hdr[k].strip()) for k in ("nx ", "ny ", "nz ") if k in hdr] or [int(v) for k, v in hdr.items() if k.strip() in ("nx", "ny", "nz")]
+    m = read_mfem_mesh(golden_path("meshes", name + ".mesh"))
+    assert m.etype == etype
+    cells = int(np.prod(n))
+    assert m.ne == cells * (2 if etype == "tri" else 1)
+    assert np.allclose(m.verts.min(axis=0), 0.0) and np.all(m.verts.max(axis=0) > 0.0)

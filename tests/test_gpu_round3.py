@@ -315,7 +315,7 @@ def test_super_batch_edges_projections_and_observation_operator(gpu_ctx, hex_hie
 
 
 def test_fp32_krylov_vectors_on_every_preconditioner_path(gpu_ctx, hex_hierarchy, seeded_rng):
-    """The preconditioned MINRES vectors z are stored in fp32 (zreal, csrc/kernels.hpp; pmc_krylov_z_bytes): the last kernel
+    """The preconditioned MINRES vectors z are stored in fp32 by default (zvec, csrc/kernels.hpp; pmc_krylov_z_bytes): the last kernel
     of each preconditioner block writes them, the operator products and the w / x updates read them.  Solver configurations
     other than the default one end in other kernels: M-block degree 3 / 4 (typed last Chebyshev step, cheb_step_z; on Darcy
     any degree but 2 also leaves the element-grouped form: pair_spmm_z), V-cycle smoothing degree 3 (the general cycle),
