@@ -42,15 +42,6 @@ static constexpr bool kEgLateCoef = PMC_EG_LATE_COEF != 0;  // see eg_row_produc
 // sell_row_range takes the lean gather loop (see sell_row_part) from this batch width on: at NB = 32 the one-column loop
 // needs 170-184 registers (two waves per SIMD), the lean one fits three; at NB = 16 (four waves either way) it changed nothing
 static constexpr int kLeanRangeMinNb = PMC_LEAN_RANGE_MIN_NB;
-#ifndef PMC_K5_DEEP
-#define PMC_K5_DEEP 0
-#endif
-// laboratory variant (LABEXTRA=-DPMC_K5_DEEP=1): the lean gather loop with TWO slice columns of gathers in flight per
-// wavefront, held as raw fp32 (see sell_row_range); measured in round 4, LAB_NOTES section 9
-static constexpr bool kK5Deep = PMC_K5_DEEP != 0;
-#ifndef PMC_K5_DEEP_WAVES
-#define PMC_K5_DEEP_WAVES 2
-#endif
 
 static unsigned dot_grid_bound();
 int dot_capacity(int nrows, int nb) {
@@ -427,68 +418,6 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
         cj = load_stream<NT>(cols + slot);
         if constexpr (!BV) vj = load_stream<NT>(vals + slot);
     }
-    if constexpr (kK5Deep && lean_range<NB>() && !BV && !CS && sizeof(XT) == 4) {
-        // column j + 1's gathers are issued BEFORE column j's FMAs: 2 T gathers in flight per wavefront, both buffers raw fp32
-        RawVec<XT, C> xa[T], xb[T];
-        auto issue = [&](int cc, RawVec<XT, C>(&buf)[T]) {
-            unsigned at[T];
-#pragma unroll
-            for (int rs = 0; rs < T; ++rs) at[rs] = (unsigned)__shfl(cc, rs * G + g, kWave) * (unsigned)LD + (unsigned)(t * C);
-#pragma unroll
-            for (int rs = 0; rs < T; ++rs) load_raw<C>(x + at[rs], buf[rs]);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto consume = [&](double vv, RawVec<XT, C>(&buf)[T], bool last) {
-#pragma unroll
-            for (int rs = 0; rs < T; ++rs) {
-                const double a = __shfl(vv, rs * G + g, kWave);
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[rs][c] = fma(a, (double)buf[rs].v[c], acc[rs][c]);
-            }
-            if (last) {
-                if (pdot) {
-#pragma unroll
-                    for (int rs = 0; rs < T; ++rs)
-#pragma unroll
-                        for (int c = 0; c < C; ++c) pdot[c] = fma((double)buf[rs].v[c], acc[rs][c], pdot[c]);
-                } else if (xlast) {
-#pragma unroll
-                    for (int rs = 0; rs < T; ++rs)
-#pragma unroll
-                        for (int c = 0; c < C; ++c) xlast[rs][c] = (double)buf[rs].v[c];
-                }
-            }
-        };
-        if (width <= 0) return;
-        int c1 = cj;
-        double v1 = vj;
-        if (width > 1) {
-            c1 = load_stream<NT>(cols + slot + kWave);
-            v1 = load_stream<NT>(vals + slot + kWave);
-        }
-        issue(cj, xa);
-        int j = 0;
-        for (; j + 1 < width; j += 2, slot += 2 * kWave) {
-            int c2 = c1, c3 = c1;
-            double v2 = v1, v3 = v1;
-            if (j + 2 < width) {
-                c2 = load_stream<NT>(cols + slot + 2 * kWave);
-                v2 = load_stream<NT>(vals + slot + 2 * kWave);
-            }
-            issue(c1, xb);                         // column j + 1
-            consume(vj, xa, false);                // column j
-            if (j + 3 < width) {
-                c3 = load_stream<NT>(cols + slot + 3 * kWave);
-                v3 = load_stream<NT>(vals + slot + 3 * kWave);
-            }
-            if (j + 2 < width) issue(c2, xa);      // column j + 2
-            consume(v1, xb, j + 2 == width);       // column j + 1
-            cj = c2; vj = v2;
-            c1 = c3; v1 = v3;
-        }
-        if (j < width) consume(vj, xa, true);      // odd width: the last column is still in flight in xa
-        return;
-    }
     if constexpr (lean_range<NB>()) {
         // lean loop (as sell_row_part): 32-bit element offsets, gathered rows and fp32 per-realization values stay in their
         // storage type until the FMA, shared values are fetched across lanes after the gathers have been issued; with pdot
@@ -631,9 +560,7 @@ __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
     return SliceWalk{lo + idx * WPB + wave, hi, nb_x * WPB};
 }
 
-// MODE 0: y = Ax   1: y += Ax   2: y = r - Ax   3: y = Ax + fold_coef[k] r (the fused <dot_with, .> is still taken with Ax
-// alone: the `- beta v_old` term of the Lanczos update rides in the operator product's epilogue, see minres_solve);
-// DOT: partial sums of <dot_with, result>.
+// MODE 0: y = Ax   1: y += Ax   2: y = r - Ax ; DOT: partial sums of <dot_with, result>.
 // Wavefronts stride over the slices (grid may be smaller than the slice count: bounded partial-sum count).
 // TAG only names the instantiation: 1 = the block saddle-point operator (K5) inside the solver, 2 = the same operator
 // launched by pmc_sampler_apply_operator (the isolated roofline measurement), so that profiles show the
@@ -645,15 +572,14 @@ __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
 // few MB) disappears from the V-cycle.
 // XT: storage type of x and dot_with (fp32 or fp64 for the preconditioned Krylov vectors, zvec)
 template <int NB, int BV, int MODE, bool DOT, int TAG, bool NT = false, bool R8 = false, bool DL = false, typename XT = double>
-__global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? (kK5Deep ? PMC_K5_DEEP_WAVES : 3) : 1)) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+__global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? 3 : 1)) void sell_spmm_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                            const int* __restrict__ sched,
                                                            const int* __restrict__ cols,
                                                            const double* __restrict__ vals,
                                                            const XT* __restrict__ x, double* __restrict__ y,
                                                            const double* __restrict__ r,
                                                            const typename ident<XT>::type* __restrict__ dot_with,
-                                                           double* __restrict__ partial, int ld,
-                                                           const double* __restrict__ fold_coef = nullptr) {
+                                                           double* __restrict__ partial, int ld) {
     static_assert(!R8 || (MODE == 2 && !DOT), "fused restriction goes with the residual");
     const int LD = row_ld<NB>(ld);
     {
@@ -661,8 +587,7 @@ __global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? (
         x += c0;
         y += c0;
         if constexpr (BV) vals = shift_bv<BV>(vals, c0);
-        if constexpr (MODE == 2 || MODE == 3) r += c0;
-        if constexpr (MODE == 3) fold_coef += c0;
+        if constexpr (MODE == 2) r += c0;
         if constexpr (DOT && !DL) dot_with += c0;
         if constexpr (DOT || R8) partial += c0;
     }
@@ -693,21 +618,6 @@ __global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? (
         } else {
             sell_row_product<NB, BV, XT>(slice_off, cols, vals, x, slice, lane, LD, acc);
         }
-        double fc[MODE == 3 ? C : 1];
-        double fv[MODE == 3 ? T : 1][C];
-        if constexpr (MODE == 3) {
-            // the folded vector's rows of the whole slice are requested TOGETHER, before the first one is used (one dependent
-            // load -> fma -> store chain per row step would add T memory round trips to every slice); the gather loop's
-            // registers are dead here.  The nb coefficients come from L1 (held across the gather loop they pushed the
-            // NB = 32 kernel past three waves per SIMD)
-            load_c<C>(fold_coef + t * C, fc);
-#pragma unroll
-            for (int rs = 0; rs < T; ++rs) {
-                const int row = min(slice * kWave + rs * G + g, nrows - 1);
-                load_c_nt<NT, C>(r + (size_t)row * LD + t * C, fv[rs]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
@@ -724,6 +634,7 @@ __global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? (
 #pragma unroll
                     for (int c = 0; c < C; ++c) acc[rs][c] = rv[c] - acc[rs][c];
                 }
+                store_c_stream<NT, C>(y + at, acc[rs]);
                 if constexpr (LEAN_DL) {
                 } else if constexpr (DL) {
 #pragma unroll
@@ -734,11 +645,6 @@ __global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 && sizeof(XT) == 4 ? (
 #pragma unroll
                     for (int c = 0; c < C; ++c) p[c] = fma(w[c], acc[rs][c], p[c]);
                 }
-                if constexpr (MODE == 3) {     // fv: read once, dead afterwards (the next Lanczos vector overwrites it)
-#pragma unroll
-                    for (int c = 0; c < C; ++c) acc[rs][c] = fma(fc[c], fv[rs][c], acc[rs][c]);
-                }
-                store_c_stream<NT, C>(y + at, acc[rs]);
             } else if constexpr (R8) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;     // rows past the end add nothing to their group
@@ -1547,25 +1453,6 @@ __global__ __launch_bounds__(kBlock) void lincomb3_kernel(size_t nflat, const do
     store_c<C>(y + e, yv);
 }
 
-// v_new = c0 q' + c1 v1 written over the dead older Lanczos vector (its `- beta v_old` term already rode in the operator
-// product's epilogue, sell_spmm_kernel MODE 3): three vector streams instead of four
-template <int NB, bool NT = false>
-__global__ __launch_bounds__(kBlock) void lincomb2_kernel(size_t nflat, const double* __restrict__ c0,
-                                                          const double* __restrict__ a, const double* __restrict__ c1,
-                                                          const double* __restrict__ b, double* __restrict__ y, int ld) {
-    constexpr int C = Lay<NB>::C;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nflat) return;
-    const size_t e = i * C;
-    const int k0 = (int)(e % row_ld<NB>(ld));
-    double av[C], bv[C], yv[C];
-    load_c_nt<NT, C>(a + e, av);
-    load_c_nt<NT, C>(b + e, bv);
-#pragma unroll
-    for (int c = 0; c < C; ++c) yv[c] = c0[k0 + c] * av[c] + c1[k0 + c] * bv[c];
-    store_c<C>(y + e, yv);
-}
-
 template <int NB, bool NT, typename UT>
 __global__ __launch_bounds__(kBlock) void minres_wx_kernel(size_t nflat, const double* __restrict__ c0,
                                                            const UT* __restrict__ u, const double* __restrict__ c1,
@@ -1756,9 +1643,6 @@ __device__ __forceinline__ void scal2_body(k::MinresState* st, int k, double d2)
     if (st->active[k]) {
         if (d2 < 0.0 || d2 != d2) st->flag[k] = -1;
         const double beta_new = d2 > 0.0 ? sqrt(d2) : 0.0;
-        // coefficient of the older Lanczos vector in the NEXT update relative to the operator product's (cV2 / cV0 =
-        // - beta_new^2 / beta): what the folded epilogue of that product adds (spmm_z with fold_vec)
-        st->gF[k] = d2 > 0.0 ? -d2 / st->beta[k] : 0.0;
         const double delta = st->delta[k];
         const double rho1 = hypot(delta, beta_new);
         const double ir = rho1 > 0.0 ? 1.0 / rho1 : 0.0;
@@ -1775,14 +1659,10 @@ __device__ __forceinline__ void scal2_body(k::MinresState* st, int k, double d2)
         st->beta_old[k] = st->beta[k];
         st->beta[k] = beta_new;
         st->iters[k] = st->it + 1;
-        if (fabs(st->eta[k]) <= st->goal[k] || beta_new == 0.0 || st->flag[k] != 0) {
-            st->active[k] = 0;
-            st->gF[k] = 0.0;
-        }
+        if (fabs(st->eta[k]) <= st->goal[k] || beta_new == 0.0 || st->flag[k] != 0) st->active[k] = 0;
     } else {
         double (*cW)[kMaxBatch] = st->cW[st->it % st->ring];
         cW[0][k] = cW[1][k] = cW[2][k] = cW[3][k] = 0.0;
-        st->gF[k] = 0.0;
     }
 }
 
@@ -2686,25 +2566,13 @@ static inline bool nt_poly(const SellView& A, int nb) {
 
 template <int NB, int TAG, typename XT>
 static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const XT* x, double* y, bool accumulate,
-                        double* dot_partial, const XT* dot_with, const double* fold_vec = nullptr,
-                        const double* fold_coef = nullptr) {
+                        double* dot_partial, const XT* dot_with) {
     // <x, Ax> with a diagonal-last matrix: x_i is what the row's last slice column gathers
     const bool dl = TAG == 1 && Lay<NB>::T > 1 && A.diag_last && dot_with == x;
     if constexpr (!std::is_same<XT, double>::value) {
         // fp32-stored input (the preconditioned Krylov vectors): the operator products of the solver loop only
         if (A.bv || accumulate) throw Error(PMC_ERR_INTERNAL, "spmm: fp32 input with per-realization values / accumulation");
         const bool nt = TAG != 0 && nt_streams(A, NB, dot_partial != nullptr);
-        if (fold_vec) {
-            // the operator product of the MINRES loop with the `- beta v_old` term of the next Lanczos update in its epilogue
-            if (!(TAG == 1 && dot_partial && dl)) throw Error(PMC_ERR_INTERNAL, "spmm: folded Lanczos term needs the in-loop block operator");
-            if constexpr (TAG == 1 && Lay<NB>::T > 1) {
-                if (nt)
-                    sell_spmm_kernel<NB, false, 3, true, 1, true, false, true, XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, fold_vec, dot_with, dot_partial, nb, fold_coef);
-                else
-                    sell_spmm_kernel<NB, false, 3, true, 1, false, false, true, XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, fold_vec, dot_with, dot_partial, nb, fold_coef);
-            }
-            return;
-        }
         if (nt) {
             if (dot_partial && dl)
                 sell_spmm_kernel<NB, false, 0, true, TAG, true, false, (Lay<NB>::T > 1), XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
@@ -2722,7 +2590,6 @@ static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const
         }
         return;
     } else
-    if (fold_vec) throw Error(PMC_ERR_INTERNAL, "spmm: folded Lanczos term is implemented for fp32-stored input only");
     if (A.bv && A.f32) {
         if (dot_partial)
             sell_spmm_kernel<NB, 2, 0, true, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
@@ -2760,7 +2627,7 @@ static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const
 
 template <typename XT>
 static int spmm_t(hipStream_t st, int nb, const SellView& A, const XT* x, double* y, bool accumulate, double* dot_partial,
-                  const XT* dot_with, const double* fold_vec = nullptr, const double* fold_coef = nullptr) {
+                  const XT* dot_with) {
     check_offsets32(A, nb);
     if (A.nrows == 0) return 0;
     if (dot_partial && !dot_with) throw Error(PMC_ERR_INTERNAL, "spmm: fused dot without its second vector");
@@ -2775,7 +2642,7 @@ static int spmm_t(hipStream_t st, int nb, const SellView& A, const XT* x, double
         kernel_partial = dot_partial + (size_t)kCompressBlocks * nb;
     }
     PMC_DISPATCH_NB(nb, {
-        if (A.tag == 1) spmm_launch<NB, 1, XT>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with, fold_vec, fold_coef);
+        if (A.tag == 1) spmm_launch<NB, 1, XT>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
         else if (A.tag == 2) spmm_launch<NB, 2, XT>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
         else spmm_launch<NB, 0, XT>(st, nb, g, A, x, y, accumulate, kernel_partial, dot_with);
     });
@@ -2791,15 +2658,9 @@ int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, 
          const double* dot_with) {
     return spmm_t<double>(st, nb, A, x, y, accumulate, dot_partial, dot_with);
 }
-int spmm_z(hipStream_t st, int nb, const SellView& A, zvec x, double* y, double* dot_partial, zvec dot_with,
-           const double* fold_vec, const double* fold_coef) {
-    if (x.f32) return spmm_t<float>(st, nb, A, x.as<float>(), y, false, dot_partial, dot_with.as<float>(), fold_vec, fold_coef);
-    return spmm_t<double>(st, nb, A, x.as<double>(), y, false, dot_partial, dot_with.as<double>(), fold_vec, fold_coef);
-}
-
-bool spmm_z_can_fold(int nb, const SellView& A, zvec x) {
-    // the epilogue form exists for the in-loop block operator with fp32-stored input, diagonal-last, NB >= 4 lanes-x-columns
-    return x.f32 && A.tag == 1 && A.diag_last && !A.bv && nb >= 4;
+int spmm_z(hipStream_t st, int nb, const SellView& A, zvec x, double* y, double* dot_partial, zvec dot_with) {
+    if (x.f32) return spmm_t<float>(st, nb, A, x.as<float>(), y, false, dot_partial, dot_with.as<float>());
+    return spmm_t<double>(st, nb, A, x.as<double>(), y, false, dot_partial, dot_with.as<double>());
 }
 
 void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out,
@@ -3264,15 +3125,6 @@ void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, 
     check_launch();
 }
 
-void lincomb2(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b, double* y) {
-    const bool nt = nt_flat((size_t)n * nb);
-    PMC_DISPATCH_NB(nb, {
-        if (nt) lincomb2_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, y, nb);
-        else lincomb2_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, y, nb);
-    });
-    check_launch();
-}
-
 template <typename UT>
 static void minres_wx_t(hipStream_t st, int nb, int n, const double* c0, const UT* u, const double* c1, double* w0,
                         const double* c2, const double* w1, const double* c3, double* x) {
@@ -3326,25 +3178,12 @@ void minres_init(hipStream_t st, int nb, MinresState* s, const DotParts& d, doub
     minres_init_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, rel_tol, abs_tol, d.p2, d.n2, ring);
     check_launch();
 }
-// long partial lists go through the 64-workgroup first stage (as minres_scal21), `stage` = scal_stage_doubles() doubles
-void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d, double* stage) {
-    if (stage && d.total() >= 8 * kStageBlocks) {
-        stage_partials_kernel<<<kStageBlocks, 256, 0, st>>>(d.p1, d.n1, d.p2, d.n2, nullptr, 0, nullptr, 0, nb, stage);
-        check_launch();
-        minres_scal1_kernel<<<1, kScalBlock, 0, st>>>(s, stage, kStageBlocks, nb, nullptr, 0);
-    } else {
-        minres_scal1_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, d.p2, d.n2);
-    }
+void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d) {
+    minres_scal1_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, d.p2, d.n2);
     check_launch();
 }
-void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d, double* stage) {
-    if (stage && d.total() >= 8 * kStageBlocks) {
-        stage_partials_kernel<<<kStageBlocks, 256, 0, st>>>(d.p1, d.n1, d.p2, d.n2, nullptr, 0, nullptr, 0, nb, stage);
-        check_launch();
-        minres_scal2_kernel<<<1, kScalBlock, 0, st>>>(s, stage, kStageBlocks, nb, nullptr, 0);
-    } else {
-        minres_scal2_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, d.p2, d.n2);
-    }
+void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d) {
+    minres_scal2_kernel<<<1, kScalBlock, 0, st>>>(s, d.p1, d.n1, nb, d.p2, d.n2);
     check_launch();
 }
 size_t scal_stage_doubles() { return (size_t)2 * kStageBlocks * kMaxBatch; }

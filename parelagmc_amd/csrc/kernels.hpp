@@ -95,7 +95,6 @@ struct MinresState {
     double gamma0[kMaxBatch], gamma1[kMaxBatch], sigma0[kMaxBatch], sigma1[kMaxBatch];
     double goal[kMaxBatch], alpha[kMaxBatch], delta[kMaxBatch], rho2[kMaxBatch], rho3[kMaxBatch];
     double cV[3][kMaxBatch];  // v_new = cV0*q + cV1*v1 + cV2*v0
-    double gF[kMaxBatch];     // cV2 / cV0 of the NEXT update, known once <v, z> is: the folded operator product adds gF * v_old
     // w_new = cW0*u1 + cW1*w0 + cW2*w1 ; x += cW3*w_new.  Iteration i (0-based) writes set i % ring: ring == 1 when the
     // update follows its iteration at once, kWxDefer when updates are deferred
     double cW[kWxDefer][4][kMaxBatch];
@@ -108,11 +107,7 @@ struct MinresState {
 int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate,
           double* dot_partial, const double* dot_with);
 // the same product from a vector in zvec storage (shared values, no accumulation): the operator products of the solver loop
-// fold_vec / fold_coef (device, nb coefficients): y = A x + fold_coef[k] * fold_vec - the `- beta v_old` term of the next
-// Lanczos update in the product's epilogue; the fused dot stays <dot_with, A x>.  Only where spmm_z_can_fold says so.
-int spmm_z(hipStream_t st, int nb, const SellView& A, zvec x, double* y, double* dot_partial, zvec dot_with,
-           const double* fold_vec = nullptr, const double* fold_coef = nullptr);
-bool spmm_z_can_fold(int nb, const SellView& A, zvec x);
+int spmm_z(hipStream_t st, int nb, const SellView& A, zvec x, double* y, double* dot_partial, zvec dot_with);
 // out = r - A x and coarse[i] = sum of out over the rows 8 i .. 8 i + 7 (restriction with the transpose of an
 // "8 consecutive children, unit weights" prolongator); A.nrows must be a multiple of 8
 void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double* r, const double* x, double* out,
@@ -184,8 +179,6 @@ int convert_z(hipStream_t st, int nb, int n, const double* in, zvec out, const d
 void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, double* out);
 void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b,
               const double* c2, double* y);
-// y = c0 a + c1 b (y write-only): the Lanczos update whose third term was folded into the operator product
-void lincomb2(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b, double* y);
 void minres_wx(hipStream_t st, int nb, int n, const double* c0, zvec u, const double* c1, double* w0,
                const double* c2, const double* w1, const double* c3, double* x);
 void fill(hipStream_t st, size_t n, double* x, double v);
@@ -205,8 +198,8 @@ void minres_init(hipStream_t st, int nb, MinresState* s, const DotParts& d, doub
 // (w0, w1) <- (w1, w).  w0 is the OLDER direction on entry and on return (no role swap by the caller).
 void minres_wx_deferred(hipStream_t st, int nb, int n, const MinresState* s, const WxDeferred& B, double* w0, double* w1,
                         double* x);
-void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d, double* stage = nullptr);
-void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d, double* stage = nullptr);
+void minres_scal1(hipStream_t st, int nb, MinresState* s, const DotParts& d);
+void minres_scal2(hipStream_t st, int nb, MinresState* s, const DotParts& d);
 // scal2 of this iteration followed by scal1 of the next one (d1 = partials of the next operator product) in one launch
 // stage (scal_stage_doubles() doubles, may be null): scratch of the multi-block first reduction stage for long lists
 void minres_scal21(hipStream_t st, int nb, MinresState* s, const DotParts& d2, const DotParts& d1, double* stage = nullptr);

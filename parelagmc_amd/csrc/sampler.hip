@@ -407,11 +407,6 @@ void Sampler::solve_system(int level, int nb, bool zero_guess, int x_row0, int x
     A.apply_z = [Av](const Lanes& L, int nb_, zvec x, double* y, double* partial, double*) {
         return k::DotParts{partial, k::spmm_z(L.main, nb_, Av, x, y, partial, x)};
     };
-    A.apply_z_fold = [Av](const Lanes& L, int nb_, zvec x, double* y, double* partial, double*, const double* fold_vec,
-                          const double* fold_coef) {
-        return k::DotParts{partial, k::spmm_z(L.main, nb_, Av, x, y, partial, x, fold_vec, fold_coef)};
-    };
-    A.can_fold = [Av](int nb_, zvec x) { return k::spmm_z_can_fold(nb_, Av, x); };
     PrecFn prec = preconditioner(level, nb, degM, mgp, mg_l0);
     GraphHint hint;
     hint.key = hash_mix(hash_mix(hash_mix(0x5a, (uint64_t)level + 1), (uint64_t)nb), (uint64_t)x_row0);

@@ -468,9 +468,6 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     // kernel on this stream - not the compact index-list update of the Darcy solves (a few rows), not the two-stream
     // schedule (its update already runs beside other work) and not inside a captured graph
     const bool defer = !graphs && !late && !x_rows && wx_defer_on();
-    // `- beta v_old` of the Lanczos update in the operator product's epilogue (LinOp::apply_z_fold): one-stream schedule only
-    static const bool fold_on = [] { const char* e = lab_env("PMC_FOLD"); return !e || atoi(e) != 0; }();
-    const bool fold = fold_on && !graphs && !L.split && A.apply_z_fold && A.can_fold && A.can_fold(nb, u1);
     k::minres_init(st, nb, S, dp, o.rel_tol, o.abs_tol, defer ? k::kWxDefer : 1);
     k::fill(st, len, v0, 0.0);
     k::fill(st, len, w0, 0.0);
@@ -484,7 +481,6 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     const double* cW1 = cW0 + kMaxBatch;
     const double* cW2 = cW1 + kMaxBatch;
     const double* cW3 = cW2 + kMaxBatch;
-    const double* gF = coef(offsetof(k::MinresState, gF));
     const int* d_nactive = reinterpret_cast<const int*>(reinterpret_cast<const char*>(S) + offsetof(k::MinresState, n_active));
 
     auto poll = [&]() {
@@ -504,10 +500,9 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     // written u (both blocks of u are then the most recently written data on the chip), before the scalar recurrences
     // and the w / x update of iteration i, which do not depend on it.
     k::DotParts dp_op;
-    auto apply_op = [&](zvec u, const double* fold_vec = nullptr) {
+    auto apply_op = [&](zvec u) {
         if (timing) w.op_timer.begin(st);
-        dp_op = fold_vec ? A.apply_z_fold(L, nb, u, q, w.partial_op.p, w.partial_op.p + seg2, fold_vec, gF)
-                         : A.apply_z(L, nb, u, q, w.partial_op.p, w.partial_op.p + seg2);
+        dp_op = A.apply_z(L, nb, u, q, w.partial_op.p, w.partial_op.p + seg2);
         if (timing) w.op_timer.end(st);   // + an empty bracket: what one event record costs on this stream
     };
     // one MINRES iteration with explicit roles of the ping-pong vectors; on entry q = A u1_ and its dot are in place
@@ -519,7 +514,6 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     // of the next Lanczos update and ahead of the M-block of the preconditioner; the first stream carries the s-rows of
     // the update and the V-cycle, whose coarse levels leave most of the chip idle.  Same kernels, same arguments, same
     // results; the preconditioned vector the update reads must survive one more iteration, hence three of them.
-    bool q_folded = false;   // q = A z + gF v_old: the Lanczos update of the next iteration reads two vectors (k::lincomb2)
     struct PendingWx { zvec u; double *w0 = nullptr, *w1 = nullptr; } pend;
     auto wx = [&](hipStream_t s, zvec u_, double* w0_, double* w1_) {
         if (x_rows) k::minres_wx_idx(s, nb, x_nrows, x_rows, cW0, u_, cW1, w0_, cW2, w1_, cW3, x);
@@ -536,22 +530,12 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             k::lincomb3(L.aux, nb, A.n0, cV0, q, cV1, v1_, cV2, v0_);
             flush_wx(L.aux);
             k::lincomb3(st, nb, n - A.n0, cV0, q + off, cV1, v1_ + off, cV2, v0_ + off);
-        } else if (q_folded) {
-            // q already holds A z + gF v0_ (the previous iteration's folded product): v0_ is dead and is overwritten
-            k::lincomb2(st, nb, n, cV0, q, cV1, v1_, v0_);
         } else {
             k::lincomb3(st, nb, n, cV0, q, cV1, v1_, cV2, v0_);
         }
         k::DotParts d2 = prec(L, nb, v0_, u0_, w.partial.p, w.partial.p + seg2);   // joins the second stream
         if (d2.total() == 0) d2 = k::DotParts{w.partial.p, k::dot_z(st, nb, n, v0_, u0_, w.partial.p)};
-        if (!last && fold) {
-            // <v, z> first: it gives beta_new and with it the coefficient of v1_ (the next update's OLDER vector) that the
-            // product adds in its epilogue; then the product, then alpha and the update coefficients from <z, A z>
-            k::minres_scal2(st, nb, S, d2, stage_on() ? w.stage.p : nullptr);
-            apply_op(u0_, v1_);
-            q_folded = true;
-            k::minres_scal1(st, nb, S, dp_op, stage_on() ? w.stage.p : nullptr);
-        } else if (!last) {
+        if (!last) {
             apply_op(u0_);
             k::minres_scal21(st, nb, S, d2, dp_op, stage_on() ? w.stage.p : nullptr);
         } else {

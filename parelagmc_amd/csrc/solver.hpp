@@ -151,13 +151,6 @@ struct LinOp {
     // the same product from a preconditioned vector (zvec storage): every product inside the MINRES loop
     std::function<k::DotParts(const Lanes& L, int nb, zvec x, double* y, double* dot_partial,
                               double* dot_partial2)> apply_z;
-    // optional: the same product with the older Lanczos vector folded into its epilogue, y = A x + fold_coef[k] * fold_vec
-    // (the fused dot stays <x, A x>); can_fold(nb, x) tells whether this width / storage has the kernel.  With it the
-    // Lanczos update reads two vectors instead of three (k::lincomb2): the operator product is bound by gather latency,
-    // the update by bandwidth, so the coalesced read moves to where it costs least.
-    std::function<k::DotParts(const Lanes& L, int nb, zvec x, double* y, double* dot_partial, double* dot_partial2,
-                              const double* fold_vec, const double* fold_coef)> apply_z_fold;
-    std::function<bool(int nb, zvec x)> can_fold;
 };
 // z = B^-1 r.  When dot_partial != nullptr the preconditioner may fuse <r, z> into its last kernels and
 // return the number of partial blocks it wrote (0 = not computed, the solver then runs a separate dot).
