@@ -864,6 +864,10 @@ def main():
                     help="configs 4 and 5 with their CPU columns as well (the default run measures their GPU legs only)")
     ap.add_argument("--only-config", type=int, choices=(4, 5), default=None,
                     help="of configs 4 and 5 run only this one")
+    ap.add_argument("--inline-setup", action="store_true",
+                    help="build the configurations' operators in this process instead of in background worker processes "
+                         "(use it under rocprofv3: its preloaded library may have initialised the GPU, and a process that has "
+                         "must not start another program)")
     ap.add_argument("--seed", type=int, default=20261003)
     args = ap.parse_args()
 
@@ -891,7 +895,7 @@ def main():
         for k in (4, 5):
             if args.only_config in (None, k):
                 kinds.append(f"c{k}")
-    pool = SetupPool(kinds)
+    pool = SetupPool([] if args.inline_setup else kinds)
 
     import torch
     import torch.distributed as dist

@@ -22,7 +22,7 @@ def find(d, suffix):
     return max(hits, key=os.path.getmtime)
 
 
-for src, dst, what in (("prof_bench", "bench", "python bench.py --steps 20 --warmup 5"),
+for src, dst, what in (("prof_bench", "bench", "python bench.py --steps 20 --warmup 5 --inline-setup"),
                        ("prof_s1", "bench_s1", "python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-extras"),
                        ("prof_s1_r6", "bench_s1_r6", "python bench.py --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras"),
                        ("prof_c3", "c3_darcy_op", "python scripts/c3_darcy_op.py"),

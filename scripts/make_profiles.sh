@@ -37,7 +37,7 @@ runpy() {   # name, script
   echo "$name done"
 }
 PROF=(--kernel-trace --stats)
-if [ -z "$SKIP_BENCH_PROFILE" ]; then run prof_bench --steps 20 --warmup 5 || exit 1; fi
+if [ -z "$SKIP_BENCH_PROFILE" ]; then run prof_bench --steps 20 --warmup 5 --inline-setup || exit 1; fi
 run prof_s1 --streams 1 --steps 40 --no-cpu-baseline --no-extras || exit 1
 run prof_s1_r6 --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras || exit 1
 runpy prof_c3 scripts/c3_darcy_op.py || exit 1
