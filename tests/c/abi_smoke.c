@@ -88,6 +88,41 @@ int main(int argc, char** argv) {
             return 1;
         }
     }
+    {   /* ABI 3: (i) a caller built against another header version is refused at pmc_ctx_create already (the macro passes
+           PMC_ABI_VERSION); (ii) precond_storage = PMC_STORAGE_FP64 - everything stored fp64, as the reference is - gives the
+           same field; (iii) pmc_sampler_mult = invA[level]->Mult on the right-hand side Eval builds gives Eval's field */
+        pmc_ctx* none_ctx = NULL;
+        if (pmc_ctx_create_abi(0, PMC_ABI_VERSION - 1, &none_ctx) == PMC_OK || none_ctx != NULL) {
+            fprintf(stderr, "caller of ABI version %d accepted\n", PMC_ABI_VERSION - 1);
+            return 1;
+        }
+        pmc_solver_opts o64 = opts;
+        o64.precond_storage = PMC_STORAGE_FP64;
+        pmc_sampler* s64 = NULL;
+        CHECK(pmc_sampler_create(ctx, p.s_nlevels, p.s_nlevels, sl, p.alpha, p.g, p.lognormal, &o64, &s64));
+        if (pmc_sampler_krylov_z_bytes(s64) != 8 || pmc_sampler_krylov_z_bytes(smp) != 4) { fprintf(stderr, "storage widths\n"); return 1; }
+        const int ns = p.sl[0].n_s, nu = p.sl[0].n_u;
+        double* s = (double*)malloc(8 * (size_t)p.nbatch * ns);
+        CHECK(pmc_sampler_eval(s64, 0, 0, p.nbatch, p.xi, s, NULL, -1, 0, NULL, PMC_MEM_HOST, NULL));
+        const double e64 = rel_err(s, p.s_expect[0], (size_t)p.nbatch * ns);
+        printf("sampler level 0, fp64 storage: rel. error vs oracle %.2e\n", e64);
+        if (!(e64 < 1e-9)) return 1;
+        {
+            double* rhs = (double*)calloc((size_t)(nu + ns), 8);
+            double* sol = (double*)malloc(8 * (size_t)(nu + ns));
+            for (int i = 0; i < ns; ++i) rhs[nu + i] = -p.g * sqrt(p.sl[0].w[i]) * p.xi[i];   /* src/PDESampler.cpp:423-428 */
+            pmc_stats st1;
+            CHECK(pmc_sampler_mult(smp, 0, 1, rhs, sol, 0, PMC_MEM_HOST, &st1));
+            if (p.lognormal)
+                for (int i = 0; i < ns; ++i) sol[nu + i] = exp(sol[nu + i]);                  /* :529-533 */
+            const double em = rel_err(sol + nu, p.s_expect[0], (size_t)ns);
+            printf("pmc_sampler_mult: s-block rel. error vs oracle %.2e, %d iterations\n", em, st1.iterations);
+            if (!(em < 1e-9) || st1.converged != 1) return 1;
+            free(rhs); free(sol);
+        }
+        free(s);
+        pmc_sampler_destroy(s64);
+    }
     /* error paths return codes, never abort */
     if (pmc_sampler_eval(smp, p.s_nlevels, 0, 1, p.xi, p.xi, NULL, -1, 0, NULL, PMC_MEM_HOST, NULL) == PMC_OK) {
         fprintf(stderr, "out-of-range level accepted\n");

@@ -191,3 +191,55 @@ def test_ratio_manager_cuts_its_plugin_calls_like_the_mlmc_manager(gpu_ctx, hex_
     assert np.allclose(out[0]["sums"], out[1]["sums"], rtol=1e-9, atol=1e-12)
     ds.close()
     smp.close()
+
+
+def test_sampler_mult_is_the_reference_solver_seam(gpu_ctx, hex_hierarchy, seeded_rng):
+    """pmc_sampler_mult = invA[level]->Mult(rhs, sol) (/root/reference/src/PDESampler.cpp:397,521): ARBITRARY right-hand sides
+    (a nonzero u-block, which Eval never produces), full [u; s] solutions against the oracle's sparse direct solve of the block
+    system, on every level, host pointers; iterative_mode (:510) from a perturbed solution converges to the same vector in
+    fewer iterations; the s-block equals what Eval returns for the right-hand side Eval builds."""
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    import scipy.sparse.linalg as spla
+    sp = build_sampler_problem(hex_hierarchy, corlen=0.1)
+    so = SamplerOracle(sp)
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(rel_tol=1e-12, abs_tol=1e-300))
+    for lvl in range(3):
+        L = sp.levels[lvl]
+        n = L.n_u + L.n_s
+        rhs = seeded_rng.standard_normal((3, n))
+        x, st = smp.Solve(lvl, rhs, return_stats=True)
+        assert all(t[1] == 1 for t in st)
+        lu = spla.splu(so.block_operator(lvl))
+        ref = np.stack([lu.solve(b) for b in rhs])
+        assert rel(x, ref) < 1e-9, lvl
+        x2, st2 = smp.Solve(lvl, rhs, guess=ref * (1.0 + 1e-4 * seeded_rng.standard_normal(ref.shape)), return_stats=True)
+        assert rel(x2, ref) < 1e-9 and max(t[0] for t in st2) < max(t[0] for t in st)
+        xi = seeded_rng.standard_normal((2, L.n_s))
+        b = np.zeros((2, n))
+        b[:, L.n_u:] = -sp.matern_g * np.sqrt(L.w_diag) * xi
+        assert rel(smp.Solve(lvl, b)[:, L.n_u:], smp.Eval(lvl, xi)) < 1e-9
+    smp.close()
+
+
+@pytest.mark.parametrize("storage", [0, 1])
+def test_preconditioner_is_symmetric_positive_definite(gpu_ctx, hex_hierarchy_small, seeded_rng, storage):
+    """What MINRES needs of B^-1 (block Jacobi: M-block polynomial | V-cycle; the reference's "BJ-GS" block,
+    examples/example_helpers/CreateSamplerParameterList.hpp:68-113): <x, B^-1 y> == <B^-1 x, y> and <x, B^-1 x> > 0, through
+    pmc_sampler_apply_preconditioner, for fp32 and fp64 storage inside the preconditioner (fp32: symmetric to rounding)."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(precond_storage=storage, mini_max_rows=0))
+    for lvl in range(2):
+        n = sp.levels[lvl].n_u + sp.levels[lvl].n_s
+        v = seeded_rng.standard_normal((4, n))
+        z = smp.ApplyPreconditioner(lvl, v)
+        G = v @ z.T                                   # G[i, j] = <v_i, B^-1 v_j>
+        assert np.all(np.diag(G) > 0)
+        assert np.abs(G - G.T).max() <= (1e-6 if storage == 0 else 1e-11) * np.abs(G).max()
+        assert np.all(np.linalg.eigvalsh(0.5 * (G + G.T)) > 0)
+        # linearity
+        assert rel(smp.ApplyPreconditioner(lvl, (2.0 * v[0] - 3.0 * v[1])[None])[0], 2.0 * z[0] - 3.0 * z[1]) < (1e-6 if storage == 0 else 1e-12)
+    smp.close()
