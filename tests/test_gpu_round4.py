@@ -196,8 +196,8 @@ def test_ratio_manager_cuts_its_plugin_calls_like_the_mlmc_manager(gpu_ctx, hex_
 def test_sampler_mult_is_the_reference_solver_seam(gpu_ctx, hex_hierarchy, seeded_rng):
     """pmc_sampler_mult = invA[level]->Mult(rhs, sol) (/root/reference/src/PDESampler.cpp:397,521): ARBITRARY right-hand sides
     (a nonzero u-block, which Eval never produces), full [u; s] solutions against the oracle's sparse direct solve of the block
-    system, on every level, host pointers; iterative_mode (:510) from a perturbed solution converges to the same vector in
-    fewer iterations; the s-block equals what Eval returns for the right-hand side Eval builds."""
+    system, on every level, host pointers; iterative_mode (:510) from a perturbed solution starts from a residual four orders smaller and converges to the
+    same vector; the s-block equals what Eval returns for the right-hand side Eval builds."""
     from oracle.sampler_oracle import SamplerOracle
     from parelagmc_amd import capi
     from parelagmc_amd.fe import build_sampler_problem
@@ -215,7 +215,9 @@ def test_sampler_mult_is_the_reference_solver_seam(gpu_ctx, hex_hierarchy, seede
         ref = np.stack([lu.solve(b) for b in rhs])
         assert rel(x, ref) < 1e-9, lvl
         x2, st2 = smp.Solve(lvl, rhs, guess=ref * (1.0 + 1e-4 * seeded_rng.standard_normal(ref.shape)), return_stats=True)
-        assert rel(x2, ref) < 1e-9 and max(t[0] for t in st2) < max(t[0] for t in st)
+        # the tolerance is relative to the solve's OWN initial residual (as MFEM's): the warm start begins four orders lower
+        assert rel(x2, ref) < 1e-9 and all(t[1] == 1 for t in st2)
+        assert all(t2[2] < 1e-2 * t1[2] for t1, t2 in zip(st, st2))
         xi = seeded_rng.standard_normal((2, L.n_s))
         b = np.zeros((2, n))
         b[:, L.n_u:] = -sp.matern_g * np.sqrt(L.w_diag) * xi
