@@ -140,7 +140,8 @@ def gpu_numa_cpus(local_rank):
         lo, _, hi = part.partition("-")
         cpus.update(range(int(lo), int(hi or lo) + 1))
     cpus &= os.sched_getaffinity(0)
-    return {"numa_node": numa, "cpus": sorted(cpus)} if len(cpus) >= 2 else None
+    # a rank needs room for its lane threads and its setup worker: with fewer than 8 usable CPUs on that node stay unpinned
+    return {"numa_node": numa, "cpus": sorted(cpus)} if len(cpus) >= 8 else None
 
 
 def pin_rank_to_gpu_numa(local_rank):
