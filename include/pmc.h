@@ -124,6 +124,19 @@ typedef struct pmc_sampler_level {
                              ignored (may be zeroed) on the last level                        */
 } pmc_sampler_level;
 
+/* One level of the HYBRIDIZED sampler: the reference's alternative solver of the same system ("Hybridization" in the
+ * sampler's parameter list, src/PDESampler.cpp:291,307-311,383-389; ParELAG's HybridHdivL2 does the element-local
+ * elimination).  Eliminating (u, s) element by element from [M B^T; B -alpha*W][u; s] = [0; f] leaves one Lagrange
+ * multiplier per face:   H lambda = G f,   s = z_diag .* f - G^T lambda   (exact, not an approximation). */
+typedef struct pmc_hybrid_level {
+    int32_t n_lambda, n_s;
+    pmc_csr H;             /* n_lambda x n_lambda, SPD                                              */
+    pmc_csr G;             /* n_lambda x n_s                                                        */
+    const double* z_diag;  /* n_s, the (s, s) entry of the local inverses (negative)                */
+    const double* w_diag;  /* n_s, diag(W) > 0 as in pmc_sampler_level                              */
+    pmc_csr P;             /* n_s(level) x n_s(level+1) = ComputeTrueP(sform); ignored on the last  */
+} pmc_hybrid_level;
+
 /* One level of the Darcy hierarchy = what DarcySolver precomputes (src/DarcySolver.cpp:
  * 194-227 B/Bt/P, :297-319 obs, :360-384 ess_data, :386-414 rhs) plus the element
  * decomposition of the mass matrix that ComputeMassOperator(uform,k) re-assembles per sample
@@ -197,6 +210,14 @@ int pmc_normal_fill(pmc_ctx* ctx, double mean, double sigma2, uint64_t first_sam
 int pmc_sampler_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_sampler_level* levels,
                        double alpha, double matern_g, int lognormal, const pmc_solver_opts* opts,
                        pmc_sampler** out);
+/* The same sampler with the hybridized solver (pmc_hybrid_level): MINRES on H with one V-cycle of an internal aggregation
+ * multigrid as preconditioner.  Every level is a Monte Carlo level.  The handle behaves like any other pmc_sampler
+ * (Sample / Eval / projections / batch width); init_s / use_init are accepted and ignored (the multiplier has no
+ * counterpart of a coarse field), pmc_sampler_mult / _apply_preconditioner / _apply_operator act on multiplier vectors
+ * of n_lambda entries, pmc_sampler_nnz reports nnz(H). */
+int pmc_sampler_create_hybrid(pmc_ctx* ctx, int nlevels, const pmc_hybrid_level* levels, double alpha, double matern_g,
+                              int lognormal, const pmc_solver_opts* opts, pmc_sampler** out);
+int pmc_sampler_is_hybrid(const pmc_sampler* s);
 void pmc_sampler_destroy(pmc_sampler* s);
 /* Output map of the embedded variants.  PMC_PROJ_GATHER: s = sbar[gather_idx]
  * (src/EmbeddedPDESampler.cpp:552-556); PMC_PROJ_L2: s = inv_w_orig .* (Gt sbar)

@@ -52,6 +52,11 @@ class pmc_sampler_level(C.Structure):
                 ("w_diag", C.POINTER(C.c_double)), ("P", pmc_csr)]
 
 
+class pmc_hybrid_level(C.Structure):
+    _fields_ = [("n_lambda", C.c_int32), ("n_s", C.c_int32), ("H", pmc_csr), ("G", pmc_csr),
+                ("z_diag", C.POINTER(C.c_double)), ("w_diag", C.POINTER(C.c_double)), ("P", pmc_csr)]
+
+
 class pmc_darcy_level(C.Structure):
     _fields_ = [("n_u", C.c_int32), ("n_p", C.c_int32), ("M_pattern", pmc_csr), ("c_ptr", C.POINTER(C.c_int32)),
                 ("c_elem", C.POINTER(C.c_int32)), ("c_val", C.POINTER(C.c_double)), ("B", pmc_csr),
@@ -86,6 +91,9 @@ SYMBOLS = {
     "pmc_normal_fill": (C.c_int, [_VP, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_int, C.c_int, _DP, C.c_int]),
     "pmc_sampler_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_sampler_level), C.c_double, C.c_double,
                                      C.c_int, C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
+    "pmc_sampler_create_hybrid": (C.c_int, [_VP, C.c_int, C.POINTER(pmc_hybrid_level), C.c_double, C.c_double, C.c_int,
+                                            C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
+    "pmc_sampler_is_hybrid": (C.c_int, [_VP]),
     "pmc_sampler_destroy": (None, [_VP]),
     "pmc_sampler_set_projection": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_csr), C.POINTER(C.c_int32),
                                              C.POINTER(C.c_double), C.c_int]),
@@ -346,13 +354,22 @@ class PDESampler:
         lib = ctx.lib
         keep = _Keep()
         nl = len(problem.levels)
-        arr = (pmc_sampler_level * nl)()
-        for i, L in enumerate(problem.levels):
-            arr[i] = pmc_sampler_level(L.n_u, L.n_s, keep.csr(L.M), keep.csr(L.B), keep.f64(L.w_diag), keep.csr(L.P))
         h = _VP()
         o = opts if opts is not None else solver_opts()
-        _check(lib.pmc_sampler_create(ctx.h, nl, problem.n_mc_levels, arr, problem.alpha, problem.matern_g,
-                                      1 if problem.lognormal else 0, C.byref(o), C.byref(h)))
+        self.hybrid = hasattr(problem.levels[0], "n_lambda")     # fe.HybridSamplerProblem: the hybridized solver
+        if self.hybrid:
+            harr = (pmc_hybrid_level * nl)()
+            for i, L in enumerate(problem.levels):
+                harr[i] = pmc_hybrid_level(L.n_lambda, L.n_s, keep.csr(L.H), keep.csr(L.G), keep.f64(L.z_diag),
+                                           keep.f64(L.w_diag), keep.csr(L.P))
+            _check(lib.pmc_sampler_create_hybrid(ctx.h, nl, harr, problem.alpha, problem.matern_g,
+                                                 1 if problem.lognormal else 0, C.byref(o), C.byref(h)))
+        else:
+            arr = (pmc_sampler_level * nl)()
+            for i, L in enumerate(problem.levels):
+                arr[i] = pmc_sampler_level(L.n_u, L.n_s, keep.csr(L.M), keep.csr(L.B), keep.f64(L.w_diag), keep.csr(L.P))
+            _check(lib.pmc_sampler_create(ctx.h, nl, problem.n_mc_levels, arr, problem.alpha, problem.matern_g,
+                                          1 if problem.lognormal else 0, C.byref(o), C.byref(h)))
         self.h = h
         ctx._adopt(self)
         self.nlevels = problem.n_mc_levels

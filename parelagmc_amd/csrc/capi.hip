@@ -307,6 +307,25 @@ int pmc_sampler_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_sampl
         for (int l = 0; l < (*out)->impl.nlevels; ++l) (*out)->impl.lv[l].out_size = (*out)->impl.lv[l].n_s;
     });
 }
+int pmc_sampler_create_hybrid(pmc_ctx* c, int nlevels, const pmc_hybrid_level* levels, double alpha, double matern_g,
+                              int lognormal, const pmc_solver_opts* opts, pmc_sampler** out) {
+    return guarded([&] {
+        PMC_REQUIRE(c != nullptr && out != nullptr, "pmc_sampler_create_hybrid: NULL argument");
+        *out = nullptr;
+        pmc_solver_opts o;
+        pmc_solver_opts_default(&o);
+        if (opts) {
+            check_abi(*opts);
+            o = *opts;
+        }
+        PMC_REQUIRE(o.max_iter >= 1 && o.mg_smooth_degree >= 1 && o.mg_coarse_degree >= 1 && o.mg_smooth_ratio > 1.0 &&
+                        o.mg_coarse_ratio > 1.0 && (o.precond_storage == PMC_STORAGE_FP32 || o.precond_storage == PMC_STORAGE_FP64),
+                    "solver options out of range");
+        *out = new pmc_sampler(*c, nlevels, levels, alpha, matern_g, lognormal != 0, o);
+        for (int l = 0; l < (*out)->impl.nlevels; ++l) (*out)->impl.lv[l].out_size = (*out)->impl.lv[l].n_s;
+    });
+}
+int pmc_sampler_is_hybrid(const pmc_sampler* s) { return s ? (s->impl.hybrid ? 1 : 0) : PMC_ERR_INVALID; }
 void pmc_sampler_destroy(pmc_sampler* s) {
     if (!s) return;
     (void)hipSetDevice(s->impl.ctx.device);

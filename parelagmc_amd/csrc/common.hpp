@@ -88,8 +88,9 @@ HostCsr csr_block2x2(const HostCsr& M, const HostCsr& Bt, const HostCsr& B, cons
 
 // algebraic coarsening helpers (setup): piecewise-constant aggregation
 HostCsr csr_galerkin_agg(const HostCsr& A, const std::vector<int>& agg, int nc);
-int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg, bool allow_weak = false);
-int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg, bool allow_weak = false);
+int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg, bool allow_weak = false, bool join_singletons = false);
+int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg, bool allow_weak = false,
+                   bool join_singletons = false);
 HostCsr prolongator_from_agg(const std::vector<int>& agg, int nc);
 
 HostCsr csr_spgemm(const HostCsr& A, const HostCsr& B);
@@ -106,6 +107,9 @@ struct AmgLevelHost {
 };
 std::vector<AmgLevelHost> sa_hierarchy(const HostCsr& K0, const std::vector<double>& w0, int passes, double theta,
                                        int min_size, int max_levels);
+// plain aggregation (indicator prolongators), matching by coupling magnitude: SPD operators with couplings of either sign
+// (passes0 matching passes on the finest level, `passes` below it)
+std::vector<AmgLevelHost> agg_hierarchy(const HostCsr& A0, int passes0, int passes, double theta, int min_size, int max_levels);
 
 // ---- SELL-64 device matrix ---------------------------------------------------------------
 // Rows are grouped in slices of 64 (one wavefront); inside a slice entries are stored

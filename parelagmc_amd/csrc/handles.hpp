@@ -24,6 +24,11 @@ struct SamplerLevel {
     DevBuf<int> gather;
     DevBuf<double> inv_w;
     HostCsr P_host;         // ComputeTrueP(sform) as handed over (MLSampler::GetTrueP); empty on the last level
+    // hybridized sampler (Sampler::hybrid): A = H on the multipliers (n_u = n_lambda), rhs = Gz (z f), s = z f - Gl lambda
+    Sell Gz;                // G diag(1 / z): n_lambda x n_s
+    Sell Gl;                // G^T: n_s x n_lambda
+    Sell Ptz;               // diag(z) P^T of the next finer level: restriction of a finer xi that lands on z f directly
+    DevBuf<double> zw_sqrt; // z .* sqrt(w)
 };
 
 struct Sampler {
@@ -36,12 +41,16 @@ struct Sampler {
     Multigrid mg;                                  // caller's levels: transfers between MC levels + geometric V-cycle
     std::vector<std::unique_ptr<Multigrid>> amg;   // per MC level: internal smoothed-aggregation hierarchy (if selected)
     double anisotropy = 1.0;
+    bool hybrid = false;                           // pmc_sampler_create_hybrid: multiplier system, amg[l] its V-cycle
     MinresWork work;
     DevBuf<double> rhs, sol, tA, tB, cx, cd, cx2, stage_in, stage_out, stage_emb, mini_scratch;
     DevBuf<pmc_stats> mini_stats;
 
     Sampler(Ctx& c, int nlevels, int n_mc, const pmc_sampler_level* in, double alpha, double g, bool lognormal,
             const pmc_solver_opts& o);
+    Sampler(Ctx& c, int nlevels, const pmc_hybrid_level* in, double alpha, double g, bool lognormal, const pmc_solver_opts& o);
+    // rows of the vectors the Krylov solver of `level` iterates on
+    size_t system_rows(int level) const { return hybrid ? (size_t)lv[level].n_u : (size_t)lv[level].n_u + lv[level].n_s; }
     void set_projection(int level, int kind, const pmc_csr* Gt, const int32_t* idx, const double* inv_w, int orig_size);
     void sample(int level, uint64_t first_id, int nbatch, double* xi, int memspace);
     void eval(int level, int xi_level, int nbatch, const double* xi, double* s_out, const double* init_s, int init_level,

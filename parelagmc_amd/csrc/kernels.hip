@@ -2812,6 +2812,17 @@ void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const d
     check_launch();
 }
 
+void vc_residual32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out) {
+    check_offsets32(A, nb);
+    if (A.nrows == 0) return;
+    if (A.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual32: shared values expected");
+    const dim3 g = grid_slices(A.nslices);
+    PMC_DISPATCH_NB(nb, {
+        vc_residual_kernel<NB, float, double, float, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
+    });
+    check_launch();
+}
+
 void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res, const double* xc) {
     check_offsets32(SP, nb);
     if (SP.nrows == 0) return;

@@ -137,6 +137,7 @@ void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* di
                     double c1);
 void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out,
                               double* coarse);
+void vc_residual32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out);   // no restriction
 void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res, const double* xc);
 int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
                     double* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial);

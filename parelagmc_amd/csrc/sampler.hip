@@ -47,9 +47,8 @@ HostCsr schur_host(const HostCsr& B, const HostCsr& Bt, const std::vector<double
     return S;
 }
 
-std::unique_ptr<Multigrid> build_sa_chain(const HostCsr& K, const std::vector<double>& w, const pmc_solver_opts& o,
-                                          hipStream_t st) {
-    std::vector<AmgLevelHost> lv = sa_hierarchy(K, w, /*passes=*/2, /*theta=*/0.25, /*min_size=*/256, /*max_levels=*/14);
+// device V-cycle levels of an algebraic hierarchy (setup)
+static std::unique_ptr<Multigrid> build_chain(const std::vector<AmgLevelHost>& lv, const pmc_solver_opts& o, hipStream_t st) {
     std::unique_ptr<Multigrid> mg(new Multigrid());
     mg->smooth_degree = o.mg_smooth_degree;
     mg->smooth_ratio = o.mg_smooth_ratio;
@@ -81,12 +80,31 @@ std::unique_ptr<Multigrid> build_sa_chain(const HostCsr& K, const std::vector<do
         m.S.h_cols.clear(); m.S.h_cols.shrink_to_fit();
         if (m.is_last) { mg->L.resize(l + 1); break; }
         if (l + 1 < lv.size()) {
-            sell_build(m.P, lv[l].P, true, false, st);
-            sell_build(m.Pt, csr_transpose(lv[l].P), true, false, st);
+            const HostCsr& P = lv[l].P;
+            sell_build(m.P, P, true, false, st);
+            sell_build(m.Pt, csr_transpose(P), true, false, st);
+            // indicator prolongator (plain aggregation): the coarse correction is folded into the post-smoothing
+            bool injection = true;
+            std::vector<int> parent(P.nrows, 0);
+            for (int i = 0; i < P.nrows && injection; ++i) {
+                injection = (P.rowptr[i + 1] - P.rowptr[i] == 1) && P.vals[P.rowptr[i]] == 1.0;
+                if (injection) parent[i] = P.colind[P.rowptr[i]];
+            }
+            if (injection) {
+                sell_build(m.SP, csr_spgemm(S, P), true, false, st);
+                m.parent.upload(parent, st);
+                m.has_sp = true;
+                PMC_HIP(hipStreamSynchronize(st));
+            }
         }
     }
     mg->build_tails(st);
     return mg;
+}
+
+std::unique_ptr<Multigrid> build_sa_chain(const HostCsr& K, const std::vector<double>& w, const pmc_solver_opts& o,
+                                          hipStream_t st) {
+    return build_chain(sa_hierarchy(K, w, /*passes=*/2, /*theta=*/0.25, /*min_size=*/256, /*max_levels=*/14), o, st);
 }
 
 static std::vector<double> l1_inverse(const HostCsr& M) {
@@ -227,6 +245,83 @@ Sampler::Sampler(Ctx& c, int nlevels_, int n_mc_, const pmc_sampler_level* in, d
     }
 }
 
+// Hybridized sampler (pmc_sampler_create_hybrid): the multiplier system H lambda = G f of every level, an aggregation
+// multigrid on H as its preconditioner, and the element-local back-substitution s = z f - G^T lambda.
+Sampler::Sampler(Ctx& c, int nlevels_, const pmc_hybrid_level* in, double alpha_, double g_, bool logn, const pmc_solver_opts& o)
+    : ctx(c), nlevels(nlevels_), n_mc(nlevels_), alpha(alpha_), g(g_), lognormal(logn), opts(o), hybrid(true) {
+    PMC_REQUIRE(nlevels >= 1, "hybrid sampler: need at least one level");
+    PMC_REQUIRE(in != nullptr, "hybrid sampler: levels is NULL");
+    PMC_REQUIRE(alpha > 0.0, "sampler: alpha must be positive");
+    ctx.activate();
+    hipStream_t st = ctx.stream;
+    lv.resize(nlevels);
+    mg.L.resize(nlevels);     // only the transfers between Monte Carlo levels live here
+    amg.resize(nlevels);
+    for (int l = 0; l < nlevels; ++l) {
+        const pmc_hybrid_level& L = in[l];
+        SamplerLevel& d = lv[l];
+        PMC_REQUIRE(L.n_lambda > 0 && L.n_s > 0, "hybrid sampler level: empty block");
+        PMC_REQUIRE(L.z_diag != nullptr && L.w_diag != nullptr, "hybrid sampler level: z_diag / w_diag is NULL");
+        d.n_u = L.n_lambda;
+        d.n_s = L.n_s;
+        HostCsr H = csr_from_c(L.H, true, "hybrid H");
+        HostCsr G = csr_from_c(L.G, true, "hybrid G");
+        PMC_REQUIRE(H.nrows == L.n_lambda && H.ncols == L.n_lambda, "hybrid H: wrong shape");
+        PMC_REQUIRE(G.nrows == L.n_lambda && G.ncols == L.n_s, "hybrid G: wrong shape");
+        csr_sort_rows(H);
+        csr_sort_rows(G);
+        for (double v : csr_diag(H)) PMC_REQUIRE(v > 0.0, "hybrid H must have a positive diagonal");
+        std::vector<double> zw(L.n_s);
+        for (int i = 0; i < L.n_s; ++i) {
+            PMC_REQUIRE(L.w_diag[i] > 0.0, "sampler w_diag must be positive");
+            PMC_REQUIRE(L.z_diag[i] != 0.0, "hybrid z_diag must not vanish");
+            zw[i] = L.z_diag[i] * std::sqrt(L.w_diag[i]);
+        }
+        d.zw_sqrt.upload(zw, st);
+        {
+            std::vector<double> wsq(L.n_s);
+            for (int i = 0; i < L.n_s; ++i) wsq[i] = std::sqrt(L.w_diag[i]);
+            d.w_sqrt.upload(wsq, st);
+        }
+        d.nnz = H.nnz();
+        sell_build(d.A, H, true, false, st, diag_last_on());
+        sell_build(d.Gl, csr_transpose(G), true, false, st);
+        for (int i = 0; i < G.nrows; ++i)
+            for (int p = G.rowptr[i]; p < G.rowptr[i + 1]; ++p) G.vals[p] /= L.z_diag[G.colind[p]];
+        sell_build(d.Gz, G, true, false, st);
+        PMC_HIP(hipStreamSynchronize(st));
+        // aggregates of ~9 rows per level (three matching passes + singletons joined): 19 -> 21 iterations at 400 k multipliers
+        // against aggregates of ~4.4, but two kernel-launched levels above the LDS tail instead of four (measured, LAB_NOTES 9.11)
+        int passes0 = 3, passes1 = 3;
+        if (const char* e = lab_env("PMC_HYB_PASSES0")) passes0 = atoi(e);
+        if (const char* e = lab_env("PMC_HYB_PASSES1")) passes1 = atoi(e);
+        amg[l] = build_chain(agg_hierarchy(H, passes0, passes1, /*theta=*/0.25, /*min_size=*/256, /*max_levels=*/14), o, st);
+        amg[l]->f32_any_injection = true;
+        mg.L[l].n = L.n_s;
+        if (l + 1 < nlevels) {
+            HostCsr P = csr_from_c(L.P, true, "sampler P");
+            PMC_REQUIRE(P.nrows == L.n_s && P.ncols == in[l + 1].n_s, "sampler P: wrong shape");
+            d.P_host = P;
+            sell_build(mg.L[l].P, P, true, false, st);
+            HostCsr Pt = csr_transpose(P);
+            sell_build(mg.L[l].Pt, Pt, true, false, st);
+            // the last restriction of a finer xi lands on z f of the coarser level: rows scaled by that level's z
+            for (int i = 0; i < Pt.nrows; ++i)
+                for (int p = Pt.rowptr[i]; p < Pt.rowptr[i + 1]; ++p) Pt.vals[p] *= in[l + 1].z_diag[i];
+            sell_build(lv[l + 1].Ptz, Pt, true, false, st);
+        }
+        PMC_HIP(hipStreamSynchronize(st));
+        if (getenv("PMC_VERBOSE")) {
+            const Multigrid& h = *amg[l];
+            fprintf(stderr, "[pmc] hybrid sampler level %d: n_lambda %d n_s %d nnz(H) %lld | V-cycle levels", l, d.n_u, d.n_s,
+                    (long long)d.nnz);
+            for (size_t q = 0; q < h.L.size(); ++q)
+                fprintf(stderr, " %d%s%s", h.L[q].n, h.L[q].has_sp ? "i" : "", (q < h.tail.size() && h.tail[q].p) ? "t" : "");
+            fprintf(stderr, "\n");
+        }
+    }
+}
+
 void Sampler::set_projection(int level, int kind, const pmc_csr* Gt, const int32_t* idx, const double* inv_w,
                              int orig_size) {
     PMC_REQUIRE(level >= 0 && level < n_mc, "set_projection: level out of range");
@@ -259,7 +354,7 @@ void Sampler::set_projection(int level, int kind, const pmc_csr* Gt, const int32
 void Sampler::ensure(int level, int nb) {
     size_t nmax = 0, smax = 0;
     for (int l = 0; l <= level; ++l) {
-        nmax = std::max(nmax, (size_t)lv[l].n_u + lv[l].n_s);
+        nmax = std::max(nmax, (size_t)lv[l].n_u + lv[l].n_s);   // hybrid: multipliers in rhs / sol, z f and the field behind
         smax = std::max(smax, (size_t)lv[l].n_s);
     }
     for (int l = level; l < nlevels; ++l) smax = std::max(smax, (size_t)lv[l].n_s);
@@ -269,8 +364,10 @@ void Sampler::ensure(int level, int nb) {
     sol.ensure(nmax * nb);
     tA.ensure(smax * nb);
     tB.ensure(smax * nb);
-    cx.ensure((size_t)lv[level].n_u * nb);
-    cd.ensure((size_t)lv[level].n_u * nb);
+    if (!hybrid) {   // scratch of the M-block polynomial
+        cx.ensure((size_t)lv[level].n_u * nb);
+        cd.ensure((size_t)lv[level].n_u * nb);
+    }
     stage_in.ensure(smax * nb);
     stage_out.ensure(smax * nb);
     stage_emb.ensure(smax * nb);
@@ -299,6 +396,28 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     const int n_u = d.n_u, n_s = d.n_s;
     ensure(level, nb);
     if (stats) ctx.phase_mark(0);
+    if (hybrid) {
+        // fz = z f with f = -g W^{1/2} xi (restricted from xi_level); rhs = G f = Gz fz; lambda = H^-1 rhs; s = fz - G^T lambda.
+        // rhs / sol hold [lambda-sized vector | fz resp. s]: n_u + n_s rows each, as in the saddle-point layout
+        double* fz = rhs.p + (size_t)n_u * nb;
+        if (xi_level == level) {
+            k::interleave(st, nb, n_s, xi_d, d.zw_sqrt.p, -g, fz);
+        } else {
+            double* cur = tA.p;
+            double* nxt = tB.p;
+            k::interleave(st, nb, lv[xi_level].n_s, xi_d, lv[xi_level].w_sqrt.p, -g, cur);
+            for (int l = xi_level; l < level; ++l) {
+                const bool final_step = l + 1 == level;
+                k::spmm(st, nb, final_step ? view(d.Ptz) : view(mg.L[l].Pt), cur, final_step ? fz : nxt, false, nullptr, nullptr);
+                std::swap(cur, nxt);
+            }
+        }
+        k::spmm(st, nb, view(d.Gz), fz, rhs.p, false, nullptr, nullptr);
+        if (stats) ctx.phase_mark(1);
+        solve_system(level, nb, true, 0, n_u, stats);
+        double* field = sol.p + (size_t)n_u * nb;
+        k::residual(st, nb, view(d.Gl), fz, sol.p, field);
+    } else {
     // rhs_s = -g W^{1/2} xi on xi_level, restricted with Ps^T (PDESampler.cpp:423-438); rhs_u = 0 (:441-442)
     k::fill(st, (size_t)n_u * nb, rhs.p, 0.0);
     double* rhs_s = rhs.p + (size_t)n_u * nb;
@@ -336,6 +455,7 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
     if (stats) ctx.phase_mark(1);
     // only the s-block of the solution is ever read (PDESampler.cpp:526): maintain only those rows
     solve_system(level, nb, zero_guess, n_u, n_s, stats);
+    }
     // outputs (:526-533 and the embedded variants' maps)
     const double* sol_s = sol.p + (size_t)n_u * nb;
     if (d.proj == PMC_PROJ_NONE) {
@@ -354,7 +474,7 @@ void Sampler::eval_chunk(int level, int xi_level, int nb, const double* xi_d, do
 void Sampler::solve_system(int level, int nb, bool zero_guess, int x_row0, int x_nrows, pmc_stats* stats) {
     hipStream_t st = ctx.stream;
     SamplerLevel& d = lv[level];
-    const int n_u = d.n_u, n_s = d.n_s, n = n_u + n_s;
+    const int n_u = d.n_u, n_s = d.n_s, n = (int)system_rows(level);
     const bool use_amg = level < (int)amg.size() && amg[level];
     Multigrid* mgp = use_amg ? amg[level].get() : &mg;
     const int mg_l0 = use_amg ? 0 : level;
@@ -369,7 +489,7 @@ void Sampler::solve_system(int level, int nb, bool zero_guess, int x_row0, int x
     // (cube_tet_embed: lambda_max / lambda_min = 22 against 8 on uniform tetrahedra) pay for degree 4 (69.6 -> 55.9
     // iterations, 20.0 -> 19.5 ms per batch at 314 k DoF), well shaped ones do not
     const int degM = opts.cheb_degree_M > 0 ? opts.cheb_degree_M : (d.ratio_M > 16.0 ? 4 : 2);
-    const bool mini = n <= mini_max_rows && degM == 2 && opts.use_graph == 0 && mgp->use_tail &&
+    const bool mini = !hybrid && n <= mini_max_rows && degM == 2 && opts.use_graph == 0 && mgp->use_tail &&
                       mg_l0 < (int)mgp->tail.size() && mgp->tail[mg_l0].p != nullptr;
     if (mini) {
         MiniSamplerParams mp{};
@@ -398,7 +518,7 @@ void Sampler::solve_system(int level, int nb, bool zero_guess, int x_row0, int x
     } else {
     LinOp A;
     A.n = n;
-    A.n0 = n_u;
+    A.n0 = hybrid ? 0 : n_u;
     SellView Av = view(d.A);
     Av.tag = 1;
     A.apply = [Av](const Lanes& L, int nb_, const double* x, double* y, double* partial, double*) {
@@ -424,6 +544,13 @@ void Sampler::solve_system(int level, int nb, bool zero_guess, int x_row0, int x
 PrecFn Sampler::preconditioner(int level, int nb, int degM, Multigrid* mgp, int mg_l0) {
     SamplerLevel& d = lv[level];
     const int n_u = d.n_u;
+    if (hybrid) {   // SPD multiplier system: the V-cycle alone
+        (void)nb; (void)degM;
+        return [=](const Lanes& L, int nb_, const double* r, zvec z, double* dot_partial, double*) {
+            const int nblk = mgp->vcycle_z(L.main, nb_, mg_l0, r, z, dot_partial);
+            return k::DotParts{dot_partial, nblk, nullptr, 0};
+        };
+    }
     const SellView Mv = view(d.M);
     const double* dinvM = d.dinvM.p;
     ChebParams cpM{degM, 1.0, d.ratio_M, d.M_scaled.p};
@@ -453,7 +580,7 @@ void Sampler::apply_preconditioner(int level, int nbatch, const double* r_in, do
     ctx.activate();
     hipStream_t st = ctx.stream;
     SamplerLevel& d = lv[level];
-    const size_t n = (size_t)d.n_u + d.n_s;
+    const size_t n = system_rows(level);
     const int nb = nbatch;
     ensure(level, nb);
     DevBuf<double> stage, zi(n * nb), part((size_t)2 * dot_capacity((int)n, nb) * nb);
@@ -481,11 +608,11 @@ void Sampler::mult(int level, int nbatch, const double* rhs_in, double* sol_io, 
     PMC_REQUIRE(nbatch >= 1 && rhs_in != nullptr && sol_io != nullptr, "Mult: bad arguments");
     ctx.activate();
     hipStream_t st = ctx.stream;
-    const size_t n = (size_t)lv[level].n_u + lv[level].n_s;
+    const size_t n = system_rows(level);
     DevBuf<double> stage_r, stage_x;
     int done = 0;
     while (done < nbatch) {
-        int nb = batch_width(n);
+        int nb = batch_width((size_t)lv[level].n_u + lv[level].n_s);
         while (nb > nbatch - done) nb >>= 1;
         ensure(level, nb);
         const double* r_d = rhs_in + (size_t)done * n;
@@ -517,7 +644,7 @@ void Sampler::apply_operator(int level, int nb, const double* x, double* y, int 
     ctx.activate();
     hipStream_t st = ctx.stream;
     SamplerLevel& d = lv[level];
-    const size_t n = (size_t)d.n_u + d.n_s;
+    const size_t n = system_rows(level);
     DevBuf<double> xi(n * nb), yi(n * nb), stage;
     const double* xd = x;
     double* yd = y;

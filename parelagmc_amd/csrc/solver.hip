@@ -193,7 +193,8 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     lv.ensure(nb);
     const bool tail_here = use_tail && l < (int)tail.size() && tail[l].p;
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
-    const bool f32_shared = !last && !lv.bv && lv.has_sp && lv.p_oct && smooth_degree == 2 && lv.vals_scaled.p && f32_intermediates;
+    const bool f32_shared = !last && !lv.bv && lv.has_sp && (lv.p_oct || f32_any_injection) && smooth_degree == 2 &&
+                            lv.vals_scaled.p && f32_intermediates;
     const bool f32_bv = !last && lv.bv && lv.f32 && lv.p_oct && smooth_degree == 2 && lv.scaled32.p && f32_intermediates;
     if (ztarget && target) throw Error(PMC_ERR_INTERNAL, "V-cycle: two result buffers");
     const bool ends_here = tail_here || last;
@@ -225,7 +226,12 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         k::vc_presmooth32(st, nb, As, lv.dinv.p, r, xf, c0, c1);
         MgLevel& lc = L[l + 1];
         lc.ensure(nb);
-        k::vc_residual_restrict8_32(st, nb, A, r, xf, resf, lc.r.p);
+        if (lv.p_oct) {
+            k::vc_residual_restrict8_32(st, nb, A, r, xf, resf, lc.r.p);
+        } else {
+            k::vc_residual32(st, nb, A, r, xf, resf);
+            k::spmm_z(st, nb, view(lv.Pt), zvec(resf, true), lc.r.p, nullptr, zvec());
+        }
         double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, zvec(), nullptr, nullptr, side);
         k::vc_residual_coarse32(st, nb, view(lv.SP), resf, xc);
         const int nblk = ztarget ? k::vc_postsmooth32_z(st, nb, As, lv.dinv.p, resf, xf, ztarget, c0, c1, r, lv.parent.p, xc, dot_partial)

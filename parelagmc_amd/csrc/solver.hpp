@@ -108,6 +108,9 @@ struct Multigrid {
     // pmc_solver_opts.precond_storage: the intermediates of a level (iterate, residuals) of the structured hierarchies live
     // in fp32 (k::vc_* kernels) or - false - in fp64 like everything else
     bool f32_intermediates = true;
+    // the fp32-intermediate kernels also on levels whose indicator prolongator is NOT over groups of 8 consecutive rows
+    // (aggregation hierarchies: the restriction is then a separate product with P^T)
+    bool f32_any_injection = false;
     void build_tails(hipStream_t st);
     // per-realization hierarchies: give every level of at most max_rows rows transposed value copies so that
     // build_tails can include them; refresh_bv_tail(nb) re-fills the copies (call after every numeric refresh)

@@ -252,7 +252,7 @@ HostCsr csr_galerkin_agg(const HostCsr& A, const std::vector<int>& agg, int nc) 
 // One pass of pairwise matching along the strongest negative coupling (Notay-style): every unmatched row joins its
 // strongest unmatched neighbour j with -a_ij >= theta * max_k(-a_ik), otherwise it stays alone.  Returns the number of
 // aggregates; agg[i] = aggregate of row i.  On anisotropic operators this coarsens along the strong direction only.
-int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg, bool allow_weak) {
+int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg, bool allow_weak, bool join_singletons) {
     const int n = A.nrows;
     agg.assign(n, -1);
     // visit rows by increasing number of strong neighbours... plain index order keeps the mesh ordering's locality
@@ -278,20 +278,45 @@ int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg, bool a
         if (best >= 0) agg[best] = nc;
         ++nc;
     }
-    return nc;
+    if (!join_singletons) return nc;
+    // a row whose neighbours were all taken before its turn joins the PAIR of its strongest neighbour (aggregates of at
+    // most 3): without this 2-6 % of the rows of a face-based operator stay alone in every pass and the coarsening stalls
+    std::vector<int> size(nc, 0);
+    for (int i = 0; i < n; ++i) size[agg[i]]++;
+    for (int i = 0; i < n; ++i) {
+        if (size[agg[i]] != 1) continue;
+        int best = -1;
+        double bval = 0.0;
+        for (int p = A.rowptr[i]; p < A.rowptr[i + 1]; ++p) {
+            const int j = A.colind[p];
+            if (j == i || size[agg[j]] != 2) continue;
+            const double s = -A.vals[p];
+            if (s > bval) { bval = s; best = j; }
+        }
+        if (best < 0) continue;
+        size[agg[i]] = 0;
+        agg[i] = agg[best];
+        size[agg[best]] = 3;
+    }
+    std::vector<int> remap(nc, -1);
+    int nc2 = 0;
+    for (int c = 0; c < nc; ++c)
+        if (size[c] > 0) remap[c] = nc2++;
+    for (int& a : agg) a = remap[a];
+    return nc2;
 }
 
 // `passes` rounds of pairwise matching (aggregates of up to 2^passes rows).  K = the coupling part of the operator that
 // steers the matching; returns agg and the number of aggregates.
-int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg, bool allow_weak) {
+int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg, bool allow_weak, bool join_singletons) {
     std::vector<int> cur;
-    int nc = pairwise_match(K, theta, cur, allow_weak);
+    int nc = pairwise_match(K, theta, cur, allow_weak, join_singletons);
     agg = cur;
     HostCsr Kc = K;
     for (int pass = 1; pass < passes; ++pass) {
         Kc = csr_galerkin_agg(Kc, cur, nc);
         std::vector<int> nxt;
-        const int nc2 = pairwise_match(Kc, theta, nxt, allow_weak);
+        const int nc2 = pairwise_match(Kc, theta, nxt, allow_weak, join_singletons);
         if (nc2 == nc) break;
         for (int& a : agg) a = nxt[a];
         cur = nxt;
@@ -310,6 +335,35 @@ HostCsr prolongator_from_agg(const std::vector<int>& agg, int nc) {
     for (int i = 0; i < P.nrows; ++i) { P.rowptr[i] = i; P.colind[i] = agg[i]; }
     P.rowptr[P.nrows] = P.nrows;
     return P;
+}
+
+// Plain (unsmoothed) aggregation hierarchy of an SPD operator whose off-diagonal entries have either sign (the hybridized
+// sampler's multiplier system: positive couplings across right / obtuse dihedral angles): the matching is steered by the
+// MAGNITUDE of the couplings, the prolongator is the aggregates' indicator (an injection - the V-cycle folds the coarse
+// correction into the post-smoothing, MgLevel::has_sp), coarse operators are Galerkin sums.
+std::vector<AmgLevelHost> agg_hierarchy(const HostCsr& A0, int passes0, int passes, double theta, int min_size, int max_levels) {
+    std::vector<AmgLevelHost> out;
+    HostCsr A = A0;
+    for (int lvl = 0;; ++lvl) {
+        AmgLevelHost L;
+        const int n = A.nrows;
+        if (n <= min_size || lvl + 1 >= max_levels) { L.S = std::move(A); out.push_back(std::move(L)); break; }
+        HostCsr Ka = A;
+        for (int i = 0; i < n; ++i)
+            for (int p = Ka.rowptr[i]; p < Ka.rowptr[i + 1]; ++p)
+                if (Ka.colind[p] != i) Ka.vals[p] = -std::fabs(Ka.vals[p]);
+        std::vector<int> agg;
+        const int nc = aggregate_rows(Ka, lvl == 0 ? passes0 : passes, theta, agg, true, true);
+        if (getenv("PMC_VERBOSE"))
+            fprintf(stderr, "[pmc]   aggregation level %d: n %d, %.1f entries/row -> %d rows\n", lvl, n, (double)A.nnz() / n, nc);
+        if (nc * 10 > n * 9 || nc < 1) { L.S = std::move(A); out.push_back(std::move(L)); break; }
+        L.P = prolongator_from_agg(agg, nc);
+        HostCsr Ac = csr_galerkin_agg(A, agg, nc);
+        L.S = std::move(A);
+        out.push_back(std::move(L));
+        A = std::move(Ac);
+    }
+    return out;
 }
 
 }  // namespace pmc

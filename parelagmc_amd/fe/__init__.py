@@ -8,6 +8,7 @@ from .mesh import (Mesh, box_mesh, build_faces, element_volumes, kuhn_cube_tet, 
 from .problems import (DarcyLevel, DarcyProblem, Hierarchy, SamplerLevel, SamplerProblem,  # noqa: F401
                        build_darcy_problem, build_hierarchy, build_sampler_problem,
                        elements_near_points, l2_projection_ops, matern_coefficient)
+from .hybrid import HybridLevel, HybridSamplerProblem, build_hybrid_sampler_problem  # noqa: F401
 from .rt0 import build_spaces, mass_contributions, mass_matrix, prolongation_p0  # noqa: F401
 from .transfer import (box_intersection_gt, clipped_intersection_gt, intersection_gt,  # noqa: F401
                        l2_projection_hierarchy)

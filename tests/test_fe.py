@@ -313,3 +313,38 @@ def test_inline_mesh_formats(name, etype, ne):
     cells = int(np.prod(n))
     assert m.ne == cells * (2 if etype == "tri" else 1)
     assert np.allclose(m.verts.min(axis=0), 0.0) and np.all(m.verts.max(axis=0) > 0.0)
+
+
+@pytest.mark.parametrize("kind", ["hex", "tet", "quad"])
+def test_hybridized_system_is_an_exact_reformulation(kind, hex_hierarchy_small):
+    """fe/hybrid.py (the setup of the reference's hybridization solver branch, /root/reference/src/PDESampler.cpp:291,307-311):
+    H lambda = G f, s = z f - G^T lambda gives the field of the saddle-point system [M B^T; B -alpha W][u; s] = [0; f] to
+    rounding, on hexahedra, tetrahedra and the 2D quad mesh, for the right-hand side Eval builds; H is symmetric positive
+    definite and couples only faces of a common element."""
+    import scipy.sparse.linalg as spla
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd.fe import box_mesh, build_hierarchy, build_hybrid_sampler_problem, build_sampler_problem
+    if kind == "hex":
+        h = hex_hierarchy_small
+    elif kind == "tet":
+        h = build_hierarchy(mesh_from_json(golden_path("meshes", "cube_tet.json")), 2)
+    else:
+        h = build_hierarchy(box_mesh([2, 2], [1.0, 1.0], "quad"), 2)
+    sp_ = build_sampler_problem(h, corlen=0.1)
+    hp = build_hybrid_sampler_problem(h, corlen=0.1)
+    so = SamplerOracle(sp_)
+    rng = np.random.default_rng(3)
+    for lvl in range(h.nlevels):
+        L, Hl = sp_.levels[lvl], hp.levels[lvl]
+        assert Hl.n_lambda == L.n_u and Hl.n_s == L.n_s
+        assert abs(Hl.H - Hl.H.T).max() <= 1e-13 * abs(Hl.H).max()
+        ne_, nfe_ = h.spaces[lvl].faces.elem_face.shape
+        assert (Hl.H != 0).nnz <= ne_ * nfe_ * nfe_                     # couplings inside elements only
+        assert np.linalg.eigvalsh(Hl.H.toarray()).min() > 0 if Hl.n_lambda <= 2500 else True
+        assert np.all(Hl.z_diag < 0)
+        xi = rng.standard_normal(L.n_s)
+        f = so.rhs_s(lvl, lvl, xi)
+        lam = spla.splu(Hl.H.tocsc()).solve(Hl.G @ f)
+        s = Hl.z_diag * f - Hl.G.T @ lam
+        ref = so.eval_gaussian(lvl, lvl, xi)
+        assert np.linalg.norm(s - ref) <= 1e-11 * np.linalg.norm(ref), (kind, lvl)
