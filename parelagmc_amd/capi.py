@@ -478,7 +478,7 @@ class PDESampler:
         """y = [M Bt; B -aW] x (the block operator's Mult).  x: (nbatch, n_u+n_s) numpy or a
         DeviceArray (then pass nbatch via x.n).  Returns (y, avg_kernel_ms, algorithmic_bytes)."""
         L = self.problem.levels[level]
-        n = L.n_u + L.n_s
+        n = L.n_lambda if self.hybrid else L.n_u + L.n_s     # hybrid: y = H x
         if isinstance(x, np.ndarray):
             x = _f64(np.atleast_2d(x))
             nb = x.shape[0]
@@ -506,7 +506,7 @@ class PDESampler:
         """invA[level]->Mult(rhs, sol) (pmc_sampler_mult): the full solution [u; s] of A x = rhs.  rhs: (nbatch, n_u+n_s)
         numpy or a DeviceArray; guess (same kind): initial guess (iterative_mode)."""
         L = self.problem.levels[level]
-        n = L.n_u + L.n_s
+        n = L.n_lambda if self.hybrid else L.n_u + L.n_s     # hybrid: H lambda = rhs on the multipliers
         if isinstance(rhs, np.ndarray):
             rhs = _f64(np.atleast_2d(rhs))
             nb = rhs.shape[0]

@@ -318,6 +318,10 @@ Sampler::Sampler(Ctx& c, int nlevels_, const pmc_hybrid_level* in, double alpha_
             for (size_t q = 0; q < h.L.size(); ++q)
                 fprintf(stderr, " %d%s%s", h.L[q].n, h.L[q].has_sp ? "i" : "", (q < h.tail.size() && h.tail[q].p) ? "t" : "");
             fprintf(stderr, "\n");
+            for (size_t q = 0; q < h.L.size(); ++q)
+                fprintf(stderr, "[pmc]   V-cycle level %zu: S %lld entries in %lld slots, S P %lld in %lld, lmax %.3f\n", q,
+                        (long long)h.L[q].S.nnz, (long long)h.L[q].S.nslots, (long long)h.L[q].SP.nnz, (long long)h.L[q].SP.nslots,
+                        h.L[q].lmax);
         }
     }
 }

@@ -48,6 +48,8 @@ class HybridSamplerProblem:
     matern_g: float
     dim: int
     lognormal: bool
+    # embedded variants: per level, indices of the original-mesh elements (attr == 1), as SamplerProblem.orig_index
+    orig_index: Optional[List[np.ndarray]] = None
 
 
 def hybrid_level_ops(space: LevelSpaces, alpha: float, P) -> HybridLevel:
@@ -81,9 +83,15 @@ def hybrid_level_ops(space: LevelSpaces, alpha: float, P) -> HybridLevel:
     return HybridLevel(nf, ne, H, G, z.copy(), space.vol.copy(), P)
 
 
-def build_hybrid_sampler_problem(h: Hierarchy, corlen=0.1, lognormal=False, n_mc_levels=None) -> HybridSamplerProblem:
+def build_hybrid_sampler_problem(h: Hierarchy, corlen=0.1, lognormal=False, n_mc_levels=None,
+                                 embedded=False) -> HybridSamplerProblem:
+    """The hybridized twin of build_sampler_problem (same arguments).  Only the Monte Carlo levels are built: the
+    multiplier system brings its own algebraic hierarchy, coarser mesh levels have no role in it."""
     dim = h.spaces[0].mesh.dim
     alpha = 1.0 / (corlen * corlen)
     nmc = h.nlevels if n_mc_levels is None else n_mc_levels
-    levels = [hybrid_level_ops(h.spaces[i], alpha, h.P[i] if i < h.nlevels - 1 else None) for i in range(nmc)]
-    return HybridSamplerProblem(levels, nmc, corlen, alpha, matern_coefficient(corlen, dim), dim, lognormal)
+    levels = [hybrid_level_ops(h.spaces[i], alpha, h.P[i] if i < nmc - 1 else None) for i in range(nmc)]
+    orig = None
+    if embedded:
+        orig = [np.nonzero(h.spaces[i].mesh.elem_attr == 1)[0].astype(np.int32) for i in range(nmc)]
+    return HybridSamplerProblem(levels, nmc, corlen, alpha, matern_coefficient(corlen, dim), dim, lognormal, orig)

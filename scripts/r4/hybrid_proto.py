@@ -160,7 +160,7 @@ def hierarchy(K, passes, smoothed):
             lmax = (abs(Kc) @ np.ones(Kc.shape[0]) / d).max()
             P = (P - (4.0 / (3.0 * lmax)) * (sp.diags(1.0 / d) @ (Kc @ P))).tocsr()
         lv.append(level_tuple(Kc, P))
-        Kc = (P.T @ Kc @ P).tocsr()
+        Kc = ((P.T @ Kc @ P) * (1.0 / float(os.environ.get("OMEGA", "1")))).tocsr()   # over-correction of plain aggregation
     return lv
 
 def pcg(Aop, prec, b, rel=1e-6, maxit=300):

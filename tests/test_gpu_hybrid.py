@@ -1,0 +1,208 @@
+"""GPU tests of the HYBRIDIZED sampler (pmc_sampler_create_hybrid): the reference's alternative solver of PDESampler::Eval
+("Hybridization" in the parameter lists, /root/reference/src/PDESampler.cpp:291,307-311,451-480).  The field it returns is the
+field of the saddle-point system - the oracle (oracle/sampler_oracle.py, sparse direct solves of [M B^T; B -alpha W]) is the
+checker throughout; the hybrid operators come from parelagmc_amd/fe/hybrid.py."""
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = dict(rel_tol=1e-12, abs_tol=1e-300, max_iter=300)
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+def _pair(h, **kw):
+    from parelagmc_amd.fe import build_hybrid_sampler_problem, build_sampler_problem
+    return build_sampler_problem(h, **kw), build_hybrid_sampler_problem(h, **kw)
+
+
+@pytest.mark.parametrize("tol,bound", [(TIGHT, 1e-9), (dict(), 1e-5)])
+def test_hybrid_sampler_matches_direct_solve_all_levels(gpu_ctx, hex_hierarchy, seeded_rng, tol, bound):
+    """every level, xi drawn on the finest level (restricted with P^T, the last step landing on z f directly) and on the
+    level itself - against the oracle's direct solves of the saddle-point system"""
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    sp, hp = _pair(hex_hierarchy, corlen=0.1)
+    so = SamplerOracle(sp)
+    smp = capi.PDESampler(gpu_ctx, hp, capi.solver_opts(**tol))
+    assert smp.hybrid and gpu_ctx.lib.pmc_sampler_is_hybrid(smp.h) == 1
+    assert smp.GetNNZ(0) == hp.levels[0].H.nnz
+    xi = seeded_rng.standard_normal((3, sp.levels[0].n_s))
+    for lvl in range(3):
+        assert smp.xi_size(lvl) == sp.levels[lvl].n_s == smp.SampleSize(lvl)
+        s, st = smp.Eval(lvl, xi, xi_level=0, return_stats=True)
+        ref = np.stack([so.eval(lvl, 0, x)[0] for x in xi])
+        assert rel(s, ref) < bound
+        assert all(t[1] == 1 for t in st) and all(0 < t[0] <= 300 for t in st)
+    for lvl in (1, 2):
+        x = seeded_rng.standard_normal((2, sp.levels[lvl].n_s))
+        assert rel(smp.Eval(lvl, x), np.stack([so.eval(lvl, lvl, v)[0] for v in x])) < bound
+    x = seeded_rng.standard_normal((2, sp.levels[1].n_s))      # xi of level 1 evaluated on level 2
+    assert rel(smp.Eval(2, x, xi_level=1), np.stack([so.eval(2, 1, v)[0] for v in x])) < bound
+    # GetTrueP hands back what was given
+    assert abs(smp.GetTrueP(0) - hp.levels[0].P).max() == 0.0
+    smp.close()
+
+
+@pytest.mark.parametrize("mesh,nref", [("cube_tet", 2), ("inline_quad", 3)])
+def test_hybrid_sampler_on_simplices_and_in_2d(gpu_ctx, seeded_rng, mesh, nref):
+    """tetrahedra (H has positive couplings across obtuse dihedral angles: the aggregation matches by magnitude) and the 2D
+    quadrilateral mesh of config 1"""
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hierarchy, mesh_from_json
+    h = build_hierarchy(mesh_from_json(golden_path("meshes", mesh + ".json")), nref)
+    sp, hp = _pair(h, corlen=0.1, n_mc_levels=2)
+    so = SamplerOracle(sp)
+    smp = capi.PDESampler(gpu_ctx, hp, capi.solver_opts(**TIGHT))
+    xi = seeded_rng.standard_normal((2, sp.levels[0].n_s))
+    for lvl in range(2):
+        s, st = smp.Eval(lvl, xi, xi_level=0, return_stats=True)
+        assert rel(s, np.stack([so.eval(lvl, 0, x)[0] for x in xi])) < 1e-9
+        assert all(t[1] == 1 for t in st)
+    smp.close()
+
+
+def test_hybrid_embedded_gather_l2_projection_lognormal_and_embed_output(gpu_ctx, seeded_rng):
+    from oracle.sampler_oracle import SamplerOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import box_mesh, build_hierarchy, l2_projection_ops
+    m = box_mesh([6, 6, 6], [3.0, 3.0, 3.0], "hex", origin=[-0.5, -0.5, -0.5])
+    cen = m.verts[m.elems].mean(1)
+    m.elem_attr[:] = np.where(np.all((cen > 0) & (cen < 2), axis=1), 1, 2)
+    h = build_hierarchy(m, 1)
+    sp, hp = _pair(h, corlen=0.1, embedded=True, lognormal=True)
+    assert all(np.array_equal(a, b) for a, b in zip(sp.orig_index, hp.orig_index))
+    so = SamplerOracle(sp)
+    l2 = l2_projection_ops(h, sp.orig_index)
+    ga = capi.PDESampler(gpu_ctx, hp, capi.solver_opts(**TIGHT), projection="gather")
+    pr = capi.PDESampler(gpu_ctx, hp, capi.solver_opts(**TIGHT), projection="l2", l2_ops=l2)
+    xi = seeded_rng.standard_normal((3, sp.levels[0].n_s))
+    for lvl in range(2):
+        assert ga.SampleSize(lvl) == len(sp.orig_index[lvl])
+        a, emb = ga.Eval(lvl, xi, xi_level=0, want_embed=True)
+        b = pr.Eval(lvl, xi, xi_level=0)
+        ref = np.stack([so.eval(lvl, 0, x, projection=("gather", sp.orig_index[lvl]))[0] for x in xi])
+        assert rel(a, ref) < 1e-9 and rel(b, ref) < 1e-9
+        gauss = np.stack([so.eval_gaussian(lvl, 0, x) for x in xi])       # embed_s: the Gaussian field on the sampler mesh
+        assert rel(emb, gauss) < 1e-9
+    # use_init is accepted and ignored (the reference: "The HybridizationSolver cannot be used in iterative mode")
+    a0 = ga.Eval(0, xi, xi_level=0)
+    a1 = ga.Eval(0, xi, xi_level=0, init_s=np.zeros((3, sp.levels[1].n_s)), init_level=1, use_init=True)
+    assert np.array_equal(a0, a1)
+    ga.close()
+    pr.close()
+
+
+@pytest.mark.parametrize("nbatch", [1, 3, 32, 37, 70])
+def test_hybrid_ragged_batches_equal_single_evaluations(gpu_ctx, hex_hierarchy_small, nbatch):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hybrid_sampler_problem
+    hp = build_hybrid_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    smp = capi.PDESampler(gpu_ctx, hp, capi.solver_opts(**TIGHT))
+    xi = smp.Sample(0, first_id=11, nbatch=nbatch)
+    s = smp.Eval(0, xi)
+    for k in sorted({0, nbatch // 2, nbatch - 1}):
+        assert rel(s[k], smp.Eval(0, xi[k:k + 1])[0]) < 1e-10
+    # device-resident operands give the same bits as host operands
+    d = gpu_ctx.empty(nbatch * smp.SampleSize(0))
+    smp.Eval(0, gpu_ctx.array(xi), xi_level=0, s_out=d)
+    assert np.array_equal(d.download().reshape(nbatch, -1), s)
+    smp.close()
+
+
+@pytest.mark.parametrize("storage", ["fp32", "fp64"])
+def test_hybrid_true_residual_and_field_at_full_size(gpu_ctx, storage):
+    """cube_tet r = 5 (399 360 multipliers, 196 608 elements; BASELINE config 2): lambda = H^-1 G f from the solver seam
+    (pmc_sampler_mult), TRUE residual formed with the fp64 operator kernel, and the field against the saddle-point sampler
+    of the same handle family on the same xi, both at 1e-10."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hierarchy, mesh_from_json
+    h = build_hierarchy(mesh_from_json(golden_path("meshes", "cube_tet.json")), 5)
+    sp, hp = _pair(h, corlen=0.1, n_mc_levels=1)
+    L = hp.levels[0]
+    st_ = capi.PMC_STORAGE_FP32 if storage == "fp32" else capi.PMC_STORAGE_FP64
+    o = capi.solver_opts(rel_tol=1e-10, abs_tol=1e-300, precond_storage=st_)
+    hy = capi.PDESampler(gpu_ctx, hp, o)
+    sa = capi.PDESampler(gpu_ctx, sp, o)
+    assert hy.z_bytes() == (4 if storage == "fp32" else 8)
+    xi = hy.Sample(0, first_id=3, nbatch=2)
+    f = -hp.matern_g * np.sqrt(L.w_diag) * xi
+    rhs = (L.G @ f.T).T.copy()
+    lam, st = hy.Solve(0, rhs, return_stats=True)
+    assert all(t[1] == 1 for t in st) and all(t[0] < 60 for t in st), st
+    Hl = hy.Mult(0, lam)[0]
+    assert rel(Hl[0], L.H @ lam[0]) < 1e-13                       # the device operator is H
+    r = rhs - Hl
+    z = hy.ApplyPreconditioner(0, r)
+    pnorm = np.sqrt(np.einsum("ij,ij->i", r, z))
+    eta0, eta = np.array([t[2] for t in st]), np.array([t[3] for t in st])
+    assert np.all(pnorm / eta0 <= 1e-10) and np.all(np.abs(pnorm / eta - 1.0) < 1e-2), (pnorm, eta, eta0)
+    # element-local back-substitution of the solver's lambda = what Eval returns
+    s_h, sth = hy.Eval(0, xi, return_stats=True)
+    assert rel(s_h, L.z_diag * f - (L.G.T @ lam.T).T) < 1e-12
+    s_s, sts = sa.Eval(0, xi, return_stats=True)
+    assert rel(s_h, s_s) < 1e-8
+    print("hybrid r=5 %s: iterations %s against %s of the saddle-point solve at 1e-10" %
+          (storage, [t[0] for t in sth], [t[0] for t in sts]))
+    assert max(t[0] for t in sth) * 1.7 < min(t[0] for t in sts)   # measured 31-35 against 72
+    hy.close()
+    sa.close()
+
+
+def test_hybrid_preconditioner_is_symmetric_positive_definite(gpu_ctx, hex_hierarchy_small, seeded_rng):
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hybrid_sampler_problem
+    hp = build_hybrid_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    smp = capi.PDESampler(gpu_ctx, hp, capi.solver_opts(precond_storage=capi.PMC_STORAGE_FP64))
+    n = hp.levels[0].n_lambda
+    a, b = seeded_rng.standard_normal((2, n))
+    za, zb = smp.ApplyPreconditioner(0, np.stack([a, b]))
+    assert abs(a @ zb - b @ za) < 1e-10 * abs(a @ zb)
+    assert a @ za > 0 and b @ zb > 0
+    smp.close()
+
+
+def test_mlmc_manager_runs_unchanged_on_a_hybrid_sampler(gpu_ctx, hex_hierarchy_small):
+    """the managers see a pmc_sampler: the same InitRun with the hybridized handle gives the sums of the saddle-point handle
+    (same generator, same realizations) to the solver tolerance"""
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem
+    sp, hp = _pair(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    out = []
+    for prob in (sp, hp):
+        smp = capi.PDESampler(gpu_ctx, prob, capi.solver_opts(**TIGHT))
+        mgr = host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False, batch=4)
+        out.append(mgr.InitRun([5, 9]))
+        mgr.close()
+        smp.close()
+    ds.close()
+    assert np.allclose(out[0]["sums"], out[1]["sums"], rtol=1e-7, atol=1e-9)
+    assert out[0]["estimate"] == pytest.approx(out[1]["estimate"], rel=1e-7)
+
+
+def test_hybrid_error_paths(gpu_ctx, hex_hierarchy_small):
+    import copy
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hybrid_sampler_problem
+    hp = build_hybrid_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    bad = copy.copy(hp)
+    bad.levels = [copy.copy(hp.levels[0]), hp.levels[1]]
+    bad.levels[0].G = hp.levels[0].G[:-1]
+    with pytest.raises(capi.PmcError):
+        capi.PDESampler(gpu_ctx, bad)
+    bad.levels[0] = copy.copy(hp.levels[0])
+    bad.levels[0].z_diag = np.zeros_like(hp.levels[0].z_diag)
+    with pytest.raises(capi.PmcError):
+        capi.PDESampler(gpu_ctx, bad)
+    smp = capi.PDESampler(gpu_ctx, hp)
+    with pytest.raises(capi.PmcError):
+        smp.Eval(2, np.zeros((1, hp.levels[0].n_s)), xi_level=0)
+    smp.close()
