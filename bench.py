@@ -38,6 +38,18 @@ def build_problem(nref, extra_coarse=True):
     return build_sampler_problem(h, corlen=0.1, lognormal=False, n_mc_levels=1)
 
 
+def build_hybrid_problem(nref):
+    """the hybridized form of build_problem's system (the reference's "Hybridization" solver option): level 0 only - the
+    multiplier system brings its own algebraic hierarchy"""
+    from parelagmc_amd.fe import build_hierarchy, build_hybrid_sampler_problem, mesh_from_json
+    mesh = mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet.json"))
+    return build_hybrid_sampler_problem(build_hierarchy(mesh, nref), corlen=0.1, lognormal=False, n_mc_levels=1)
+
+
+def is_hybrid(problem):
+    return hasattr(problem.levels[0], "n_lambda")
+
+
 def build_config3():
     from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy, build_sampler_problem
     h = build_hierarchy(box_mesh([4, 4, 4], [2, 2, 2], "hex"), 4)
@@ -47,9 +59,11 @@ def build_config3():
 
 
 def build_config4():
-    from parelagmc_amd.fe import build_hierarchy, build_sampler_problem, mesh_from_json
+    """(saddle-point form, hybridized form) of the same three levels"""
+    from parelagmc_amd.fe import build_hierarchy, build_hybrid_sampler_problem, build_sampler_problem, mesh_from_json
     h = build_hierarchy(mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet_embed.json")), 4)
-    return build_sampler_problem(h, corlen=0.1, embedded=True, lognormal=True, n_mc_levels=3)
+    kw = dict(corlen=0.1, embedded=True, lognormal=True, n_mc_levels=3)
+    return build_sampler_problem(h, **kw), build_hybrid_sampler_problem(h, **kw)
 
 
 def build_config5():
@@ -70,7 +84,8 @@ def _setup_worker(kind):
     configuration - what the reference does once in BuildHierarchy (/root/reference/src/PDESampler.cpp:177-334,
     src/DarcySolver.cpp:60-244), outside every timed region"""
     t0 = time.perf_counter()
-    out = {"r6": lambda: build_problem(6), "c3": build_config3, "c4": build_config4, "c5": build_config5}[kind]()
+    out = {"r6": lambda: (build_problem(6), build_hybrid_problem(6)), "c3": build_config3, "c4": build_config4,
+           "c5": build_config5}[kind]()
     return out, time.perf_counter() - t0
 
 
@@ -113,6 +128,14 @@ class SetupPool:
                 out, dt = _setup_worker(kind)
         self.seconds[kind] = dt
         return out
+
+    def wait(self):
+        """block until every worker has delivered: the results arrive in THIS process through a pipe and are unpickled by
+        the executor's thread under the GIL - hundreds of MB for the large configurations, which would otherwise land in
+        the timed region and stall the lanes' launch threads (measured: 2 440 instead of 2 700 samples/s)"""
+        if self.fut:
+            import concurrent.futures as cf
+            cf.wait(list(self.fut.values()))
 
     def close(self):
         if self.pool:
@@ -227,6 +250,80 @@ def solver_bytes_per_iteration(problem, nb, zb=4):
         total += mat(nnzS, ns_l) + 2 * F * ns_l + V * nc                       # res - (S P) xc   (S P has the pattern of S)
         total += mat(nnzS, ns_l) + 12.0 * ns_l + (2 * F + V + out) * ns_l + V * nc   # post-smoothing + coarse correction + dot
     return total
+
+
+def hybrid_bytes_per_iteration(hp, smp, nb, zb=4):
+    """ALGORITHMIC bytes one MINRES iteration on the multiplier system moves on the FINEST level of its V-cycle plus the
+    Krylov part - a lower bound of the iteration's bytes (the coarser levels of the aggregation hierarchy, ~12 % of the finest
+    level's rows, and the product with S P are left out), so the solver fraction derived from it is conservative."""
+    L = hp.levels[0]
+    n, nnz = L.n_lambda, L.H.nnz
+    V, Z, F = 8.0 * nb, float(zb) * nb, float(zb) * nb
+    post = smp.smoother_bytes(0, nb)
+    nc = max(0.0, (post - 12.0 * nnz - 12.0 * n - (2 * F + V + Z) * n) / V)    # rows of the first coarse level
+    total = 12.0 * nnz + 4.0 * n + (Z + V) * n                 # K5 on H: q = H u
+    total += V * 4 * n                                         # v_new = c0 q + c1 v1 + c2 v0
+    total += (4 * Z + 6 * V) / 4.0 * n                         # w / x updates on ALL rows, four iterations per pass
+    total += 12.0 * nnz + 12.0 * n + (V + F) * n               # pre-smoothing: r in, x out
+    total += 12.0 * nnz + 4.0 * n + (V + 2 * F) * n            # residual: r, x in; res out
+    total += 12.0 * n + F * n + V * nc                         # restriction P^T res
+    total += 2 * F * n + V * nc                                # res - (S P) xc, without the bytes of S P
+    total += post
+    return total
+
+
+def hybrid_roofline(farm, hp, nb, tag, next_batch, iters_total, dt):
+    """Roofline block of the hybridized solver.  The largest single kernel of its iteration is the post-smoothing of the finest
+    V-cycle level (k::vc_postsmooth32): `achieved` = its algorithmic bytes / the raw HIP-event bracket around every launch
+    of three solo batches of lane 0.  `operator` = the Krylov operator K5 on H (the CSR SpMM the metric names) bracketed in
+    the same batches; `solver` = the whole iteration."""
+    ctx, smp = farm.lanes[0][0], farm.lanes[0][1]
+    L = hp.levels[0]
+    zb = smp.z_bytes()
+    smp.set_operator_timing(True)
+    smp.operator_time()
+    smp.smoother_time()
+    for j in range(3):
+        check_stats(farm.one_batch(0, next_batch + j), "the in-loop kernel pass")
+    gap_ms = smp.operator_event_overhead()
+    op_ms, op_n = smp.operator_time()
+    sm_ms, sm_n, sm_gap = smp.smoother_time()
+    smp.set_operator_timing(False)
+    x = ctx.array(np.random.default_rng(0).standard_normal(nb * L.n_lambda))
+    _, k_ms, k_bytes = smp.Mult(0, x, repeat=50)
+    op_bytes = k_bytes - nb * (8.0 - zb) * L.n_lambda
+    sm_bytes = smp.smoother_bytes(0, nb)
+    op_raw = op_ms / max(op_n, 1)
+    sbytes = hybrid_bytes_per_iteration(hp, smp, nb, zb)
+    operator = {"kernel": f"pmc::sell_spmm_kernel<{nb}, 0, 0, true, 1, ...> = K5 on H (n_lambda = {L.n_lambda}, "
+                          f"nnz = {L.H.nnz}) with the fused <u, Hu>, in the MINRES loop",
+                "achieved": op_bytes / (op_raw * 1e-3) / 1e9, "frac": op_bytes / (op_raw * 1e-3) / 1e9 / PEAK_GBS,
+                "bytes_per_launch": op_bytes, "avg_kernel_ms": op_raw, "launches": op_n,
+                "event_overhead_ms": gap_ms / max(op_n, 1),
+                "traffic": traffic_entry(f"{tag}_hyb_k5_nb{nb}_inloop"),
+                "isolated": {"achieved": k_bytes / (k_ms * 1e-3) / 1e9, "avg_kernel_ms": k_ms,
+                             "frac": k_bytes / (k_ms * 1e-3) / 1e9 / PEAK_GBS}}
+    solver = {"bytes_per_iteration": sbytes, "batch_iterations": iters_total,
+              "what": "finest V-cycle level + Krylov vectors only (a lower bound of the bytes: conservative)",
+              "achieved": sbytes * iters_total / dt / 1e9, "frac": sbytes * iters_total / dt / 1e9 / PEAK_GBS}
+    if sm_n == 0:
+        # everything stored fp64 (PMC_STORAGE_FP64): the V-cycle runs the generic fp64 kernels, which are not bracketed -
+        # the block is the operator's then
+        out = dict(operator)
+        out.update({"bound": "hbm", "peak": PEAK_GBS, "unit": "GB/s", "solver": solver,
+                    "timing": "raw HIP-event bracket around every in-loop launch"})
+        return out
+    sm_raw = sm_ms / sm_n
+    ach = sm_bytes / (sm_raw * 1e-3) / 1e9
+    return {"bound": "hbm",
+            "kernel": f"pmc::vc_poly2_kernel<{nb}, float, {'float' if zb == 4 else 'double'}, float, true, true, 0> = "
+                      "post-smoothing of the finest level of the multiplier V-cycle (one-pass degree-2 polynomial of the "
+                      "residual + coarse correction + fused <r, z>), as launched inside the MINRES loop; one lane alone on the GPU",
+            "achieved": ach, "peak": PEAK_GBS, "unit": "GB/s", "frac": ach / PEAK_GBS,
+            "traffic": traffic_entry(f"{tag}_hyb_post_nb{nb}_inloop"), "traffic_provenance": traffic_provenance(),
+            "bytes_per_launch": sm_bytes, "avg_kernel_ms": sm_raw, "launches": sm_n,
+            "timing": "raw HIP-event bracket around every in-loop launch", "event_overhead_ms": sm_gap / max(sm_n, 1),
+            "operator": operator, "solver": solver}
 
 
 def lib_sha256():
@@ -630,13 +727,14 @@ def config4(seed, sp, lanes=4, cpu=True, nrep=4):
         c = capi.Context(0, seed=seed)
         L[i] = (c, capi.PDESampler(c, sp, projection="gather"), None)
     in_threads(make, lanes)
-    out = {"workload": "EmbeddedPDESampler cube_tet_embed r=4, DoF " + str([lv.n_u + lv.n_s for lv in sp.levels[:3]]) +
+    out = {"solver": "hybridization" if is_hybrid(sp) else "saddle-point MINRES-BJ-GS",
+           "workload": "EmbeddedPDESampler cube_tet_embed r=4, DoF " + str([lv.n_u + lv.n_s for lv in sp.levels[:3]]) +
                        f", original elements {[len(i) for i in sp.orig_index[:3]]}, per level nsamples x (Sample + Eval), {lanes} lanes",
            "levels": level_rates(L, (0, 1, 2), nrep=nrep, darcy=False)}
     for c, sm, _ in L:
         sm.close()
         c.close()
-    if cpu:
+    if cpu and not is_hybrid(sp):
         try:
             out["cpu_baseline"] = cpu_level_rates(sp, None, seed, (0, 1, 2), (1, 2, 8))
         except Exception as e:   # noqa: BLE001
@@ -738,7 +836,8 @@ def timed_farm(farm, steps, first_step, warmup=2):
     return time.perf_counter() - t0, st
 
 
-def sampler_point(problem, dev, seed, nb, ns, steps, tag, what, cpu_per_core=None, opts=None, roofline=True):
+def sampler_point(problem, dev, seed, nb, ns, steps, tag, what, cpu_per_core=None, opts=None, roofline=True,
+                  cpu_problem=None):
     """One sampler-only figure on level 0 of `problem` (the harness shape of the headline: `ns` lanes x `nb` realizations per
     step): value, iterations, K5 roofline of the in-loop launches, and - cpu_per_core - the CPU column beside it."""
     farm = SamplerFarm(problem, dev, seed, nb, ns, opts=opts)
@@ -750,13 +849,17 @@ def sampler_point(problem, dev, seed, nb, ns, steps, tag, what, cpu_per_core=Non
     zb = farm.lanes[0][1].z_bytes()
     out = {"workload": what, "value": steps * nb * ns / dt, "unit": "samples/s", "steps": steps, "batch": nb, "streams": ns,
            "mean_minres_iterations": float(np.mean(it)), "precond_storage": "fp32" if zb == 4 else "fp64"}
-    if roofline:
+    if is_hybrid(problem):
+        out["solver"] = "hybridization"
+    if roofline and is_hybrid(problem):
+        out["roofline"] = hybrid_roofline(farm, problem, nb, tag, (2 + steps + 1) * ns, bi, dt)
+    elif roofline:
         out["roofline"] = operator_roofline(farm, problem, nb, tag, (2 + steps + 1) * ns,
                                             solver_bytes_per_iteration(problem, nb, zb), bi, dt)
     farm.close()
     if cpu_per_core:
         try:
-            out["cpu_baseline"] = cpu_baseline(problem, seed, cpu_per_core)
+            out["cpu_baseline"] = cpu_baseline(cpu_problem if cpu_problem is not None else problem, seed, cpu_per_core)
         except Exception as e:   # noqa: BLE001
             out["cpu_baseline"] = {"error": repr(e)}
     return out
@@ -869,6 +972,11 @@ def main():
                     help="build the configurations' operators in this process instead of in background worker processes "
                          "(use it under rocprofv3: its preloaded library may have initialised the GPU, and a process that has "
                          "must not start another program)")
+    ap.add_argument("--solver", choices=("hybrid", "saddle"), default="hybrid",
+                    help="solver of the headline: hybrid = the reference's Hybridization option (element-local elimination to "
+                         "the SPD multiplier system, MINRES + aggregation V-cycle; pmc_sampler_create_hybrid), saddle = its "
+                         "default MINRES-BJ-GS on the saddle-point system (pmc_sampler_create).  The other one is measured "
+                         "under extra.")
     ap.add_argument("--seed", type=int, default=20261003)
     args = ap.parse_args()
 
@@ -916,18 +1024,21 @@ def main():
 
     from parelagmc_amd import capi
 
-    problem = build_problem(args.refine)
+    problem = build_problem(args.refine)          # the saddle-point form: CPU baseline, extra.saddle_point_minres
     L = problem.levels[0]
+    hybrid = args.solver == "hybrid"
+    head = build_hybrid_problem(args.refine) if hybrid else problem
     dev = (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0
     red_dev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     nb, ns = args.batch, max(1, args.streams)
-    farm = SamplerFarm(problem, dev, args.seed, nb, ns, world, rank)
+    farm = SamplerFarm(head, dev, args.seed, nb, ns, world, rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    pool.wait()
     for i in range(args.warmup):
         farm.step(i)
     barrier()
@@ -965,8 +1076,12 @@ def main():
     out = None
     zb = farm.lanes[0][1].z_bytes()
     if rank == 0:
-        sbytes = solver_bytes_per_iteration(problem, nb, zb)
         next_batch = (args.warmup + args.steps + 1) * ns
+        solver_text = (f"solver: hybridization (the reference's alternative to its default, src/PDESampler.cpp:291,307-311: "
+                       f"element-local elimination to H lambda = G f on {head.levels[0].n_lambda} multipliers, nnz(H)="
+                       f"{head.levels[0].H.nnz}; MINRES + one aggregation V-cycle; s = z f - G^T lambda) - the same field to "
+                       f"the solver tolerance; the default MINRES-BJ-GS path is extra.saddle_point_minres"
+                       if hybrid else "solver: MINRES-BJ-GS on the saddle-point system (the reference's default)")
         out = {
             "metric": "MC samples/sec (SPDE field + Darcy QoI) at stated DoF; SpMV HBM GB/s vs roofline",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -975,7 +1090,8 @@ def main():
             "config": {"workload": f"PDESampler cube_tet r={args.refine}, {L.n_u + L.n_s} DoF "
                                    f"(n_s={L.n_s}, n_u={L.n_u}, nnz(A)={L.nnz}), 1 MC level, corlen 0.1: the SPDE field only, as "
                                    f"BASELINE config 2 is (the Darcy QoI leg is measured on config 3 under extra.mlmc_config3), "
-                                   f"MINRES 300/1e-6/1e-12, {ns} x {nb} realizations per step, all converged",
+                                   f"MINRES 300/1e-6/1e-12, {ns} x {nb} realizations per step, all converged; " + solver_text,
+                       "solver": "hybridization" if hybrid else "saddle-point MINRES-BJ-GS",
                        "mean_minres_iterations": acc[0] / max(acc[1], 1.0), "batch": nb, "streams": ns,
                        "parallelism": f"sample-farm x{world}",
                        # pmc_solver_opts.precond_storage of this run: operators, Krylov vectors, products, recurrences and
@@ -983,7 +1099,9 @@ def main():
                        # preconditioner is stored (extra.fp64_storage: the same run with everything stored fp64)
                        "precond_storage": "fp32" if zb == 4 else "fp64"},
             "devices": min(world, ndev), "ranks": per_rank,
-            "roofline": operator_roofline(farm, problem, nb, f"r{args.refine}", next_batch, sbytes, acc[2], dt),
+            "roofline": (hybrid_roofline(farm, head, nb, f"r{args.refine}", next_batch, acc[2], dt) if hybrid else
+                         operator_roofline(farm, problem, nb, f"r{args.refine}", next_batch,
+                                           solver_bytes_per_iteration(problem, nb, zb), acc[2], dt)),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, args.seed, 8)
@@ -1003,16 +1121,27 @@ def main():
     cpu = not args.no_cpu_baseline
     if extras:
         # everything fp64 (pmc_solver_opts.precond_storage = PMC_STORAGE_FP64): the same harness, a third of the steps
+        if hybrid:
+            # the reference's DEFAULT solver on the same workload: the headline of rounds 1-3, with its K5 roofline
+            attempt("saddle_point_minres", lambda: sampler_point(
+                problem, dev, args.seed, nb, ns, max(4, args.steps // 2), f"r{args.refine}",
+                f"the headline workload with the reference's default solver: MINRES-BJ-GS on the saddle-point system "
+                f"({L.n_u + L.n_s} DoF, nnz(A)={L.nnz}), {ns} x {nb} realizations per step"))
+        else:
+            attempt("hybridization", lambda: sampler_point(
+                build_hybrid_problem(args.refine), dev, args.seed, nb, ns, max(4, args.steps // 2), f"r{args.refine}",
+                "the headline workload with the hybridized solver"))
         attempt("fp64_storage", lambda: sampler_point(
-            problem, dev, args.seed, nb, ns, max(4, args.steps // 3), f"r{args.refine}_fp64",
+            head, dev, args.seed, nb, ns, max(4, args.steps // 3), f"r{args.refine}_fp64",
             f"the headline workload with precond_storage = fp64 (everything stored fp64, as the reference is: "
             f"/root/reference/src/PDESampler.cpp:279-333)", opts=capi.solver_opts(precond_storage=capi.PMC_STORAGE_FP64)))
         # the drop-in path of INTEGRATION.md section 2: one realization per call, host pointers
         attempt("dropin_nb1", lambda: {
             "what": "one Sample + one Eval (+ SolveFwd) per call with nbatch = 1 and HOST pointers, one handle: what the "
                     "reference's unchanged serial manager would drive (src/MLMC_Manager.cpp:113-173)",
-            "config2": dropin_sampler(problem, dev, args.seed, 16, 0),
-            "config2_hipgraph": dropin_sampler(problem, dev, args.seed, 16, 1)})
+            "config2": dropin_sampler(head, dev, args.seed, 16, 0),
+            "config2_saddle_point_minres": dropin_sampler(problem, dev, args.seed, 16, 0),
+            "config2_saddle_point_minres_hipgraph": dropin_sampler(problem, dev, args.seed, 16, 1)})
     if not args.no_mlmc and not args.no_extras:
         probs3 = pool.get("c3")
         if world == 1:
@@ -1076,15 +1205,28 @@ def main():
                 if rank == 0:
                     extra["mlmc_farm"] = {"error": repr(e)}
     if extras:
-        for k, fn in ((4, config4), (5, config5)):
-            if args.only_config in (None, k):
-                attempt(f"c{k}", lambda k=k, fn=fn: fn(args.seed, pool.get(f"c{k}"), cpu=args.all_configs and cpu,
-                                                      nrep=3 if k == 4 else 2))
+        if args.only_config in (None, 4):
+            def c4():
+                sp4, hp4 = pool.get("c4")
+                m = config4(args.seed, hp4 if hybrid else sp4, cpu=False, nrep=3)
+                # the other solver on the same levels (tetrahedra with badly shaped cells: the block-diagonal preconditioner
+                # of the saddle-point system needs 44-69 iterations there) and, with --all-configs, the CPU column
+                m["other_solver"] = config4(args.seed, sp4 if hybrid else hp4, cpu=args.all_configs and cpu, nrep=3)
+                return m
+            attempt("c4", c4)
+        if args.only_config in (None, 5):
+            # hexahedra: the saddle-point form is the sparser one there (M couples 3 faces, H 11) and stays the faster solver
+            attempt("c5", lambda: config5(args.seed, pool.get("c5"), cpu=args.all_configs and cpu, nrep=2))
         if not args.no_r6 and args.refine != 6:
-            attempt("r6", lambda: sampler_point(
-                pool.get("r6"), dev, args.seed, nb, ns, 12, "r6",
-                "PDESampler cube_tet r=6, 4743168 DoF: operator + vectors exceed the 256 MiB Infinity Cache, every kernel is "
-                "HBM-bound", cpu_per_core=1 if cpu else None))
+            def r6():
+                p6, h6 = pool.get("r6")
+                what = ("PDESampler cube_tet r=6, 4743168 DoF: operator + vectors exceed the 256 MiB Infinity Cache, every "
+                        "kernel is HBM-bound")
+                m = sampler_point(h6 if hybrid else p6, dev, args.seed, nb, ns, 12, "r6", what,
+                                  cpu_per_core=1 if cpu else None, cpu_problem=p6)
+                m["other_solver"] = sampler_point(p6 if hybrid else h6, dev, args.seed, nb, ns, 6, "r6", what)
+                return m
+            attempt("r6", r6)
         extra["setup_seconds_in_worker_processes"] = dict(pool.seconds)
     pool.close()
     if rank == 0 and extra:

@@ -214,7 +214,9 @@ int pmc_sampler_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_sam
  * multigrid as preconditioner.  Every level is a Monte Carlo level.  The handle behaves like any other pmc_sampler
  * (Sample / Eval / projections / batch width); init_s / use_init are accepted and ignored (the multiplier has no
  * counterpart of a coarse field), pmc_sampler_mult / _apply_preconditioner / _apply_operator act on multiplier vectors
- * of n_lambda entries, pmc_sampler_nnz reports nnz(H). */
+ * of n_lambda entries, pmc_sampler_nnz reports nnz(H).  Of pmc_solver_opts the Krylov fields, precond_storage,
+ * mg_smooth_degree / mg_coarse_* apply; the smoothing interval of the aggregation hierarchy is [lmax / (2 mg_smooth_ratio),
+ * lmax] (default 16); cheb_*_M, schur_scale, mg_coarsening and mini_max_rows have no role. */
 int pmc_sampler_create_hybrid(pmc_ctx* ctx, int nlevels, const pmc_hybrid_level* levels, double alpha, double matern_g,
                               int lognormal, const pmc_solver_opts* opts, pmc_sampler** out);
 int pmc_sampler_is_hybrid(const pmc_sampler* s);
@@ -280,6 +282,13 @@ int pmc_sampler_operator_time(pmc_sampler* s, double* total_ms, int64_t* launche
 /* Behind every timed launch an EMPTY event bracket is recorded as well: returns and clears the sum of those [ms] - what
  * the event pair itself adds to a bracket on that stream (call before pmc_sampler_operator_time clears the count). */
 int pmc_sampler_operator_event_overhead(pmc_sampler* s, double* total_ms);
+/* Hybridized samplers, while pmc_sampler_set_operator_timing is on: the post-smoothing kernel of the finest level of the
+ * multiplier V-cycle (k::vc_postsmooth32: the largest single kernel of an iteration) is bracketed the same way.
+ * pmc_sampler_smoother_bytes: algorithmic bytes of one such launch = 12 B per entry of H + 12 B per row + nbatch x
+ * ((4 + 4 + 8 + z) n_lambda + 8 n_coarse): residual and pre-smoothed iterate (fp32) and r read, z written, the coarse
+ * correction read once.  Both report 0 for a saddle-point sampler. */
+int pmc_sampler_smoother_time(pmc_sampler* s, double* total_ms, int64_t* launches, double* event_overhead_ms);
+int pmc_sampler_smoother_bytes(const pmc_sampler* s, int level, int nbatch, double* bytes);
 
 /* ---- DarcySolver ------------------------------------------------------------------------ */
 int pmc_darcy_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_darcy_level* levels,

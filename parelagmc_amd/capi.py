@@ -94,6 +94,8 @@ SYMBOLS = {
     "pmc_sampler_create_hybrid": (C.c_int, [_VP, C.c_int, C.POINTER(pmc_hybrid_level), C.c_double, C.c_double, C.c_int,
                                             C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
     "pmc_sampler_is_hybrid": (C.c_int, [_VP]),
+    "pmc_sampler_smoother_time": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "pmc_sampler_smoother_bytes": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pmc_sampler_destroy": (None, [_VP]),
     "pmc_sampler_set_projection": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_csr), C.POINTER(C.c_int32),
                                              C.POINTER(C.c_double), C.c_int]),
@@ -473,6 +475,18 @@ class PDESampler:
         ms = C.c_double(0.0)
         _check(self.ctx.lib.pmc_sampler_operator_event_overhead(self.h, C.byref(ms)))
         return ms.value
+
+    def smoother_time(self):
+        """(total ms, launches, event overhead ms) of the bracketed post-smoothing launches (hybridized samplers) since the
+        last call"""
+        ms, n, g = C.c_double(0.0), C.c_int64(0), C.c_double(0.0)
+        _check(self.ctx.lib.pmc_sampler_smoother_time(self.h, C.byref(ms), C.byref(n), C.byref(g)))
+        return ms.value, n.value, g.value
+
+    def smoother_bytes(self, level, nbatch):
+        b = C.c_double(0.0)
+        _check(self.ctx.lib.pmc_sampler_smoother_bytes(self.h, level, nbatch, C.byref(b)))
+        return b.value
 
     def Mult(self, level, x, repeat=1):
         """y = [M Bt; B -aW] x (the block operator's Mult).  x: (nbatch, n_u+n_s) numpy or a

@@ -426,6 +426,22 @@ int pmc_sampler_operator_time(pmc_sampler* s, double* total_ms, int64_t* launche
     });
 }
 
+int pmc_sampler_smoother_time(pmc_sampler* s, double* total_ms, int64_t* launches, double* event_overhead_ms) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr, "sampler is NULL");
+        if (total_ms) *total_ms = s->impl.vc_timer.ms;
+        if (launches) *launches = s->impl.vc_timer.launches;
+        if (event_overhead_ms) *event_overhead_ms = s->impl.vc_timer.gap_ms;
+        s->impl.vc_timer.clear();
+    });
+}
+int pmc_sampler_smoother_bytes(const pmc_sampler* s, int level, int nbatch, double* bytes) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr && bytes != nullptr, "pmc_sampler_smoother_bytes: NULL argument");
+        *bytes = s->impl.smoother_bytes(level, nbatch);
+    });
+}
+
 int pmc_sampler_operator_event_overhead(pmc_sampler* s, double* total_ms) {
     return guarded([&] {
         PMC_REQUIRE(s != nullptr && total_ms != nullptr, "operator_event_overhead: bad arguments");

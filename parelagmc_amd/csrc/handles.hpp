@@ -42,6 +42,7 @@ struct Sampler {
     std::vector<std::unique_ptr<Multigrid>> amg;   // per MC level: internal smoothed-aggregation hierarchy (if selected)
     double anisotropy = 1.0;
     bool hybrid = false;                           // pmc_sampler_create_hybrid: multiplier system, amg[l] its V-cycle
+    OpTimer vc_timer;                              // hybrid: the finest level's post-smoothing launches (with work.op_timer.on)
     MinresWork work;
     DevBuf<double> rhs, sol, tA, tB, cx, cd, cx2, stage_in, stage_out, stage_emb, mini_scratch;
     DevBuf<pmc_stats> mini_stats;
@@ -50,6 +51,8 @@ struct Sampler {
             const pmc_solver_opts& o);
     Sampler(Ctx& c, int nlevels, const pmc_hybrid_level* in, double alpha, double g, bool lognormal, const pmc_solver_opts& o);
     // rows of the vectors the Krylov solver of `level` iterates on
+    // algorithmic bytes of one launch of the timed post-smoothing kernel (level 0 of the hybrid V-cycle of `level`)
+    double smoother_bytes(int level, int nb) const;
     size_t system_rows(int level) const { return hybrid ? (size_t)lv[level].n_u : (size_t)lv[level].n_u + lv[level].n_s; }
     void set_projection(int level, int kind, const pmc_csr* Gt, const int32_t* idx, const double* inv_w, int orig_size);
     void sample(int level, uint64_t first_id, int nbatch, double* xi, int memspace);

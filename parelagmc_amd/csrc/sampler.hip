@@ -48,13 +48,15 @@ HostCsr schur_host(const HostCsr& B, const HostCsr& Bt, const std::vector<double
 }
 
 // device V-cycle levels of an algebraic hierarchy (setup)
-static std::unique_ptr<Multigrid> build_chain(const std::vector<AmgLevelHost>& lv, const pmc_solver_opts& o, hipStream_t st) {
+static std::unique_ptr<Multigrid> build_chain(const std::vector<AmgLevelHost>& lv, const pmc_solver_opts& o, hipStream_t st,
+                                              double ratio_scale = 1.0, bool f32_any_injection = false) {
     std::unique_ptr<Multigrid> mg(new Multigrid());
     mg->smooth_degree = o.mg_smooth_degree;
-    mg->smooth_ratio = o.mg_smooth_ratio;
+    mg->smooth_ratio = ratio_scale * o.mg_smooth_ratio;
     mg->coarse_degree = o.mg_coarse_degree;
     mg->coarse_ratio = o.mg_coarse_ratio;
     mg->f32_intermediates = o.precond_storage != PMC_STORAGE_FP64;
+    mg->f32_any_injection = f32_any_injection;
     mg->L.resize(lv.size());
     for (size_t l = 0; l < lv.size(); ++l) {
         MgLevel& m = mg->L[l];
@@ -295,8 +297,11 @@ Sampler::Sampler(Ctx& c, int nlevels_, const pmc_hybrid_level* in, double alpha_
         int passes0 = 3, passes1 = 3;
         if (const char* e = lab_env("PMC_HYB_PASSES0")) passes0 = atoi(e);
         if (const char* e = lab_env("PMC_HYB_PASSES1")) passes1 = atoi(e);
-        amg[l] = build_chain(agg_hierarchy(H, passes0, passes1, /*theta=*/0.25, /*min_size=*/256, /*max_levels=*/14), o, st);
-        amg[l]->f32_any_injection = true;
+        // the aggregation hierarchy of H smooths on [lmax / (2 r), lmax], r = mg_smooth_ratio - twice the interval ratio of the
+        // Schur-complement hierarchies (measured at 400 k multipliers, 4 lanes x 32: r = 8 2 630, 12 ... 30 2 900, 50 2 650
+        // samples/s; 21 -> 20 iterations)
+        amg[l] = build_chain(agg_hierarchy(H, passes0, passes1, /*theta=*/0.25, /*min_size=*/256, /*max_levels=*/14), o, st,
+                             /*ratio_scale=*/2.0, /*f32_any_injection=*/true);
         mg.L[l].n = L.n_s;
         if (l + 1 < nlevels) {
             HostCsr P = csr_from_c(L.P, true, "sampler P");
@@ -532,10 +537,13 @@ void Sampler::solve_system(int level, int nb, bool zero_guess, int x_row0, int x
         return k::DotParts{partial, k::spmm_z(L.main, nb_, Av, x, y, partial, x)};
     };
     PrecFn prec = preconditioner(level, nb, degM, mgp, mg_l0);
+    mgp->smooth_timer = (hybrid && work.op_timer.on && opts.use_graph == 0) ? &vc_timer : nullptr;
+    vc_timer.on = mgp->smooth_timer != nullptr;
     GraphHint hint;
     hint.key = hash_mix(hash_mix(hash_mix(0x5a, (uint64_t)level + 1), (uint64_t)nb), (uint64_t)x_row0);
     hint.sig = hash_ptr(hash_ptr(hash_ptr(mgp->signature(mg_l0), cx.p), cd.p), cx2.p);
     MinresResult res = minres_solve(ctx, nb, A, prec, rhs.p, sol.p, zero_guess, opts, work, x_row0, x_nrows, nullptr, hint);
+    if (vc_timer.on) vc_timer.harvest();   // minres_solve has synchronised the stream
     if (stats) {
         ctx.phase_mark(2);
         for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
@@ -575,6 +583,16 @@ PrecFn Sampler::preconditioner(int level, int nb, int degM, Multigrid* mgp, int 
         L.join();
         return k::DotParts{dot_partial, nblk_s, dot_partial2, nblk_u};   // <r, z> = s-block partials + u-block partials
     };
+}
+
+// post-smoothing of the finest V-cycle level: shared matrix (scaled values + column indices), 1 / diagonal and parent index
+// per row; per realization res (fp32), the pre-smoothed iterate (fp32) and r (fp64, for the fused <r, z>) read, z written,
+// and the coarse correction (fp64) gathered once per coarse row
+double Sampler::smoother_bytes(int level, int nb) const {
+    if (!hybrid || level < 0 || level >= n_mc || !amg[level] || amg[level]->L.size() < 2) return 0.0;
+    const MgLevel& m = amg[level]->L[0];
+    const double zb = opts.precond_storage == PMC_STORAGE_FP64 ? 8.0 : 4.0;
+    return 12.0 * (double)m.S.nnz + 12.0 * m.n + (double)nb * ((4.0 + 4.0 + 8.0 + zb) * m.n + 8.0 * amg[level]->L[1].n);
 }
 
 void Sampler::apply_preconditioner(int level, int nbatch, const double* r_in, double* z_out, int memspace) {

@@ -234,8 +234,11 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         }
         double* xc = cycle(st, nb, l + 1, l0, lc.r.p, nullptr, zvec(), nullptr, nullptr, side);
         k::vc_residual_coarse32(st, nb, view(lv.SP), resf, xc);
+        const bool timed = smooth_timer && smooth_timer->on && l == l0;
+        if (timed) smooth_timer->begin(st);
         const int nblk = ztarget ? k::vc_postsmooth32_z(st, nb, As, lv.dinv.p, resf, xf, ztarget, c0, c1, r, lv.parent.p, xc, dot_partial)
                                  : k::vc_postsmooth32(st, nb, As, lv.dinv.p, resf, xf, out, c0, c1, r, lv.parent.p, xc, dot_partial);
+        if (timed) smooth_timer->end(st);
         if (dot_blocks) *dot_blocks = dot_partial ? nblk : 0;
         return ztarget ? nullptr : out;
     }

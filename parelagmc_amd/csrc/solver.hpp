@@ -94,6 +94,7 @@ struct MgLevel {
     const double* scaled_ptr() const { return (bv && f32) ? reinterpret_cast<const double*>(scaled32.p) : vals_scaled.p; }
 };
 
+struct OpTimer;
 struct Multigrid {
     std::vector<MgLevel> L;      // [0] finest
     int smooth_degree = 2;
@@ -111,6 +112,9 @@ struct Multigrid {
     // the fp32-intermediate kernels also on levels whose indicator prolongator is NOT over groups of 8 consecutive rows
     // (aggregation hierarchies: the restriction is then a separate product with P^T)
     bool f32_any_injection = false;
+    // in-situ timing (HIP events) of the top level's post-smoothing kernel - the largest single kernel of a cycle on an
+    // aggregation hierarchy; set per solve by the owner, null = off
+    OpTimer* smooth_timer = nullptr;
     void build_tails(hipStream_t st);
     // per-realization hierarchies: give every level of at most max_rows rows transposed value copies so that
     // build_tails can include them; refresh_bv_tail(nb) re-fills the copies (call after every numeric refresh)

@@ -38,6 +38,15 @@ class HybridLevel:
     w_diag: np.ndarray        # (n_s,)
     P: Optional[sp.csr_matrix]  # s-space prolongator to the next coarser level (couples xi between levels), None on the last
 
+    @property
+    def n_u(self) -> int:
+        """flux unknowns of the saddle-point form of this level: one per face, as the multipliers"""
+        return self.n_lambda
+
+    @property
+    def nnz(self) -> int:
+        return int(self.H.nnz)
+
 
 @dataclasses.dataclass
 class HybridSamplerProblem:

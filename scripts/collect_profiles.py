@@ -24,11 +24,13 @@ def find(d, suffix):
 
 for src, dst, what in (("prof_bench", "bench", "python bench.py --steps 20 --warmup 5 --inline-setup"),
                        ("prof_s1", "bench_s1", "python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-extras"),
+                       ("prof_s1_saddle", "bench_s1_saddle", "python bench.py --solver saddle --streams 1 --steps 40 --no-cpu-baseline --no-extras"),
                        ("prof_s1_r6", "bench_s1_r6", "python bench.py --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras"),
+                       ("prof_s1_r6_saddle", "bench_s1_r6_saddle", "python bench.py --solver saddle --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras"),
                        ("prof_c3", "c3_darcy_op", "python scripts/c3_darcy_op.py"),
                        ("prof_s1_onestream", "lab_s1_onestream",
                         "LABORATORY library (libpmc_lab.so, PMC_SPLIT_MIN=0: one lane on ONE stream, every kernel alone on the chip) "
-                        "python bench.py --streams 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras")):
+                        "python bench.py --solver saddle --streams 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras")):
     try:
         stats = find(src, "kernel_stats.csv")
     except FileNotFoundError:
@@ -55,32 +57,70 @@ def mean(d, key):
 
 
 out = {}
-for refine, nvec in ((5, 595968), (6, 4743168)):
-    fetch = per_kernel(find(f"pmc_fetch_r{refine}", "counter_collection.csv"))
-    write = per_kernel(find(f"pmc_write_r{refine}", "counter_collection.csv"))
-    for name, acc in (("fetch_size", fetch), ("write_size", write)):
-        with open(os.path.join(P, f"{tag}_pmc_{name}_r{refine}.csv"), "w") as f:
-            f.write("kernel,launches,mean_counter_value_KB\n")
-            for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-                f.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.3f}\n")
-    # one lane alone on the GPU splits the Lanczos update into a u-row and an s-row launch (two streams): compare totals
-    # (the bench runs the large levels 32 realizations per launch; older passes 16)
-    nbw = 32 if any("lincomb3_kernel<32" in k for k in fetch) else 16
-    lv = [x for k, vals in fetch.items() if f"lincomb3_kernel<{nbw}" in k for x in vals]
-    split = len(set(round(x / 1024.0) for x in lv)) > 1 and max(lv) > 1.5 * min(lv)
-    lf = sum(lv) / len(lv) * (2 if split else 1)
-    read_kb = 3 * nvec * nbw * 8 / 1024.0
-    for key, kern in ((f"r{refine}_nb{nbw}_inloop", f"sell_spmm_kernel<{nbw}, 0, 0, true, 1,"),
-                      (f"r{refine}_nb{nbw}", f"sell_spmm_kernel<{nbw}, 0, 0, false, 2,"),
-                      (f"r{refine}_nb1", "sell_spmm_kernel<1, 0, 0, false, 2,")):
-        fr, n = mean(fetch, kern)
-        wr, _ = mean(write, kern)
-        if fr is None or wr is None:
-            continue
-        out[key] = {"kernel": f"pmc::{kern} ...> on A", "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB_raw": wr,
-                    "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
-    out[f"r{refine}_correction"] = ("FETCH_SIZE x2 on gfx950; cross-check in the same pass on the flat lincomb3_kernel: raw "
-                                    f"{lf:.0f} KB for {read_kb:.0f} KB actually read (ratio {read_kb / lf:.3f})")
+
+
+def dump(name, acc, suffix):
+    with open(os.path.join(P, f"{tag}_pmc_{name}_{suffix}.csv"), "w") as f:
+        f.write("kernel,launches,mean_counter_value_KB\n")
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            f.write(f"\"{k}\",{len(v)},{sum(v) / len(v):.3f}\n")
+
+
+def entry(fetch, write, kern, what):
+    fr, n = mean(fetch, kern)
+    wr, _ = mean(write, kern)
+    if fr is None or wr is None:
+        return None
+    return {"kernel": f"pmc::{kern} ...> {what}", "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB_raw": wr,
+            "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
+
+
+for refine, nvec, nlam in ((5, 595968, 399360), (6, 4743168, 3170304)):
+    # saddle-point passes (--solver saddle): K5 on A in the loop / isolated / one column; the flat lincomb3 kernel as the
+    # cross-check of the FETCH_SIZE correction
+    try:
+        fetch = per_kernel(find(f"pmc_fetch_r{refine}s", "counter_collection.csv"))
+        write = per_kernel(find(f"pmc_write_r{refine}s", "counter_collection.csv"))
+    except FileNotFoundError as e:
+        print("no saddle-point counter passes:", e)
+        fetch = write = None
+    if fetch is not None:
+        dump("fetch_size", fetch, f"r{refine}_saddle")
+        dump("write_size", write, f"r{refine}_saddle")
+        # one lane alone on the GPU splits the Lanczos update into a u-row and an s-row launch (two streams): compare totals
+        nbw = 32
+        lv = [x for k, vals in fetch.items() if f"lincomb3_kernel<{nbw}" in k for x in vals]
+        split = len(set(round(x / 1024.0) for x in lv)) > 1 and max(lv) > 1.5 * min(lv)
+        lf = sum(lv) / len(lv) * (2 if split else 1)
+        read_kb = 3 * nvec * nbw * 8 / 1024.0
+        for key, kern in ((f"r{refine}_nb{nbw}_inloop", f"sell_spmm_kernel<{nbw}, 0, 0, true, 1,"),
+                          (f"r{refine}_nb{nbw}", f"sell_spmm_kernel<{nbw}, 0, 0, false, 2,"),
+                          (f"r{refine}_nb1", "sell_spmm_kernel<1, 0, 0, false, 2,")):
+            e = entry(fetch, write, kern, "on A")
+            if e:
+                out[key] = e
+        out[f"r{refine}_correction"] = ("FETCH_SIZE x2 on gfx950; cross-check in the same pass on the flat lincomb3_kernel: raw "
+                                        f"{lf:.0f} KB for {read_kb:.0f} KB actually read (ratio {read_kb / lf:.3f})")
+    # hybridized passes (the default solver of bench.py): post-smoothing of the finest V-cycle level, K5 on H
+    try:
+        fetch = per_kernel(find(f"pmc_fetch_r{refine}", "counter_collection.csv"))
+        write = per_kernel(find(f"pmc_write_r{refine}", "counter_collection.csv"))
+    except FileNotFoundError as e:
+        print("no hybrid counter passes:", e)
+        continue
+    dump("fetch_size", fetch, f"r{refine}")
+    dump("write_size", write, f"r{refine}")
+    for key, kern, what in ((f"r{refine}_hyb_post_nb32_inloop", "vc_poly2_kernel<32, float, float, float, true, true, 0>",
+                             "post-smoothing of the finest level of the multiplier V-cycle, in the MINRES loop"),
+                            (f"r{refine}_hyb_k5_nb32_inloop", "sell_spmm_kernel<32, 0, 0, true, 1,", "K5 on H, in the MINRES loop")):
+        e = entry(fetch, write, kern.rstrip(">") if kern.endswith(">") else kern, what)
+        if e:
+            out[key] = e
+    lv = [x for k, vals in fetch.items() if "lincomb3_kernel<32" in k for x in vals]
+    if lv:
+        read_kb = 3 * nlam * 32 * 8 / 1024.0
+        out[f"r{refine}_hyb_correction"] = (f"lincomb3_kernel in the hybrid pass: raw {sum(lv) / len(lv):.0f} KB for {read_kb:.0f} KB "
+                                            f"actually read (ratio {read_kb / (sum(lv) / len(lv)):.3f})")
 # Darcy operator of config 3 (u-rows [M(k) | B^T] x with the fused dot, in the MINRES loop)
 try:
     fetch = per_kernel(find("pmc_fetch_c3", "counter_collection.csv"))
@@ -120,7 +160,7 @@ try:
                         "the tree's sources differ from the ones the passes ran, or are uncommitted: no commit named")
 except Exception:   # noqa: BLE001
     out["head"] = None
-out["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py [--refine 6] --steps 2 --warmup 1 "
-                  "--streams 1 --no-cpu-baseline --no-mlmc (separate passes, scripts/make_profiles.sh)")
+out["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py [--solver saddle] [--refine 6] "
+                  "--steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-extras (separate passes, scripts/make_profiles.sh)")
 json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

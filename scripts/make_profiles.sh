@@ -5,10 +5,12 @@
 #      sits in the tree when it is called)
 #   1. rocprofv3 --kernel-trace --stats of the DEFAULT bench command (the driver's)  -> gpurun_out/prof_bench/
 #   2. the same for one lane per GPU (--streams 1): per-kernel time without overlap   -> gpurun_out/prof_s1/
-#   3. the same at the HBM-bound r = 6, one lane                                      -> gpurun_out/prof_s1_r6/
+#      (the headline's solver, hybridization) and gpurun_out/prof_s1_saddle/ (--solver saddle: MINRES-BJ-GS on the
+#      saddle-point system, the K5 of extra.saddle_point_minres)
+#   3. the same at the HBM-bound r = 6, one lane                                      -> gpurun_out/prof_s1_r6{,_saddle}/
 #   4. the Darcy operator + M-block polynomial of config 3 in the MINRES loop, one lane (scripts/c3_darcy_op.py) -> gpurun_out/prof_c3/
-#   5. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) on short single-lane runs at r = 5, at r = 6 and on the config-3 Darcy
-#      kernels                                                            -> gpurun_out/pmc_{fetch,write}_{r5,r6,c3}/
+#   5. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) on short single-lane runs at r = 5 and r = 6 (both solvers) and on the
+#      config-3 Darcy kernels                                   -> gpurun_out/pmc_{fetch,write}_{r5,r5s,r6,r6s,c3}/
 #   6. (laboratory library present) one lane on ONE stream, every kernel alone on the chip: standalone rows of the flat
 #      vector kernels (lincomb3, w / x update) against the streaming ceiling          -> gpurun_out/prof_s1_onestream/
 # scripts/collect_profiles.py rNN then copies the summaries into profiles/ (tracked) and rebuilds profiles/pmc_traffic.json.
@@ -39,20 +41,24 @@ runpy() {   # name, script
 PROF=(--kernel-trace --stats)
 if [ -z "$SKIP_BENCH_PROFILE" ]; then run prof_bench --steps 20 --warmup 5 --inline-setup || exit 1; fi
 run prof_s1 --streams 1 --steps 40 --no-cpu-baseline --no-extras || exit 1
+run prof_s1_saddle --solver saddle --streams 1 --steps 40 --no-cpu-baseline --no-extras || exit 1
 run prof_s1_r6 --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras || exit 1
+run prof_s1_r6_saddle --solver saddle --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras || exit 1
 runpy prof_c3 scripts/c3_darcy_op.py || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
   PROF=(--kernel-trace --pmc $c)
   n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
   run pmc_${n}_r5 --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
+  run pmc_${n}_r5s --solver saddle --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
   run pmc_${n}_r6 --refine 6 --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
+  run pmc_${n}_r6s --solver saddle --refine 6 --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
   runpy pmc_${n}_c3 scripts/c3_darcy_op.py || exit 1
 done
 if [ -f $R/parelagmc_amd/lib/libpmc_lab.so ]; then
   PROF=(--kernel-trace --stats)
   cp $R/parelagmc_amd/lib/libpmc.so /tmp/libpmc_product.so
   cp $R/parelagmc_amd/lib/libpmc_lab.so $R/parelagmc_amd/lib/libpmc.so
-  PMC_SPLIT_MIN=0 run prof_s1_onestream --streams 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras
+  PMC_SPLIT_MIN=0 run prof_s1_onestream --solver saddle --streams 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras
   rc=$?
   cp /tmp/libpmc_product.so $R/parelagmc_amd/lib/libpmc.so
   [ $rc = 0 ] || exit 1

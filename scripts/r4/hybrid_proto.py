@@ -187,7 +187,7 @@ b = G @ f
 for passes in (2, 3):
     for smoothed in ((False,) if not DIRECT else (False, True)):
         lv = hierarchy(H, passes, smoothed)
-        mg = MG(lv, deg=2, ratio=8.0)
+        mg = MG(lv, deg=int(os.environ.get("DEG", "2")), ratio=float(os.environ.get("RATIO", "8.0")))
         x, it = pcg(H, lambda r: mg.v(0, r), b)
         s_it = z * f - G.T @ x
         opc = sum(t[0].nnz for t in lv) / lv[0][0].nnz

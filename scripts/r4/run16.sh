@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -k 10 400 python scripts/r4/hybrid_opts.py > gpurun_out/r4_hyb_opts.txt 2>&1 || { tail -5 gpurun_out/r4_hyb_opts.txt; exit 1; }
+cat gpurun_out/r4_hyb_opts.txt
+bash scripts/r4/run15.sh
