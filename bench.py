@@ -1140,6 +1140,7 @@ def main():
             "what": "one Sample + one Eval (+ SolveFwd) per call with nbatch = 1 and HOST pointers, one handle: what the "
                     "reference's unchanged serial manager would drive (src/MLMC_Manager.cpp:113-173)",
             "config2": dropin_sampler(head, dev, args.seed, 16, 0),
+            "config2_hipgraph": dropin_sampler(head, dev, args.seed, 16, 1),
             "config2_saddle_point_minres": dropin_sampler(problem, dev, args.seed, 16, 0),
             "config2_saddle_point_minres_hipgraph": dropin_sampler(problem, dev, args.seed, 16, 1)})
     if not args.no_mlmc and not args.no_extras:

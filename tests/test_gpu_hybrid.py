@@ -206,3 +206,25 @@ def test_hybrid_error_paths(gpu_ctx, hex_hierarchy_small):
     with pytest.raises(capi.PmcError):
         smp.Eval(2, np.zeros((1, hp.levels[0].n_s)), xi_level=0)
     smp.close()
+
+
+def test_hybrid_hipgraph_replay_and_wide_column_groups_give_the_eager_field(gpu_ctx, hex_hierarchy_small):
+    """opts.use_graph captures the MINRES iterations of the multiplier solve as it does the saddle-point one; a small level
+    runs 64 ... 256 realizations per launch as column groups of 32: both must return the eager single-group bits / field"""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hybrid_sampler_problem
+    hp = build_hybrid_sampler_problem(hex_hierarchy_small, corlen=0.1)
+    eager = capi.PDESampler(gpu_ctx, hp, capi.solver_opts(**TIGHT))
+    graph = capi.PDESampler(gpu_ctx, hp, capi.solver_opts(use_graph=1, **TIGHT))
+    w = eager.BatchWidth(1)
+    assert w >= 64                                   # 8^3 ... 4^3 hexes: far below the width-32 threshold
+    xi = eager.Sample(1, first_id=5, nbatch=w)
+    a, st = eager.Eval(1, xi, return_stats=True)
+    assert all(t[1] == 1 for t in st)
+    for _ in range(2):                               # capture, then replay
+        b = graph.Eval(1, xi)
+        assert rel(b, a) < 1e-10
+    for k in (0, w // 2 + 1, w - 1):                 # a column of the wide launch against its own launch of one
+        assert rel(a[k], eager.Eval(1, xi[k:k + 1])[0]) < 1e-10
+    eager.close()
+    graph.close()
