@@ -17,6 +17,7 @@ What is restated (reference lines, all under /root/reference):
   * Darcy system, BCs, QoI               src/DarcySolver.cpp:386-414 (rhs), :360-384 (ess_data),
                                          :297-319 (observation functional), :472-520 (assemble),
                                          :416-437 (Q, C)
+  * hybridization branch of Eval         src/PDESampler.cpp:291,307-311,451-480 (RefHybrid: element-local elimination)
   * element matrices                     SURVEY.md Appendix A.5: cell (hx, hy, hz); a u-dof is the
                                          total flux through a face along +axis; the two faces of one
                                          direction couple with  h_a / A_a * [[1/3, 1/6], [1/6, 1/3]],
@@ -191,6 +192,69 @@ class RefSampler:
             r = self.levels[l].prolongation(self.levels[l + 1]).T @ r
         L = self.levels[level]
         return self._solver(level).solve(np.concatenate([np.zeros(L.n_u), r]))[L.n_u:]
+
+
+class RefHybrid:
+    """The sampler's hybridization solver restated from the closed forms (src/PDESampler.cpp:291,307-311,451-480: the
+    "Hybridization" branch of Eval; ParELAG's HybridHdivL2 does the elimination).  Fluxes are broken across faces, one Lagrange
+    multiplier per face re-imposes continuity (on a boundary face: u.n = 0, every boundary face being essential for the sampler,
+    :210-214).  All cells of a HexLevel are equal, so ONE 7 x 7 inverse gives every element's blocks:
+
+        [[X, y], [y^T, z]] = [[M_e, b_e^T], [b_e, -alpha |e|]]^-1,   H = sum_e C_e X C_e^T,  G = sum_e C_e y,
+        H lambda = G f,    s = z f - G^T lambda.
+
+    Multiplier sign convention of THIS module: C_e = +1 for the cell on the low side of a face (the face is that cell's high
+    face), -1 for the cell on its high side; a boundary face has its one cell with the sign that rule gives it."""
+
+    def __init__(self, levels, corlen):
+        self.levels = levels
+        self.alpha = 1.0 / (corlen * corlen)
+        self.g = matern_g(corlen, 3)
+        self._ops = {}
+
+    def local_inverse(self, l):
+        L = self.levels[l]
+        A = np.zeros((7, 7))
+        b = np.zeros(6)
+        for axis in range(3):
+            scale = L.h[axis] / (L.vol / L.h[axis])
+            lo, hi = 2 * axis, 2 * axis + 1
+            A[lo, lo] = A[hi, hi] = scale / 3.0
+            A[lo, hi] = A[hi, lo] = scale / 6.0
+            b[lo], b[hi] = -1.0, 1.0                       # global +axis orientation: outward on the high face
+        A[:6, 6] = A[6, :6] = b
+        A[6, 6] = -self.alpha * L.vol
+        Ai = np.linalg.inv(A)
+        return Ai[:6, :6], Ai[:6, 6], Ai[6, 6]
+
+    def operators(self, l):
+        """(H, G, z) of level l in this module's face / cell numbering"""
+        if l in self._ops:
+            return self._ops[l]
+        L = self.levels[l]
+        X, y, z = self.local_inverse(l)
+        faces = np.empty((L.n_s, 6), dtype=np.int64)       # local order: x-low, x-high, y-low, y-high, z-low, z-high
+        c = np.empty(6)
+        for axis in range(3):
+            lo, hi = L.cell_faces(axis)
+            faces[:, 2 * axis], faces[:, 2 * axis + 1] = lo, hi
+            c[2 * axis], c[2 * axis + 1] = -1.0, 1.0       # the cell sits on the HIGH side of its low face
+        Xc = c[:, None] * X * c[None, :]
+        rows = np.repeat(faces, 6, axis=1).ravel()
+        cols = np.tile(faces, (1, 6)).ravel()
+        H = sp.coo_matrix((np.tile(Xc.ravel(), L.n_s), (rows, cols)), shape=(L.n_u, L.n_u)).tocsr()
+        G = sp.coo_matrix((np.tile(c * y, L.n_s), (faces.ravel(), np.repeat(np.arange(L.n_s), 6))), shape=(L.n_u, L.n_s)).tocsr()
+        self._ops[l] = (H, G, np.full(L.n_s, z))
+        return self._ops[l]
+
+    def eval(self, level, xi_level, xi):
+        """Gaussian field on `level` from white noise of xi_level <= level: the hybridized solve, sparse direct"""
+        f = -self.g * np.sqrt(self.levels[xi_level].w_diag()) * xi
+        for l in range(xi_level, level):
+            f = self.levels[l].prolongation(self.levels[l + 1]).T @ f
+        H, G, z = self.operators(level)
+        lam = spla.spsolve(H.tocsc(), G @ f)
+        return z * f - G.T @ lam
 
 
 class RefDarcy:
