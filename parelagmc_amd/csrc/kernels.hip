@@ -195,6 +195,28 @@ __device__ __forceinline__ void load_raw(const float* __restrict__ p, RawVec<flo
     }
 }
 
+// The T = 8 gathers of one slice column (fp32 rows, four columns per lane) as ONE point of use.  hipcc sinks loads from
+// __restrict__ pointers past __builtin_amdgcn_sched_barrier (they carry no ordering against it) down to their first use; in
+// the kernels whose gathered fp32 values die in their own FMA group that turned "eight gathers in flight" into load - wait -
+// convert - fma, eight times per slice column (ISA of vc_residual_kernel<32, float, ...> and vc_poly2_kernel<32, float, ...>,
+// round 4: a level of 44 k rows took 67-74 us per launch where the fp64-gather kernel on the same matrix took 30).  An empty
+// asm that takes all eight results as operands cannot be split: every load is issued before it.
+typedef float pmc_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pin_gathers(RawVec<float, 4> (&xr)[8]) {
+    pmc_f4 q0 = {xr[0].v[0], xr[0].v[1], xr[0].v[2], xr[0].v[3]}, q1 = {xr[1].v[0], xr[1].v[1], xr[1].v[2], xr[1].v[3]};
+    pmc_f4 q2 = {xr[2].v[0], xr[2].v[1], xr[2].v[2], xr[2].v[3]}, q3 = {xr[3].v[0], xr[3].v[1], xr[3].v[2], xr[3].v[3]};
+    pmc_f4 q4 = {xr[4].v[0], xr[4].v[1], xr[4].v[2], xr[4].v[3]}, q5 = {xr[5].v[0], xr[5].v[1], xr[5].v[2], xr[5].v[3]};
+    pmc_f4 q6 = {xr[6].v[0], xr[6].v[1], xr[6].v[2], xr[6].v[3]}, q7 = {xr[7].v[0], xr[7].v[1], xr[7].v[2], xr[7].v[3]};
+    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7));
+    const pmc_f4 q[8] = {q0, q1, q2, q3, q4, q5, q6, q7};
+#pragma unroll
+    for (int rs = 0; rs < 8; ++rs)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xr[rs].v[c] = q[rs][c];
+}
+template <typename XT, int C, int T>
+__device__ __forceinline__ void pin_gathers(RawVec<XT, C> (&)[T]) {}
+
 // Vector streams without reuse inside the iteration (MINRES w / x updates of large levels): non-temporal variants, so that a
 // flat kernel running beside a gather kernel (second stream, other lanes) does not sweep that kernel's rows out of L2.
 // Measured at 0.6 M rows x 16: one lane 1096 -> 1112, four lanes 1446 -> 1454 samples/s; small levels keep the cached
@@ -446,6 +468,7 @@ __device__ __forceinline__ void sell_row_range(const int* __restrict__ cols, con
                     load_raw<C>(reinterpret_cast<const float*>(vals) + ((size_t)(slot - lane + rs * G + g) * LD + t * C), avf[rs]);
                 if constexpr (BV == 1) load_c<C>(vals + ((size_t)(slot - lane + rs * G + g) * LD + t * C), avd[rs]);
             }
+            if (!pdot && !xlast) pin_gathers(xr);   // (with pdot / xlast the values live past the FMAs and stay grouped)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rs = 0; rs < T; ++rs) {
@@ -870,42 +893,61 @@ __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices
         double acc[T][C];
         const int off = slice_off[slice];
         sell_row_range_t<NB, XT, NT, BV>(cols, vals_scaled, r, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+        // row steps in pairs: the own-row reads of both (and the parent indices of the coarse correction) are issued before
+        // either is consumed - rows past the end re-read the last row and store nothing
+        // (pairs only where the gathers above leave the registers for it - the fp32-gather instantiations; the fp64-gather
+        // ones, with sixteen 16-byte gathers in flight, would drop from three to two waves per SIMD)
+        constexpr int H = (T >= 2 && sizeof(XT) == 4) ? 2 : 1;
 #pragma unroll
-        for (int rs = 0; rs < T; ++rs) {
-            const int row = slice * kWave + rs * G + g;
-            if (row >= nrows) continue;
-            const size_t at = (size_t)row * LD + t * C;
-            double rv[C], xv[C], di[C];
-            load_v<C>(r + at, rv);
-            if constexpr (BV != 0) {
-                load_c<C>(dinv + at, di);
-            } else {
-                const double sdi = dinv[row];
+        for (int h0 = 0; h0 < T; h0 += H) {
+            double rv[H][C], di[H][C], x0[H][C], pc[H][C], wv[H][C];
+            size_t at[H];
+            int par[H];
+            bool ok[H];
 #pragma unroll
-                for (int c = 0; c < C; ++c) di[c] = sdi;
-            }
+            for (int u = 0; u < H; ++u) {
+                const int row = slice * kWave + (h0 + u) * G + g;
+                ok[u] = row < nrows;
+                const int rowc = ok[u] ? row : nrows - 1;
+                at[u] = (size_t)rowc * LD + t * C;
+                load_v<C>(r + at[u], rv[u]);
+                if constexpr (BV != 0) {
+                    load_c<C>(dinv + at[u], di[u]);
+                } else {
+                    const double sdi = dinv[rowc];
 #pragma unroll
-            for (int c = 0; c < C; ++c) xv[c] = di[c] * (c0 * rv[c] - c1 * acc[rs][c]);
-            if (xadd) {
-                double x0[C];
-                load_v<C>(xadd + at, x0);
-#pragma unroll
-                for (int c = 0; c < C; ++c) xv[c] += x0[c];
+                    for (int c = 0; c < C; ++c) di[u][c] = sdi;
+                }
+                if (xadd) load_v<C>(xadd + at[u], x0[u]);
+                if (padd_idx) par[u] = padd_idx[rowc];
+                if constexpr (DOT) load_c<C>(dot_with + at[u], wv[u]);
             }
             if (padd_idx) {
-                double pc[C];
-                load_c<C>(padd_x + (size_t)padd_idx[row] * LD + t * C, pc);
 #pragma unroll
-                for (int c = 0; c < C; ++c) xv[c] += pc[c];
+                for (int u = 0; u < H; ++u) load_c<C>(padd_x + (size_t)par[u] * LD + t * C, pc[u]);
             }
-            round_to<OT>(xv);
-            if constexpr (DOT) {
-                double wv[C];
-                load_c<C>(dot_with + at, wv);
 #pragma unroll
-                for (int c = 0; c < C; ++c) p[c] = fma(wv[c], xv[c], p[c]);
+            for (int u = 0; u < H; ++u) {
+                double xv[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) xv[c] = di[u][c] * (c0 * rv[u][c] - c1 * acc[h0 + u][c]);
+                if (xadd) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) xv[c] += x0[u][c];
+                }
+                if (padd_idx) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) xv[c] += pc[u][c];
+                }
+                round_to<OT>(xv);
+                if (ok[u]) {
+                    if constexpr (DOT) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) p[c] = fma(wv[u][c], xv[c], p[c]);
+                    }
+                    store_v_stream<NT, C>(xout + at[u], xv);
+                }
             }
-            store_v_stream<NT, C>(xout + at, xv);
         }
     }
     if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
@@ -936,15 +978,24 @@ __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nsli
         double acc[T][C];
         const int off = slice_off[slice];
         sell_row_range_t<NB, XT, false, BV>(cols, vals, x, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+        // the own-row reads of H row steps are issued together (rows past the end re-read the last row): one latency per
+        // batch instead of one per row step - these launches are single occupancy rounds of dependent loads
+        constexpr int H = T >= 4 ? 4 : T;
+        double rvb[H][C];
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
+            if (rs % H == 0) {
+#pragma unroll
+                for (int u = 0; u < H; ++u) {
+                    const int ru = row + u * G;
+                    load_v<C>(r + (size_t)(ru < nrows ? ru : nrows - 1) * LD + t * C, rvb[u]);
+                }
+            }
             if (row < nrows) {
                 const size_t at = (size_t)row * LD + t * C;
-                double rv[C];
-                load_v<C>(r + at, rv);
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[rs][c] = rv[c] - acc[rs][c];
+                for (int c = 0; c < C; ++c) acc[rs][c] = rvb[rs % H][c] - acc[rs][c];
                 if constexpr (STORE) store_v<C>(y + at, acc[rs]);
             } else if constexpr (R8) {
 #pragma unroll

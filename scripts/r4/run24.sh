@@ -1,0 +1,9 @@
+#!/bin/bash
+# fp32-gather V-cycle kernels with their gathers pinned in flight and the epilogue reads batched: parity tests, farm shape, profile
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_hybrid.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3 || exit 1
+timeout -k 10 300 python scripts/r4/hybrid_farm.py 5 both 4,1 > gpurun_out/r4_pin_farm.txt 2>&1 || { tail -5 gpurun_out/r4_pin_farm.txt; exit 1; }
+cat gpurun_out/r4_pin_farm.txt
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4_prof_hyb -o p -- python3 scripts/r4/hybrid_prof.py 5 > gpurun_out/r4_prof_hyb.log 2>&1
+echo "prof rc=$?"
