@@ -216,6 +216,21 @@ __device__ __forceinline__ void pin_gathers(RawVec<float, 4> (&xr)[8]) {
 }
 template <typename XT, int C, int T>
 __device__ __forceinline__ void pin_gathers(RawVec<XT, C> (&)[T]) {}
+// the same for sixteen widened values (8 row steps x 2 columns or 4 x 4): the own-row reads of an epilogue, issued together
+template <int R, int C>
+__device__ __forceinline__ void pin_block(double (&a)[R][C]) {
+    if constexpr (R == 8 && C == 2)
+        asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]),
+                     "+v"(a[3][1]), "+v"(a[4][0]), "+v"(a[4][1]), "+v"(a[5][0]), "+v"(a[5][1]), "+v"(a[6][0]), "+v"(a[6][1]),
+                     "+v"(a[7][0]), "+v"(a[7][1]));
+    else if constexpr (R == 4 && C == 4)
+        asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]),
+                     "+v"(a[1][3]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[2][2]), "+v"(a[2][3]), "+v"(a[3][0]), "+v"(a[3][1]),
+                     "+v"(a[3][2]), "+v"(a[3][3]));
+    else if constexpr (R == 2 && C == 4)
+        asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]),
+                     "+v"(a[1][3]));
+}
 
 // Vector streams without reuse inside the iteration (MINRES w / x updates of large levels): non-temporal variants, so that a
 // flat kernel running beside a gather kernel (second stream, other lanes) does not sweep that kernel's rows out of L2.
@@ -804,19 +819,39 @@ __global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 ? 3 : 1)) void sell_po
         } else {
             sell_row_product<NB, BV>(slice_off, cols, vals_scaled, r, slice, lane, LD, acc);
         }
+        // own-row reads in batches of H row steps (shared values only: the per-realization instantiations have no registers
+        // to spare); rows past the end re-read the last row and store nothing
+        constexpr int H = (BV == 0 && T >= 4) ? 2 : 1;   // (4 spills in the fp64-output instantiations: 168 registers are the cap)
+        double rvb[H][C], dib[H];
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
             const int row = slice * kWave + rs * G + g;
+            if constexpr (H > 1) {
+                if (rs % H == 0) {
+#pragma unroll
+                    for (int u = 0; u < H; ++u) {
+                        const int rc = min(row + u * G, nrows - 1);
+                        load_c<C>(r + (size_t)rc * LD + t * C, rvb[u]);
+                        dib[u] = dinv[rc];
+                    }
+                    pin_block(rvb);
+                }
+            }
             if (row >= nrows) continue;
             const size_t at = (size_t)row * LD + t * C;
             double rv[C], xv[C], di[C];
-            load_c<C>(r + at, rv);
-            if constexpr (BV) {
-                load_c<C>(dinv + at, di);
-            } else {
-                const double s = dinv[row];
+            if constexpr (H > 1) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) di[c] = s;
+                for (int c = 0; c < C; ++c) { rv[c] = rvb[rs % H][c]; di[c] = dib[rs % H]; }
+            } else {
+                load_c<C>(r + at, rv);
+                if constexpr (BV) {
+                    load_c<C>(dinv + at, di);
+                } else {
+                    const double s = dinv[row];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) di[c] = s;
+                }
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) xv[c] = di[c] * (c0 * rv[c] - c1 * acc[rs][c]);
@@ -1267,6 +1302,17 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
             double acc[TH][C];
             eg_row_product<NB, false, kEgNt, TH, XT>(cols1, w1, e12, coef, gw, x1, nullptr, nrows, slice, lane, LD, rs0, acc);
             sell_row_part<NB, false, false, kEgNt, TH, XT>(cols2, vals2, x2, nullptr, o2, w2, lane, LD, rs0, acc);
+            // the dot operand of all TH row steps is requested at once (rows past the end re-read the last row): the guarded
+            // per-row-step form left the compiler one load - wait - fma chain per row step
+            double wv[DOT ? TH : 1][C];
+            if constexpr (DOT) {
+#pragma unroll
+                for (int q = 0; q < TH; ++q) {
+                    const int rowc = min(slice * kWave + (rs0 + q) * G + g, nrows - 1);
+                    load_v<C>(dot_with + (size_t)rowc * LD + t * C, wv[q]);
+                }
+                pin_block(wv);
+            }
 #pragma unroll
             for (int q = 0; q < TH; ++q) {
                 const int row = slice * kWave + (rs0 + q) * G + g;
@@ -1274,10 +1320,8 @@ __global__ __launch_bounds__(kBlock) void eg_pair_spmm_kernel(
                 const size_t at = (size_t)row * LD + t * C;
                 store_c_stream<kEgNt, C>(y + at, acc[q]);
                 if constexpr (DOT) {
-                    double wv[C];
-                    load_v<C>(dot_with + at, wv);
 #pragma unroll
-                    for (int c = 0; c < C; ++c) p[c] = fma(wv[c], acc[q][c], p[c]);
+                    for (int c = 0; c < C; ++c) p[c] = fma(wv[q][c], acc[q][c], p[c]);
                 }
             }
         }
@@ -1311,20 +1355,28 @@ __global__ __launch_bounds__(kBlock) void eg_poly2_kernel(int nrows, int nslices
         for (int rs0 = 0; rs0 < T; rs0 += TH) {
             double acc[TH][C];
             eg_row_product<NB, true, kEgNt, TH>(cols, w, e12, coef, gw, r, dinv, nrows, slice, lane, LD, rs0, acc);
+            // own-row reads of all TH row steps at once (see eg_pair_spmm_kernel)
+            double rv[TH][C], di[TH][C];
+#pragma unroll
+            for (int q = 0; q < TH; ++q) {
+                const size_t atc = (size_t)min(slice * kWave + (rs0 + q) * G + g, nrows - 1) * LD + t * C;
+                load_c<C>(r + atc, rv[q]);
+                load_c<C>(dinv + atc, di[q]);
+            }
+            pin_block(rv);
+            pin_block(di);
 #pragma unroll
             for (int q = 0; q < TH; ++q) {
                 const int row = slice * kWave + (rs0 + q) * G + g;
                 if (row >= nrows) continue;
                 const size_t at = (size_t)row * LD + t * C;
-                double rv[C], di[C], xv[C];
-                load_c<C>(r + at, rv);
-                load_c<C>(dinv + at, di);
+                double xv[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) xv[c] = di[c] * (c0 * rv[c] - c1 * acc[q][c]);
+                for (int c = 0; c < C; ++c) xv[c] = di[q][c] * (c0 * rv[q][c] - c1 * acc[q][c]);
                 round_to<OT>(xv);
                 if constexpr (DOT) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) p[c] = fma(rv[c], xv[c], p[c]);
+                    for (int c = 0; c < C; ++c) p[c] = fma(rv[q][c], xv[c], p[c]);
                 }
                 store_v_stream<kEgNt, C>(xout + at, xv);
             }
