@@ -410,11 +410,15 @@ int batch_width(size_t rows, bool darcy) {
     // 16); PMC_S_WIDE_ROWS: the sampler's own limit
     static const size_t l32 = lim("PMC_WIDE_ROWS", 300000),
                         l32s = lim("PMC_S_WIDE_ROWS", lab_env("PMC_WIDE_ROWS") ? l32 : sampler_wide_rows()),
-                        l64 = lim("PMC_W64_ROWS", 150000), l128 = lim("PMC_W128_ROWS", 40000), l256 = lim("PMC_W256_ROWS", 20000);
+                        l64 = lim("PMC_W64_ROWS", 150000), l128 = lim("PMC_W128_ROWS", 40000), l256 = lim("PMC_W256_ROWS", 20000),
+                        // sampler levels up to 500 k rows: two column groups per launch (config 4's 314 k-row level, four lanes:
+                        // hybridized 5 735 -> 6 441, saddle-point 1 474 -> 1 512 realizations/s; a 600 k-row level gains 30 % with
+                        // one lane and nothing with four, LAB_NOTES 9.15)
+                        l64s = lim("PMC_S_W64_ROWS", lab_env("PMC_W64_ROWS") ? l64 : 500000);
     if (rows > (darcy ? l32 : l32s)) return 16;
     if (rows <= l256) return 256;
     if (rows <= l128) return 128;
-    if (rows <= l64) return 64;
+    if (rows <= (darcy ? l64 : l64s)) return 64;
     return 32;
 }
 
