@@ -6,6 +6,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
+from parelagmc_amd import capi  # noqa: E402
+if os.environ.get("HYB_LIB"):
+    capi.LIB_PATH = os.path.join(ROOT, "parelagmc_amd", "lib", os.environ["HYB_LIB"])
 from parelagmc_amd.fe import (box_mesh, build_darcy_problem, build_hierarchy, build_hybrid_sampler_problem,  # noqa: E402
                               build_sampler_problem, l2_projection_hierarchy, mesh_from_json)
 
