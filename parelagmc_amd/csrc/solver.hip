@@ -191,8 +191,13 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
                          double* dot_partial, int* dot_blocks, const std::function<void()>* side) {
     MgLevel& lv = L[l];
     lv.ensure(nb);
-    const bool tail_here = use_tail && l < (int)tail.size() && tail[l].p;
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
+    // A launch of few realizations (the drop-in path: one per call) runs the LDS tail on as many compute units as it has
+    // realizations, and a tail that starts at a level of several thousand rows with 17-27 entries each is bound by ONE
+    // unit's L2 port (LAB_NOTES 9.16: 142 us per cycle - half of a one-realization Eval of the hybridized sampler).  Such
+    // a level runs as kernels then and the tail starts one level further down.
+    const bool tail_later = nb <= 8 && lv.n > 4096 && !last && l + 1 < (int)tail.size() && tail[l + 1].p;
+    const bool tail_here = use_tail && l < (int)tail.size() && tail[l].p && !tail_later;
     const bool f32_shared = !last && !lv.bv && lv.has_sp && (lv.p_oct || f32_any_injection) && smooth_degree == 2 &&
                             lv.vals_scaled.p && f32_intermediates;
     const bool f32_bv = !last && lv.bv && lv.f32 && lv.p_oct && smooth_degree == 2 && lv.scaled32.p && f32_intermediates;
