@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := parelagmc_amd/csrc
 OBJDIR := build/obj
-SRCS := $(CSRC)/kernels.hip $(CSRC)/sparse.hip $(CSRC)/solver.hip $(CSRC)/sampler.hip $(CSRC)/darcy.hip $(CSRC)/capi.hip
+SRCS := $(CSRC)/kernels.hip $(CSRC)/sparse.hip $(CSRC)/solver.hip $(CSRC)/sampler.hip $(CSRC)/darcy.hip $(CSRC)/capi.hip $(CSRC)/hybrid_build.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.hpp) include/pmc.h
 EXTRA ?=

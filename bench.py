@@ -30,6 +30,152 @@ sys.path.insert(0, ROOT)
 PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
+LINE_CAP = 4096     # the driver keeps ~8 000 characters of stdout: the ONE JSON line stays well below that (BENCH_r04: a 21.7 kB
+#                     line lost its head - metric, value, roofline - and was recorded as unparsed)
+
+
+def _r(x, nd=4):
+    """a scalar for the compact line: floats rounded to nd significant digits, everything else as it is"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{nd}g}")
+
+
+def _get(d, *path):
+    for k in path:
+        if isinstance(d, dict):
+            d = d.get(k)
+        elif isinstance(d, list) and isinstance(k, int) and -len(d) <= k < len(d):
+            d = d[k]
+        else:
+            return None
+    return d
+
+
+def compact_line(full):
+    """The ONE stdout line of bench.py: headline, config, roofline, cpu_baseline and an `extra` of SCALARS (and short lists of
+    scalars) only, at most LINE_CAP bytes whatever the rank count.  Everything else - per-rank dicts, timer tables, prose, the
+    nested roofline blocks of every secondary figure - is in the full record (bench_full.json, path in `full_record`)."""
+    cfg = full.get("config", {})
+    rf = full.get("roofline", {}) or {}
+    hybrid = cfg.get("solver") == "hybridization"
+    ex = full.get("extra", {}) or {}
+    sad = ex.get("saddle_point_minres", {}) if hybrid else {}
+    # K5 on the saddle-point operator A (the CSR SpMM BASELINE.json's metric names): the headline's own block when the
+    # headline runs the default solver, extra.saddle_point_minres otherwise
+    saddle_k5 = _get(sad, "roofline", "frac") if hybrid else rf.get("frac")
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _r(out["value"], 6), _r(out["ms_per_step"], 6)
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:200], "solver": cfg.get("solver"), "batch": cfg.get("batch"),
+                     "streams": cfg.get("streams"), "precond_storage": cfg.get("precond_storage"),
+                     "mean_minres_iterations": _r(cfg.get("mean_minres_iterations")), "parallelism": cfg.get("parallelism"),
+                     "tolerance": cfg.get("tolerance")}
+    out["roofline"] = {"bound": "hbm", "kernel": str(rf.get("kernel", ""))[:80], "achieved": _r(rf.get("achieved")),
+                       "peak": rf.get("peak", PEAK_GBS), "unit": "GB/s", "frac": _r(rf.get("frac")),
+                       "traffic": _r(rf.get("traffic"), 6), "bytes_per_launch": _r(rf.get("bytes_per_launch"), 9),
+                       "avg_kernel_ms": _r(rf.get("avg_kernel_ms")), "launches": rf.get("launches"),
+                       "operator_frac": _r(_get(rf, "operator", "frac")) if hybrid else _r(rf.get("frac")),
+                       "operator_traffic": _r(_get(rf, "operator", "traffic"), 6) if hybrid else _r(rf.get("traffic"), 6),
+                       "operator_bytes_per_launch": _r(_get(rf, "operator", "bytes_per_launch"), 9) if hybrid else None,
+                       "saddle_k5_frac": _r(saddle_k5), "spmv_nb1_frac": _r(_get(sad if hybrid else full, "roofline", "spmv_nb1", "frac")),
+                       "solver_frac": _r(_get(rf, "solver", "frac")),
+                       "traffic_matches_library": _get(rf, "traffic_provenance", "matches_running_library")}
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit", "samples/s"), "cores": cb.get("cores"),
+                               "kind": cb.get("kind"), "solver": cb.get("solver"), "iterations": _r(cb.get("iterations")),
+                               "sample": str(cb.get("sample", ""))[:160]}
+        for k in ("saddle_value", "saddle_iterations", "error"):
+            if cb.get(k) is not None:
+                out["cpu_baseline"][k] = _r(cb[k]) if k != "error" else str(cb[k])[:120]
+    if full.get("n_gpus", 1) > 1:
+        sec = [r.get("seconds") for r in full.get("ranks", []) if isinstance(r, dict)]
+        out["rank_seconds"] = {"min": _r(min(sec)), "max": _r(max(sec))} if sec else None
+        out["devices"] = full.get("devices")
+    e = {}
+
+    def put(key, v):
+        if v is not None:
+            e[key] = v
+
+    def lv(block, key):
+        L = _get(block, "levels")
+        return [_r(x.get(key)) for x in L] if isinstance(L, list) else None
+    put("saddle_value", _r(sad.get("value")))
+    put("saddle_iterations", _r(sad.get("mean_minres_iterations")))
+    put("saddle_solver_frac", _r(_get(sad, "roofline", "solver", "frac")))
+    put("hybrid_value", _r(_get(ex, "hybridization", "value")))
+    put("fp64_value", _r(_get(ex, "fp64_storage", "value")))
+    put("dropin_eval_ms", _r(_get(ex, "dropin_nb1", "config2", "ms_per_Eval")))
+    put("dropin_samples_per_s", _r(_get(ex, "dropin_nb1", "config2", "samples_per_s")))
+    put("dropin_saddle_eval_ms", _r(_get(ex, "dropin_nb1", "config2_saddle_point_minres", "ms_per_Eval")))
+    c3 = ex.get("mlmc_config3", {})
+    put("c3_value", _r(c3.get("realizations_per_s")))
+    put("c3_cpu", _r(_get(c3, "cpu_baseline", "realizations_per_s")))
+    put("c3_eg_spmm_frac", _r(_get(c3, "roofline", "frac")))
+    put("c3_eg_poly_frac", _r(_get(c3, "roofline", "m_block_polynomial", "frac")))
+    put("c3_eg_poly_traffic", _r(_get(c3, "roofline", "m_block_polynomial", "traffic"), 6))
+    put("c3_dropin_round", _r(_get(ex, "dropin_nb1_config3", "round_64_256_1024_realizations_per_s")))
+    hx = ex.get("hex64", {})
+    put("hex64_value", _r(hx.get("value")))
+    put("hex64_k5_frac", _r(_get(hx, "roofline", "frac")))
+    put("hex64_cpu", _r(_get(hx, "cpu_baseline", "value")))
+    put("c4_values", lv(ex.get("c4"), "realizations_per_s"))
+    put("c4_iterations", lv(ex.get("c4"), "sampler_iterations_mean"))
+    put("c4_other_solver_values", lv(_get(ex, "c4", "other_solver"), "realizations_per_s"))
+    put("c5_values", lv(ex.get("c5"), "realizations_per_s"))
+    put("c5_mlmc_round", _r(_get(ex, "c5", "mlmc_round", "realizations_per_s")))
+    r6 = ex.get("r6", {})
+    put("r6_value", _r(r6.get("value")))
+    put("r6_iterations", _r(r6.get("mean_minres_iterations")))
+    put("r6_frac", _r(_get(r6, "roofline", "frac")))
+    put("r6_operator_frac", _r(_get(r6, "roofline", "operator", "frac")))
+    put("r6_solver_frac", _r(_get(r6, "roofline", "solver", "frac")))
+    put("r6_cpu", _r(_get(r6, "cpu_baseline", "value")))
+    put("r6_other_solver_value", _r(_get(r6, "other_solver", "value")))
+    put("r6_saddle_k5_frac", _r(_get(r6, "other_solver", "roofline", "frac")))
+    fm = ex.get("mlmc_farm", {})
+    put("farm_value", _r(fm.get("realizations_per_s")))
+    put("farm_collective", str(fm["collective"])[:60] if fm.get("collective") else None)
+    put("farm_allreduces_in_round", fm.get("allreduces_in_round"))
+    put("farm_allreduce_ms_max", _r(max(fm["allreduce_ms_per_rank"])) if fm.get("allreduce_ms_per_rank") else None)
+    put("farm_error", str(fm["error"])[:120] if fm.get("error") else None)
+    errs = sorted(k for k, v in ex.items() if isinstance(v, dict) and "error" in v)
+    put("errors", errs or None)
+    if e:
+        out["extra"] = e
+    out["full_record"] = full.get("full_record")
+    line = json.dumps(out, separators=(",", ":"))
+    while len(line) >= LINE_CAP and out.get("extra"):       # cannot happen with the fields above; the cap holds regardless
+        out["extra"].pop(next(reversed(out["extra"])))
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) < LINE_CAP, len(line)
+    return line
+
+
+def write_full_record(full):
+    """the complete record (every nested block the compact line leaves out) -> bench_full.json beside bench.py and, when the
+    directory exists, gpurun_out/bench_full.json; returns the path written first (None if neither is writable)"""
+    first = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if not os.path.isdir(d):
+            continue
+        try:
+            with open(os.path.join(d, "bench_full.json"), "w") as f:
+                json.dump(full, f, indent=1)
+            first = first or os.path.relpath(os.path.join(d, "bench_full.json"), ROOT)
+        except OSError:
+            pass
+    return first
+
+
 def build_problem(nref, extra_coarse=True):
     from parelagmc_amd.fe import build_hierarchy, build_sampler_problem, mesh_from_json
     mesh = mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet.json"))
@@ -1087,10 +1233,11 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"PDESampler cube_tet r={args.refine}, {L.n_u + L.n_s} DoF "
-                                   f"(n_s={L.n_s}, n_u={L.n_u}, nnz(A)={L.nnz}), 1 MC level, corlen 0.1: the SPDE field only, as "
-                                   f"BASELINE config 2 is (the Darcy QoI leg is measured on config 3 under extra.mlmc_config3), "
-                                   f"MINRES 300/1e-6/1e-12, {ns} x {nb} realizations per step, all converged; " + solver_text,
+            "config": {"workload": f"PDESampler cube_tet r={args.refine}, {L.n_u + L.n_s} DoF (n_s={L.n_s}, n_u={L.n_u}, "
+                                   f"nnz(A)={L.nnz}), 1 MC level, corlen 0.1, SPDE field only (BASELINE config 2), "
+                                   f"{ns} x {nb} realizations per step, all converged",
+                       "workload_detail": "the Darcy QoI leg is measured on config 3 under extra.mlmc_config3; " + solver_text,
+                       "tolerance": "MINRES 300 / rel 1e-6 / abs 1e-12",
                        "solver": "hybridization" if hybrid else "saddle-point MINRES-BJ-GS",
                        "mean_minres_iterations": acc[0] / max(acc[1], 1.0), "batch": nb, "streams": ns,
                        "parallelism": f"sample-farm x{world}",
@@ -1236,7 +1383,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        out["full_record"] = write_full_record(out)
+        print(json.dumps(out), file=sys.stderr)          # the full record on stderr as well (a log keeps it)
+        sys.stderr.flush()
+        print(compact_line(out))                         # stdout: ONE line, < LINE_CAP bytes
 
 
 if __name__ == "__main__":

@@ -137,6 +137,24 @@ typedef struct pmc_hybrid_level {
     pmc_csr P;             /* n_s(level) x n_s(level+1) = ComputeTrueP(sform); ignored on the last  */
 } pmc_hybrid_level;
 
+/* What PDESampler::BuildHierarchy holds for one level BEFORE it eliminates boundary rows - the input of the element-local
+ * elimination (pmc_hybrid_build).  The reference hands A[i] plus the level's de Rham sequence to
+ * prec_factory->BuildSolver(A[i], state) (src/PDESampler.cpp:302-318; extra parameter "L2MassWeight" = alpha, :307-311) and
+ * ParELAG's HybridHdivL2 reads the element matrices from the sequence; here they arrive as the same element decomposition of
+ * the u-mass matrix that pmc_darcy_level carries for ComputeMassOperator(uform, k). */
+typedef struct pmc_hybrid_elements {
+    int32_t n_u, n_s;
+    pmc_csr M_pattern;       /* n_u x n_u, sparsity of the u-mass matrix (vals ignored, may be NULL)                */
+    const int32_t* c_ptr;    /* nnz(M)+1: contributions of stored entry p are c_ptr[p] .. c_ptr[p+1]                */
+    const int32_t* c_elem;   /* element of each contribution                                                         */
+    const double* c_val;     /* element-matrix value (global face orientation)                                       */
+    pmc_csr B;               /* n_s x n_u as assembled, NO boundary elimination: row e lists every face of element e
+                                with the sign of its outward normal against the face's global normal (:232-234)     */
+    const double* w_diag;    /* n_s, diag(W) > 0                                                                     */
+    pmc_csr P;               /* n_s(level) x n_s(level+1) = ComputeTrueP(sform); ignored (may be zeroed) on the last */
+} pmc_hybrid_elements;
+typedef struct pmc_hybrid_system pmc_hybrid_system;
+
 /* One level of the Darcy hierarchy = what DarcySolver precomputes (src/DarcySolver.cpp:
  * 194-227 B/Bt/P, :297-319 obs, :360-384 ess_data, :386-414 rhs) plus the element
  * decomposition of the mass matrix that ComputeMassOperator(uform,k) re-assembles per sample
@@ -220,6 +238,16 @@ int pmc_sampler_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_sam
 int pmc_sampler_create_hybrid(pmc_ctx* ctx, int nlevels, const pmc_hybrid_level* levels, double alpha, double matern_g,
                               int lognormal, const pmc_solver_opts* opts, pmc_sampler** out);
 int pmc_sampler_is_hybrid(const pmc_sampler* s);
+/* The element-local elimination itself (host code, setup): one dense (n_fe + 1)^2 inverse per element,
+ * [[X, y], [y^T, z]]_e = [[M_e, b_e^T], [b_e, -alpha w_e]]^-1, H = sum_e C_e X_e C_e^T, G = sum_e C_e y_e, C_e = sign(B[e, f]).
+ * pmc_hybrid_system_level fills `view` with pointers into the system (valid until pmc_hybrid_system_destroy) - the arrays
+ * pmc_sampler_create_hybrid takes.  pmc_sampler_create_hybrid_from_elements = build every level, create, destroy: the one call
+ * that stands where the reference's `if (if_solver_hybridization)` branch builds its solver (src/PDESampler.cpp:302-318). */
+int pmc_hybrid_build(const pmc_hybrid_elements* level, double alpha, pmc_hybrid_system** out);
+int pmc_hybrid_system_level(const pmc_hybrid_system* sys, pmc_hybrid_level* view);
+void pmc_hybrid_system_destroy(pmc_hybrid_system* sys);
+int pmc_sampler_create_hybrid_from_elements(pmc_ctx* ctx, int nlevels, const pmc_hybrid_elements* levels, double alpha,
+                                            double matern_g, int lognormal, const pmc_solver_opts* opts, pmc_sampler** out);
 void pmc_sampler_destroy(pmc_sampler* s);
 /* Output map of the embedded variants.  PMC_PROJ_GATHER: s = sbar[gather_idx]
  * (src/EmbeddedPDESampler.cpp:552-556); PMC_PROJ_L2: s = inv_w_orig .* (Gt sbar)

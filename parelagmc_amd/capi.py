@@ -57,6 +57,12 @@ class pmc_hybrid_level(C.Structure):
                 ("z_diag", C.POINTER(C.c_double)), ("w_diag", C.POINTER(C.c_double)), ("P", pmc_csr)]
 
 
+class pmc_hybrid_elements(C.Structure):
+    _fields_ = [("n_u", C.c_int32), ("n_s", C.c_int32), ("M_pattern", pmc_csr), ("c_ptr", C.POINTER(C.c_int32)),
+                ("c_elem", C.POINTER(C.c_int32)), ("c_val", C.POINTER(C.c_double)), ("B", pmc_csr),
+                ("w_diag", C.POINTER(C.c_double)), ("P", pmc_csr)]
+
+
 class pmc_darcy_level(C.Structure):
     _fields_ = [("n_u", C.c_int32), ("n_p", C.c_int32), ("M_pattern", pmc_csr), ("c_ptr", C.POINTER(C.c_int32)),
                 ("c_elem", C.POINTER(C.c_int32)), ("c_val", C.POINTER(C.c_double)), ("B", pmc_csr),
@@ -94,6 +100,11 @@ SYMBOLS = {
     "pmc_sampler_create_hybrid": (C.c_int, [_VP, C.c_int, C.POINTER(pmc_hybrid_level), C.c_double, C.c_double, C.c_int,
                                             C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
     "pmc_sampler_is_hybrid": (C.c_int, [_VP]),
+    "pmc_hybrid_build": (C.c_int, [C.POINTER(pmc_hybrid_elements), C.c_double, C.POINTER(_VP)]),
+    "pmc_hybrid_system_level": (C.c_int, [_VP, C.POINTER(pmc_hybrid_level)]),
+    "pmc_hybrid_system_destroy": (None, [_VP]),
+    "pmc_sampler_create_hybrid_from_elements": (C.c_int, [_VP, C.c_int, C.POINTER(pmc_hybrid_elements), C.c_double, C.c_double,
+                                                          C.c_int, C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
     "pmc_sampler_smoother_time": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pmc_sampler_smoother_bytes": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pmc_sampler_destroy": (None, [_VP]),

@@ -32,3 +32,72 @@ def test_spawned_ranks_propagate_failure():
 def test_launcher_world_size_must_match_gpus():
     r = _run(["--gpus", "2"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def _canned_full_record():
+    """a complete record as bench.py assembled it in round 4 (21.7 kB as ONE line: the driver kept only its tail)"""
+    import json
+    with open(os.path.join(ROOT, "profiles", "r04_bench_output.log")) as f:
+        return json.loads([ln for ln in f.read().splitlines() if ln.startswith("{")][-1])
+
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def test_compact_line_fits_the_drivers_window_and_keeps_the_contract():
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = _canned_full_record()
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line) < bench.LINE_CAP <= 4096
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["value"] == float(f"{full['value']:.6g}") and d["metric"] == full["metric"]
+    assert len(d["config"]["workload"]) <= 200 and len(d["roofline"]["kernel"]) <= 80
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_kernel_ms", "operator_frac",
+              "saddle_k5_frac", "solver_frac"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-3
+    assert abs(d["roofline"]["saddle_k5_frac"] - full["extra"]["saddle_point_minres"]["roofline"]["frac"]) < 1e-3
+    for k in ("value", "cores", "kind", "unit", "sample"):
+        assert k in d["cpu_baseline"], k
+    # extra: scalars and flat lists of scalars only
+    for k, v in d["extra"].items():
+        assert not isinstance(v, dict), k
+        if isinstance(v, list):
+            assert all(not isinstance(x, (dict, list)) for x in v), k
+    assert d["extra"]["c3_value"] > 0 and len(d["extra"]["c4_values"]) == 3 and len(d["extra"]["c5_values"]) == 4
+
+
+def test_compact_line_with_eight_ranks_and_a_farm_block_stays_below_the_cap():
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = _canned_full_record()
+    full["n_gpus"] = 8
+    full["ranks"] = [dict(full["ranks"][0], rank=r, device=r, cpu_affinity={"pinned": True, "numa_node": r // 4, "ncpus": 48})
+                     for r in range(8)]
+    full.pop("cpu_baseline")
+    full["extra"] = {"mlmc_farm": dict(full["extra"]["mlmc_config3"], allreduce_ms=0.3, allreduces_in_round=1,
+                                       allreduce_ms_per_rank=[0.3] * 8, collective="rccl (pmc_allreduce_sum_f64 of the "
+                                       "library's communicator)", ranks_in_rccl_communicator=8)}
+    line = bench.compact_line(full)
+    assert len(line) < bench.LINE_CAP
+    d = json.loads(line)
+    assert d["n_gpus"] == 8 and d["rank_seconds"]["max"] >= d["rank_seconds"]["min"]
+    assert d["extra"]["farm_allreduces_in_round"] == 1 and "ranks" not in d
+
+
+def test_compact_line_survives_failed_secondary_figures():
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = _canned_full_record()
+    full["extra"] = {k: {"error": "RuntimeError('x' * 5000)" + "y" * 5000, "wall_s": 1.0} for k in full["extra"]}
+    full["cpu_baseline"] = {"error": "z" * 9000}
+    d = json.loads(bench.compact_line(full))
+    assert "mlmc_config3" in d["extra"]["errors"] and d["value"] > 0
