@@ -90,7 +90,7 @@ def compact_line(full):
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
         out["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit", "samples/s"), "cores": cb.get("cores"),
-                               "kind": cb.get("kind"), "solver": cb.get("solver"), "iterations": _r(cb.get("iterations")),
+                               "kind": cb.get("kind"), "solver": str(cb.get("solver", ""))[:72], "iterations": _r(cb.get("iterations")),
                                "sample": str(cb.get("sample", ""))[:160]}
         for k in ("saddle_value", "saddle_iterations", "error"):
             if cb.get(k) is not None:
@@ -139,6 +139,7 @@ def compact_line(full):
     put("r6_operator_frac", _r(_get(r6, "roofline", "operator", "frac")))
     put("r6_solver_frac", _r(_get(r6, "roofline", "solver", "frac")))
     put("r6_cpu", _r(_get(r6, "cpu_baseline", "value")))
+    put("r6_cpu_saddle", _r(_get(r6, "cpu_baseline", "saddle_value")))
     put("r6_other_solver_value", _r(_get(r6, "other_solver", "value")))
     put("r6_saddle_k5_frac", _r(_get(r6, "other_solver", "roofline", "frac")))
     fm = ex.get("mlmc_farm", {})
@@ -187,9 +188,13 @@ def build_problem(nref, extra_coarse=True):
 def build_hybrid_problem(nref):
     """the hybridized form of build_problem's system (the reference's "Hybridization" solver option): level 0 only - the
     multiplier system brings its own algebraic hierarchy"""
+    from parelagmc_amd.capi import library_hybrid_builder
     from parelagmc_amd.fe import build_hierarchy, build_hybrid_sampler_problem, mesh_from_json
     mesh = mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet.json"))
-    return build_hybrid_sampler_problem(build_hierarchy(mesh, nref), corlen=0.1, lognormal=False, n_mc_levels=1)
+    # H, G, z from the library's own element-local elimination (pmc_hybrid_build: what a C++ caller of libpmc.so uses;
+    # host code - loading the library does not open the GPU, scripts/r5/kfd_probe.py)
+    return build_hybrid_sampler_problem(build_hierarchy(mesh, nref), corlen=0.1, lognormal=False, n_mc_levels=1,
+                                        builder=library_hybrid_builder)
 
 
 def is_hybrid(problem):
@@ -206,10 +211,11 @@ def build_config3():
 
 def build_config4():
     """(saddle-point form, hybridized form) of the same three levels"""
+    from parelagmc_amd.capi import library_hybrid_builder
     from parelagmc_amd.fe import build_hierarchy, build_hybrid_sampler_problem, build_sampler_problem, mesh_from_json
     h = build_hierarchy(mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet_embed.json")), 4)
     kw = dict(corlen=0.1, embedded=True, lognormal=True, n_mc_levels=3)
-    return build_sampler_problem(h, **kw), build_hybrid_sampler_problem(h, **kw)
+    return build_sampler_problem(h, **kw), build_hybrid_sampler_problem(h, builder=library_hybrid_builder, **kw)
 
 
 def build_config5():
@@ -340,25 +346,51 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PMC_CPU_CORES", "16"))))
 
 
-def cpu_baseline(problem, seed, nsamples_per_core=12):
-    """Reference algorithm restated in C (oracle/c/pmc_ref.c), farmed over the host cores: a bounded
-    sample of the same workload."""
-    from oracle.cport import CPort
+def cpu_baseline(problem, seed, nsamples_per_core=12, hybrid_problem=None):
+    """The reference's algorithms restated in C (oracle/c/pmc_ref.c), farmed over the host cores on a bounded sample of the
+    same workload.  problem: saddle-point form -> the reference's default MINRES-BJ-GS; hybrid_problem (when the GPU figure
+    beside it runs the hybridized solver): the reference's "Hybridization" entry, PCG + AMG V-cycle on H lambda = G f with
+    back-substitution.  `value` is ALWAYS the solver the GPU figure ran (like for like, named in `solver`); the other one is
+    reported as saddle_value."""
+    from oracle.cport import CPort, HybridCPort
     from oracle.rng_oracle import normal_fill
     cores = host_cores()
-    cp = CPort(problem)
     ns = nsamples_per_core * cores
     n = problem.levels[0].n_s
     xi = np.stack([normal_fill(n, seed, i, 0) for i in range(ns)])
+    cp = CPort(problem)
     rhs = cp.rhs(0, 0, xi)
     if nsamples_per_core >= 4:
         cp.solve(0, rhs[:cores], nthreads=cores)      # warm-up (page in, thread pool); not for the one-per-core samples
     t0 = time.perf_counter()
-    _, iters = cp.solve(0, rhs, nthreads=cores)
+    sol, iters = cp.solve(0, rhs, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": ns / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{ns} realizations ({nsamples_per_core} per core), MINRES(300,1e-6)+BJ[symGS x3 | V-cycle], "
-                      f"mean {float(np.mean(np.abs(iters))):.1f} iterations, {dt:.1f} s wall"}
+    sad = {"value": ns / dt, "iterations": float(np.mean(np.abs(iters))), "seconds": dt,
+           "solver": "MINRES(300,1e-6)+BJ[symGS x3 | V-cycle] on the saddle-point system"}
+    out = {"unit": "samples/s", "cores": cores, "kind": "port"}
+    if hybrid_problem is None:
+        out.update({"value": sad["value"], "solver": sad["solver"], "iterations": sad["iterations"],
+                    "sample": f"{ns} realizations ({nsamples_per_core} per core), {dt:.1f} s wall"})
+        return out
+    hc = HybridCPort(hybrid_problem)
+    t0 = time.perf_counter()
+    hc.hierarchy(0)
+    setup = time.perf_counter() - t0
+    f = hc.rhs(0, 0, xi)
+    if nsamples_per_core >= 4:
+        hc.solve(0, f[:cores], nthreads=cores)
+    t0 = time.perf_counter()
+    sh, ith = hc.solve(0, f, nthreads=cores)
+    dth = time.perf_counter() - t0
+    diff = float(np.linalg.norm(sh - sol[:, problem.levels[0].n_u:]) / np.linalg.norm(sh))
+    out.update({"value": ns / dth, "solver": "PCG(300,1e-6)+AMG V(1,1) symGS on H lambda = G f, back-substitution "
+                                             "(the reference's Hybridization entry; smoothed aggregation for BoomerAMG)",
+                "iterations": float(np.mean(np.abs(ith))), "all_converged": bool(np.all(ith > 0) and np.all(iters > 0)),
+                "operator_complexity": hc.operator_complexity(0), "amg_setup_seconds_once": setup,
+                "saddle_value": sad["value"], "saddle_iterations": sad["iterations"], "saddle_solver": sad["solver"],
+                "field_difference_between_the_two_cpu_solvers": diff,
+                "sample": f"{ns} realizations ({nsamples_per_core} per core) with either solver: {dth:.1f} s / {dt:.1f} s wall"})
+    return out
 
 
 def solver_bytes_per_iteration(problem, nb, zb=4):
@@ -983,7 +1015,7 @@ def timed_farm(farm, steps, first_step, warmup=2):
 
 
 def sampler_point(problem, dev, seed, nb, ns, steps, tag, what, cpu_per_core=None, opts=None, roofline=True,
-                  cpu_problem=None):
+                  cpu_problem=None, cpu_hybrid_problem=None):
     """One sampler-only figure on level 0 of `problem` (the harness shape of the headline: `ns` lanes x `nb` realizations per
     step): value, iterations, K5 roofline of the in-loop launches, and - cpu_per_core - the CPU column beside it."""
     farm = SamplerFarm(problem, dev, seed, nb, ns, opts=opts)
@@ -1005,7 +1037,8 @@ def sampler_point(problem, dev, seed, nb, ns, steps, tag, what, cpu_per_core=Non
     farm.close()
     if cpu_per_core:
         try:
-            out["cpu_baseline"] = cpu_baseline(cpu_problem if cpu_problem is not None else problem, seed, cpu_per_core)
+            out["cpu_baseline"] = cpu_baseline(cpu_problem if cpu_problem is not None else problem, seed, cpu_per_core,
+                                               hybrid_problem=cpu_hybrid_problem)
         except Exception as e:   # noqa: BLE001
             out["cpu_baseline"] = {"error": repr(e)}
     return out
@@ -1251,7 +1284,10 @@ def main():
                                            solver_bytes_per_iteration(problem, nb, zb), acc[2], dt)),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(problem, args.seed, 8)
+            try:
+                out["cpu_baseline"] = cpu_baseline(problem, args.seed, 8, hybrid_problem=head if hybrid else None)
+            except Exception as e:   # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)}
     farm.close()
     extra = {}
 
@@ -1371,7 +1407,7 @@ def main():
                 what = ("PDESampler cube_tet r=6, 4743168 DoF: operator + vectors exceed the 256 MiB Infinity Cache, every "
                         "kernel is HBM-bound")
                 m = sampler_point(h6 if hybrid else p6, dev, args.seed, nb, ns, 12, "r6", what,
-                                  cpu_per_core=1 if cpu else None, cpu_problem=p6)
+                                  cpu_per_core=1 if cpu else None, cpu_problem=p6, cpu_hybrid_problem=h6 if hybrid else None)
                 m["other_solver"] = sampler_point(p6 if hybrid else h6, dev, args.seed, nb, ns, 6, "r6", what)
                 return m
             attempt("r6", r6)

@@ -435,3 +435,151 @@ int pmc_ref_darcy_batch(int nlevels, const dlevel_t* lv, int level, int k_divide
     }
     return fail ? -2 : 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * The reference's OTHER sampler solver, "Hybridization"
+ * (/root/reference/examples/example_parameterlists/example_parameters.xml:200-212: "the hybridized system is then solved by
+ * BoomerAMG-preconditioned CG, after that the solution of the original system is obtained by back substitution";
+ * selected in src/PDESampler.cpp:289-311, applied in :383-389 / :451-480):
+ *   rhs_lambda = G f,   PCG on H lambda = rhs_lambda with ONE AMG V(1,1)-cycle as preconditioner,   s = z f - G^T lambda.
+ * BoomerAMG is not available: the V-cycle runs over a smoothed-aggregation hierarchy of H built by the caller
+ * (oracle/cport.py::HybridCPort: greedy aggregation below, damped-Jacobi prolongator smoothing, Galerkin products),
+ * symmetric Gauss-Seidel smoothing - the standard AMG of the same class.  Stopping rule = MFEM's CGSolver:
+ * sqrt(<B r, r>) <= max(rel * initial, abs).  [UNVERIFIED: the XML entry sets no tolerances; the values of the other library
+ * entries (1e-6 / 1e-12) are used.]
+ */
+
+/* Greedy aggregation (Vanek, Mandel, Brezina 1996) on the strength graph |a_ij| >= theta * sqrt(a_ii a_jj).
+ * agg[i] receives the aggregate of row i; returns the number of aggregates. */
+int pmc_ref_aggregate(int n, const int* rp, const int* ci, const double* v, double theta, int* agg) {
+    double* d = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    if (!d) return -1;
+    for (int i = 0; i < n; ++i) {
+        d[i] = 1.0;
+        for (int p = rp[i]; p < rp[i + 1]; ++p)
+            if (ci[p] == i) d[i] = fabs(v[p]);
+        agg[i] = -1;
+    }
+    int na = 0;
+#define STRONG(i, p) (ci[p] != (i) && fabs(v[p]) >= theta * sqrt(d[i] * d[ci[p]]))
+    /* phase 1: a row whose strong neighbourhood is untouched becomes the root of a new aggregate */
+    for (int i = 0; i < n; ++i) {
+        if (agg[i] >= 0) continue;
+        int free_nb = 1, has_nb = 0;
+        for (int p = rp[i]; p < rp[i + 1]; ++p)
+            if (STRONG(i, p)) {
+                has_nb = 1;
+                if (agg[ci[p]] >= 0) { free_nb = 0; break; }
+            }
+        if (!free_nb || !has_nb) continue;
+        agg[i] = na;
+        for (int p = rp[i]; p < rp[i + 1]; ++p)
+            if (STRONG(i, p)) agg[ci[p]] = na;
+        ++na;
+    }
+    /* phase 2: remaining rows join the aggregate of their strongest aggregated neighbour (of phase 1) */
+    int* tmp = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    if (!tmp) { free(d); return -1; }
+    memcpy(tmp, agg, sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (tmp[i] >= 0) continue;
+        double best = -1.0;
+        for (int p = rp[i]; p < rp[i + 1]; ++p)
+            if (STRONG(i, p) && tmp[ci[p]] >= 0 && fabs(v[p]) > best) { best = fabs(v[p]); agg[i] = tmp[ci[p]]; }
+    }
+    free(tmp);
+    /* phase 3: what is left forms aggregates with its remaining strong neighbours (or stays alone) */
+    for (int i = 0; i < n; ++i) {
+        if (agg[i] >= 0) continue;
+        agg[i] = na;
+        for (int p = rp[i]; p < rp[i + 1]; ++p)
+            if (STRONG(i, p) && agg[ci[p]] < 0) agg[ci[p]] = na;
+        ++na;
+    }
+#undef STRONG
+    free(d);
+    return na;
+}
+
+typedef struct {
+    int n_lambda, n_s;
+    csr_t G, Gt;        /* n_lambda x n_s and its transpose */
+    const double* z;    /* n_s */
+} hsys_t;
+
+/* preconditioned CG on mg[0].S (= H), zero initial guess; returns iterations (negative: not converged) */
+static int pcg(int nlev, const level_t* mg, mgwork_t* mw, const double* b, double* x, int max_iter, double rel_tol,
+               double abs_tol, double* work) {
+    const csr_t* H = &mg[0].S;
+    const int n = H->nrows;
+    double *r = work, *zz = work + n, *p = work + 2 * n, *q = work + 3 * n;
+    memset(x, 0, sizeof(double) * n);
+    memcpy(r, b, sizeof(double) * n);
+    vcycle(nlev, mg, mw, 0, r, zz);
+    memcpy(p, zz, sizeof(double) * n);
+    double nom = dot(n, zz, r);
+    if (!(nom >= 0.0)) return -1;
+    const double goal = fmax(rel_tol * rel_tol * nom, abs_tol * abs_tol);
+    if (nom <= goal) return 0;
+    for (int it = 1; it <= max_iter; ++it) {
+        spmv(H, p, q);
+        const double den = dot(n, p, q);
+        if (!(den > 0.0)) return -it;
+        const double alpha = nom / den;
+        for (int i = 0; i < n; ++i) { x[i] += alpha * p[i]; r[i] -= alpha * q[i]; }
+        vcycle(nlev, mg, mw, 0, r, zz);
+        const double betanom = dot(n, zz, r);
+        if (betanom <= goal) return it;
+        const double beta = betanom / nom;
+        for (int i = 0; i < n; ++i) p[i] = zz[i] + beta * p[i];
+        nom = betanom;
+    }
+    return -max_iter;
+}
+
+/* For nsamples right-hand sides f (n_s each): lambda = H^-1 G f by PCG-AMG, s = z f - G^T lambda.  mg: nlev levels of the AMG
+ * hierarchy of H (level_t with S = operator of the level, P / Pt its transfer to / from the next coarser one; n_s = rows). */
+int pmc_ref_hybrid_batch(int nlev, const level_t* mg, const hsys_t* sys, int nsamples, const double* f, double* s_out,
+                         int max_iter, double rel_tol, double abs_tol, int nthreads, int* iters) {
+    if (nlev < 1 || nsamples < 0) return -1;
+    const int n = sys->n_lambda, ns = sys->n_s;
+    int fail = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        double* work = (double*)malloc(sizeof(double) * 6 * (size_t)n);
+        mgwork_t* mw = (mgwork_t*)calloc((size_t)nlev, sizeof(mgwork_t));
+        int ok = work != NULL && mw != NULL;
+        for (int l = 0; ok && l < nlev; ++l) {
+            const size_t m = (size_t)mg[l].S.nrows;
+            mw[l].r = (double*)malloc(sizeof(double) * m);
+            mw[l].x = (double*)malloc(sizeof(double) * m);
+            mw[l].t = (double*)malloc(sizeof(double) * m);
+            ok = mw[l].r && mw[l].x && mw[l].t;
+        }
+        if (!ok) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+            double *b = work + 4 * (size_t)n, *lam = work + 5 * (size_t)n;
+#pragma omp for schedule(dynamic, 1)
+            for (int i = 0; i < nsamples; ++i) {
+                const double* fi = f + (size_t)i * ns;
+                double* si = s_out + (size_t)i * ns;
+                spmv(&sys->G, fi, b);
+                const int it = pcg(nlev, mg, mw, b, lam, max_iter, rel_tol, abs_tol, work);
+                if (iters) iters[i] = it;
+                spmv(&sys->Gt, lam, si);
+                for (int e = 0; e < ns; ++e) si[e] = sys->z[e] * fi[e] - si[e];
+            }
+        }
+        if (mw)
+            for (int l = 0; l < nlev; ++l) { free(mw[l].r); free(mw[l].x); free(mw[l].t); }
+        free(mw);
+        free(work);
+    }
+    return fail ? -2 : 0;
+}

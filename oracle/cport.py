@@ -177,3 +177,110 @@ class DarcyCPort:
         if rc != 0:
             raise RuntimeError(f"pmc_ref_darcy_batch failed ({rc})")
         return (Q, iters, sol) if return_solution else (Q, iters)
+
+
+class _hsys(C.Structure):
+    _fields_ = [("n_lambda", C.c_int), ("n_s", C.c_int), ("G", _csr), ("Gt", _csr), ("z", C.POINTER(C.c_double))]
+
+
+class HybridCPort:
+    """ctypes driver of pmc_ref_hybrid_batch: the reference's "Hybridization" solver restated on the CPU - PCG on
+    H lambda = G f with one AMG V(1,1)-cycle (symmetric Gauss-Seidel), back-substitution s = z f - G^T lambda
+    (/root/reference/examples/example_parameterlists/example_parameters.xml:200-212, src/PDESampler.cpp:383-389,451-480).
+    BoomerAMG is not available: the hierarchy is smoothed aggregation built here (greedy aggregation in C, damped-Jacobi
+    prolongator smoothing, Galerkin products).  problem: fe.HybridSamplerProblem (H, G, z_diag, w_diag, P per level)."""
+
+    def __init__(self, problem, theta=0.08, min_rows=400, max_levels=12):
+        self.lib = C.CDLL(build())
+        self.lib.pmc_ref_hybrid_batch.restype = C.c_int
+        self.lib.pmc_ref_aggregate.restype = C.c_int
+        self.p = problem
+        self._keep = []
+        self._helper = CPort.__new__(CPort)
+        self._helper._keep = self._keep
+        self.theta, self.min_rows, self.max_levels = theta, min_rows, max_levels
+        self._built = {}
+
+    def _aggregate(self, A):
+        A = A.tocsr()
+        rp = np.ascontiguousarray(A.indptr, np.int32)
+        ci = np.ascontiguousarray(A.indices, np.int32)
+        v = np.ascontiguousarray(A.data, np.float64)
+        agg = np.empty(A.shape[0], np.int32)
+        na = self.lib.pmc_ref_aggregate(A.shape[0], rp.ctypes.data_as(C.POINTER(C.c_int)), ci.ctypes.data_as(C.POINTER(C.c_int)),
+                                        v.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(self.theta),
+                                        agg.ctypes.data_as(C.POINTER(C.c_int)))
+        if na <= 0:
+            raise RuntimeError("pmc_ref_aggregate failed")
+        return agg, na
+
+    def hierarchy(self, level):
+        """[(A_l, P_l)] smoothed-aggregation levels of H(level); P_l maps level l+1 -> l (None on the last)"""
+        if level in self._built:
+            return self._built[level]
+        A = self.p.levels[level].H.tocsr().astype(np.float64)
+        out = []
+        while True:
+            n = A.shape[0]
+            if n <= self.min_rows or len(out) + 1 >= self.max_levels:
+                out.append((A, None))
+                break
+            agg, na = self._aggregate(A)
+            if na >= 0.8 * n:                 # coarsening stalled
+                out.append((A, None))
+                break
+            T = sp.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, na))
+            T = T @ sp.diags(1.0 / np.sqrt(np.asarray(T.power(2).sum(axis=0)).ravel()))     # orthonormal columns
+            dinv = 1.0 / A.diagonal()
+            # omega = 4 / (3 rho(D^-1 A)), rho by a few power iterations
+            x = np.random.default_rng(0).standard_normal(n)
+            rho = 1.0
+            for _ in range(12):
+                y = dinv * (A @ x)
+                rho = float(np.linalg.norm(y) / np.linalg.norm(x))
+                x = y / np.linalg.norm(y)
+            P = (T - sp.diags((4.0 / 3.0) / (1.05 * rho) * dinv) @ (A @ T)).tocsr()
+            P.sort_indices()
+            out.append((A, P))
+            A = (P.T @ A @ P).tocsr()
+            A.sort_indices()
+        mg = (_level * len(out))()
+        h = self._helper
+        empty = sp.csr_matrix((0, 0))
+        for i, (Al, Pl) in enumerate(out):
+            Pm = Pl if Pl is not None else empty
+            mg[i] = _level(0, Al.shape[0], h._csr(empty), h._csr(empty), h._csr(empty), h._csr(Al), h._f64(np.zeros(1)),
+                           h._csr(Pm), h._csr(Pm.T.tocsr()))
+        L = self.p.levels[level]
+        sys_ = _hsys(L.n_lambda, L.n_s, h._csr(L.G), h._csr(L.G.T.tocsr()), h._f64(L.z_diag))
+        self._built[level] = (out, mg, sys_)
+        return self._built[level]
+
+    def operator_complexity(self, level):
+        out = self.hierarchy(level)[0]
+        return sum(A.nnz for A, _ in out) / out[0][0].nnz
+
+    def rhs(self, level, xi_level, xi):
+        """(nsamples, n_s(level)) f = -g W^{1/2} xi restricted with P^T (src/PDESampler.cpp:423-442)"""
+        xi = np.atleast_2d(xi)
+        r = -self.p.matern_g * xi * np.sqrt(self.p.levels[xi_level].w_diag)[None, :]
+        for lvl in range(xi_level, level):
+            r = (self.p.levels[lvl].P.T @ r.T).T
+        return np.ascontiguousarray(r)
+
+    def solve(self, level, f, max_iter=300, rel_tol=1e-6, abs_tol=1e-12, nthreads=0):
+        out, mg, sys_ = self.hierarchy(level)
+        f = np.ascontiguousarray(np.atleast_2d(f), np.float64)
+        ns = f.shape[0]
+        s = np.empty_like(f)
+        iters = np.zeros(ns, np.int32)
+        rc = self.lib.pmc_ref_hybrid_batch(len(out), mg, C.byref(sys_), ns, f.ctypes.data_as(C.POINTER(C.c_double)),
+                                           s.ctypes.data_as(C.POINTER(C.c_double)), max_iter, C.c_double(rel_tol),
+                                           C.c_double(abs_tol), nthreads, iters.ctypes.data_as(C.POINTER(C.c_int)))
+        if rc != 0:
+            raise RuntimeError(f"pmc_ref_hybrid_batch failed ({rc})")
+        return s, iters
+
+    def eval(self, level, xi_level, xi, **kw):
+        s, iters = self.solve(level, self.rhs(level, xi_level, xi), **kw)
+        return (np.exp(s) if self.p.lognormal else s), iters

@@ -220,6 +220,39 @@ class _Keep:
         return _ptr(a, C.c_uint8)
 
 
+def hybrid_build(pattern, c_ptr, c_elem, c_val, B, w_diag, alpha, P=None):
+    """pmc_hybrid_build (host code of libpmc.so, no GPU needed): the element-local elimination of one sampler level from the
+    element decomposition of the u-mass matrix (fe.rt0.mass_contributions), B without boundary elimination and diag(W).
+    Returns (H, G, z_diag) as scipy CSR / numpy COPIES of what pmc_hybrid_system_level exposes."""
+    import scipy.sparse as sp
+    lib = load_library()
+    keep = _Keep()
+    n_s, n_u = B.shape
+    lv = pmc_hybrid_elements(n_u, n_s, keep.csr(pattern), keep.i32(c_ptr), keep.i32(c_elem), keep.f64(c_val), keep.csr(B),
+                             keep.f64(w_diag), keep.csr(P))
+    h = _VP()
+    _check(lib.pmc_hybrid_build(C.byref(lv), float(alpha), C.byref(h)))
+    try:
+        v = pmc_hybrid_level()
+        _check(lib.pmc_hybrid_system_level(h, C.byref(v)))
+
+        def mat(c):
+            rp = np.ctypeslib.as_array(c.rowptr, (c.nrows + 1,)).copy()
+            nnz = int(rp[-1])
+            return sp.csr_matrix((np.ctypeslib.as_array(c.vals, (nnz,)).copy(), np.ctypeslib.as_array(c.colind, (nnz,)).copy(), rp),
+                                 shape=(c.nrows, c.ncols))
+        return mat(v.H), mat(v.G), np.ctypeslib.as_array(v.z_diag, (n_s,)).copy()
+    finally:
+        lib.pmc_hybrid_system_destroy(h)
+
+
+def library_hybrid_builder(space, alpha):
+    """fe.hybrid's `builder` hook: the library's own elimination (pmc_hybrid_build) instead of the numpy stand-in"""
+    from .fe.rt0 import mass_contributions
+    pat, c_ptr, c_elem, c_val = mass_contributions(space.emass)
+    return hybrid_build(pat, c_ptr, c_elem, c_val, space.B, space.vol, alpha)
+
+
 def solver_opts(**kw) -> pmc_solver_opts:
     o = pmc_solver_opts()
     load_library().pmc_solver_opts_default(C.byref(o))

@@ -61,7 +61,12 @@ class HybridSamplerProblem:
     orig_index: Optional[List[np.ndarray]] = None
 
 
-def hybrid_level_ops(space: LevelSpaces, alpha: float, P) -> HybridLevel:
+def hybrid_level_ops(space: LevelSpaces, alpha: float, P, builder=None) -> HybridLevel:
+    """builder: None = the numpy elimination below; a callable (space, alpha) -> (H, G, z_diag) = somebody else's - the
+    library's own pmc_hybrid_build through capi.library_hybrid_builder (what a C++ caller of libpmc.so uses)"""
+    if builder is not None:
+        H, G, z = builder(space, alpha)
+        return HybridLevel(space.n_u, space.n_s, H, G, z, space.vol.copy(), P)
     ft = space.faces
     ef = ft.elem_face
     ne, nfe = ef.shape
@@ -93,13 +98,13 @@ def hybrid_level_ops(space: LevelSpaces, alpha: float, P) -> HybridLevel:
 
 
 def build_hybrid_sampler_problem(h: Hierarchy, corlen=0.1, lognormal=False, n_mc_levels=None,
-                                 embedded=False) -> HybridSamplerProblem:
+                                 embedded=False, builder=None) -> HybridSamplerProblem:
     """The hybridized twin of build_sampler_problem (same arguments).  Only the Monte Carlo levels are built: the
     multiplier system brings its own algebraic hierarchy, coarser mesh levels have no role in it."""
     dim = h.spaces[0].mesh.dim
     alpha = 1.0 / (corlen * corlen)
     nmc = h.nlevels if n_mc_levels is None else n_mc_levels
-    levels = [hybrid_level_ops(h.spaces[i], alpha, h.P[i] if i < nmc - 1 else None) for i in range(nmc)]
+    levels = [hybrid_level_ops(h.spaces[i], alpha, h.P[i] if i < nmc - 1 else None, builder) for i in range(nmc)]
     orig = None
     if embedded:
         orig = [np.nonzero(h.spaces[i].mesh.elem_attr == 1)[0].astype(np.int32) for i in range(nmc)]

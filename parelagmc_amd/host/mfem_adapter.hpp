@@ -43,8 +43,53 @@ struct SamplerLevelOps {
     const mfem::SparseMatrix* P = nullptr;   ///< ComputeTrueP(sform) to the next coarser level (:189-193); null on the last
 };
 
+/// What the same level holds BEFORE the boundary elimination - the input of the hybridized solver (the reference hands
+/// A[i] and the de Rham sequence to prec_factory->BuildSolver(A[i], state), src/PDESampler.cpp:302-318; ParELAG's
+/// HybridHdivL2 reads the element matrices from the sequence)
+struct HybridLevelOps {
+    const mfem::SparseMatrix* M_pattern = nullptr;   ///< sparsity of the u-mass matrix
+    const mfem::Array<int>* c_ptr = nullptr;         ///< element decomposition, as DarcyLevelOps
+    const mfem::Array<int>* c_elem = nullptr;
+    const mfem::Vector* c_val = nullptr;
+    const mfem::SparseMatrix* B = nullptr;           ///< W * D as assembled, NO eliminated columns (:232-234)
+    const mfem::Vector* w_diag = nullptr;
+    const mfem::SparseMatrix* P = nullptr;
+};
+
 class DevicePDESampler {
   public:
+    /// prec_type == "Hybridization" (src/PDESampler.cpp:291,307-311): element-local elimination inside the library
+    /// (pmc_hybrid_build), MINRES + aggregation V-cycle on the multiplier system; every level is a Monte Carlo level
+    DevicePDESampler(int device_id, const std::vector<HybridLevelOps>& levels, double alpha, double matern_coeff,
+                     bool lognormal, const pmc_solver_opts* opts = nullptr, uint64_t seed = 0)
+        : nlevels_((int)levels.size()) {
+        check(pmc_ctx_create(device_id, &ctx_), "pmc_ctx_create");
+        try {
+            check(pmc_rng_seed(ctx_, seed, 1, 0), "pmc_rng_seed");
+            std::vector<pmc_hybrid_elements> lv(levels.size());
+            for (size_t i = 0; i < levels.size(); ++i) {
+                const HybridLevelOps& L = levels[i];
+                if (!L.M_pattern || !L.c_ptr || !L.c_elem || !L.c_val || !L.B || !L.w_diag)
+                    throw std::runtime_error("DevicePDESampler: hybrid level operators missing");
+                lv[i] = pmc_hybrid_elements{};
+                lv[i].n_u = L.M_pattern->Height();
+                lv[i].n_s = L.B->Height();
+                lv[i].M_pattern = as_csr(*L.M_pattern);
+                lv[i].c_ptr = L.c_ptr->GetData();
+                lv[i].c_elem = L.c_elem->GetData();
+                lv[i].c_val = L.c_val->GetData();
+                lv[i].B = as_csr(*L.B);
+                lv[i].w_diag = L.w_diag->GetData();
+                if (L.P) lv[i].P = as_csr(*L.P);
+            }
+            check(pmc_sampler_create_hybrid_from_elements(ctx_, (int)lv.size(), lv.data(), alpha, matern_coeff,
+                                                          lognormal ? 1 : 0, opts, &h_),
+                  "pmc_sampler_create_hybrid_from_elements");
+        } catch (...) {
+            pmc_ctx_destroy(ctx_);
+            throw;
+        }
+    }
     /// n_mc_levels <= levels.size(): further levels only deepen the V-cycle of the preconditioner
     DevicePDESampler(int device_id, const std::vector<SamplerLevelOps>& levels, int n_mc_levels, double alpha,
                      double matern_coeff, bool lognormal, const pmc_solver_opts* opts = nullptr, uint64_t seed = 0)

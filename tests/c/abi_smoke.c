@@ -123,6 +123,77 @@ int main(int argc, char** argv) {
         free(s);
         pmc_sampler_destroy(s64);
     }
+    {   /* The hybridized solver (the reference's "Hybridization" option, src/PDESampler.cpp:302-318) reached from C alone:
+           the element-local elimination runs inside the library (pmc_hybrid_build) on what BuildHierarchy holds - the
+           element decomposition of the u-mass matrix and B without boundary elimination (the Darcy levels of the problem
+           file carry both for the same mesh), diag(W), alpha - and the field must equal the oracle's like the default one */
+        if (p.d_nlevels < p.s_nlevels) { fprintf(stderr, "problem file: fewer Darcy than sampler levels\n"); return 1; }
+        pmc_hybrid_elements* he = (pmc_hybrid_elements*)calloc((size_t)p.s_nlevels, sizeof(pmc_hybrid_elements));
+        for (int l = 0; l < p.s_nlevels; ++l) {
+            const t_dlevel* D = &p.dl[l];
+            if (D->n_u != p.sl[l].n_u || D->n_p != p.sl[l].n_s) { fprintf(stderr, "level %d: sampler / Darcy sizes differ\n", l); return 1; }
+            he[l].n_u = D->n_u; he[l].n_s = D->n_p;
+            he[l].M_pattern = as_csr(&D->M);
+            he[l].c_ptr = D->c_ptr; he[l].c_elem = D->c_elem; he[l].c_val = D->c_val;
+            he[l].B = as_csr(&D->B);
+            he[l].w_diag = p.sl[l].w;
+            if (p.sl[l].has_p) he[l].P = as_csr(&p.sl[l].P);
+        }
+        pmc_hybrid_system* hs = NULL;
+        pmc_hybrid_level hv;
+        CHECK(pmc_hybrid_build(&he[0], p.alpha, &hs));
+        CHECK(pmc_hybrid_system_level(hs, &hv));
+        if (hv.n_lambda != p.sl[0].n_u || hv.n_s != p.sl[0].n_s || hv.H.nrows != hv.n_lambda || hv.G.ncols != hv.n_s) {
+            fprintf(stderr, "hybrid system shapes\n");
+            return 1;
+        }
+        for (int i = 0; i < hv.n_s; ++i)
+            if (!(hv.z_diag[i] < 0.0)) { fprintf(stderr, "z_diag[%d] = %g is not negative\n", i, hv.z_diag[i]); return 1; }
+        for (int i = 0; i < hv.n_lambda; ++i) {          /* SPD: positive diagonal */
+            double d = 0.0;
+            for (int q = hv.H.rowptr[i]; q < hv.H.rowptr[i + 1]; ++q)
+                if (hv.H.colind[q] == i) d = hv.H.vals[q];
+            if (!(d > 0.0)) { fprintf(stderr, "H[%d, %d] = %g\n", i, i, d); return 1; }
+        }
+        /* the two-step way: the view handed to pmc_sampler_create_hybrid (single level) */
+        pmc_sampler* h1 = NULL;
+        hv.P.rowptr = NULL; hv.P.colind = NULL; hv.P.vals = NULL; hv.P.nrows = hv.P.ncols = 0;
+        CHECK(pmc_sampler_create_hybrid(ctx, 1, &hv, p.alpha, p.g, p.lognormal, &opts, &h1));
+        pmc_hybrid_system_destroy(hs);                   /* the sampler keeps its own copy */
+        /* the one-call way, every level */
+        pmc_sampler* hyb = NULL;
+        CHECK(pmc_sampler_create_hybrid_from_elements(ctx, p.s_nlevels, he, p.alpha, p.g, p.lognormal, &opts, &hyb));
+        if (pmc_sampler_is_hybrid(hyb) != 1 || pmc_sampler_is_hybrid(smp) != 0) { fprintf(stderr, "pmc_sampler_is_hybrid\n"); return 1; }
+        for (int l = 0; l < p.s_nlevels; ++l) {
+            const int ns = pmc_sampler_sample_size(hyb, l);
+            double* s = (double*)malloc(8 * (size_t)p.nbatch * ns);
+            pmc_stats* st = (pmc_stats*)calloc((size_t)p.nbatch, sizeof(pmc_stats));
+            CHECK(pmc_sampler_eval(hyb, l, 0, p.nbatch, p.xi, s, NULL, -1, 0, NULL, PMC_MEM_HOST, st));
+            const double e = rel_err(s, p.s_expect[l], (size_t)p.nbatch * ns);
+            printf("hybridized sampler (built in C) level %d: rel. error vs oracle %.2e, %d iterations\n", l, e, st[0].iterations);
+            if (!(e < 1e-9) || st[0].converged != 1) return 1;
+            if (l == 0) {
+                double* s1 = (double*)malloc(8 * (size_t)p.nbatch * ns);
+                CHECK(pmc_sampler_eval(h1, 0, 0, p.nbatch, p.xi, s1, NULL, -1, 0, NULL, PMC_MEM_HOST, NULL));
+                if (!(rel_err(s1, s, (size_t)p.nbatch * ns) < 1e-12)) { fprintf(stderr, "two-step and one-call construction differ\n"); return 1; }
+                free(s1);
+            }
+            free(s); free(st);
+        }
+        {   /* a B with eliminated (zeroed) columns is refused with a message, not misread */
+            double* bz = (double*)malloc(8 * (size_t)p.dl[0].B.nnz);
+            memcpy(bz, p.dl[0].B.v, 8 * (size_t)p.dl[0].B.nnz);
+            bz[0] = 0.0;
+            pmc_hybrid_elements badl = he[0];
+            badl.B.vals = bz;
+            pmc_hybrid_system* none = NULL;
+            if (pmc_hybrid_build(&badl, p.alpha, &none) != PMC_ERR_INVALID || none != NULL) { fprintf(stderr, "eliminated B accepted\n"); return 1; }
+            free(bz);
+        }
+        pmc_sampler_destroy(h1);
+        pmc_sampler_destroy(hyb);
+        free(he);
+    }
     /* error paths return codes, never abort */
     if (pmc_sampler_eval(smp, p.s_nlevels, 0, 1, p.xi, p.xi, NULL, -1, 0, NULL, PMC_MEM_HOST, NULL) == PMC_OK) {
         fprintf(stderr, "out-of-range level accepted\n");

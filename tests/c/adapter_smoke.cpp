@@ -107,6 +107,22 @@ int main(int argc, char** argv) {
                 }
             }
         std::printf("adapter darcy: %d levels ok\n", p.d_nlevels);
+        {   // the hybridized solver through the adapter: the same MFEM objects a ParELAGMC class holds before it eliminates
+            // boundary rows (the Darcy levels carry the element decomposition and the un-eliminated B of the same mesh)
+            std::vector<mfem_adapter::HybridLevelOps> hops(p.s_nlevels);
+            for (int l = 0; l < p.s_nlevels; ++l)
+                hops[l] = {&dM[l], &c_ptr[l], &c_elem[l], &c_val[l], &dB[l], &w[l], p.sl[l].has_p ? &P[l] : nullptr};
+            mfem_adapter::DevicePDESampler hyb(0, hops, p.alpha, p.g, p.lognormal != 0, &opts, 7);
+            for (int b = 0; b < p.nbatch; ++b) {
+                mfem::Vector xi(p.xi + (size_t)b * n0, n0), s, u;
+                for (int l = p.s_nlevels - 1; l >= 0; --l) {
+                    hyb.Eval(l, xi, s, u, l < p.s_nlevels - 1);     // use_init is accepted and ignored (src/PDESampler.cpp:472)
+                    const double e = rel_err(s.GetData(), p.s_expect[l] + (size_t)b * p.sl[l].n_s, (size_t)p.sl[l].n_s);
+                    if (!(e < 1e-9)) { std::fprintf(stderr, "adapter hybrid sampler level %d sample %d: rel. error %.2e\n", l, b, e); return 1; }
+                }
+            }
+            std::printf("adapter hybridized sampler: %d levels ok, last solve %d iterations\n", p.s_nlevels, hyb.GetNumIters());
+        }
 
         // ---- the mirror classes with the reference's names, straight from C++
         PDESampler ps(sampler.context(), sampler.handle());

@@ -123,12 +123,15 @@ def test_sampler_operators_and_fields_from_the_independent_builder():
         np.testing.assert_allclose(ref.eval(1, 1, to_ref(xi, 1))[cperms[1]], s11, rtol=0, atol=1e-10 * np.abs(s11).max())
 
 
-def test_hybridized_system_from_the_closed_forms():
+@pytest.mark.parametrize("builder", ["numpy", "library"])
+def test_hybridized_system_from_the_closed_forms(builder):
     """oracle/fe_ref.RefHybrid (one 7 x 7 inverse per level, this module's own multiplier signs) (i) reproduces the field of
     the independent saddle-point direct solve - the hybridized system IS the sampler's system - and (ii) equals, entry by entry
     after geometric matching and the per-face multiplier sign, the H, G, z the HIP path receives (fe/hybrid.py)"""
     h = build_hierarchy(box_mesh([4, 4, 4], [2.0, 2.0, 2.0], "hex"), 1)
-    hp = build_hybrid_sampler_problem(h, corlen=0.1)
+    # "library": pmc_hybrid_build, the C++ elimination a caller of libpmc.so uses (host code, no GPU)
+    from parelagmc_amd import capi
+    hp = build_hybrid_sampler_problem(h, corlen=0.1, builder=capi.library_hybrid_builder if builder == "library" else None)
     levels = fe_ref.hex_hierarchy([4, 4, 4], [2.0, 2.0, 2.0], 1)
     ref, hyb = fe_ref.RefSampler(levels, 0.1), fe_ref.RefHybrid(levels, 0.1)
     rng = np.random.default_rng(11)

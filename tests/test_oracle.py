@@ -168,6 +168,30 @@ def test_c_port_of_reference_solver_matches_direct_solve(hex_hierarchy, seeded_r
         assert np.linalg.norm(s - ref) <= 1e-5 * np.linalg.norm(ref) and (it > 0).all() and (it <= 300).all()
 
 
+def test_c_port_of_the_hybridization_solver_matches_direct_solve(hex_hierarchy_small, seeded_rng):
+    """oracle/c/pmc_ref.c::pmc_ref_hybrid_batch (the reference's "Hybridization" entry restated: PCG on H lambda = G f with one
+    AMG V-cycle, back-substitution; /root/reference/examples/example_parameterlists/example_parameters.xml:200-212) - the
+    like-for-like CPU column of the hybridized GPU solver - against the saddle-point direct-solve oracle, on hexahedra (3
+    levels incl. the P^T coupling of xi) and on tetrahedra"""
+    import os
+    from conftest import ROOT
+    from oracle.cport import HybridCPort
+    from parelagmc_amd.fe import build_hierarchy, build_hybrid_sampler_problem, mesh_from_json
+    tets = build_hierarchy(mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet.json")), 3)
+    for h, nl in ((hex_hierarchy_small, 2), (tets, 2)):
+        sp = build_sampler_problem(h, corlen=0.1, n_mc_levels=nl)
+        hp = build_hybrid_sampler_problem(h, corlen=0.1, n_mc_levels=nl)
+        so, hc = SamplerOracle(sp), HybridCPort(hp)
+        xi = seeded_rng.standard_normal((3, sp.levels[0].n_s))
+        for lvl in range(nl):
+            ref = np.stack([so.eval(lvl, 0, x)[0] for x in xi])
+            s, it = hc.eval(lvl, 0, xi, rel_tol=1e-12, abs_tol=1e-30, nthreads=2)
+            assert np.linalg.norm(s - ref) <= 1e-9 * np.linalg.norm(ref) and (it > 0).all()
+            s, it = hc.eval(lvl, 0, xi, nthreads=2)                 # 300 / 1e-6 / 1e-12
+            assert np.linalg.norm(s - ref) <= 1e-5 * np.linalg.norm(ref) and (it > 0).all() and (it <= 30).all()
+            assert 1.0 <= hc.operator_complexity(lvl) < 4.0
+
+
 def test_oracle_statistically_matches_reference_goldens_on_coarse_levels():
     """The reference's DarcyRandomInputTest golden (examples/CMakeLists.txt:91-95: 10-sample means of the effective
     permeability, 2.103 on the 8^3 and 1.998 on the 4^3 level, L2ProjectionPDESampler on the enlarged box) is a sample of the
