@@ -302,6 +302,8 @@ Sampler::Sampler(Ctx& c, int nlevels_, const pmc_hybrid_level* in, double alpha_
         // samples/s; 21 -> 20 iterations)
         amg[l] = build_chain(agg_hierarchy(H, passes0, passes1, /*theta=*/0.25, /*min_size=*/256, /*max_levels=*/14), o, st,
                              /*ratio_scale=*/2.0, /*f32_any_injection=*/true);
+        amg[l]->tail_later_nb = 8;
+        if (const char* e = lab_env("PMC_TAIL_LATER_NB")) amg[l]->tail_later_nb = atoi(e);
         mg.L[l].n = L.n_s;
         if (l + 1 < nlevels) {
             HostCsr P = csr_from_c(L.P, true, "sampler P");

@@ -196,7 +196,7 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     // realizations, and a tail that starts at a level of several thousand rows with 17-27 entries each is bound by ONE
     // unit's L2 port (LAB_NOTES 9.16: 142 us per cycle - half of a one-realization Eval of the hybridized sampler).  Such
     // a level runs as kernels then and the tail starts one level further down.
-    const bool tail_later = nb <= 8 && lv.n > 4096 && !last && l + 1 < (int)tail.size() && tail[l + 1].p;
+    const bool tail_later = nb <= tail_later_nb && lv.n > 4096 && !last && l + 1 < (int)tail.size() && tail[l + 1].p;
     const bool tail_here = use_tail && l < (int)tail.size() && tail[l].p && !tail_later;
     const bool f32_shared = !last && !lv.bv && lv.has_sp && (lv.p_oct || f32_any_injection) && smooth_degree == 2 &&
                             lv.vals_scaled.p && f32_intermediates;

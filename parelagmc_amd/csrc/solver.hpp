@@ -112,6 +112,11 @@ struct Multigrid {
     // the fp32-intermediate kernels also on levels whose indicator prolongator is NOT over groups of 8 consecutive rows
     // (aggregation hierarchies: the restriction is then a separate product with P^T)
     bool f32_any_injection = false;
+    // launches of at most this many realizations start the LDS tail one level further down when the tail's first level has
+    // more than 4 096 rows (0 = never).  Set by the owner for the hierarchy it was measured on - the aggregation hierarchy of
+    // the hybridized sampler (LAB_NOTES 9.16); the structured and per-realization (Darcy) hierarchies keep 0, so a
+    // realization of a ragged remainder chunk takes the same kernels as one of a full launch there.
+    int tail_later_nb = 0;
     // in-situ timing (HIP events) of the top level's post-smoothing kernel - the largest single kernel of a cycle on an
     // aggregation hierarchy; set per solve by the owner, null = off
     OpTimer* smooth_timer = nullptr;

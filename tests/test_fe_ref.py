@@ -184,3 +184,113 @@ def test_darcy_known_answer_and_goldens_from_the_independent_builder():
                 Qo, _, solo = do.solve_fwd(l, k, return_solution=True)
                 assert abs(Q - Qo) <= 1e-10 * abs(Qo)
                 np.testing.assert_allclose(solo[:lv[l].n_u], s * sol[:lv[l].n_u][fperm], atol=1e-10 * np.abs(sol).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tetrahedra (the headline mesh family): SURVEY Appendix A.5's RT0 element matrices by quadrature, own faces / orientations
+
+
+def _tet_hierarchy(name, nref):
+    from conftest import ROOT
+    from parelagmc_amd.fe import mesh_from_json
+    return build_hierarchy(mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", name + ".json")), nref)
+
+
+def _tet_maps(space, ref):
+    """as _maps for a TetLevel built from the same vertex / element DATA: cells are in the same order by construction
+    (checked through their centroids), faces are matched by centroid, signs read off the divergence matrices"""
+    np.testing.assert_allclose(element_centroids(space.mesh), ref.cell_centroids(), atol=1e-14)
+    fc = space.mesh.verts[space.faces.face_verts].mean(axis=1)
+    fperm = _match(fc, ref.face_centroids())
+    Bp = space.B.tocsr()
+    Br = ref.divergence()[:, fperm].tocsr()
+    assert (Bp != 0).multiply(Br != 0).nnz == Bp.nnz == Br.nnz
+    coo = sp.csr_matrix(Bp.multiply(Br)).tocoo()
+    s = np.zeros(space.n_u)
+    s[coo.col] = coo.data
+    assert abs(sp.csr_matrix(Bp.multiply(Br)) - sp.csr_matrix(abs(Br) @ sp.diags(s))).max() == 0.0
+    assert set(np.unique(s)) <= {-1.0, 1.0}
+    return fperm, s
+
+
+@pytest.mark.parametrize("name,nref", [("cube_tet", 0), ("cube_tet", 1), ("cube_tet", 2), ("cube_tet_embed", 1)])
+def test_tet_operators_equal_the_quadrature_restatement_entry_by_entry(name, nref):
+    """M_e, M, M(c), B, W of fe/rt0.py on tetrahedra (the barycentric closed form) == SURVEY A.5's
+    M_e[i, j] = +-(1 / (9 |T|^2)) int (x - v_i).(x - v_j) evaluated by quadrature with this oracle's own faces and signs"""
+    h = _tet_hierarchy(name, nref)
+    rng = np.random.default_rng(17)
+    for space in h.spaces:
+        ref = fe_ref.TetLevel(space.mesh.verts, space.mesh.elems)
+        assert ref.n_u == space.n_u and ref.n_s == space.n_s
+        # the refinement handed over is conforming and fills the domain: own volume sum, every face has 1 or 2 elements
+        box = np.prod(space.mesh.verts.max(axis=0) - space.mesh.verts.min(axis=0))
+        assert abs(ref.vol.sum() - box) <= 1e-12 * box
+        np.testing.assert_allclose(space.vol, ref.w_diag(), rtol=1e-13)
+        fperm, s = _tet_maps(space, ref)
+        S = sp.diags(s)
+        c = np.exp(rng.standard_normal(space.n_s))
+        for coeff in (None, c):
+            Mp = mass_matrix(space.emass, coeff)
+            Mr = (S @ ref.mass(coeff)[fperm][:, fperm] @ S).tocsr()
+            assert abs(Mp - Mr).max() <= 1e-13 * abs(Mr).max()
+        # element matrices themselves: the product's COO entries against Me[e, i, j] of the oracle
+        Me = ref.element_mass()
+        inv = np.empty(space.n_u, np.int64)
+        inv[fperm] = np.arange(space.n_u)                 # reference face -> product face
+        pf = inv[ref.elem_face]                           # (ne, 4) product face ids in the oracle's local order
+        dense = {}
+        em = space.emass
+        for r_, c_, e_, v_ in zip(em.rows, em.cols, em.elem, em.vals):
+            dense[(int(e_), int(r_), int(c_))] = v_
+        worst = 0.0
+        for e in range(0, space.n_s, max(1, space.n_s // 97)):          # a sample of elements, every entry of each
+            for i in range(4):
+                for j in range(4):
+                    want = Me[e, i, j] * s[pf[e, i]] * s[pf[e, j]]
+                    got = dense.get((e, int(pf[e, i]), int(pf[e, j])), 0.0)      # exact zeros are not stored by the product
+                    worst = max(worst, abs(got - want) / abs(Me[e]).max())
+        assert worst <= 1e-13
+        # boundary faces
+        np.testing.assert_array_equal(space.faces.face_elem[:, 1] < 0, ref.boundary_faces()[fperm])
+
+
+@pytest.mark.parametrize("builder", ["numpy", "library"])
+def test_tet_hybridized_system_and_fields_from_the_quadrature_restatement(builder):
+    """H, G, z the HIP path receives on tetrahedra (fe/hybrid.py, and pmc_hybrid_build = what a C++ caller uses) == the
+    oracle's own element-local elimination entry by entry (after the per-face multiplier sign), and the fields of the
+    independent saddle-point direct solve, of the independent hybridized solve and of the product-side oracle agree"""
+    from parelagmc_amd import capi
+    h = _tet_hierarchy("cube_tet", 2)
+    kw = dict(corlen=0.1, n_mc_levels=2)
+    hp = build_hybrid_sampler_problem(h, builder=capi.library_hybrid_builder if builder == "library" else None, **kw)
+    spb = build_sampler_problem(h, **kw)
+    so = SamplerOracle(spb)
+    levels = [fe_ref.TetLevel(sp_.mesh.verts, sp_.mesh.elems) for sp_ in h.spaces]
+    ref = fe_ref.RefTetSampler(levels, 0.1)
+    rng = np.random.default_rng(23)
+    # P0 prolongator by the oracle's own parent search
+    assert abs(h.P[0] - levels[0].prolongation(levels[1])).max() == 0.0
+    for l in range(2):
+        space, L = h.spaces[l], hp.levels[l]
+        fperm, s = _tet_maps(space, levels[l])
+        hy = fe_ref.RefTetHybrid(levels[l], 0.1)
+        np.testing.assert_allclose(L.z_diag, hy.z, rtol=1e-12)
+        Hr, Gr = hy.H[fperm][:, fperm].tocsr(), hy.G[fperm].tocsr()
+        d = np.zeros(space.n_u)
+        coo = sp.csr_matrix(L.G.multiply(Gr)).tocoo()
+        d[coo.row] = np.sign(coo.data)
+        assert set(np.unique(d)) <= {-1.0, 1.0}
+        D = sp.diags(d)
+        assert abs(L.G - D @ Gr).max() <= 1e-12 * abs(Gr).max()
+        assert abs(L.H - D @ Hr @ D).max() <= 1e-12 * abs(Hr).max()
+        # sampler operators after boundary elimination
+        M, B, w = ref.operators(l)
+        S = sp.diags(s)
+        assert abs(spb.levels[l].M - S @ M[fperm][:, fperm] @ S).max() <= 1e-13 * abs(M).max()
+        assert abs(spb.levels[l].B - B[:, fperm] @ S).max() == 0.0
+        xi = rng.standard_normal(levels[l].n_s)
+        a, b, c = ref.eval(l, l, xi), hy.eval(xi), so.eval(l, l, xi)[0]
+        assert np.linalg.norm(a - b) <= 1e-11 * np.linalg.norm(a)
+        assert np.linalg.norm(a - c) <= 1e-11 * np.linalg.norm(a)
+    xi = rng.standard_normal(levels[0].n_s)
+    assert np.linalg.norm(ref.eval(1, 0, xi) - so.eval(1, 0, xi)[0]) <= 1e-11 * np.linalg.norm(ref.eval(1, 0, xi))
