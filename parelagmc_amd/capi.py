@@ -160,7 +160,9 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # PMC_LIB (harness only - the library itself reads no PMC_* variable): another build of the library, e.g. the laboratory
+    # one for a profiling pass, selected WITHOUT overwriting the product's file
+    p = path or os.environ.get("PMC_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise PmcError(-2, f"{p} not found - build it with `make` / __graft_entry__.build() (no CPU fallback)")
     lib = C.CDLL(p)

@@ -371,7 +371,7 @@ int pmc_sampler_apply_preconditioner(pmc_sampler* s, int level, int nbatch, cons
 }
 int pmc_sampler_batch_width(const pmc_sampler* s, int level) {
     if (!s || level < 0 || level >= s->impl.nlevels) return PMC_ERR_INVALID;
-    return batch_width((size_t)s->impl.lv[level].n_u + s->impl.lv[level].n_s);
+    return batch_width((size_t)s->impl.lv[level].n_u + s->impl.lv[level].n_s, false, s->impl.ctx.device);
 }
 int pmc_sampler_true_p(const pmc_sampler* s, int level, pmc_csr* out) {
     return guarded([&] {
@@ -524,7 +524,7 @@ int pmc_darcy_poly_bytes(const pmc_darcy* d, int level, int nbatch, double* byte
 }
 int pmc_darcy_batch_width(const pmc_darcy* d, int level) {
     if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;
-    return batch_width((size_t)d->impl.lv[level].n_u + d->impl.lv[level].n_p, true);
+    return batch_width((size_t)d->impl.lv[level].n_u + d->impl.lv[level].n_p, true, d->impl.ctx.device);
 }
 int64_t pmc_darcy_nnz(const pmc_darcy* d, int level) {
     if (!d || level < 0 || level >= d->impl.nlevels) return PMC_ERR_INVALID;

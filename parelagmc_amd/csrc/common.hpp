@@ -212,7 +212,8 @@ inline const char* lab_env(const char* name) {
 // realizations per launch; sampler levels up to 5 M rows (PMC_S_WIDE_ROWS) and Darcy levels small enough to be bound by
 // launch latency take 32 (PMC_WIDE_ROWS: limit, default 300 000 rows; set, it applies to both kinds, 0 = always 16), and the smaller the level the more column groups of 32 one launch carries - 64, 128 or 256
 // realizations (PMC_W64_ROWS / PMC_W128_ROWS / PMC_W256_ROWS: limits, 0 = never) - until a launch fills the chip.
-int batch_width(size_t rows, bool darcy = false);
+// device: the handle's device (the 32-wide limit of sampler levels comes from ITS memory)
+int batch_width(size_t rows, bool darcy, int device);
 static constexpr int kGroup = 32;      // widest compile-time interleave (Lay<32>); wider batches are column groups of it
 static constexpr int kMaxBatch = 256;  // widest batch of one launch: 8 column groups
 inline bool valid_batch(int nb) {

@@ -586,7 +586,7 @@ void Darcy::compute_G(int level, int nbatch, const double* kf, double* G, double
     std::vector<double> q(kMaxBatch);
     int done = 0;
     while (done < nbatch) {
-        int nb = batch_width((size_t)d.n_u + d.n_p, true);
+        int nb = batch_width((size_t)d.n_u + d.n_p, true, ctx.device);
         while (nb > nbatch - done) nb >>= 1;
         const double* k_d = kf + (size_t)done * d.n_p;
         if (memspace == PMC_MEM_HOST) {
@@ -767,7 +767,7 @@ void Darcy::solve_fwd(int level, int nbatch, const double* kf, double* Q, double
     const size_t n = (size_t)d.n_u + d.n_p;
     int done = 0;
     while (done < nbatch) {
-        int nb = batch_width((size_t)d.n_u + d.n_p, true);
+        int nb = batch_width((size_t)d.n_u + d.n_p, true, ctx.device);
         while (nb > nbatch - done) nb >>= 1;
         const double* k_d = kf + (size_t)done * d.n_p;
         const int row0 = (sol_kind == 2) ? d.n_u : 0;

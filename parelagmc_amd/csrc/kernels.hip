@@ -888,18 +888,132 @@ __global__ __launch_bounds__(kBlock, (NB >= 32 && BV == 0 ? 3 : 1)) void sell_po
 // consistent - measured (z rounded to fp32 after every application, cube_tet r = 4): identical iteration counts at 1e-6 ...
 // 1e-12 and fields equal to the unrounded run's to 7e-16.  What it saves is 87 MB of the 1 089 MB an iteration moves at r = 5.
 
+// DEEP gather loop for levels too small to fill the chip (NB = 32, shared values): J slice columns - J x 8 gathers per lane -
+// are in flight together.  A launch of a few hundred to a few thousand wavefronts (one per 64-row slice) runs less than one
+// wavefront per SIMD; each walks its slice's columns as a chain of dependent round trips to L2, so the launch lasts
+// `slice width` x latency whatever its size (round 5: the five V-cycle kernels of the 4 964-row level of the hybridized
+// hierarchy - 78 wavefronts, 17-27 columns - took ~38 us each, those of the 43 622-row level ~30 us).  With J columns per
+// trip the chain is J times shorter; registers (J x 32 for the raw fp32 rows) are no concern at that occupancy.  Same FMA
+// order per accumulator as the one-column loop (column after column), out-of-range columns re-read the last column with
+// weight zero: bit-identical results.
+typedef float pmc_f4x __attribute__((ext_vector_type(4)));
+template <int J>
+__device__ __forceinline__ void pin_deep(pmc_f4x (&q)[J][8]) {
+    if constexpr (J == 2)
+        asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]), "+v"(q[0][4]), "+v"(q[0][5]), "+v"(q[0][6]),
+                     "+v"(q[0][7]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(q[1][3]), "+v"(q[1][4]), "+v"(q[1][5]),
+                     "+v"(q[1][6]), "+v"(q[1][7]));
+    else if constexpr (J == 4)
+        asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]), "+v"(q[0][4]), "+v"(q[0][5]), "+v"(q[0][6]),
+                     "+v"(q[0][7]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(q[1][3]), "+v"(q[1][4]), "+v"(q[1][5]),
+                     "+v"(q[1][6]), "+v"(q[1][7]), "+v"(q[2][0]), "+v"(q[2][1]), "+v"(q[2][2]), "+v"(q[2][3]), "+v"(q[2][4]),
+                     "+v"(q[2][5]), "+v"(q[2][6]), "+v"(q[2][7]), "+v"(q[3][0]), "+v"(q[3][1]), "+v"(q[3][2]), "+v"(q[3][3]),
+                     "+v"(q[3][4]), "+v"(q[3][5]), "+v"(q[3][6]), "+v"(q[3][7]));
+}
+typedef double pmc_d2x __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pin_deep_d(pmc_d2x (&q)[2][8][2]) {
+    asm volatile("" : "+v"(q[0][0][0]), "+v"(q[0][0][1]), "+v"(q[0][1][0]), "+v"(q[0][1][1]), "+v"(q[0][2][0]), "+v"(q[0][2][1]),
+                 "+v"(q[0][3][0]), "+v"(q[0][3][1]), "+v"(q[0][4][0]), "+v"(q[0][4][1]), "+v"(q[0][5][0]), "+v"(q[0][5][1]),
+                 "+v"(q[0][6][0]), "+v"(q[0][6][1]), "+v"(q[0][7][0]), "+v"(q[0][7][1]), "+v"(q[1][0][0]), "+v"(q[1][0][1]),
+                 "+v"(q[1][1][0]), "+v"(q[1][1][1]), "+v"(q[1][2][0]), "+v"(q[1][2][1]), "+v"(q[1][3][0]), "+v"(q[1][3][1]),
+                 "+v"(q[1][4][0]), "+v"(q[1][4][1]), "+v"(q[1][5][0]), "+v"(q[1][5][1]), "+v"(q[1][6][0]), "+v"(q[1][6][1]),
+                 "+v"(q[1][7][0]), "+v"(q[1][7][1]));
+}
+template <int NB, typename XT, int J>
+__device__ __forceinline__ void sell_row_range_deep(const int* __restrict__ cols, const double* __restrict__ vals,
+                                                    const XT* __restrict__ x, int off, int width, int lane, int LD,
+                                                    double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
+    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    static_assert(C == 4 && T == 8, "the deep loop is written for the 32-wide layout");
+    static_assert((sizeof(XT) == 4 && (J == 2 || J == 4)) || (sizeof(XT) == 8 && J == 2), "columns per trip");
+    const int g = lane / T, t = lane % T;
+#pragma unroll
+    for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
+    int slot = off + lane;
+    int cj[J];
+    double vj[J];
+#pragma unroll
+    for (int u = 0; u < J; ++u) {
+        const bool ok = u < width;
+        const int at = ok ? slot + u * kWave : slot;
+        cj[u] = width > 0 ? cols[at] : 0;
+        vj[u] = (ok && width > 0) ? vals[at] : 0.0;
+    }
+    for (int j = 0; j < width; j += J, slot += J * kWave) {
+        int cn[J];
+        double vn[J];
+#pragma unroll
+        for (int u = 0; u < J; ++u) {   // the next trip's (index, value) pairs: requested before this trip's gathers
+            const bool ok = j + J + u < width;
+            const int at = ok ? slot + (J + u) * kWave : slot;
+            cn[u] = cols[at];
+            vn[u] = ok ? vals[at] : 0.0;
+        }
+        unsigned at[J][T];
+#pragma unroll
+        for (int u = 0; u < J; ++u)
+#pragma unroll
+            for (int rs = 0; rs < T; ++rs) at[u][rs] = (unsigned)__shfl(cj[u], rs * G + g, kWave) * (unsigned)LD + (unsigned)(t * C);
+        if constexpr (sizeof(XT) == 4) {
+            pmc_f4x q[J][8];
+#pragma unroll
+            for (int u = 0; u < J; ++u)
+#pragma unroll
+                for (int rs = 0; rs < T; ++rs) q[u][rs] = *reinterpret_cast<const pmc_f4x*>(x + at[u][rs]);
+            pin_deep<J>(q);
+#pragma unroll
+            for (int u = 0; u < J; ++u)
+#pragma unroll
+                for (int rs = 0; rs < T; ++rs) {
+                    const double a = __shfl(vj[u], rs * G + g, kWave);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[rs][c] = fma(a, (double)q[u][rs][c], acc[rs][c]);
+                }
+        } else {
+            pmc_d2x q[2][8][2];
+#pragma unroll
+            for (int u = 0; u < J; ++u)
+#pragma unroll
+                for (int rs = 0; rs < T; ++rs) {
+                    q[u][rs][0] = reinterpret_cast<const pmc_d2x*>(x + at[u][rs])[0];
+                    q[u][rs][1] = reinterpret_cast<const pmc_d2x*>(x + at[u][rs])[1];
+                }
+            pin_deep_d(q);
+#pragma unroll
+            for (int u = 0; u < J; ++u)
+#pragma unroll
+                for (int rs = 0; rs < T; ++rs) {
+                    const double a = __shfl(vj[u], rs * G + g, kWave);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[rs][c] = fma(a, q[u][rs][c >> 1][c & 1], acc[rs][c]);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < J; ++u) {
+            cj[u] = cn[u];
+            vj[u] = vn[u];
+        }
+    }
+}
+
 // acc = A x for one slice, shared fp64 values, gathered vector of type XT (the T > 1 schedule of sell_row_range; T == 1
 // walks the slice columns one by one)
-template <int NB, typename XT, bool NT = false, int BV = 0>
+// DEEP > 1 (NB = 32, shared values): sell_row_range_deep with that many slice columns per trip
+template <int NB, typename XT, bool NT = false, int BV = 0, int DEEP = 1>
 __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, const double* __restrict__ vals,
                                                  const XT* __restrict__ x, int off, int width, int lane, int LD,
                                                  double (&acc)[Lay<NB>::T][Lay<NB>::C]) {
-    sell_row_range<NB, BV, false, true, NT, XT>(cols, vals, x, nullptr, off, width, lane, LD, acc);
+    if constexpr (DEEP > 1 && NB == 32 && BV == 0)
+        sell_row_range_deep<NB, XT, DEEP>(cols, vals, x, off, width, lane, LD, acc);
+    else
+        sell_row_range<NB, BV, false, true, NT, XT>(cols, vals, x, nullptr, off, width, lane, LD, acc);
 }
 
 // out = dinv (c0 r - c1 As r) (+ xadd) (+ padd_x[padd_idx]) with r of type XT (gathered and read at the own row), out of
 // type OT, xadd of type AT; DOT: partials of <dot_with, out> (dot_with fp64).  See sell_poly2_kernel.
-template <int NB, typename XT, typename OT, typename AT, bool DOT, bool NT = false, int BV = 0>
+template <int NB, typename XT, typename OT, typename AT, bool DOT, bool NT = false, int BV = 0, int DEEP = 1>
 __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                           const int* __restrict__ cols, const double* __restrict__ vals_scaled,
                                                           const double* __restrict__ dinv, const XT* __restrict__ r, OT* xout,
@@ -927,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
         const int off = slice_off[slice];
-        sell_row_range_t<NB, XT, NT, BV>(cols, vals_scaled, r, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+        sell_row_range_t<NB, XT, NT, BV, DEEP>(cols, vals_scaled, r, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
         // row steps in pairs: the own-row reads of both (and the parent indices of the coarse correction) are issued before
         // either is consumed - rows past the end re-read the last row and store nothing
         // (pairs only where the gathers above leave the registers for it - the fp32-gather instantiations; the fp64-gather
@@ -991,7 +1105,7 @@ __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices
 // y = r - A x with x of type XT (gathered), r of type RT, y of type YT; R8: rows also summed in groups of 8 into `coarse`
 // (fp64), see sell_spmm_kernel
 // BV: 0 shared fp64 values, 2 per-realization fp32 values; STORE = false: only the restricted sums are wanted (y unused)
-template <int NB, typename XT, typename RT, typename YT, bool R8, int BV = 0, bool STORE = true>
+template <int NB, typename XT, typename RT, typename YT, bool R8, int BV = 0, bool STORE = true, int DEEP = 1>
 __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                              const int* __restrict__ cols, const double* __restrict__ vals,
                                                              const XT* __restrict__ x, const RT* r, YT* y,
@@ -1012,7 +1126,7 @@ __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nsli
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
         const int off = slice_off[slice];
-        sell_row_range_t<NB, XT, false, BV>(cols, vals, x, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+        sell_row_range_t<NB, XT, false, BV, DEEP>(cols, vals, x, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
         // the own-row reads of H row steps are issued together (rows past the end re-read the last row): one latency per
         // batch instead of one per row step - these launches are single occupancy rounds of dependent loads
         constexpr int H = T >= 4 ? 4 : T;
@@ -2888,12 +3002,27 @@ int poly2_z(hipStream_t st, int nb, const SellView& As, const double* dinv, bool
     return poly2_t<double>(st, nb, As, dinv, dinv_bv, r, xout.as<double>(), c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x);
 }
 
+// a level runs the deep gather loop (sell_row_range_deep) when its launch has at most this many wavefronts - about two per
+// SIMD of the chip (PMC_DEEP_WAVES in laboratory builds; 0 = never)
+static inline bool deep_level(const SellView& A, int nb) {
+    static const long limit = [] {
+        const char* e = lab_env("PMC_DEEP_WAVES");
+        return e ? atol(e) : 0L;   // off in the product: measured neutral on config 2 (LAB_NOTES 10), kept for laboratory runs
+    }();
+    return nb >= kGroup && !A.bv && (long)A.nslices * (nb / kGroup) <= limit;
+}
+
 void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const double* r, float* xout, double c0,
                     double c1) {
     check_offsets32(As, nb);
     if (As.nrows == 0) return;
     if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_presmooth32: shared values expected");
     const dim3 g = grid_slices(As.nslices);
+    if (deep_level(As, nb)) {
+        vc_poly2_kernel<kGroup, double, float, float, false, false, 0, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+        check_launch();
+        return;
+    }
     PMC_DISPATCH_NB(nb, {
         if (nt_poly(As, NB))
             vc_poly2_kernel<NB, double, float, float, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
@@ -2920,6 +3049,11 @@ void vc_residual32(hipStream_t st, int nb, const SellView& A, const double* r, c
     if (A.nrows == 0) return;
     if (A.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual32: shared values expected");
     const dim3 g = grid_slices(A.nslices);
+    if (deep_level(A, nb)) {
+        vc_residual_kernel<kGroup, float, double, float, false, 0, true, 4><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
+        check_launch();
+        return;
+    }
     PMC_DISPATCH_NB(nb, {
         vc_residual_kernel<NB, float, double, float, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
     });
@@ -2931,6 +3065,11 @@ void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res
     if (SP.nrows == 0) return;
     if (SP.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual_coarse32: shared values expected");
     const dim3 g = grid_slices(SP.nslices);
+    if (deep_level(SP, nb)) {
+        vc_residual_kernel<kGroup, double, float, float, false, 0, true, 2><<<groups(g, nb), kBlock, 0, st>>>(SP.nrows, SP.nslices, SP.slice_off, SP.cols, SP.vals, xc, res, res, nullptr, nb);
+        check_launch();
+        return;
+    }
     PMC_DISPATCH_NB(nb, {
         vc_residual_kernel<NB, double, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(SP.nrows, SP.nslices, SP.slice_off, SP.cols, SP.vals, xc, res, res, nullptr, nb);
     });
@@ -2945,6 +3084,14 @@ static int vc_postsmooth32_t(hipStream_t st, int nb, const SellView& As, const d
     if (As.nrows == 0) return 0;
     if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_postsmooth32: shared values expected");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
+    if (deep_level(As, nb)) {
+        if (dot_partial)
+            vc_poly2_kernel<kGroup, float, OT, float, true, false, 0, 4><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
+        else
+            vc_poly2_kernel<kGroup, float, OT, float, false, false, 0, 4><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
+        check_launch();
+        return dot_partial ? (int)g.x : 0;
+    }
     PMC_DISPATCH_NB(nb, {
         if (nt_poly(As, NB)) {
             if (dot_partial)

@@ -599,7 +599,7 @@ double Sampler::smoother_bytes(int level, int nb) const {
 
 void Sampler::apply_preconditioner(int level, int nbatch, const double* r_in, double* z_out, int memspace) {
     PMC_REQUIRE(level >= 0 && level < n_mc, "apply_preconditioner: level out of range");
-    PMC_REQUIRE(valid_batch(nbatch) && nbatch <= batch_width((size_t)lv[level].n_u + lv[level].n_s) && r_in != nullptr && z_out != nullptr,
+    PMC_REQUIRE(valid_batch(nbatch) && nbatch <= batch_width((size_t)lv[level].n_u + lv[level].n_s, false, ctx.device) && r_in != nullptr && z_out != nullptr,
                 "apply_preconditioner: nbatch must be a launch width of the level");
     ctx.activate();
     hipStream_t st = ctx.stream;
@@ -636,7 +636,7 @@ void Sampler::mult(int level, int nbatch, const double* rhs_in, double* sol_io, 
     DevBuf<double> stage_r, stage_x;
     int done = 0;
     while (done < nbatch) {
-        int nb = batch_width((size_t)lv[level].n_u + lv[level].n_s);
+        int nb = batch_width((size_t)lv[level].n_u + lv[level].n_s, false, ctx.device);
         while (nb > nbatch - done) nb >>= 1;
         ensure(level, nb);
         const double* r_d = rhs_in + (size_t)done * n;
@@ -738,7 +738,7 @@ void Sampler::eval(int level, int xi_level, int nbatch, const double* xi, double
     // init_level a chunk's embed rows (n_s each) would overwrite init rows (n_init < n_s each) of later chunks before
     // they are read: keep a private copy of init_s for the whole call then.
     DevBuf<double> init_copy;
-    const int width = batch_width((size_t)lv[level].n_u + lv[level].n_s);
+    const int width = batch_width((size_t)lv[level].n_u + lv[level].n_s, false, ctx.device);
     const bool several_chunks = !valid_batch(nbatch) || nbatch > width;   // exactly when the loop below cuts the call
     if (use_init && memspace == PMC_MEM_DEVICE && emb_out == init_s && n_init != n_s && several_chunks) {
         init_copy.alloc((size_t)n_init * nbatch);
@@ -747,7 +747,7 @@ void Sampler::eval(int level, int xi_level, int nbatch, const double* xi, double
     }
     int done = 0;
     while (done < nbatch) {
-        int nb = batch_width((size_t)lv[level].n_u + lv[level].n_s);
+        int nb = batch_width((size_t)lv[level].n_u + lv[level].n_s, false, ctx.device);
         while (nb > nbatch - done) nb >>= 1;
         const double* xi_d = xi + (size_t)done * n_xi;
         const double* init_d = use_init ? init_s + (size_t)done * n_init : nullptr;

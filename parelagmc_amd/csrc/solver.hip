@@ -393,16 +393,25 @@ static bool stage_on() {
 // lanes, each with a sampler and a Darcy solver); half the memory is left to the operators and the other plugin.  288 GB:
 // 5.1 M rows (config 5's 6.46 M-row level therefore runs 16 wide, as measured necessary in round 3).  Deterministic: the
 // TOTAL memory is asked, not what happens to be free, so every lane and every rank of a farm picks the same width.
-static size_t sampler_wide_rows() {
-    static const size_t v = [] {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return (size_t)5000000;
-        return (size_t)((double)total_b * 0.5 / (110.0 * 32.0 * 8.0));
-    }();
+static size_t sampler_wide_rows(int device) {
+    // per DEVICE (the handle's, never "the current one": a manager lane thread that has not activated its context would ask
+    // device 0 - and create a primary context there), cached; hipDeviceTotalMem needs no current device
+    static std::atomic<size_t> cache[64];
+    const int slot = device & 63;
+    size_t v = cache[slot].load(std::memory_order_relaxed);
+    if (v == 0) {
+        size_t total_b = 0;
+        hipDevice_t dev;
+        if (hipDeviceGet(&dev, device) != hipSuccess || hipDeviceTotalMem(&total_b, dev) != hipSuccess || total_b == 0)
+            v = (size_t)5000000;
+        else
+            v = (size_t)((double)total_b * 0.5 / (110.0 * 32.0 * 8.0));
+        cache[slot].store(v, std::memory_order_relaxed);
+    }
     return v;
 }
 
-int batch_width(size_t rows, bool darcy) {
+int batch_width(size_t rows, bool darcy, int device) {
     static const auto lim = [](const char* name, size_t dflt) {
         const char* e = lab_env(name);
         return e ? (size_t)atoll(e) : dflt;
@@ -414,12 +423,13 @@ int batch_width(size_t rows, bool darcy) {
     // PMC_WIDE_ROWS: limit of the 32-wide launches for Darcy levels, and for sampler levels too when it is set (0 = always
     // 16); PMC_S_WIDE_ROWS: the sampler's own limit
     static const size_t l32 = lim("PMC_WIDE_ROWS", 300000),
-                        l32s = lim("PMC_S_WIDE_ROWS", lab_env("PMC_WIDE_ROWS") ? l32 : sampler_wide_rows()),
+                        l32s_lab = lim("PMC_S_WIDE_ROWS", lab_env("PMC_WIDE_ROWS") ? l32 : 0),
                         l64 = lim("PMC_W64_ROWS", 150000), l128 = lim("PMC_W128_ROWS", 40000), l256 = lim("PMC_W256_ROWS", 20000),
                         // sampler levels up to 500 k rows: two column groups per launch (config 4's 314 k-row level, four lanes:
                         // hybridized 5 735 -> 6 441, saddle-point 1 474 -> 1 512 realizations/s; a 600 k-row level gains 30 % with
                         // one lane and nothing with four, LAB_NOTES 9.15)
                         l64s = lim("PMC_S_W64_ROWS", lab_env("PMC_W64_ROWS") ? l64 : 500000);
+    const size_t l32s = l32s_lab ? l32s_lab : (darcy ? 0 : sampler_wide_rows(device));
     if (rows > (darcy ? l32 : l32s)) return 16;
     if (rows <= l256) return 256;
     if (rows <= l128) return 128;

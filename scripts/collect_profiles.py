@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def find(d, suffix):
@@ -23,6 +23,7 @@ def find(d, suffix):
 
 
 for src, dst, what in (("prof_bench", "bench", "python bench.py --steps 20 --warmup 5 --inline-setup"),
+                       ("prof_l4", "bench_l4", "python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras"),
                        ("prof_s1", "bench_s1", "python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-extras"),
                        ("prof_s1_saddle", "bench_s1_saddle", "python bench.py --solver saddle --streams 1 --steps 40 --no-cpu-baseline --no-extras"),
                        ("prof_s1_r6", "bench_s1_r6", "python bench.py --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras"),

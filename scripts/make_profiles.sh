@@ -4,6 +4,7 @@
 #      GPU box, at run time - scripts/collect_profiles.py copies it into profiles/pmc_traffic.json instead of hashing whatever
 #      sits in the tree when it is called)
 #   1. rocprofv3 --kernel-trace --stats of the DEFAULT bench command (the driver's)  -> gpurun_out/prof_bench/
+#   1b. the headline alone (--no-extras: four lanes, hybridized), the kernel mix `value` is measured on -> gpurun_out/prof_l4/
 #   2. the same for one lane per GPU (--streams 1): per-kernel time without overlap   -> gpurun_out/prof_s1/
 #      (the headline's solver, hybridization) and gpurun_out/prof_s1_saddle/ (--solver saddle: MINRES-BJ-GS on the
 #      saddle-point system, the K5 of extra.saddle_point_minres)
@@ -40,6 +41,7 @@ runpy() {   # name, script
 }
 PROF=(--kernel-trace --stats)
 if [ -z "$SKIP_BENCH_PROFILE" ]; then run prof_bench --steps 20 --warmup 5 --inline-setup || exit 1; fi
+run prof_l4 --steps 40 --warmup 5 --no-cpu-baseline --no-extras || exit 1     # the headline's own kernel mix: four lanes, hybridized
 run prof_s1 --streams 1 --steps 40 --no-cpu-baseline --no-extras || exit 1
 run prof_s1_saddle --solver saddle --streams 1 --steps 40 --no-cpu-baseline --no-extras || exit 1
 run prof_s1_r6 --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras || exit 1
@@ -56,10 +58,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 if [ -f $R/parelagmc_amd/lib/libpmc_lab.so ]; then
   PROF=(--kernel-trace --stats)
-  cp $R/parelagmc_amd/lib/libpmc.so /tmp/libpmc_product.so
-  cp $R/parelagmc_amd/lib/libpmc_lab.so $R/parelagmc_amd/lib/libpmc.so
-  PMC_SPLIT_MIN=0 run prof_s1_onestream --solver saddle --streams 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras
-  rc=$?
-  cp /tmp/libpmc_product.so $R/parelagmc_amd/lib/libpmc.so
-  [ $rc = 0 ] || exit 1
+  # the laboratory library is SELECTED through the harness's loader override, never copied over the product's file
+  PMC_LIB=$R/parelagmc_amd/lib/libpmc_lab.so PMC_SPLIT_MIN=0 run prof_s1_onestream --solver saddle --streams 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras || exit 1
 fi
