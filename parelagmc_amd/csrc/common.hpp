@@ -92,6 +92,10 @@ int pairwise_match(const HostCsr& A, double theta, std::vector<int>& agg, bool a
 int aggregate_rows(const HostCsr& K, int passes, double theta, std::vector<int>& agg, bool allow_weak = false,
                    bool join_singletons = false);
 HostCsr prolongator_from_agg(const std::vector<int>& agg, int nc);
+// renumbering that makes every aggregate of the indicator prolongator P a run of consecutive rows inside one 64-row slice
+// (new2old; empty = not possible) + per slice the segments [seg_ptr[s], seg_ptr[s + 1]): coarse id, (first row in slice << 8) | rows
+std::vector<int> agg_pack_rows(const HostCsr& P, std::vector<int>& seg_ptr, std::vector<int>& seg_cid, std::vector<int>& seg_pos);
+HostCsr csr_permute(const HostCsr& A, const std::vector<int>& new2old, bool rows, bool cols);
 
 HostCsr csr_spgemm(const HostCsr& A, const HostCsr& B);
 // P(i, i / 8) == 1 is the only entry of row i, for every row, and P has 8 rows per column

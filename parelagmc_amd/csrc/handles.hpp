@@ -29,6 +29,9 @@ struct SamplerLevel {
     Sell Gl;                // G^T: n_s x n_lambda
     Sell Ptz;               // diag(z) P^T of the next finer level: restriction of a finer xi that lands on z f directly
     DevBuf<double> zw_sqrt; // z .* sqrt(w)
+    // internal numbering of the multipliers (aggregates of the V-cycle's finest level contiguous, agg_pack_rows): internal
+    // row i is the caller's row lam_new2old[i]; empty = the caller's numbering
+    DevBuf<int> lam_new2old, lam_old2new;
 };
 
 struct Sampler {

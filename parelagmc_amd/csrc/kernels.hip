@@ -1013,8 +1013,19 @@ __device__ __forceinline__ void sell_row_range_t(const int* __restrict__ cols, c
 
 // out = dinv (c0 r - c1 As r) (+ xadd) (+ padd_x[padd_idx]) with r of type XT (gathered and read at the own row), out of
 // type OT, xadd of type AT; DOT: partials of <dot_with, out> (dot_with fp64).  See sell_poly2_kernel.
+#ifndef PMC_VC_MIN_WAVES
+#define PMC_VC_MIN_WAVES 3   // post-smoothing of the 400 k-row multiplier level: 172 -> 168 registers, 83.6 -> 79.7 us (LAB_NOTES 10.3)
+#endif
+#ifndef PMC_VC_MIN_WAVES_D
+#define PMC_VC_MIN_WAVES_D 1
+#endif
+// wavefronts per SIMD the fp32-gather V-cycle kernels of the 32-wide layout are compiled for (laboratory macro)
+template <int NB, typename XT, int BV, int DEEP>
+constexpr int vc_min_waves() {
+    return (NB >= 32 && BV == 0 && DEEP == 1) ? (sizeof(XT) == 4 ? PMC_VC_MIN_WAVES : PMC_VC_MIN_WAVES_D) : 1;
+}
 template <int NB, typename XT, typename OT, typename AT, bool DOT, bool NT = false, int BV = 0, int DEEP = 1>
-__global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
+__global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                           const int* __restrict__ cols, const double* __restrict__ vals_scaled,
                                                           const double* __restrict__ dinv, const XT* __restrict__ r, OT* xout,
                                                           double c0, double c1, double* __restrict__ partial, const AT* xadd,
@@ -1105,12 +1116,20 @@ __global__ __launch_bounds__(kBlock) void vc_poly2_kernel(int nrows, int nslices
 // y = r - A x with x of type XT (gathered), r of type RT, y of type YT; R8: rows also summed in groups of 8 into `coarse`
 // (fp64), see sell_spmm_kernel
 // BV: 0 shared fp64 values, 2 per-realization fp32 values; STORE = false: only the restricted sums are wanted (y unused)
-template <int NB, typename XT, typename RT, typename YT, bool R8, int BV = 0, bool STORE = true, int DEEP = 1>
+// RAGG (aggregation levels renumbered by agg_pack_rows: every aggregate a run of consecutive rows inside one slice): the
+// wavefront keeps its 64 x NB residual tile - the fp32 values it has just stored - in LDS and sums its own aggregates from it
+// in increasing row order: coarse[cid] = sum of the rows of segment (cid, first row, rows).  No other wavefront touches those
+// coarse rows: deterministic, no atomics, and the separate product with P^T (one more pass over the residual) is gone.
+template <int NB, typename XT, typename RT, typename YT, bool R8, int BV = 0, bool STORE = true, int DEEP = 1, bool RAGG = false>
 __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                              const int* __restrict__ cols, const double* __restrict__ vals,
                                                              const XT* __restrict__ x, const RT* r, YT* y,
-                                                             double* __restrict__ coarse, int ld) {
+                                                             double* __restrict__ coarse, int ld,
+                                                             const int* __restrict__ seg_ptr = nullptr,
+                                                             const int* __restrict__ seg_cid = nullptr,
+                                                             const int* __restrict__ seg_pos = nullptr) {
     static_assert(STORE || R8, "a residual that is neither stored nor restricted");
+    static_assert(!RAGG || (!R8 && STORE && BV == 0 && sizeof(YT) == 4), "fused aggregate restriction: shared values, fp32 residual");
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int LD = row_ld<NB>(ld);
     {
@@ -1118,10 +1137,12 @@ __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nsli
         x += g0; r += g0;
         if constexpr (STORE) y += g0;
         if constexpr (BV != 0) vals = shift_bv<BV>(vals, g0);
-        if constexpr (R8) coarse += g0;
+        if constexpr (R8 || RAGG) coarse += g0;
     }
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
+    __shared__ float tile_all[RAGG ? (kBlock / kWave) * kWave * NB : 1];
+    float* tile = tile_all + (RAGG ? (threadIdx.x / kWave) * kWave * NB : 0);
     const SliceWalk sw = slice_walk(nslices);
     for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
@@ -1146,6 +1167,10 @@ __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nsli
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[rs][c] = rvb[rs % H][c] - acc[rs][c];
                 if constexpr (STORE) store_v<C>(y + at, acc[rs]);
+                if constexpr (RAGG) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) tile[(rs * G + g) * NB + t * C + c] = (float)acc[rs][c];
+                }
             } else if constexpr (R8) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
@@ -1162,6 +1187,24 @@ __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nsli
                 }
                 if ((g & 7) == 0 && row < nrows) store_c<C>(coarse + (size_t)(row >> 3) * LD + t * C, s);
             }
+        }
+        if constexpr (RAGG) {
+            // the tile is private to this wavefront: its own LDS writes are complete once the wait below has passed
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int s0 = seg_ptr[slice], s1 = seg_ptr[slice + 1];
+            for (int sg = s0 + g; sg < s1; sg += G) {
+                const int pos = seg_pos[sg], first = pos >> 8, len = pos & 255;
+                double sum[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) sum[c] = 0.0;
+                for (int q = 0; q < len; ++q)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) sum[c] += (double)tile[(first + q) * NB + t * C + c];
+                store_c<C>(coarse + (size_t)seg_cid[sg] * LD + t * C, sum);
+            }
+            __builtin_amdgcn_wave_barrier();    // the next slice overwrites the tile
         }
     }
 }
@@ -2040,17 +2083,19 @@ __global__ __launch_bounds__(kBlock) void normal_fill_kernel(int n, int nbatch, 
 // ------------------------------------------------------------------------------------------
 // layout changes fused with the sampler's pointwise maps
 // out[i*NB + k] = scale * in[k*n + i] * (w ? w[i] : 1)        (K2: rhs_s = -g W^{1/2} xi)
+// src (optional): row i of the result takes row src[i] of the input (a renumbering of the rows)
 template <int NB>
 __global__ __launch_bounds__(kBlock) void interleave_kernel(int n, const double* __restrict__ in,
                                                             const double* __restrict__ w, double scale,
-                                                            double* __restrict__ out, int ld) {
+                                                            double* __restrict__ out, int ld, const int* __restrict__ src) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int LD = row_ld<NB>(ld), c0 = col0<NB>();
     const double f = w ? scale * w[i] : scale;
+    const int is = src ? src[i] : i;
     double v[NB];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) v[k] = f * in[(size_t)(c0 + k) * n + i];
+    for (int k = 0; k < NB; ++k) v[k] = f * in[(size_t)(c0 + k) * n + is];
     store_row<NB>(out + (size_t)i * LD + c0, v);
 }
 
@@ -3060,6 +3105,18 @@ void vc_residual32(hipStream_t st, int nb, const SellView& A, const double* r, c
     check_launch();
 }
 
+void vc_residual_restrict_agg32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out,
+                                double* coarse, const int* seg_ptr, const int* seg_cid, const int* seg_pos) {
+    check_offsets32(A, nb);
+    if (A.nrows == 0) return;
+    if (A.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual_restrict_agg32: shared values expected");
+    const dim3 g = grid_slices(A.nslices);
+    PMC_DISPATCH_NB(nb, {
+        vc_residual_kernel<NB, float, double, float, false, 0, true, 1, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, coarse, nb, seg_ptr, seg_cid, seg_pos);
+    });
+    check_launch();
+}
+
 void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res, const double* xc) {
     check_offsets32(SP, nb);
     if (SP.nrows == 0) return;
@@ -3469,8 +3526,8 @@ void normal_fill(hipStream_t st, int n, int nbatch, uint64_t seed, uint64_t firs
     check_launch();
 }
 
-void interleave(hipStream_t st, int nb, int n, const double* in, const double* w, double scale, double* out) {
-    PMC_DISPATCH_NB(nb, { interleave_kernel<NB><<<groups(grid_rows(n), nb), kBlock, 0, st>>>(n, in, w, scale, out, nb); });
+void interleave(hipStream_t st, int nb, int n, const double* in, const double* w, double scale, double* out, const int* src) {
+    PMC_DISPATCH_NB(nb, { interleave_kernel<NB><<<groups(grid_rows(n), nb), kBlock, 0, st>>>(n, in, w, scale, out, nb, src); });
     check_launch();
 }
 

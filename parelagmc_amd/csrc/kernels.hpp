@@ -138,6 +138,9 @@ void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* di
 void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out,
                               double* coarse);
 void vc_residual32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out);   // no restriction
+// residual + restriction of an aggregation level renumbered by agg_pack_rows (segments per slice: seg_ptr / seg_cid / seg_pos)
+void vc_residual_restrict_agg32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out,
+                                double* coarse, const int* seg_ptr, const int* seg_cid, const int* seg_pos);
 void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res, const double* xc);
 int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
                     double* xout, double c0, double c1, const double* r, const int* parent, const double* xc, double* dot_partial);
@@ -210,7 +213,8 @@ size_t scal_stage_doubles();
 void normal_fill(hipStream_t st, int n, int nbatch, uint64_t seed, uint64_t first_id, uint32_t stream, double mean,
                  double sigma, double* out, uint64_t id_stride = 1);
 // out[i*nb+k] = scale * in[k*n+i] * (w ? w[i] : 1)
-void interleave(hipStream_t st, int nb, int n, const double* in, const double* w, double scale, double* out);
+void interleave(hipStream_t st, int nb, int n, const double* in, const double* w, double scale, double* out,
+                const int* src = nullptr);
 // out[k*m+i] = post(rowscale[i] * in[(idx?idx[i]:i)*nb + k])
 void deinterleave(hipStream_t st, int nb, int m, const double* in, const int* idx, const double* rowscale, bool do_exp,
                   double* out);

@@ -48,8 +48,12 @@ HostCsr schur_host(const HostCsr& B, const HostCsr& Bt, const std::vector<double
 }
 
 // device V-cycle levels of an algebraic hierarchy (setup)
+struct AggSegments {   // agg_pack_rows' tables of the finest level (empty: the restriction stays a product with P^T)
+    std::vector<int> ptr, cid, pos;
+};
 static std::unique_ptr<Multigrid> build_chain(const std::vector<AmgLevelHost>& lv, const pmc_solver_opts& o, hipStream_t st,
-                                              double ratio_scale = 1.0, bool f32_any_injection = false) {
+                                              double ratio_scale = 1.0, bool f32_any_injection = false,
+                                              const AggSegments* seg0 = nullptr) {
     std::unique_ptr<Multigrid> mg(new Multigrid());
     mg->smooth_degree = o.mg_smooth_degree;
     mg->smooth_ratio = ratio_scale * o.mg_smooth_ratio;
@@ -96,6 +100,12 @@ static std::unique_ptr<Multigrid> build_chain(const std::vector<AmgLevelHost>& l
                 sell_build(m.SP, csr_spgemm(S, P), true, false, st);
                 m.parent.upload(parent, st);
                 m.has_sp = true;
+                if (l == 0 && seg0 && !seg0->ptr.empty()) {
+                    m.seg_ptr.upload(seg0->ptr, st);
+                    m.seg_cid.upload(seg0->cid, st);
+                    m.seg_pos.upload(seg0->pos, st);
+                    m.p_agg = true;
+                }
                 PMC_HIP(hipStreamSynchronize(st));
             }
         }
@@ -286,22 +296,45 @@ Sampler::Sampler(Ctx& c, int nlevels_, const pmc_hybrid_level* in, double alpha_
             d.w_sqrt.upload(wsq, st);
         }
         d.nnz = H.nnz();
+        // aggregates of ~9 rows per level (three matching passes + singletons joined): 19 -> 21 iterations at 400 k multipliers
+        // against aggregates of ~4.4, but two kernel-launched levels above the LDS tail instead of four (measured, LAB_NOTES 9.11)
+        int passes0 = 3, passes1 = 3;
+        if (const char* e = lab_env("PMC_HYB_PASSES0")) passes0 = atoi(e);
+        if (const char* e = lab_env("PMC_HYB_PASSES1")) passes1 = atoi(e);
+        std::vector<AmgLevelHost> hier = agg_hierarchy(H, passes0, passes1, /*theta=*/0.25, /*min_size=*/256, /*max_levels=*/14);
+        // The multipliers are internal unknowns: renumber them so that every aggregate of the finest level is a run of
+        // consecutive rows inside one SELL slice - the restriction of the V-cycle's finest level is then taken by the residual
+        // kernel itself (k::vc_residual_restrict_agg32).  H, G and the level's prolongator move to the new numbering; vectors
+        // that cross the boundary in multiplier numbering (pmc_sampler_mult / _apply_operator / _apply_preconditioner) are
+        // renumbered on the way in and out (lam_new2old / lam_old2new).
+        AggSegments seg0;
+        bool pack = hier.size() >= 2 && o.precond_storage != PMC_STORAGE_FP64;
+        if (const char* e = lab_env("PMC_AGG_PACK")) pack = pack && atoi(e) != 0;
+        if (pack) {
+            std::vector<int> new2old = agg_pack_rows(hier[0].P, seg0.ptr, seg0.cid, seg0.pos);
+            if (!new2old.empty()) {
+                std::vector<int> old2new(new2old.size());
+                for (size_t i = 0; i < new2old.size(); ++i) old2new[(size_t)new2old[i]] = (int)i;
+                H = csr_permute(H, new2old, true, true);
+                G = csr_permute(G, new2old, true, false);
+                hier[0].P = csr_permute(hier[0].P, new2old, true, false);
+                hier[0].S = H;
+                d.lam_new2old.upload(new2old, st);
+                d.lam_old2new.upload(old2new, st);
+            } else {
+                seg0 = AggSegments();
+            }
+        }
         sell_build(d.A, H, true, false, st, diag_last_on());
         sell_build(d.Gl, csr_transpose(G), true, false, st);
         for (int i = 0; i < G.nrows; ++i)
             for (int p = G.rowptr[i]; p < G.rowptr[i + 1]; ++p) G.vals[p] /= L.z_diag[G.colind[p]];
         sell_build(d.Gz, G, true, false, st);
         PMC_HIP(hipStreamSynchronize(st));
-        // aggregates of ~9 rows per level (three matching passes + singletons joined): 19 -> 21 iterations at 400 k multipliers
-        // against aggregates of ~4.4, but two kernel-launched levels above the LDS tail instead of four (measured, LAB_NOTES 9.11)
-        int passes0 = 3, passes1 = 3;
-        if (const char* e = lab_env("PMC_HYB_PASSES0")) passes0 = atoi(e);
-        if (const char* e = lab_env("PMC_HYB_PASSES1")) passes1 = atoi(e);
         // the aggregation hierarchy of H smooths on [lmax / (2 r), lmax], r = mg_smooth_ratio - twice the interval ratio of the
         // Schur-complement hierarchies (measured at 400 k multipliers, 4 lanes x 32: r = 8 2 630, 12 ... 30 2 900, 50 2 650
         // samples/s; 21 -> 20 iterations)
-        amg[l] = build_chain(agg_hierarchy(H, passes0, passes1, /*theta=*/0.25, /*min_size=*/256, /*max_levels=*/14), o, st,
-                             /*ratio_scale=*/2.0, /*f32_any_injection=*/true);
+        amg[l] = build_chain(hier, o, st, /*ratio_scale=*/2.0, /*f32_any_injection=*/true, &seg0);
         amg[l]->tail_later_nb = 8;
         if (const char* e = lab_env("PMC_TAIL_LATER_NB")) amg[l]->tail_later_nb = atoi(e);
         mg.L[l].n = L.n_s;
@@ -614,7 +647,8 @@ void Sampler::apply_preconditioner(int level, int nbatch, const double* r_in, do
         PMC_HIP(hipMemcpyAsync(stage.p, r_in, sizeof(double) * n * nb, hipMemcpyHostToDevice, st));
         r_d = stage.p;
     }
-    k::interleave(st, nb, (int)n, r_d, nullptr, 1.0, rhs.p);
+    // hybrid handles: multiplier vectors cross the boundary in the caller's numbering (see lam_new2old)
+    k::interleave(st, nb, (int)n, r_d, nullptr, 1.0, rhs.p, hybrid ? d.lam_new2old.p : nullptr);
     const bool use_amg = level < (int)amg.size() && amg[level];
     Multigrid* mgp = use_amg ? amg[level].get() : &mg;
     const int degM = opts.cheb_degree_M > 0 ? opts.cheb_degree_M : (d.ratio_M > 16.0 ? 4 : 2);
@@ -622,7 +656,7 @@ void Sampler::apply_preconditioner(int level, int nbatch, const double* r_in, do
     // the result is taken in fp64: with PMC_STORAGE_FP32 the solver additionally rounds it to fp32 (6e-8 relative)
     prec(ctx.lanes(false), nb, rhs.p, zvec(zi.p, false), part.p, part.p + (size_t)dot_capacity((int)n, nb) * nb);
     double* out_d = memspace == PMC_MEM_HOST ? stage.p : z_out;
-    k::deinterleave(st, nb, (int)n, zi.p, nullptr, nullptr, false, out_d);
+    k::deinterleave(st, nb, (int)n, zi.p, hybrid ? d.lam_old2new.p : nullptr, nullptr, false, out_d);
     if (memspace == PMC_MEM_HOST) PMC_HIP(hipMemcpyAsync(z_out, stage.p, sizeof(double) * n * nb, hipMemcpyDeviceToHost, st));
     PMC_HIP(hipStreamSynchronize(st));
 }
@@ -650,11 +684,12 @@ void Sampler::mult(int level, int nbatch, const double* rhs_in, double* sol_io, 
         }
         double* xdev = memspace == PMC_MEM_HOST ? stage_x.p : x_d;
         if (stats) ctx.phase_mark(0);
-        k::interleave(st, nb, (int)n, r_d, nullptr, 1.0, rhs.p);
-        if (use_guess) k::interleave(st, nb, (int)n, xdev, nullptr, 1.0, sol.p);
+        const int* n2o = hybrid ? lv[level].lam_new2old.p : nullptr;
+        k::interleave(st, nb, (int)n, r_d, nullptr, 1.0, rhs.p, n2o);
+        if (use_guess) k::interleave(st, nb, (int)n, xdev, nullptr, 1.0, sol.p, n2o);
         if (stats) ctx.phase_mark(1);
         solve_system(level, nb, !use_guess, 0, (int)n, stats ? stats + done : nullptr);
-        k::deinterleave(st, nb, (int)n, sol.p, nullptr, nullptr, false, xdev);
+        k::deinterleave(st, nb, (int)n, sol.p, hybrid ? lv[level].lam_old2new.p : nullptr, nullptr, false, xdev);
         if (memspace == PMC_MEM_HOST) PMC_HIP(hipMemcpyAsync(x_d, stage_x.p, sizeof(double) * n * nb, hipMemcpyDeviceToHost, st));
         PMC_HIP(hipStreamSynchronize(st));
         done += nb;
@@ -678,7 +713,7 @@ void Sampler::apply_operator(int level, int nb, const double* x, double* y, int 
         xd = stage.p;
         yd = stage.p;
     }
-    k::interleave(st, nb, (int)n, xd, nullptr, 1.0, xi.p);
+    k::interleave(st, nb, (int)n, xd, nullptr, 1.0, xi.p, hybrid ? d.lam_new2old.p : nullptr);
     SellView Av = view(d.A);
     Av.tag = 2;   // own kernel instantiation: the profile row of these launches holds nothing else
     k::spmm(st, nb, Av, xi.p, yi.p, false, nullptr, nullptr);   // untimed first touch
@@ -707,7 +742,7 @@ void Sampler::apply_operator(int level, int nb, const double* x, double* y, int 
             total_ms += ms1;
         }
     }
-    k::deinterleave(st, nb, (int)n, yi.p, nullptr, nullptr, false, yd);
+    k::deinterleave(st, nb, (int)n, yi.p, hybrid ? d.lam_old2new.p : nullptr, nullptr, false, yd);
     if (memspace == PMC_MEM_HOST) PMC_HIP(hipMemcpyAsync(y, stage.p, sizeof(double) * n * nb, hipMemcpyDeviceToHost, st));
     PMC_HIP(hipStreamSynchronize(st));
     if (avg_ms) {

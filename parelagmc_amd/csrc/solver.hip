@@ -233,6 +233,8 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         lc.ensure(nb);
         if (lv.p_oct) {
             k::vc_residual_restrict8_32(st, nb, A, r, xf, resf, lc.r.p);
+        } else if (lv.p_agg) {
+            k::vc_residual_restrict_agg32(st, nb, A, r, xf, resf, lc.r.p, lv.seg_ptr.p, lv.seg_cid.p, lv.seg_pos.p);
         } else {
             k::vc_residual32(st, nb, A, r, xf, resf);
             k::spmm_z(st, nb, view(lv.Pt), zvec(resf, true), lc.r.p, nullptr, zvec());

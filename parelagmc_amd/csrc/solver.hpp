@@ -87,6 +87,10 @@ struct MgLevel {
     // P has exactly the children 8 i .. 8 i + 7 of parent i with unit weights (uniform refinement with contiguous
     // children): the restriction is fused into the residual kernel (k::residual_restrict8)
     bool p_oct = false;
+    // aggregation level whose rows were renumbered by agg_pack_rows (every aggregate a run of consecutive rows inside one
+    // slice): the restriction is fused into the residual kernel through per-slice segment tables
+    bool p_agg = false;
+    DevBuf<int> seg_ptr, seg_cid, seg_pos;
     DevBuf<double> r, xa, xb, d, res;
     void ensure(int nb);
     SellView sview() const { return bv ? (f32 ? view_bv32(S, vals32.p) : view_bv(S, vals_bv.p)) : view(S); }

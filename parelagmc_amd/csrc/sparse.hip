@@ -337,6 +337,109 @@ HostCsr prolongator_from_agg(const std::vector<int>& agg, int nc) {
     return P;
 }
 
+// Renumbering of the fine rows of an aggregation level so that the restriction P^T res can be taken inside the residual
+// kernel: every aggregate becomes a run of CONSECUTIVE rows that lies inside one 64-row SELL slice (= one wavefront), which
+// then sums its own aggregates from the tile it has just computed (k::vc_residual_restrict_agg32) - the separate product with
+// P^T (one more read of the residual, 32 us per iteration at 400 k multipliers) disappears.  Aggregates keep their coarse
+// numbers and, up to the packing, their order (the coarse ids follow the fine ordering in windows of 512: mesh locality of
+// the gathers stays); a slice is filled exactly by taking the next aggregates in order and, when the next one does not
+// fit, the EARLIEST subset of the following `window` aggregates that fills the remaining rows (subset sum over at most 63
+// rows).  Returns new2old (new row i holds old row new2old[i]) and the segment tables, or an empty vector when some slice
+// cannot be filled exactly (the caller then keeps the separate restriction).
+std::vector<int> agg_pack_rows(const HostCsr& P, std::vector<int>& seg_ptr, std::vector<int>& seg_cid,
+                               std::vector<int>& seg_pos) {
+    const int n = P.nrows, nc = P.ncols;
+    seg_ptr.clear(); seg_cid.clear(); seg_pos.clear();
+    std::vector<int> size(nc, 0), start(nc + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        if (P.rowptr[i + 1] - P.rowptr[i] != 1 || P.vals[P.rowptr[i]] != 1.0) return {};
+        ++size[P.colind[P.rowptr[i]]];
+    }
+    for (int c = 0; c < nc; ++c) {
+        if (size[c] < 1 || size[c] > 64) return {};
+        start[c + 1] = start[c] + size[c];
+    }
+    std::vector<int> members(n), fill(nc, 0);
+    for (int i = 0; i < n; ++i) {          // rows of an aggregate in increasing (old) order
+        const int c = P.colind[P.rowptr[i]];
+        members[start[c] + fill[c]++] = i;
+    }
+    std::vector<int> new2old;
+    new2old.reserve(n);
+    std::vector<char> placed(nc, 0);
+    const int nslices = (n + 63) / 64;
+    seg_ptr.assign(1, 0);
+    constexpr int window = 96;
+    int next = 0;                          // first aggregate not yet placed
+    auto place = [&](int c, int pos) {
+        placed[c] = 1;
+        seg_cid.push_back(c);
+        seg_pos.push_back((pos << 8) | size[c]);
+        for (int q = 0; q < size[c]; ++q) new2old.push_back(members[start[c] + q]);
+    };
+    for (int sl = 0; sl < nslices; ++sl) {
+        const int cap = std::min(64, n - sl * 64);
+        while (next < nc && placed[next]) ++next;
+        // candidates: the next unplaced aggregates in order
+        int cand[window], ncand = 0;
+        for (int c = next; c < nc && ncand < window; ++c)
+            if (!placed[c]) cand[ncand++] = c;
+        // 0/1 subset sum over the candidates in order: a sum keeps the FIRST way it was reached, so the subset found for `cap`
+        // prefers the earliest aggregates
+        int from[65], via[65];
+        for (int t = 0; t <= 64; ++t) { from[t] = -2; via[t] = -1; }
+        from[0] = -1;
+        for (int k = 0; k < ncand && from[cap] == -2; ++k) {
+            const int sz = size[cand[k]];
+            for (int t = cap; t >= sz; --t)
+                if (from[t] == -2 && from[t - sz] != -2) {
+                    from[t] = t - sz;
+                    via[t] = k;
+                }
+        }
+        if (from[cap] == -2) return {};
+        bool take[window] = {false};
+        for (int t = cap; t > 0; t = from[t]) take[via[t]] = true;
+        int used = 0;
+        for (int k = 0; k < ncand; ++k)
+            if (take[k]) {
+                place(cand[k], used);
+                used += size[cand[k]];
+            }
+        seg_ptr.push_back((int)seg_cid.size());
+    }
+    if ((int)new2old.size() != n) return {};
+    return new2old;
+}
+
+// rows (and, sym, columns) of A renumbered: row i of the result is row new2old[i] of A
+HostCsr csr_permute(const HostCsr& A, const std::vector<int>& new2old, bool rows, bool cols) {
+    HostCsr B;
+    B.nrows = A.nrows;
+    B.ncols = A.ncols;
+    std::vector<int> old2new;
+    if (cols) {
+        PMC_REQUIRE((int)new2old.size() == A.ncols, "csr_permute: column permutation size");
+        old2new.resize(A.ncols);
+        for (int i = 0; i < A.ncols; ++i) old2new[new2old[i]] = i;
+    }
+    if (rows) PMC_REQUIRE((int)new2old.size() == A.nrows, "csr_permute: row permutation size");
+    B.rowptr.assign(A.nrows + 1, 0);
+    B.colind.resize(A.colind.size());
+    B.vals.resize(A.vals.size());
+    int at = 0;
+    for (int i = 0; i < A.nrows; ++i) {
+        const int src = rows ? new2old[i] : i;
+        for (int p = A.rowptr[src]; p < A.rowptr[src + 1]; ++p, ++at) {
+            B.colind[at] = cols ? old2new[A.colind[p]] : A.colind[p];
+            B.vals[at] = A.vals[p];
+        }
+        B.rowptr[i + 1] = at;
+    }
+    csr_sort_rows(B);
+    return B;
+}
+
 // Plain (unsmoothed) aggregation hierarchy of an SPD operator whose off-diagonal entries have either sign (the hybridized
 // sampler's multiplier system: positive couplings across right / obtuse dihedral angles): the matching is steered by the
 // MAGNITUDE of the couplings, the prolongator is the aggregates' indicator (an injection - the V-cycle folds the coarse
