@@ -1844,9 +1844,18 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
     __syncthreads();
     lds[threadIdx.x] = s;
     __syncthreads();
+    // narrow batches (nb < 32: the one-realization-per-call path hands over ONE column) leave 64 ... 1 024 groups per
+    // column: fold them pairwise down to 32 before the serial sum - at nb = 1 thread 0 otherwise walks 1 024 dependent LDS
+    // reads, 26 us per MINRES iteration of a 215 us iteration (round 5).  nb >= 32 takes the loop below unchanged.
+    int groups = nq;
+    for (int stride = nq >> 1; stride >= 32; stride >>= 1) {
+        if (q < stride) lds[threadIdx.x] += lds[threadIdx.x + stride * nb];
+        __syncthreads();
+        groups = stride;
+    }
     double t = 0.0;
     if ((int)threadIdx.x < nb)
-        for (int g = 0; g < nq; ++g) t += lds[g * nb + threadIdx.x];
+        for (int g = 0; g < groups; ++g) t += lds[g * nb + threadIdx.x];
     return t;   // valid for threadIdx.x < nb
 }
 
@@ -2358,6 +2367,9 @@ static constexpr int kTailThreads = 1024;
 #define PMC_TAIL_INLINE __device__ __forceinline__
 static constexpr size_t kTailLdsBytes = 160 * 1024 - 1024;   // dynamic LDS budget (static reduction scratch on top)
 
+#ifndef PMC_TAIL_WIDE
+#define PMC_TAIL_WIDE 0
+#endif
 __device__ __forceinline__ double tail_row_dot(const int* __restrict__ off, const int* __restrict__ cols,
                                                const double* __restrict__ vals, int vstride, size_t vk, int row,
                                                const double* xl) {
@@ -2366,6 +2378,28 @@ __device__ __forceinline__ double tail_row_dot(const int* __restrict__ off, cons
     const int width = (off[slice + 1] - o) >> 6;
     double acc = 0.0;
     int slot = o + lane;
+#if PMC_TAIL_WIDE
+    // wide slices (aggregation hierarchies of the hybridized sampler: 17-27 entries per row): 16 pairs per trip - a sweep over
+    // such a level is a chain of trips to L2 (one workgroup per realization, ~1 us each), and the chain is what a pass
+    // costs (LAB_NOTES 10.4).  Same summation order as the 8-wide loop: bit-identical.
+    if (width > 12) {
+        for (int j0 = 0; j0 < width; j0 += 16, slot += 16 * kWave) {
+            int c[16];
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool ok = j0 + u < width;
+                const int at = ok ? slot + u * kWave : slot;
+                c[u] = cols[at];
+                v[u] = ok ? vals[(size_t)at * vstride + vk] : 0.0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = fma(v[u], xl[c[u]], acc);
+        }
+        return acc;
+    }
+#endif
     // 8 (index, value) pairs are requested together, then the 8 LDS gathers: two memory latencies per 8 entries
     // instead of one dependent chain per entry (rows have 1..8 entries on these levels)
     for (int j0 = 0; j0 < width; j0 += 8, slot += 8 * kWave) {

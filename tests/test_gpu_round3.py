@@ -35,7 +35,14 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    # stdout carries the compact line (< 4 kB whatever the rank count); per-rank dicts and the farm block are in the full record
+    assert len(lines[0]) < 4096
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == W and line["scaling"] == "weak" and line["rank_seconds"]["max"] >= line["rank_seconds"]["min"] > 0
+    assert line["extra"]["farm_allreduces_in_round"] == 1 and line["extra"]["farm_collective"].startswith("gloo")
+    assert "ranks" not in line
+    out = json.load(open(os.path.join(ROOT, line["full_record"])))
+    assert abs(out["value"] - line["value"]) < 1e-3 * out["value"]
     assert out["n_gpus"] == W and out["scaling"] == "weak"
     ranks = out["ranks"]
     assert [x["rank"] for x in ranks] == list(range(W))
