@@ -444,7 +444,10 @@ def hybrid_bytes_per_iteration(hp, smp, nb, zb=4):
     total += (4 * Z + 6 * V) / 4.0 * n                         # w / x updates on ALL rows, four iterations per pass
     total += 12.0 * nnz + 12.0 * n + (V + F) * n               # pre-smoothing: r in, x out
     total += 12.0 * nnz + 4.0 * n + (V + 2 * F) * n            # residual: r, x in; res out
-    total += 12.0 * n + F * n + V * nc                         # restriction P^T res
+    fused = bool(smp.vcycle_levels(0)[0]["fused_restriction"])
+    # restriction P^T res: inside the residual kernel (multipliers renumbered, csrc/sparse.hip::agg_pack_rows: the segment
+    # tables + the coarse rows written) or a separate product that reads the residual once more
+    total += (8.0 * nc + V * nc) if fused else (12.0 * n + F * n + V * nc)
     total += 2 * F * n + V * nc                                # res - (S P) xc, without the bytes of S P
     total += post
     return total
@@ -494,7 +497,7 @@ def hybrid_roofline(farm, hp, nb, tag, next_batch, iters_total, dt):
     sm_raw = sm_ms / sm_n
     ach = sm_bytes / (sm_raw * 1e-3) / 1e9
     return {"bound": "hbm",
-            "kernel": f"pmc::vc_poly2_kernel<{nb}, float, {'float' if zb == 4 else 'double'}, float, true, true, 0> = "
+            "kernel": f"pmc::vc_poly2_kernel<{nb}, float, {'float' if zb == 4 else 'double'}, float, true, true, 0, 1> = "
                       "post-smoothing of the finest level of the multiplier V-cycle (one-pass degree-2 polynomial of the "
                       "residual + coarse correction + fused <r, z>), as launched inside the MINRES loop; one lane alone on the GPU",
             "achieved": ach, "peak": PEAK_GBS, "unit": "GB/s", "frac": ach / PEAK_GBS,

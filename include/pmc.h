@@ -317,6 +317,12 @@ int pmc_sampler_operator_event_overhead(pmc_sampler* s, double* total_ms);
  * correction read once.  Both report 0 for a saddle-point sampler. */
 int pmc_sampler_smoother_time(pmc_sampler* s, double* total_ms, int64_t* launches, double* event_overhead_ms);
 int pmc_sampler_smoother_bytes(const pmc_sampler* s, int level, int nbatch, double* bytes);
+/* Sizes of the V-cycle hierarchy the sampler runs on `level` (diagnostics: what scripts/collect_profiles.py prices the
+ * per-kernel roofline table with): info[0] = rows, [1] = entries of the level operator, [2] = its stored SELL slots,
+ * [3] = entries of S P (0 when the coarse correction is not folded), [4] = slots of S P, [5] = 1 when the level runs inside
+ * the LDS tail kernel (launches of more than 8 realizations), [6] = 1 when its restriction is fused into the residual kernel.
+ * Returns the number of V-cycle levels through *nvlevels; vlevel out of range is an error. */
+int pmc_sampler_vcycle_info(const pmc_sampler* s, int level, int vlevel, int* nvlevels, int64_t info[7]);
 
 /* ---- DarcySolver ------------------------------------------------------------------------ */
 int pmc_darcy_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_darcy_level* levels,

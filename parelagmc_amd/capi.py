@@ -107,6 +107,7 @@ SYMBOLS = {
                                                           C.c_int, C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
     "pmc_sampler_smoother_time": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pmc_sampler_smoother_bytes": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "pmc_sampler_vcycle_info": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "pmc_sampler_destroy": (None, [_VP]),
     "pmc_sampler_set_projection": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_csr), C.POINTER(C.c_int32),
                                              C.POINTER(C.c_double), C.c_int]),
@@ -442,6 +443,17 @@ class PDESampler:
     def BatchWidth(self, level):
         """realizations of `level` one launch of the solver kernels carries (pmc_sampler_batch_width)"""
         return self.ctx.lib.pmc_sampler_batch_width(self.h, level)
+
+    def vcycle_levels(self, level):
+        """[{rows, nnz, slots, sp_nnz, sp_slots, in_tail, fused_restriction}] of the V-cycle hierarchy of `level`"""
+        out, nv, info = [], C.c_int(0), (C.c_int64 * 7)()
+        v = 0
+        while True:
+            _check(self.ctx.lib.pmc_sampler_vcycle_info(self.h, level, v, C.byref(nv), info))
+            out.append(dict(zip(("rows", "nnz", "slots", "sp_nnz", "sp_slots", "in_tail", "fused_restriction"), [int(x) for x in info])))
+            v += 1
+            if v >= nv.value:
+                return out
 
     def z_bytes(self):
         """bytes per entry of the preconditioned Krylov vectors of this handle (4: PMC_STORAGE_FP32, 8: PMC_STORAGE_FP64)"""

@@ -442,6 +442,28 @@ int pmc_sampler_smoother_bytes(const pmc_sampler* s, int level, int nbatch, doub
     });
 }
 
+int pmc_sampler_vcycle_info(const pmc_sampler* s, int level, int vlevel, int* nvlevels, int64_t info[7]) {
+    return guarded([&] {
+        PMC_REQUIRE(s != nullptr && nvlevels != nullptr && info != nullptr, "pmc_sampler_vcycle_info: NULL argument");
+        PMC_REQUIRE(level >= 0 && level < s->impl.n_mc, "pmc_sampler_vcycle_info: level out of range");
+        const bool own = level < (int)s->impl.amg.size() && s->impl.amg[level];
+        const Multigrid& mg = own ? *s->impl.amg[level] : s->impl.mg;
+        const int first = own ? 0 : level;
+        *nvlevels = (int)mg.L.size() - first;
+        PMC_REQUIRE(vlevel >= 0 && vlevel < *nvlevels, "pmc_sampler_vcycle_info: vlevel out of range");
+        const MgLevel& m = mg.L[(size_t)(first + vlevel)];
+        bool in_tail = false;
+        for (int l = first; l <= first + vlevel; ++l) in_tail = in_tail || (l < (int)mg.tail.size() && mg.tail[l].p != nullptr);
+        info[0] = m.n;
+        info[1] = m.S.nnz;
+        info[2] = m.S.nslots;
+        info[3] = m.has_sp ? m.SP.nnz : 0;
+        info[4] = m.has_sp ? m.SP.nslots : 0;
+        info[5] = in_tail ? 1 : 0;
+        info[6] = (m.p_agg || m.p_oct) ? 1 : 0;
+    });
+}
+
 int pmc_sampler_operator_event_overhead(pmc_sampler* s, double* total_ms) {
     return guarded([&] {
         PMC_REQUIRE(s != nullptr && total_ms != nullptr, "operator_event_overhead: bad arguments");

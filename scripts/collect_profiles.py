@@ -44,6 +44,13 @@ for src, dst, what in (("prof_bench", "bench", "python bench.py --steps 20 --war
         f.write(f"# {what} under rocprofv3 --kernel-trace --stats (scripts/make_profiles.sh)\n" + lines[-1])
 
 
+# per (kernel, grid) rows and the per-kernel roofline table (scripts/by_grid.py, scripts/roofline_table.py on the GPU box)
+for src, dst in (("prof_s1_by_grid.csv", "bench_s1_by_grid.csv"), ("prof_l4_by_grid.csv", "bench_l4_by_grid.csv"),
+                 ("roofline_table.json", "roofline_table.json"), ("roofline_table.txt", "roofline_table.txt")):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, f"{tag}_{dst}"))
+
+
 def per_kernel(path):
     acc = collections.defaultdict(list)
     with open(path) as f:

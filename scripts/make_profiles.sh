@@ -29,6 +29,7 @@ run() {   # name, then the bench arguments
   local name=$1; shift
   rm -rf $R/gpurun_out/$name
   timeout -k 10 700 rocprofv3 "${PROF[@]}" -d $R/gpurun_out/$name -o p --output-format csv -- python3 $R/bench.py "$@" > $R/gpurun_out/$name.log 2>&1 || return 1
+  python3 $R/scripts/by_grid.py $R/gpurun_out/$name $R/gpurun_out/${name}_by_grid.csv    # per (kernel, grid) rows, before the trace goes
   rm -f $R/gpurun_out/$name/*kernel_trace.csv $R/gpurun_out/$name/*/*kernel_trace.csv
   echo "$name done"
 }
@@ -39,25 +40,48 @@ runpy() {   # name, script
   rm -f $R/gpurun_out/$name/*kernel_trace.csv $R/gpurun_out/$name/*/*kernel_trace.csv
   echo "$name done"
 }
-PROF=(--kernel-trace --stats)
-if [ -z "$SKIP_BENCH_PROFILE" ]; then run prof_bench --steps 20 --warmup 5 --inline-setup || exit 1; fi
-run prof_l4 --steps 40 --warmup 5 --no-cpu-baseline --no-extras || exit 1     # the headline's own kernel mix: four lanes, hybridized
-run prof_s1 --streams 1 --steps 40 --no-cpu-baseline --no-extras || exit 1
-run prof_s1_saddle --solver saddle --streams 1 --steps 40 --no-cpu-baseline --no-extras || exit 1
-run prof_s1_r6 --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras || exit 1
-run prof_s1_r6_saddle --solver saddle --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras || exit 1
-runpy prof_c3 scripts/c3_darcy_op.py || exit 1
-for c in FETCH_SIZE WRITE_SIZE; do
-  PROF=(--kernel-trace --pmc $c)
-  n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
-  run pmc_${n}_r5 --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
-  run pmc_${n}_r5s --solver saddle --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
-  run pmc_${n}_r6 --refine 6 --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
-  run pmc_${n}_r6s --solver saddle --refine 6 --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
-  runpy pmc_${n}_c3 scripts/c3_darcy_op.py || exit 1
-done
-if [ -f $R/parelagmc_amd/lib/libpmc_lab.so ]; then
+# STAGE (a gpurun call lasts at most 20 minutes and every call starts from a fresh copy of the tree; gpurun_out/ is merged back
+# after each): 1 = default bench + the headline alone; 2 = one lane at r = 5, both solvers, with their counter passes and the
+# per-kernel roofline table; 3 = r = 6, config 3 and the one-stream laboratory pass; unset = everything in one go
+STAGE=${STAGE:-all}
+want() { [ "$STAGE" = all ] || [ "$STAGE" = "$1" ]; }
+pmc_pass() {   # suffix, bench arguments: the FETCH_SIZE and WRITE_SIZE passes of one configuration
+  local suf=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    PROF=(--kernel-trace --pmc $c)
+    n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+    run pmc_${n}_$suf "$@" || return 1
+  done
   PROF=(--kernel-trace --stats)
-  # the laboratory library is SELECTED through the harness's loader override, never copied over the product's file
-  PMC_LIB=$R/parelagmc_amd/lib/libpmc_lab.so PMC_SPLIT_MIN=0 run prof_s1_onestream --solver saddle --streams 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras || exit 1
+}
+PROF=(--kernel-trace --stats)
+if want 1; then
+  if [ -z "$SKIP_BENCH_PROFILE" ]; then run prof_bench --steps 20 --warmup 5 --inline-setup || exit 1; fi
+  run prof_l4 --steps 40 --warmup 5 --no-cpu-baseline --no-extras || exit 1     # the headline's own kernel mix: four lanes, hybridized
+fi
+if want 2; then
+  run prof_s1 --streams 1 --steps 40 --no-cpu-baseline --no-extras || exit 1
+  run prof_s1_saddle --solver saddle --streams 1 --steps 40 --no-cpu-baseline --no-extras || exit 1
+  pmc_pass r5 --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
+  pmc_pass r5s --solver saddle --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
+  # per-kernel roofline table of the one-lane hybridized profile (sizes from the library, durations and counters from the passes)
+  python3 $R/scripts/roofline_table.py $R/gpurun_out/prof_s1_by_grid.csv $R/gpurun_out/pmc_fetch_r5_by_grid.csv $R/gpurun_out/pmc_write_r5_by_grid.csv > $R/gpurun_out/roofline_table.txt 2>&1 || exit 1
+  echo "roofline table done"
+fi
+if want 3; then
+  run prof_s1_r6 --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras || exit 1
+  run prof_s1_r6_saddle --solver saddle --refine 6 --streams 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras || exit 1
+  pmc_pass r6 --refine 6 --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
+  pmc_pass r6s --solver saddle --refine 6 --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-extras || exit 1
+  runpy prof_c3 scripts/c3_darcy_op.py || exit 1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    PROF=(--kernel-trace --pmc $c)
+    n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+    runpy pmc_${n}_c3 scripts/c3_darcy_op.py || exit 1
+  done
+  if [ -f $R/parelagmc_amd/lib/libpmc_lab.so ]; then
+    PROF=(--kernel-trace --stats)
+    # the laboratory library is SELECTED through the harness's loader override, never copied over the product's file
+    PMC_LIB=$R/parelagmc_amd/lib/libpmc_lab.so PMC_SPLIT_MIN=0 run prof_s1_onestream --solver saddle --streams 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras || exit 1
+  fi
 fi
