@@ -53,7 +53,7 @@ struct AggSegments {   // agg_pack_rows' tables of the finest level (empty: the 
 };
 static std::unique_ptr<Multigrid> build_chain(const std::vector<AmgLevelHost>& lv, const pmc_solver_opts& o, hipStream_t st,
                                               double ratio_scale = 1.0, bool f32_any_injection = false,
-                                              const AggSegments* seg0 = nullptr) {
+                                              const std::vector<AggSegments>* segs = nullptr) {
     std::unique_ptr<Multigrid> mg(new Multigrid());
     mg->smooth_degree = o.mg_smooth_degree;
     mg->smooth_ratio = ratio_scale * o.mg_smooth_ratio;
@@ -100,10 +100,10 @@ static std::unique_ptr<Multigrid> build_chain(const std::vector<AmgLevelHost>& l
                 sell_build(m.SP, csr_spgemm(S, P), true, false, st);
                 m.parent.upload(parent, st);
                 m.has_sp = true;
-                if (l == 0 && seg0 && !seg0->ptr.empty()) {
-                    m.seg_ptr.upload(seg0->ptr, st);
-                    m.seg_cid.upload(seg0->cid, st);
-                    m.seg_pos.upload(seg0->pos, st);
+                if (segs && l < segs->size() && !(*segs)[l].ptr.empty()) {
+                    m.seg_ptr.upload((*segs)[l].ptr, st);
+                    m.seg_cid.upload((*segs)[l].cid, st);
+                    m.seg_pos.upload((*segs)[l].pos, st);
                     m.p_agg = true;
                 }
                 PMC_HIP(hipStreamSynchronize(st));
@@ -307,23 +307,33 @@ Sampler::Sampler(Ctx& c, int nlevels_, const pmc_hybrid_level* in, double alpha_
         // kernel itself (k::vc_residual_restrict_agg32).  H, G and the level's prolongator move to the new numbering; vectors
         // that cross the boundary in multiplier numbering (pmc_sampler_mult / _apply_operator / _apply_preconditioner) are
         // renumbered on the way in and out (lam_new2old / lam_old2new).
-        AggSegments seg0;
-        bool pack = hier.size() >= 2 && o.precond_storage != PMC_STORAGE_FP64;
-        if (const char* e = lab_env("PMC_AGG_PACK")) pack = pack && atoi(e) != 0;
-        if (pack) {
-            std::vector<int> new2old = agg_pack_rows(hier[0].P, seg0.ptr, seg0.cid, seg0.pos);
-            if (!new2old.empty()) {
-                std::vector<int> old2new(new2old.size());
-                for (size_t i = 0; i < new2old.size(); ++i) old2new[(size_t)new2old[i]] = (int)i;
+        // Levels below the finest are numbered by the library anyway: they are packed the same way (their restriction fused as
+        // well), which renumbers the coarse ids the level above refers to.
+        std::vector<AggSegments> segs(hier.size());
+        // (product: the finest level only.  Packing the levels below as well re-pads their SELL slices - the LDS tail, which
+        // holds them, went from 144 to 155 us per cycle - and the first coarse level's aggregates did not pack; LAB_NOTES 10.2)
+        int pack_levels = (hier.size() >= 2 && o.precond_storage != PMC_STORAGE_FP64) ? 1 : 0;
+        if (const char* e = lab_env("PMC_AGG_PACK")) pack_levels = std::min((int)hier.size() - 1, atoi(e));
+        for (int pl = 0; pl < pack_levels; ++pl) {
+            AggSegments sg;
+            std::vector<int> new2old = agg_pack_rows(hier[(size_t)pl].P, sg.ptr, sg.cid, sg.pos);
+            if (new2old.empty()) continue;
+            std::vector<int> old2new(new2old.size());
+            for (size_t i = 0; i < new2old.size(); ++i) old2new[(size_t)new2old[i]] = (int)i;
+            hier[(size_t)pl].P = csr_permute(hier[(size_t)pl].P, new2old, true, false);
+            if (pl == 0) {
                 H = csr_permute(H, new2old, true, true);
                 G = csr_permute(G, new2old, true, false);
-                hier[0].P = csr_permute(hier[0].P, new2old, true, false);
                 hier[0].S = H;
                 d.lam_new2old.upload(new2old, st);
                 d.lam_old2new.upload(old2new, st);
             } else {
-                seg0 = AggSegments();
+                hier[(size_t)pl].S = csr_permute(hier[(size_t)pl].S, new2old, true, true);
+                // the level above names these rows as its coarse ids: prolongator columns and segment targets follow
+                hier[(size_t)pl - 1].P = csr_permute(hier[(size_t)pl - 1].P, new2old, false, true);
+                for (int& c : segs[(size_t)pl - 1].cid) c = old2new[(size_t)c];
             }
+            segs[(size_t)pl] = std::move(sg);
         }
         sell_build(d.A, H, true, false, st, diag_last_on());
         sell_build(d.Gl, csr_transpose(G), true, false, st);
@@ -334,7 +344,7 @@ Sampler::Sampler(Ctx& c, int nlevels_, const pmc_hybrid_level* in, double alpha_
         // the aggregation hierarchy of H smooths on [lmax / (2 r), lmax], r = mg_smooth_ratio - twice the interval ratio of the
         // Schur-complement hierarchies (measured at 400 k multipliers, 4 lanes x 32: r = 8 2 630, 12 ... 30 2 900, 50 2 650
         // samples/s; 21 -> 20 iterations)
-        amg[l] = build_chain(hier, o, st, /*ratio_scale=*/2.0, /*f32_any_injection=*/true, &seg0);
+        amg[l] = build_chain(hier, o, st, /*ratio_scale=*/2.0, /*f32_any_injection=*/true, &segs);
         amg[l]->tail_later_nb = 8;
         if (const char* e = lab_env("PMC_TAIL_LATER_NB")) amg[l]->tail_later_nb = atoi(e);
         mg.L[l].n = L.n_s;
