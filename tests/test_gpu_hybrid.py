@@ -251,3 +251,33 @@ def test_hybrid_config4_full_size_field_equals_the_saddle_point_field(gpu_ctx):
         assert max(t[0] for t in sta) * 2 < min(t[0] for t in stb), (sta, stb)
     hy.close()
     sa.close()
+
+
+def test_hybrid_ragged_remainder_takes_the_late_tail_and_gives_the_same_field(gpu_ctx):
+    """cube_tet r = 4 (50 688 multipliers): the first coarse level of the aggregation hierarchy has more than 4 096 rows, so a
+    launch of at most 8 realizations - the remainder chunk of a ragged call, or the drop-in path's single realization - runs
+    that level as kernels and starts the LDS tail one level further down (Multigrid::tail_later_nb, set for this hierarchy
+    only), while a full launch starts the tail there.  Different kernels, same preconditioner up to rounding: every realization
+    of a ragged call must equal the same realization evaluated alone and inside a full launch (1e-9 at rel 1e-12; within the
+    solver tolerance at the default 1e-6)."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hierarchy, build_hybrid_sampler_problem, mesh_from_json
+    h = build_hierarchy(mesh_from_json(golden_path("meshes", "cube_tet.json")), 4)
+    hp = build_hybrid_sampler_problem(h, corlen=0.1, n_mc_levels=1, builder=capi.library_hybrid_builder)
+    for opts, tol in ((capi.solver_opts(rel_tol=1e-12, abs_tol=1e-300), 1e-9), (None, 2e-5)):
+        smp = capi.PDESampler(gpu_ctx, hp, opts)
+        lv = smp.vcycle_levels(0)
+        assert lv[1]["rows"] > 4096 and lv[1]["in_tail"] == 1 and lv[0]["fused_restriction"] == 1, lv
+        w = smp.BatchWidth(0)
+        n = w + 3                                           # chunks of w, 2 and 1
+        xi = smp.Sample(0, first_id=77, nbatch=n)
+        s, st = smp.Eval(0, xi, return_stats=True)
+        assert all(t[1] == 1 for t in st)
+        full = smp.Eval(0, xi[:w])
+        for k in (0, w - 1):                                # members of the full launch
+            assert rel(s[k], full[k]) == 0.0
+        for k in (w, w + 1, w + 2, 0, w // 2):              # remainder chunks (late tail) and launch members, each alone
+            assert rel(s[k], smp.Eval(0, xi[k:k + 1])[0]) < tol
+        # a member of the full launch against the same realization in a narrow chunk of 2 (late tail)
+        assert rel(full[3], smp.Eval(0, xi[2:4])[1]) < tol
+        smp.close()
