@@ -15,6 +15,8 @@
                            RT0/P0 operators that import nothing of parelagmc_amd.fe - and stored in
                            the product's cell order (cells matched by centroid); the oracle on the
                            product's builders must reproduce them to 1e-10 or this script stops.
+  * gold_sampler_tet.npz - the same for tetrahedra (cube_tet refined 3 x / 2 x): fields from oracle/fe_ref.py's TetLevel
+                           (quadrature element matrices, own faces / signs / parent search), `--only-tet` writes this file alone.
 """
 import json
 import os
@@ -61,7 +63,38 @@ def agree(a, b, what):
         raise SystemExit(f"{what}: oracle on the product's builders and oracle/fe_ref.py disagree")
 
 
+def tet_golden():
+    """GOLD-4 (round 5): cube_tet refined 3 x / 2 x (3 072 / 384 tetrahedra, the headline's mesh family), Gaussian, correlation
+    length 0.1: fields for fixed xi from oracle/fe_ref.py's TetLevel / RefTetSampler - own faces, orientations, quadrature
+    element matrices and parent search; only the vertex coordinates and vertex quadruples of the refined meshes are taken from
+    the product as data - cross-checked against the independent hybridized solve (RefTetHybrid) and against the oracle on the
+    product's builders before anything is written.  Cells are in the product's order (TetLevel keeps the order it is given)."""
+    from parelagmc_amd.fe import mesh_from_json
+    h = build_hierarchy(mesh_from_json(os.path.join(HERE, "meshes", "cube_tet.json")), 3)
+    sp = build_sampler_problem(h, corlen=0.1, n_mc_levels=2)
+    so = SamplerOracle(sp)
+    levels = [fe_ref.TetLevel(x.mesh.verts, x.mesh.elems) for x in h.spaces[:2]]
+    rs = fe_ref.RefTetSampler(levels, 0.1)
+    rng = np.random.Generator(np.random.PCG64(20261005))
+    xi = rng.standard_normal((2, levels[0].n_s))
+    xi1 = rng.standard_normal((2, levels[1].n_s))
+    s00 = np.stack([rs.eval(0, 0, x) for x in xi])
+    s10 = np.stack([rs.eval(1, 0, x) for x in xi])
+    s11 = np.stack([rs.eval(1, 1, x) for x in xi1])
+    hy0, hy1 = fe_ref.RefTetHybrid(levels[0], 0.1), fe_ref.RefTetHybrid(levels[1], 0.1)
+    agree(np.stack([hy0.eval(x) for x in xi]), s00, "tet s00 (hybridized restatement)")
+    agree(np.stack([hy1.eval(x) for x in xi1]), s11, "tet s11 (hybridized restatement)")
+    agree(np.stack([so.eval(0, 0, x)[0] for x in xi]), s00, "tet s00")
+    agree(np.stack([so.eval(1, 0, x)[0] for x in xi]), s10, "tet s10")
+    agree(np.stack([so.eval(1, 1, x)[0] for x in xi1]), s11, "tet s11")
+    np.savez_compressed(os.path.join(HERE, "gold_sampler_tet.npz"), xi0=xi, s00=s00.astype(np.float64), s10=s10, xi1=xi1, s11=s11)
+    print("gold_sampler_tet.npz written")
+
+
 def main():
+    if "--only-tet" in sys.argv:
+        tet_golden()
+        return
     if os.path.isdir(REF_MESHES):
         # the mesh DATA files of the BASELINE configurations in their on-disk format (MFEM mesh v1.0 / INLINE), as fixtures of
         # the reader: tests/test_fe.py reads them with fe/mesh.py::read_mfem_mesh and compares with the JSON arrays below
@@ -130,6 +163,7 @@ def main():
             out[f"Q_L{lvl}_{'div' if kd else 'mul'}"] = Q
     np.savez_compressed(os.path.join(HERE, "gold_darcy_hex.npz"), **out)
     print("fixtures written")
+    tet_golden()
 
 
 if __name__ == "__main__":

@@ -281,3 +281,25 @@ def test_hybrid_ragged_remainder_takes_the_late_tail_and_gives_the_same_field(gp
         # a member of the full launch against the same realization in a narrow chunk of 2 (late tail)
         assert rel(full[3], smp.Eval(0, xi[2:4])[1]) < tol
         smp.close()
+
+
+@pytest.mark.parametrize("solver", ["hybridization", "saddle-point"])
+def test_both_device_solvers_reproduce_the_tetrahedral_golden_vectors(gpu_ctx, solver):
+    """tests/golden/gold_sampler_tet.npz (cube_tet refined 3 x / 2 x; fields from oracle/fe_ref.py's independent tetrahedral
+    operators): the HIP path against COMMITTED vectors on the headline's mesh family - fine level, coarse level from a fine xi
+    (the P^T coupling) and coarse level from its own xi; 1e-9 at rel 1e-12, 1e-5 at the default 1e-6.  The hybridized handle is
+    built from the element arrays by the library itself (pmc_hybrid_build)."""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hierarchy, build_hybrid_sampler_problem, build_sampler_problem, mesh_from_json
+    g = np.load(golden_path("gold_sampler_tet.npz"))
+    h = build_hierarchy(mesh_from_json(golden_path("meshes", "cube_tet.json")), 3)
+    kw = dict(corlen=0.1, n_mc_levels=2)
+    prob = (build_hybrid_sampler_problem(h, builder=capi.library_hybrid_builder, **kw) if solver == "hybridization"
+            else build_sampler_problem(h, **kw))
+    for opts, tol in ((capi.solver_opts(**TIGHT), 1e-9), (None, 1e-5)):
+        smp = capi.PDESampler(gpu_ctx, prob, opts)
+        for key, lvl, xl, xi in (("s00", 0, 0, g["xi0"]), ("s10", 1, 0, g["xi0"]), ("s11", 1, 1, g["xi1"])):
+            s, st = smp.Eval(lvl, xi, xi_level=xl, return_stats=True)
+            assert all(t[1] == 1 for t in st)
+            assert rel(s, g[key]) < tol, (solver, key, rel(s, g[key]))
+        smp.close()

@@ -279,3 +279,25 @@ def test_pdesamplertest_goldens_lie_inside_the_oracle_sampling_distribution(hex_
         assert fmin < 1.0 < fmax
         if lvl == 1:
             assert fmin > 0.70 and fmax < 1.30
+
+
+def test_golden_sampler_vectors_on_tetrahedra():
+    """tests/golden/gold_sampler_tet.npz: cube_tet refined 3 x / 2 x, fields computed by oracle/fe_ref.py's independent
+    tetrahedral operators (quadrature element matrices, own faces / signs / parent search).  The oracle on the product's builders
+    and both C restatements of the reference's solvers must reproduce them."""
+    import os
+    from conftest import ROOT
+    from oracle.cport import CPort, HybridCPort
+    from parelagmc_amd.fe import build_hierarchy, build_hybrid_sampler_problem, mesh_from_json
+    g = np.load(golden_path("gold_sampler_tet.npz"))
+    h = build_hierarchy(mesh_from_json(os.path.join(ROOT, "tests", "golden", "meshes", "cube_tet.json")), 3)
+    sp = build_sampler_problem(h, corlen=0.1, n_mc_levels=2)
+    hp = build_hybrid_sampler_problem(h, corlen=0.1, n_mc_levels=2)
+    so = SamplerOracle(sp)
+    for key, lvl, xl, xi in (("s00", 0, 0, g["xi0"]), ("s10", 1, 0, g["xi0"]), ("s11", 1, 1, g["xi1"])):
+        gold = g[key]
+        ref = np.stack([so.eval(lvl, xl, x)[0] for x in xi])
+        assert np.linalg.norm(ref - gold) <= 1e-10 * np.linalg.norm(gold), key
+        for port in (CPort(sp), HybridCPort(hp)):
+            s, it = port.eval(lvl, xl, xi, rel_tol=1e-12, abs_tol=1e-30, nthreads=2)
+            assert np.linalg.norm(s - gold) <= 1e-9 * np.linalg.norm(gold) and (it > 0).all(), (key, type(port).__name__)
