@@ -476,8 +476,9 @@ def hybrid_roofline(farm, hp, nb, tag, next_batch, iters_total, dt):
     sm_bytes = smp.smoother_bytes(0, nb)
     op_raw = op_ms / max(op_n, 1)
     sbytes = hybrid_bytes_per_iteration(hp, smp, nb, zb)
-    operator = {"kernel": f"pmc::sell_spmm_kernel<{nb}, 0, 0, true, 1, ...> = K5 on H (n_lambda = {L.n_lambda}, "
-                          f"nnz = {L.H.nnz}) with the fused <u, Hu>, in the MINRES loop",
+    kn, grp = min(nb, 32), (f", {nb // 32} column groups of 32 per launch" if nb > 32 else "")
+    operator = {"kernel": f"pmc::sell_spmm_kernel<{kn}, 0, 0, true, 1, ...> = K5 on H (n_lambda = {L.n_lambda}, "
+                          f"nnz = {L.H.nnz}) with the fused <u, Hu>, in the MINRES loop{grp}",
                 "achieved": op_bytes / (op_raw * 1e-3) / 1e9, "frac": op_bytes / (op_raw * 1e-3) / 1e9 / PEAK_GBS,
                 "bytes_per_launch": op_bytes, "avg_kernel_ms": op_raw, "launches": op_n,
                 "event_overhead_ms": gap_ms / max(op_n, 1),
@@ -497,9 +498,9 @@ def hybrid_roofline(farm, hp, nb, tag, next_batch, iters_total, dt):
     sm_raw = sm_ms / sm_n
     ach = sm_bytes / (sm_raw * 1e-3) / 1e9
     return {"bound": "hbm",
-            "kernel": f"pmc::vc_poly2_kernel<{nb}, float, {'float' if zb == 4 else 'double'}, float, true, true, 0, 1> = "
+            "kernel": f"pmc::vc_poly2_kernel<{kn}, float, {'float' if zb == 4 else 'double'}, float, true, true, 0, 1> = "
                       "post-smoothing of the finest level of the multiplier V-cycle (one-pass degree-2 polynomial of the "
-                      "residual + coarse correction + fused <r, z>), as launched inside the MINRES loop; one lane alone on the GPU",
+                      f"residual + coarse correction + fused <r, z>), as launched inside the MINRES loop{grp}; one lane alone on the GPU",
             "achieved": ach, "peak": PEAK_GBS, "unit": "GB/s", "frac": ach / PEAK_GBS,
             "traffic": traffic_entry(f"{tag}_hyb_post_nb{nb}_inloop"), "traffic_provenance": traffic_provenance(),
             "bytes_per_launch": sm_bytes, "avg_kernel_ms": sm_raw, "launches": sm_n,
@@ -581,16 +582,22 @@ class SamplerFarm:
     """`streams` independent batches in flight on one GPU: one context + sampler + buffers each."""
 
     def __init__(self, problem, dev, seed, nb, streams, world=1, rank=0, opts=None):
+        """nb: realizations per plugin call and lane; 0 / None = what the sampler prefers for level 0
+        (pmc_sampler_batch_width: the width one launch of its kernels carries)"""
         from parelagmc_amd import capi
-        self.nb, self.ns, self.world, self.rank = nb, streams, world, rank
+        self.ns, self.world, self.rank = streams, world, rank
         self.n = problem.levels[0].n_s
         self.lanes = [None] * streams
+        handles = [None] * streams
 
         def make(i):    # the lanes' handles are set up side by side (host-side re-layout of the operators, one copy each)
             c = capi.Context(dev, seed=seed)
             c.seed(seed, nparts=world, mypart=rank)
-            self.lanes[i] = (c, capi.PDESampler(c, problem, opts), c.empty(nb * self.n), c.empty(nb * self.n))
+            handles[i] = (c, capi.PDESampler(c, problem, opts))
         in_threads(make, streams)
+        self.nb = nb = int(nb) if nb else handles[0][1].BatchWidth(0)
+        for i, (c, sm) in enumerate(handles):
+            self.lanes[i] = (c, sm, c.empty(nb * self.n), c.empty(nb * self.n))
 
     def one_batch(self, lane, batch_index):
         c, sm, xi_d, s_d = self.lanes[lane]
@@ -659,7 +666,7 @@ def operator_roofline(farm, problem, nb, tag, next_batch, solver_bytes, iters_to
     # isolated ones fp64
     loop_bytes = k_bytes - nb * (8.0 - smp.z_bytes()) * (L.n_u + L.n_s)
     ach = loop_bytes / (raw_ms * 1e-3) / 1e9
-    out = {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{nb}, 0, 0, true, 1, ...> (tag 1 = block operator K5 as launched "
+    out = {"bound": "hbm", "kernel": f"pmc::sell_spmm_kernel<{min(nb, 32)}, 0, 0, true, 1, ...> x {max(1, nb // 32)} column group(s) (tag 1 = block operator K5 as launched "
                                      "by the MINRES loop: fused <u, Au>, diagonal-last, non-temporal streams by size; one lane "
                                      "alone on the GPU; profile rows with this prefix)",
            "achieved": ach, "peak": PEAK_GBS, "unit": "GB/s", "frac": ach / PEAK_GBS,
@@ -667,7 +674,7 @@ def operator_roofline(farm, problem, nb, tag, next_batch, solver_bytes, iters_to
            "bytes_per_launch": loop_bytes, "avg_kernel_ms": raw_ms, "launches": solo_launches,
            "timing": "raw HIP-event bracket around every in-loop launch",
            "event_overhead_ms": gap, "frac_net_of_event_overhead": loop_bytes / (max(raw_ms - gap, 1e-9) * 1e-3) / 1e9 / PEAK_GBS,
-           "isolated": {"kernel": f"pmc::sell_spmm_kernel<{nb}, 0, 0, false, 2, ...> launched back to back",
+           "isolated": {"kernel": f"pmc::sell_spmm_kernel<{min(nb, 32)}, 0, 0, false, 2, ...> launched back to back",
                         "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "frac": k_bytes / (k_ms * 1e-3) / 1e9 / PEAK_GBS,
                         "avg_kernel_ms": k_ms, "traffic": traffic_entry(f"{tag}_nb{nb}")},
            "spmv_nb1": {"achieved": k1_bytes / (k1_ms * 1e-3) / 1e9, "bytes_per_launch": k1_bytes, "avg_kernel_ms": k1_ms,
@@ -1022,6 +1029,7 @@ def sampler_point(problem, dev, seed, nb, ns, steps, tag, what, cpu_per_core=Non
     """One sampler-only figure on level 0 of `problem` (the harness shape of the headline: `ns` lanes x `nb` realizations per
     step): value, iterations, K5 roofline of the in-loop launches, and - cpu_per_core - the CPU column beside it."""
     farm = SamplerFarm(problem, dev, seed, nb, ns, opts=opts)
+    nb = farm.nb
     dt, st = timed_farm(farm, steps, 0)
     check_stats(st, what)
     it = [t[0] for t in st]
@@ -1134,8 +1142,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32,
-                    help="realizations per plugin call and lane (sampler levels up to 5 M rows run 32 per launch)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="realizations per plugin call and lane; 0 (default) = what the sampler prefers for the level "
+                         "(pmc_sampler_batch_width: 64 up to 700 k rows, 32 up to ~5 M rows)")
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batches in flight per GPU (one context + host thread each): the launch-latency-"
                          "bound coarse-level kernels of one batch overlap the bandwidth-bound kernels of the other")
@@ -1212,8 +1221,9 @@ def main():
     head = build_hybrid_problem(args.refine) if hybrid else problem
     dev = (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0
     red_dev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
-    nb, ns = args.batch, max(1, args.streams)
-    farm = SamplerFarm(head, dev, args.seed, nb, ns, world, rank)
+    ns = max(1, args.streams)
+    farm = SamplerFarm(head, dev, args.seed, args.batch, ns, world, rank)
+    nb = farm.nb
 
     def barrier():
         if world > 1:
@@ -1310,15 +1320,15 @@ def main():
         if hybrid:
             # the reference's DEFAULT solver on the same workload: the headline of rounds 1-3, with its K5 roofline
             attempt("saddle_point_minres", lambda: sampler_point(
-                problem, dev, args.seed, nb, ns, max(4, args.steps // 2), f"r{args.refine}",
+                problem, dev, args.seed, args.batch, ns, max(4, args.steps // 2), f"r{args.refine}",
                 f"the headline workload with the reference's default solver: MINRES-BJ-GS on the saddle-point system "
-                f"({L.n_u + L.n_s} DoF, nnz(A)={L.nnz}), {ns} x {nb} realizations per step"))
+                f"({L.n_u + L.n_s} DoF, nnz(A)={L.nnz}), {ns} lanes"))
         else:
             attempt("hybridization", lambda: sampler_point(
-                build_hybrid_problem(args.refine), dev, args.seed, nb, ns, max(4, args.steps // 2), f"r{args.refine}",
+                build_hybrid_problem(args.refine), dev, args.seed, args.batch, ns, max(4, args.steps // 2), f"r{args.refine}",
                 "the headline workload with the hybridized solver"))
         attempt("fp64_storage", lambda: sampler_point(
-            head, dev, args.seed, nb, ns, max(4, args.steps // 3), f"r{args.refine}_fp64",
+            head, dev, args.seed, args.batch, ns, max(4, args.steps // 3), f"r{args.refine}_fp64",
             f"the headline workload with precond_storage = fp64 (everything stored fp64, as the reference is: "
             f"/root/reference/src/PDESampler.cpp:279-333)", opts=capi.solver_opts(precond_storage=capi.PMC_STORAGE_FP64)))
         # the drop-in path of INTEGRATION.md section 2: one realization per call, host pointers
@@ -1344,9 +1354,9 @@ def main():
             attempt("dropin_nb1_config3", lambda: dropin_mlmc(probs3, dev, args.seed))
             # the north star's "~1 M DoF 3D SPDE sampler": level 0 of config 3's hierarchy on its own, 1 060 864 DoF
             attempt("hex64", lambda: sampler_point(
-                probs3[0], dev, args.seed, nb, ns, 6, "hex64",
+                probs3[0], dev, args.seed, args.batch, ns, 6, "hex64",
                 f"PDESampler cube_hex 64^3, {probs3[0].levels[0].n_u + probs3[0].levels[0].n_s} DoF, lognormal, level 0 of "
-                f"config 3's hierarchy on its own: {ns} x {nb} realizations per step", cpu_per_core=2 if cpu else None))
+                f"config 3's hierarchy on its own: {ns} lanes", cpu_per_core=2 if cpu else None))
         else:
             # every rank takes part: sharded InitRun, accumulators summed by pmc_allreduce_sum_f64 (RCCL).  The
             # communicator is set up and tried FIRST, and the ranks agree (torch.distributed) on whether it works, so
@@ -1409,9 +1419,9 @@ def main():
                 p6, h6 = pool.get("r6")
                 what = ("PDESampler cube_tet r=6, 4743168 DoF: operator + vectors exceed the 256 MiB Infinity Cache, every "
                         "kernel is HBM-bound")
-                m = sampler_point(h6 if hybrid else p6, dev, args.seed, nb, ns, 12, "r6", what,
+                m = sampler_point(h6 if hybrid else p6, dev, args.seed, args.batch, ns, 12, "r6", what,
                                   cpu_per_core=1 if cpu else None, cpu_problem=p6, cpu_hybrid_problem=h6 if hybrid else None)
-                m["other_solver"] = sampler_point(p6 if hybrid else h6, dev, args.seed, nb, ns, 6, "r6", what)
+                m["other_solver"] = sampler_point(p6 if hybrid else h6, dev, args.seed, args.batch, ns, 6, "r6", what)
                 return m
             attempt("r6", r6)
         extra["setup_seconds_in_worker_processes"] = dict(pool.seconds)

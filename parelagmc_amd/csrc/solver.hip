@@ -430,7 +430,10 @@ int batch_width(size_t rows, bool darcy, int device) {
                         // sampler levels up to 500 k rows: two column groups per launch (config 4's 314 k-row level, four lanes:
                         // hybridized 5 735 -> 6 441, saddle-point 1 474 -> 1 512 realizations/s; a 600 k-row level gains 30 % with
                         // one lane and nothing with four, LAB_NOTES 9.15)
-                        l64s = lim("PMC_S_W64_ROWS", lab_env("PMC_W64_ROWS") ? l64 : 500000);
+                        // ... and round 5, with the restriction fused and the V-cycle kernels at three waves per SIMD: the
+                        // 596 k-row level of config 2 gains at EVERY lane count (hybridized: one lane 2 100 -> 2 720, two
+                        // 2 856 -> 3 288, four 3 315 -> 3 482 samples/s; saddle-point: one lane +8.5 %, four +0.4 %): 700 k
+                        l64s = lim("PMC_S_W64_ROWS", lab_env("PMC_W64_ROWS") ? l64 : 700000);
     const size_t l32s = l32s_lab ? l32s_lab : (darcy ? 0 : sampler_wide_rows(device));
     if (rows > (darcy ? l32 : l32s)) return 16;
     if (rows <= l256) return 256;

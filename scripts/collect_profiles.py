@@ -83,6 +83,16 @@ def entry(fetch, write, kern, what):
             "hbm_bytes_per_launch": (2.0 * fr + wr) * 1024.0, "launches_averaged": n}
 
 
+def batch_of(logname, default=32):
+    """realizations per launch of a bench pass (config.batch of its JSON line): the traffic keys carry it"""
+    try:
+        with open(os.path.join(G, logname)) as f:
+            lines = [ln for ln in f if ln.startswith("{")]
+        return int(json.loads(lines[-1])["config"]["batch"])
+    except Exception:   # noqa: BLE001
+        return default
+
+
 for refine, nvec, nlam in ((5, 595968, 399360), (6, 4743168, 3170304)):
     # saddle-point passes (--solver saddle): K5 on A in the loop / isolated / one column; the flat lincomb3 kernel as the
     # cross-check of the FETCH_SIZE correction
@@ -96,13 +106,13 @@ for refine, nvec, nlam in ((5, 595968, 399360), (6, 4743168, 3170304)):
         dump("fetch_size", fetch, f"r{refine}_saddle")
         dump("write_size", write, f"r{refine}_saddle")
         # one lane alone on the GPU splits the Lanczos update into a u-row and an s-row launch (two streams): compare totals
-        nbw = 32
-        lv = [x for k, vals in fetch.items() if f"lincomb3_kernel<{nbw}" in k for x in vals]
+        nbw = batch_of(f"pmc_fetch_r{refine}s.log")      # launches wider than 32 are column groups of the <32, ...> kernels
+        lv = [x for k, vals in fetch.items() if "lincomb3_kernel<32" in k for x in vals]
         split = len(set(round(x / 1024.0) for x in lv)) > 1 and max(lv) > 1.5 * min(lv)
         lf = sum(lv) / len(lv) * (2 if split else 1)
         read_kb = 3 * nvec * nbw * 8 / 1024.0
-        for key, kern in ((f"r{refine}_nb{nbw}_inloop", f"sell_spmm_kernel<{nbw}, 0, 0, true, 1,"),
-                          (f"r{refine}_nb{nbw}", f"sell_spmm_kernel<{nbw}, 0, 0, false, 2,"),
+        for key, kern in ((f"r{refine}_nb{nbw}_inloop", "sell_spmm_kernel<32, 0, 0, true, 1,"),
+                          (f"r{refine}_nb{nbw}", "sell_spmm_kernel<32, 0, 0, false, 2,"),
                           (f"r{refine}_nb1", "sell_spmm_kernel<1, 0, 0, false, 2,")):
             e = entry(fetch, write, kern, "on A")
             if e:
@@ -118,15 +128,16 @@ for refine, nvec, nlam in ((5, 595968, 399360), (6, 4743168, 3170304)):
         continue
     dump("fetch_size", fetch, f"r{refine}")
     dump("write_size", write, f"r{refine}")
-    for key, kern, what in ((f"r{refine}_hyb_post_nb32_inloop", "vc_poly2_kernel<32, float, float, float, true, true, 0>",
+    nbh = batch_of(f"pmc_fetch_r{refine}.log")
+    for key, kern, what in ((f"r{refine}_hyb_post_nb{nbh}_inloop", "vc_poly2_kernel<32, float, float, float, true, true, 0>",
                              "post-smoothing of the finest level of the multiplier V-cycle, in the MINRES loop"),
-                            (f"r{refine}_hyb_k5_nb32_inloop", "sell_spmm_kernel<32, 0, 0, true, 1,", "K5 on H, in the MINRES loop")):
+                            (f"r{refine}_hyb_k5_nb{nbh}_inloop", "sell_spmm_kernel<32, 0, 0, true, 1,", "K5 on H, in the MINRES loop")):
         e = entry(fetch, write, kern.rstrip(">") if kern.endswith(">") else kern, what)
         if e:
             out[key] = e
     lv = [x for k, vals in fetch.items() if "lincomb3_kernel<32" in k for x in vals]
     if lv:
-        read_kb = 3 * nlam * 32 * 8 / 1024.0
+        read_kb = 3 * nlam * nbh * 8 / 1024.0
         out[f"r{refine}_hyb_correction"] = (f"lincomb3_kernel in the hybrid pass: raw {sum(lv) / len(lv):.0f} KB for {read_kb:.0f} KB "
                                             f"actually read (ratio {read_kb / (sum(lv) / len(lv)):.3f})")
 # Darcy operator of config 3 (u-rows [M(k) | B^T] x with the fused dot, in the MINRES loop)

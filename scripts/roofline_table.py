@@ -1,4 +1,4 @@
-"""Per-kernel roofline table of the headline's solver (hybridized, cube_tet r = 5, one lane, 32 realizations per launch):
+"""Per-kernel roofline table of the headline's solver (hybridized, cube_tet r = 5, one lane, pmc_sampler_batch_width realizations per launch):
 every kernel row holding at least 2 % of the device time of the one-lane profile, priced with its ALGORITHMIC bytes (the sizes
 come from the library: pmc_sampler_vcycle_info, pmc_sampler_smoother_bytes) against its rocprofv3 average duration, with the
 HBM traffic of the separate FETCH_SIZE / WRITE_SIZE passes beside it.  Runs on the GPU box at the end of
@@ -18,7 +18,6 @@ import bench  # noqa: E402
 from parelagmc_amd import capi  # noqa: E402
 
 PEAK = 8000.0
-nb = 32
 
 
 def rows_of(path):
@@ -32,12 +31,14 @@ def main():
     smp = capi.PDESampler(ctx, hp)
     lv = smp.vcycle_levels(0)
     zb = smp.z_bytes()
+    nb = smp.BatchWidth(0)        # what `bench.py --streams 1` hands over per call (64 = two column groups of 32 per launch)
+    ngroups = max(1, nb // 32)
     n = [l["rows"] for l in lv]
     V, F = 8.0 * nb, 4.0 * nb
 
-    def level_of(grid):           # slice kernels: grid = rows rounded up to a multiple of 256 threads
-        for i, r in enumerate(n):
-            if (r + 255) // 256 * 256 == grid:
+    def level_of(grid):           # slice kernels: grid = rows rounded up to a multiple of 256 threads (x column groups when
+        for i, r in enumerate(n):  # the profiler reports the total grid)
+            if (r + 255) // 256 * 256 in (grid, grid // ngroups):
                 return i
         return None
 
@@ -78,7 +79,7 @@ def main():
     def price_restriction(grid):
         # the separate restriction's grid follows its COARSE rows: P^T of level l has n[l + 1] rows
         for i in range(len(n) - 1):
-            if (n[i + 1] + 255) // 256 * 256 == grid:
+            if (n[i + 1] + 255) // 256 * 256 in (grid, grid // ngroups):
                 return (f"restriction P^T res (separate product), V-cycle level {i}", 12.0 * n[i] + 4.0 * n[i + 1] + F * n[i] + V * n[i + 1])
         return None
 
@@ -111,7 +112,8 @@ def main():
             if extra:
                 row.update(extra)
         table.append(row)
-    out = {"workload": "python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-extras (hybridized, cube_tet r = 5, one lane x 32)",
+    out = {"workload": f"python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-extras (hybridized, cube_tet r = 5, one lane x {nb})",
+           "realizations_per_launch": nb,
            "peak_GBs": PEAK, "vcycle_levels": lv, "libpmc_sha256": bench.lib_sha256(), "csrc_sha256": bench.csrc_sha256(),
            "rows_with_at_least_2_percent_of_device_time": table}
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "roofline_table.json"), "w"), indent=1)

@@ -439,11 +439,12 @@ def test_full_size_config2_properties(gpu_ctx):
     assert rel(s[0], s_red) < 1e-6
     # (iv) a level of this size runs 32 realizations per launch (batch_width, csrc/solver.hip: the lean gather loop of the
     # NB = 32 kernels): every column of a full launch equals its single evaluation, on both sides of the half-way column
-    assert smp.BatchWidth(0) == 32
-    xi32 = smp.Sample(0, first_id=100, nbatch=32)
+    w = smp.BatchWidth(0)
+    assert w == 64                                   # 596 k rows: two column groups of 32 per launch (round 5; 32 before)
+    xi32 = smp.Sample(0, first_id=100, nbatch=w)
     s32, st32 = smp.Eval(0, xi32, return_stats=True)
     assert all(t[1] == 1 for t in st32)
-    for b in (0, 15, 16, 31):
+    for b in (0, 15, 16, 31, 32, w - 1):
         assert rel(smp.Eval(0, xi32[b:b + 1])[0], s32[b]) < 1e-7, b
     smp.close()
 
