@@ -25,13 +25,20 @@ def rows_of(path):
 
 
 def main():
-    stats, fetch, write = (rows_of(a) for a in (sys.argv[1:4] + [None, None, None])[:3])
-    hp = bench.build_hybrid_problem(5)
-    ctx = capi.Context(0, seed=1)
-    smp = capi.PDESampler(ctx, hp)
-    lv = smp.vcycle_levels(0)
-    zb = smp.z_bytes()
-    nb = smp.BatchWidth(0)        # what `bench.py --streams 1` hands over per call (64 = two column groups of 32 per launch)
+    args = [a for i, a in enumerate(sys.argv[1:]) if a != "--sizes-from" and sys.argv[i] != "--sizes-from"]
+    stats, fetch, write = (rows_of(a) for a in (args[:3] + [None, None, None])[:3])
+    prev = None
+    if "--sizes-from" in sys.argv:     # re-price an existing table off the GPU box: the sizes the library reported are in it
+        prev = json.load(open(sys.argv[sys.argv.index("--sizes-from") + 1]))
+        lv, zb, nb = prev["vcycle_levels"], prev.get("z_bytes", 4), prev["realizations_per_launch"]
+        smp = ctx = None
+    else:
+        hp = bench.build_hybrid_problem(5)
+        ctx = capi.Context(0, seed=1)
+        smp = capi.PDESampler(ctx, hp)
+        lv = smp.vcycle_levels(0)
+        zb = smp.z_bytes()
+        nb = smp.BatchWidth(0)    # what `bench.py --streams 1` hands over per call (64 = two column groups of 32 per launch)
     ngroups = max(1, nb // 32)
     n = [l["rows"] for l in lv]
     V, F = 8.0 * nb, 4.0 * nb
@@ -84,7 +91,8 @@ def main():
         return None
 
     def counter(rows, name, grid):
-        v = [float(r["mean_counter_value_KB"]) for r in rows if r["kernel"] == name and int(r["grid"]) == grid]
+        # the counter passes report the TOTAL grid (x times the column groups), the kernel trace its x extent
+        v = [float(r["mean_counter_value_KB"]) for r in rows if r["kernel"] == name and int(r["grid"]) in (grid, grid * ngroups)]
         return v[0] if v else None
 
     total = sum(float(r["total_ns"]) for r in stats)
@@ -114,14 +122,17 @@ def main():
         table.append(row)
     out = {"workload": f"python bench.py --streams 1 --steps 40 --no-cpu-baseline --no-extras (hybridized, cube_tet r = 5, one lane x {nb})",
            "realizations_per_launch": nb,
-           "peak_GBs": PEAK, "vcycle_levels": lv, "libpmc_sha256": bench.lib_sha256(), "csrc_sha256": bench.csrc_sha256(),
+           "peak_GBs": PEAK, "vcycle_levels": lv, "z_bytes": zb,
+           "libpmc_sha256": prev["libpmc_sha256"] if prev else bench.lib_sha256(),
+           "csrc_sha256": prev["csrc_sha256"] if prev else bench.csrc_sha256(),
            "rows_with_at_least_2_percent_of_device_time": table}
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "roofline_table.json"), "w"), indent=1)
     for row in table:
         print(f"{row['share_of_device_time']:6.1%} {row['avg_us']:8.1f} us  {row.get('frac_of_8TBs', float('nan')):5.3f}  "
               f"{row.get('traffic_over_algorithmic', float('nan')):5.2f}x  {row.get('what', row['kernel'][:60])}")
-    smp.close()
-    ctx.close()
+    if smp is not None:
+        smp.close()
+        ctx.close()
 
 
 if __name__ == "__main__":
