@@ -439,11 +439,14 @@ def hybrid_bytes_per_iteration(hp, smp, nb, zb=4):
     V, Z, F = 8.0 * nb, float(zb) * nb, float(zb) * nb
     post = smp.smoother_bytes(0, nb)
     nc = max(0.0, (post - 12.0 * nnz - 12.0 * n - (2 * F + V + Z) * n) / V)    # rows of the first coarse level
+    # fp32 storage: the Lanczos update also writes an fp32 copy of the new vector, which the cycle's first two kernels read
+    # instead of the fp64 one (csrc/solver.hpp: MinresWork::r32)
+    R = F if zb == 4 else V
     total = 12.0 * nnz + 4.0 * n + (Z + V) * n                 # K5 on H: q = H u
-    total += V * 4 * n                                         # v_new = c0 q + c1 v1 + c2 v0
+    total += V * 4 * n + (F * n if zb == 4 else 0.0)           # v_new = c0 q + c1 v1 + c2 v0 (+ its fp32 copy)
     total += (4 * Z + 6 * V) / 4.0 * n                         # w / x updates on ALL rows, four iterations per pass
-    total += 12.0 * nnz + 12.0 * n + (V + F) * n               # pre-smoothing: r in, x out
-    total += 12.0 * nnz + 4.0 * n + (V + 2 * F) * n            # residual: r, x in; res out
+    total += 12.0 * nnz + 12.0 * n + (R + F) * n               # pre-smoothing: r in, x out
+    total += 12.0 * nnz + 4.0 * n + (R + 2 * F) * n            # residual: r, x in; res out
     fused = bool(smp.vcycle_levels(0)[0]["fused_restriction"])
     # restriction P^T res: inside the residual kernel (multipliers renumbered, csrc/sparse.hip::agg_pack_rows: the segment
     # tables + the coarse rows written) or a separate product that reads the residual once more

@@ -1694,11 +1694,12 @@ __global__ __launch_bounds__(kBlock) void convert_dot_kernel(size_t nflat, const
     if constexpr (DOT) reduce_flat_store<NB>(p, partial, row_ld<NB>(ld));
 }
 
+// y32 (optional): the result is also written in fp32 - the copy the V-cycle's first two kernels gather and read (k::vc_*_r32)
 template <int NB, bool NT = false>
 __global__ __launch_bounds__(kBlock) void lincomb3_kernel(size_t nflat, const double* __restrict__ c0,
                                                           const double* __restrict__ a, const double* __restrict__ c1,
                                                           const double* __restrict__ b, const double* __restrict__ c2,
-                                                          double* __restrict__ y, int ld) {
+                                                          double* __restrict__ y, int ld, float* __restrict__ y32 = nullptr) {
     constexpr int C = Lay<NB>::C;
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nflat) return;
@@ -1711,6 +1712,7 @@ __global__ __launch_bounds__(kBlock) void lincomb3_kernel(size_t nflat, const do
 #pragma unroll
     for (int c = 0; c < C; ++c) yv[c] = c0[k0 + c] * av[c] + c1[k0 + c] * bv[c] + c2[k0 + c] * yv[c];
     store_c<C>(y + e, yv);
+    if (y32) store_v<C>(y32 + e, yv);
 }
 
 template <int NB, bool NT, typename UT>
@@ -3111,6 +3113,23 @@ void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* di
     check_launch();
 }
 
+// the same from the fp32 copy of the right-hand side (the top level of a cycle inside the MINRES loop: the Lanczos update
+// writes that copy, k::lincomb3): r is gathered - and read at the own row - as 128-byte fp32 rows instead of 256-byte fp64 ones
+void vc_presmooth32_r32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* r32, float* xout,
+                        double c0, double c1) {
+    check_offsets32(As, nb);
+    if (As.nrows == 0) return;
+    if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_presmooth32_r32: shared values expected");
+    const dim3 g = grid_slices(As.nslices);
+    PMC_DISPATCH_NB(nb, {
+        if (nt_poly(As, NB))
+            vc_poly2_kernel<NB, float, float, float, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r32, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+        else
+            vc_poly2_kernel<NB, float, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r32, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+    });
+    check_launch();
+}
+
 void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out,
                               double* coarse) {
     check_offsets32(A, nb);
@@ -3147,6 +3166,29 @@ void vc_residual_restrict_agg32(hipStream_t st, int nb, const SellView& A, const
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
         vc_residual_kernel<NB, float, double, float, false, 0, true, 1, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, coarse, nb, seg_ptr, seg_cid, seg_pos);
+    });
+    check_launch();
+}
+
+void vc_residual_restrict_agg32_r32(hipStream_t st, int nb, const SellView& A, const float* r32, const float* x, float* out,
+                                    double* coarse, const int* seg_ptr, const int* seg_cid, const int* seg_pos) {
+    check_offsets32(A, nb);
+    if (A.nrows == 0) return;
+    if (A.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual_restrict_agg32_r32: shared values expected");
+    const dim3 g = grid_slices(A.nslices);
+    PMC_DISPATCH_NB(nb, {
+        vc_residual_kernel<NB, float, float, float, false, 0, true, 1, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r32, out, coarse, nb, seg_ptr, seg_cid, seg_pos);
+    });
+    check_launch();
+}
+
+void vc_residual32_r32(hipStream_t st, int nb, const SellView& A, const float* r32, const float* x, float* out) {
+    check_offsets32(A, nb);
+    if (A.nrows == 0) return;
+    if (A.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual32_r32: shared values expected");
+    const dim3 g = grid_slices(A.nslices);
+    PMC_DISPATCH_NB(nb, {
+        vc_residual_kernel<NB, float, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r32, out, nullptr, nb);
     });
     check_launch();
 }
@@ -3466,13 +3508,13 @@ void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, do
 }
 
 void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b,
-              const double* c2, double* y) {
+              const double* c2, double* y, float* y32) {
     // non-temporal loads on large levels (one lane 1104 -> 1129, four lanes 1400 -> 1412 samples/s); PMC_NT_LINCOMB=0: off
     static const bool nt_on = [] { const char* e = lab_env("PMC_NT_LINCOMB"); return !e || atoi(e) != 0; }();
     const bool nt = nt_on && nt_flat((size_t)n * nb);
     PMC_DISPATCH_NB(nb, {
-        if (nt) lincomb3_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y, nb);
-        else lincomb3_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y, nb);
+        if (nt) lincomb3_kernel<NB, true><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y, nb, y32);
+        else lincomb3_kernel<NB><<<grid_flat(n, nb), kBlock, 0, st>>>(flat_count(n, nb), c0, a, c1, b, c2, y, nb, y32);
     });
     check_launch();
 }

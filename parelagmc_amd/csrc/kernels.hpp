@@ -138,6 +138,12 @@ void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* di
 void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out,
                               double* coarse);
 void vc_residual32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out);   // no restriction
+// the V-cycle's first two kernels of a level from the fp32 copy of its right-hand side (written by k::lincomb3)
+void vc_presmooth32_r32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* r32, float* xout,
+                        double c0, double c1);
+void vc_residual32_r32(hipStream_t st, int nb, const SellView& A, const float* r32, const float* x, float* out);
+void vc_residual_restrict_agg32_r32(hipStream_t st, int nb, const SellView& A, const float* r32, const float* x, float* out,
+                                    double* coarse, const int* seg_ptr, const int* seg_cid, const int* seg_pos);
 // residual + restriction of an aggregation level renumbered by agg_pack_rows (segments per slice: seg_ptr / seg_cid / seg_pos)
 void vc_residual_restrict_agg32(hipStream_t st, int nb, const SellView& A, const double* r, const float* x, float* out,
                                 double* coarse, const int* seg_ptr, const int* seg_cid, const int* seg_pos);
@@ -182,7 +188,7 @@ int dot_z(hipStream_t st, int nb, int n, const double* a, zvec b, double* partia
 int convert_z(hipStream_t st, int nb, int n, const double* in, zvec out, const double* r, double* dot_partial);
 void reduce_final(hipStream_t st, int nb, int nblocks, const double* partial, double* out);
 void lincomb3(hipStream_t st, int nb, int n, const double* c0, const double* a, const double* c1, const double* b,
-              const double* c2, double* y);
+              const double* c2, double* y, float* y32 = nullptr);
 void minres_wx(hipStream_t st, int nb, int n, const double* c0, zvec u, const double* c1, double* w0,
                const double* c2, const double* w1, const double* c3, double* x);
 void fill(hipStream_t st, size_t n, double* x, double v);

@@ -582,6 +582,10 @@ void Sampler::solve_system(int level, int nb, bool zero_guess, int x_row0, int x
         return k::DotParts{partial, k::spmm_z(L.main, nb_, Av, x, y, partial, x)};
     };
     PrecFn prec = preconditioner(level, nb, degM, mgp, mg_l0);
+    // hybridized solver: the Lanczos update also writes the fp32 copy the cycle's first two kernels read (LAB_NOTES 10.9)
+    work.want_r32 = hybrid && opts.precond_storage != PMC_STORAGE_FP64 && mgp->top_reads_r32(mg_l0, nb);
+    if (const char* e = lab_env("PMC_R32")) work.want_r32 = work.want_r32 && atoi(e) != 0;
+    work.r32_valid = false;
     mgp->smooth_timer = (hybrid && work.op_timer.on && opts.use_graph == 0) ? &vc_timer : nullptr;
     vc_timer.on = mgp->smooth_timer != nullptr;
     GraphHint hint;
@@ -604,6 +608,10 @@ PrecFn Sampler::preconditioner(int level, int nb, int degM, Multigrid* mgp, int 
     if (hybrid) {   // SPD multiplier system: the V-cycle alone
         (void)nb; (void)degM;
         return [=](const Lanes& L, int nb_, const double* r, zvec z, double* dot_partial, double*) {
+            // inside the MINRES loop the Lanczos update has left an fp32 copy of r (MinresWork::r32): the cycle's first two
+            // kernels on the finest level read that
+            mgp->r32_top = work.r32_valid ? work.r32.p : nullptr;
+            work.r32_valid = false;
             const int nblk = mgp->vcycle_z(L.main, nb_, mg_l0, r, z, dot_partial);
             return k::DotParts{dot_partial, nblk, nullptr, 0};
         };

@@ -192,6 +192,10 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     MgLevel& lv = L[l];
     lv.ensure(nb);
     const bool last = (l == (int)L.size() - 1) || lv.is_last;
+    struct ClearR32 {   // whatever path the top level takes, a copy offered for THIS cycle is not seen by the next one
+        Multigrid* m; bool top;
+        ~ClearR32() { if (top) m->r32_top = nullptr; }
+    } clear_r32{this, l == l0};
     // A launch of few realizations (the drop-in path: one per call) runs the LDS tail on as many compute units as it has
     // realizations, and a tail that starts at a level of several thousand rows with 17-27 entries each is bound by ONE
     // unit's L2 port (LAB_NOTES 9.16: 142 us per cycle - half of a one-realization Eval of the hybridized sampler).  Such
@@ -228,13 +232,21 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         float* xf = reinterpret_cast<float*>(lv.xb.p);
         float* resf = reinterpret_cast<float*>(lv.res.p);
         double* out = target ? target : lv.xa.p;
-        k::vc_presmooth32(st, nb, As, lv.dinv.p, r, xf, c0, c1);
+        // top level of a cycle inside the MINRES loop of an aggregation hierarchy: the fp32 copy of r, if the caller has one
+        const float* r32 = (l == l0 && !lv.p_oct) ? r32_top : nullptr;
+        if (l == l0) r32_top = nullptr;
+        if (r32) k::vc_presmooth32_r32(st, nb, As, lv.dinv.p, r32, xf, c0, c1);
+        else k::vc_presmooth32(st, nb, As, lv.dinv.p, r, xf, c0, c1);
         MgLevel& lc = L[l + 1];
         lc.ensure(nb);
         if (lv.p_oct) {
             k::vc_residual_restrict8_32(st, nb, A, r, xf, resf, lc.r.p);
         } else if (lv.p_agg) {
-            k::vc_residual_restrict_agg32(st, nb, A, r, xf, resf, lc.r.p, lv.seg_ptr.p, lv.seg_cid.p, lv.seg_pos.p);
+            if (r32) k::vc_residual_restrict_agg32_r32(st, nb, A, r32, xf, resf, lc.r.p, lv.seg_ptr.p, lv.seg_cid.p, lv.seg_pos.p);
+            else k::vc_residual_restrict_agg32(st, nb, A, r, xf, resf, lc.r.p, lv.seg_ptr.p, lv.seg_cid.p, lv.seg_pos.p);
+        } else if (r32) {
+            k::vc_residual32_r32(st, nb, A, r32, xf, resf);
+            k::spmm_z(st, nb, view(lv.Pt), zvec(resf, true), lc.r.p, nullptr, zvec());
         } else {
             k::vc_residual32(st, nb, A, r, xf, resf);
             k::spmm_z(st, nb, view(lv.Pt), zvec(resf, true), lc.r.p, nullptr, zvec());
@@ -492,6 +504,12 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
         throw Error(PMC_ERR_INTERNAL, "minres: bad solution row range");
     const size_t xoff = (size_t)x_row0 * nb;
     const size_t seg2 = (size_t)dot_capacity(n, nb) * nb;
+    const bool r32 = w.want_r32 && z32;
+    if (r32) {
+        w.r32.ensure(len);
+        k::convert_z(st, nb, n, v1, zvec(reinterpret_cast<double*>(w.r32.p), true), nullptr, nullptr);
+        w.r32_valid = true;
+    }
     k::DotParts dp = prec(L, nb, v1, u1, w.partial.p, w.partial.p + seg2);
     if (dp.total() == 0) dp = k::DotParts{w.partial.p, k::dot_z(st, nb, n, v1, u1, w.partial.p)};
     const int every = o.check_every > 0 ? o.check_every : 1;
@@ -564,7 +582,8 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             flush_wx(L.aux);
             k::lincomb3(st, nb, n - A.n0, cV0, q + off, cV1, v1_ + off, cV2, v0_ + off);
         } else {
-            k::lincomb3(st, nb, n, cV0, q, cV1, v1_, cV2, v0_);
+            k::lincomb3(st, nb, n, cV0, q, cV1, v1_, cV2, v0_, r32 ? w.r32.p : nullptr);
+            w.r32_valid = r32;
         }
         k::DotParts d2 = prec(L, nb, v0_, u0_, w.partial.p, w.partial.p + seg2);   // joins the second stream
         if (d2.total() == 0) d2 = k::DotParts{w.partial.p, k::dot_z(st, nb, n, v0_, u0_, w.partial.p)};
@@ -615,7 +634,7 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
             for (const void* p : {(const void*)b, (const void*)x, (const void*)v0, (const void*)v1, (const void*)u0.p,
                                   (const void*)u1.p, (const void*)w0, (const void*)w1, (const void*)q,
                                   (const void*)w.partial.p, (const void*)w.partial_op.p, (const void*)S, (const void*)w.stage.p,
-                                  (const void*)x_rows})
+                                  (const void*)x_rows, (const void*)(r32 ? w.r32.p : nullptr)})
                 sig = hash_ptr(sig, p);
             sig = hash_mix(sig, ((uint64_t)x_row0 << 32) ^ (uint64_t)x_nrows);
             sig = hash_mix(sig, L.split ? 7 : 3);

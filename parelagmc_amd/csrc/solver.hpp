@@ -121,6 +121,20 @@ struct Multigrid {
     // the hybridized sampler (LAB_NOTES 9.16); the structured and per-realization (Darcy) hierarchies keep 0, so a
     // realization of a ragged remainder chunk takes the same kernels as one of a full launch there.
     int tail_later_nb = 0;
+    // fp32 copy of the right-hand side of the NEXT cycle's top level (set by the caller right before vcycle_z, consumed and
+    // cleared by it): the pre-smoothing and residual kernels of that level gather / read it instead of the fp64 vector.  The
+    // MINRES loop provides it for free-standing cost of one more fp32 stream in the Lanczos update (MinresWork::r32).
+    const float* r32_top = nullptr;
+    // would a cycle from level l0 at width nb read such a copy?  (the fp32-intermediate path of a shared-value level whose
+    // restriction is not the 8-children tree, not inside the LDS tail)
+    bool top_reads_r32(int l0, int nb) const {
+        if (l0 < 0 || l0 + 1 >= (int)L.size()) return false;
+        const MgLevel& lv = L[(size_t)l0];
+        const bool tail_later = nb <= tail_later_nb && lv.n > 4096 && l0 + 1 < (int)tail.size() && tail[(size_t)l0 + 1].p;
+        const bool tail_here = use_tail && l0 < (int)tail.size() && tail[(size_t)l0].p && !tail_later;
+        return !tail_here && !lv.is_last && !lv.bv && lv.has_sp && !lv.p_oct && f32_any_injection && smooth_degree == 2 &&
+               lv.vals_scaled.p && f32_intermediates;
+    }
     // in-situ timing (HIP events) of the top level's post-smoothing kernel - the largest single kernel of a cycle on an
     // aggregation hierarchy; set per solve by the owner, null = off
     OpTimer* smooth_timer = nullptr;
@@ -239,6 +253,11 @@ struct MinresWork {
     ZBuf u2;                                 // third preconditioned vector: only when the w / x update runs one iteration late
     ZBuf u3, u4;                             // ring of the deferred w / x update (with u0, u1, u2: kWxDefer + 1 vectors)
     DevBuf<double> partial_op;               // partials of the operator's fused <u, Au> (the preconditioner's live in `partial`)
+    // want_r32 (set by the owner of the solve): every vector handed to the preconditioner is also kept in fp32 (r32); the
+    // solver raises r32_valid right before each preconditioner call, the preconditioner's closure consumes the flag - a
+    // preconditioner applied outside the loop (pmc_sampler_apply_preconditioner) never sees a stale copy
+    DevBuf<float> r32;
+    bool want_r32 = false, r32_valid = false;
     std::map<uint64_t, int> iter_hint;       // per solver configuration: iterations its previous solve needed
     DevBuf<k::MinresState> state;
     struct GraphEntry {

@@ -61,7 +61,7 @@ def main():
                                    "note": "every workgroup re-reads the tail levels' (index, value) pairs from L2 in each of its "
                                            "passes; the HBM bytes are the level's right-hand side in and correction out"})
         if "lincomb3_kernel" in name:
-            return ("Lanczos update v = c0 q + c1 v1 + c2 v0", 4 * V * n[0], None)
+            return ("Lanczos update v = c0 q + c1 v1 + c2 v0 (+ the fp32 copy the V-cycle reads)", (4 * V + (F if zb == 4 else 0)) * n[0], None)
         if "minres_wx_deferred_kernel" in name:
             return ("w / x update, four iterations per launch", (4 * zb * nb + 6 * V) * n[0], None)
         if l is None:
@@ -71,13 +71,16 @@ def main():
             return ("K5 on H with the fused <u, Hu>", 12.0 * lv[0]["nnz"] + 4.0 * n[0] + (zb * nb + V) * n[0], None)
         if "vc_poly2_kernel<32, double, float, float, false" in name:
             return (f"pre-smoothing, V-cycle level {l}", 12.0 * lv[l]["nnz"] + 12.0 * n[l] + (V + F) * n[l], None)
-        if "vc_residual_kernel<32, float, double, float, false" in name:
+        if "vc_poly2_kernel<32, float, float, float, false" in name and l == 0:
+            return ("pre-smoothing from the fp32 copy of r, V-cycle level 0", 12.0 * lv[0]["nnz"] + 12.0 * n[0] + 2 * F * n[0], None)
+        if "vc_residual_kernel<32, float, double, float, false" in name or "vc_residual_kernel<32, float, float, float, false" in name:
             fused = bool(lv[l]["fused_restriction"])
-            b = 12.0 * lv[l]["nnz"] + 4.0 * n[l] + (V + 2 * F) * n[l] + ((8.0 + V) * nxt if fused else 0.0)
-            return (f"residual{' + fused restriction' if fused else ''}, V-cycle level {l}", b, None)
+            rin = F if "float, float, float" in name else V
+            b = 12.0 * lv[l]["nnz"] + 4.0 * n[l] + (rin + 2 * F) * n[l] + ((8.0 + V) * nxt if fused else 0.0)
+            return (f"residual{' + fused restriction' if fused else ''}{' (fp32 r)' if rin == F else ''}, V-cycle level {l}", b, None)
         if "vc_residual_kernel<32, double, float, float, false" in name:
             return (f"res - (S P) xc, V-cycle level {l}", 12.0 * lv[l]["sp_nnz"] + 4.0 * n[l] + 2 * F * n[l] + V * nxt, None)
-        if "vc_poly2_kernel<32, float, " in name:
+        if "vc_poly2_kernel<32, float, " in name:     # (DOT variants on level 0, the level-1 post-smoothing: gathers fp32 residuals)
             out = zb * nb if l == 0 else V
             return (f"post-smoothing + coarse correction{' + fused <r, z>' if l == 0 else ''}, V-cycle level {l}",
                     12.0 * lv[l]["nnz"] + 12.0 * n[l] + (2 * F + V + out) * n[l] + V * nxt, None)
