@@ -330,7 +330,15 @@ __device__ __forceinline__ void store_row(double* __restrict__ p, const double (
 
 // Column-wise block reduction.  Every lane holds partial sums p[0..C) for columns (lane % T)*C + c.
 // Deterministic: fixed xor tree over the lanes that share a column, fixed order over the 4 wavefronts.
-// Writes partial[blockIdx.x*LD + k] (partial already points at the group's first column).
+// Virtual block index / grid extent of the slice kernels.  A launch of several column groups (nb > kGroup) is laid out as
+// dim3(8, groups, chunks) (groups_xcd): the hardware deals workgroups to the 8 XCDs by their linear id x + 8 y + 8 groups z, so
+// the blocks (x, 0, z) and (x, 1, z) - the SAME slices for column group 0 and 1 - run on the same XCD right after each other and
+// the second one finds the slices' (index, value) pairs in that XCD's L2 instead of reading the matrix from HBM once more.
+// Ordinary launches are dim3(blocks, groups, 1): vblock() == blockIdx.x.
+__device__ __forceinline__ int vblock() { return (int)(blockIdx.z * gridDim.x + blockIdx.x); }
+__device__ __forceinline__ int vgrid() { return (int)(gridDim.z * gridDim.x); }
+
+// Writes partial[vblock()*LD + k] (partial already points at the group's first column).
 template <int NB>
 __device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], double* __restrict__ partial, int LD = NB) {
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T;
@@ -352,7 +360,7 @@ __device__ __forceinline__ void reduce_cols_store(double (&p)[Lay<NB>::C], doubl
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kBlock / kWave; ++w) s += lds[w][threadIdx.x];
-        partial[(size_t)blockIdx.x * LD + threadIdx.x] = s;
+        partial[(size_t)vblock() * LD + threadIdx.x] = s;
     }
 }
 
@@ -589,9 +597,9 @@ struct SliceWalk {
 };
 __device__ __forceinline__ SliceWalk slice_walk(int nslices) {
     constexpr int WPB = kBlock / kWave;                     // wavefronts = slices per workgroup and round
-    const int nblk = gridDim.x, wave = threadIdx.x / kWave;
-    if (nblk < 8) return SliceWalk{(int)blockIdx.x * WPB + wave, nslices, nblk * WPB};
-    const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    const int nblk = vgrid(), bid = vblock(), wave = threadIdx.x / kWave;
+    if (nblk < 8) return SliceWalk{bid * WPB + wave, nslices, nblk * WPB};
+    const int xcd = bid % 8, idx = bid / 8;
     const int nb_x = nblk / 8 + (xcd < nblk % 8 ? 1 : 0);   // workgroups of this XCD
     const int per = (nslices + 7) / 8;                      // slices of an XCD (the last one may get fewer)
     const int lo = min(xcd * per, nslices), hi = min(lo + per, nslices);
@@ -2793,6 +2801,18 @@ __global__ __launch_bounds__(kTailThreads) void mini_sampler_kernel(MiniSamplerP
 
 // grid of a group-capable kernel: y = number of column groups of a batch of nb realizations (1 up to kGroup)
 static inline dim3 groups(dim3 g, int nb) { return dim3(g.x, nb > kGroup ? (unsigned)(nb / kGroup) : 1u); }
+// the slice kernels' grid (see vblock()): column groups of the same slices adjacent on the same XCD
+static inline bool xcd_layout(dim3 g, int nb) {
+    // off in the product: one lane gains 2.4 % from it, four lanes lose 1 % (LAB_NOTES 10.11); laboratory switch PMC_XCD_GROUPS=1
+    static const bool on = [] { const char* e = lab_env("PMC_XCD_GROUPS"); return e && atoi(e) != 0; }();
+    return on && nb > kGroup && g.x >= 16;
+}
+static inline dim3 groups_xcd(dim3 g, int nb) {
+    if (!xcd_layout(g, nb)) return groups(g, nb);
+    return dim3(8u, (unsigned)(nb / kGroup), (g.x + 7u) / 8u);
+}
+// number of per-block dot partials such a launch writes (its virtual grid extent)
+static inline int dot_blocks(dim3 g, int nb) { return xcd_layout(g, nb) ? (int)((g.x + 7u) / 8u * 8u) : (int)g.x; }
 static inline dim3 groups(unsigned g, int nb) { return groups(dim3(g), nb); }
 static inline dim3 groups(int g, int nb) { return groups(dim3((unsigned)g), nb); }
 static inline dim3 grid_rows(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
@@ -2873,53 +2893,53 @@ static void spmm_launch(hipStream_t st, int nb, dim3 g, const SellView& A, const
         const bool nt = TAG != 0 && nt_streams(A, NB, dot_partial != nullptr);
         if (nt) {
             if (dot_partial && dl)
-                sell_spmm_kernel<NB, false, 0, true, TAG, true, false, (Lay<NB>::T > 1), XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+                sell_spmm_kernel<NB, false, 0, true, TAG, true, false, (Lay<NB>::T > 1), XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
             else if (dot_partial)
-                sell_spmm_kernel<NB, false, 0, true, TAG, true, false, false, XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+                sell_spmm_kernel<NB, false, 0, true, TAG, true, false, false, XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
             else
-                sell_spmm_kernel<NB, false, 0, false, TAG, true, false, false, XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+                sell_spmm_kernel<NB, false, 0, false, TAG, true, false, false, XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
         } else {
             if (dot_partial && dl)
-                sell_spmm_kernel<NB, false, 0, true, TAG, false, false, (Lay<NB>::T > 1), XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+                sell_spmm_kernel<NB, false, 0, true, TAG, false, false, (Lay<NB>::T > 1), XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
             else if (dot_partial)
-                sell_spmm_kernel<NB, false, 0, true, TAG, false, false, false, XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+                sell_spmm_kernel<NB, false, 0, true, TAG, false, false, false, XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
             else
-                sell_spmm_kernel<NB, false, 0, false, TAG, false, false, false, XT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+                sell_spmm_kernel<NB, false, 0, false, TAG, false, false, false, XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
         }
         return;
     } else
     if (A.bv && A.f32) {
         if (dot_partial)
-            sell_spmm_kernel<NB, 2, 0, true, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+            sell_spmm_kernel<NB, 2, 0, true, TAG><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (accumulate)
-            sell_spmm_kernel<NB, 2, 1, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, 2, 1, false, TAG><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
         else
-            sell_spmm_kernel<NB, 2, 0, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, 2, 0, false, TAG><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
     } else if (A.bv) {
         if (dot_partial)
-            sell_spmm_kernel<NB, true, 0, true, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+            sell_spmm_kernel<NB, true, 0, true, TAG><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (accumulate)
-            sell_spmm_kernel<NB, true, 1, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, true, 1, false, TAG><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
         else
-            sell_spmm_kernel<NB, true, 0, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, true, 0, false, TAG><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
     } else if (TAG != 0 && nt_streams(A, NB, dot_partial != nullptr)) {
         if (dot_partial && dl)
-            sell_spmm_kernel<NB, false, 0, true, TAG, true, false, (Lay<NB>::T > 1)><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+            sell_spmm_kernel<NB, false, 0, true, TAG, true, false, (Lay<NB>::T > 1)><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (dot_partial)
-            sell_spmm_kernel<NB, false, 0, true, TAG, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+            sell_spmm_kernel<NB, false, 0, true, TAG, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (accumulate)
-            sell_spmm_kernel<NB, false, 1, false, TAG, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, false, 1, false, TAG, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
         else
-            sell_spmm_kernel<NB, false, 0, false, TAG, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, false, 0, false, TAG, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
     } else {
         if (dot_partial && dl)
-            sell_spmm_kernel<NB, false, 0, true, TAG, false, false, (Lay<NB>::T > 1)><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+            sell_spmm_kernel<NB, false, 0, true, TAG, false, false, (Lay<NB>::T > 1)><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (dot_partial)
-            sell_spmm_kernel<NB, false, 0, true, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
+            sell_spmm_kernel<NB, false, 0, true, TAG><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, dot_with, dot_partial, nb);
         else if (accumulate)
-            sell_spmm_kernel<NB, false, 1, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, false, 1, false, TAG><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
         else
-            sell_spmm_kernel<NB, false, 0, false, TAG><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, false, 0, false, TAG><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, y, nullptr, nullptr, nullptr, nb);
     }
 }
 
@@ -2946,11 +2966,11 @@ static int spmm_t(hipStream_t st, int nb, const SellView& A, const XT* x, double
     });
     check_launch();
     if (two_stage) {
-        compress_partials_kernel<<<kCompressBlocks, 256, 0, st>>>(kernel_partial, (int)g.x, nb, dot_partial);
+        compress_partials_kernel<<<kCompressBlocks, 256, 0, st>>>(kernel_partial, dot_blocks(g, nb), nb, dot_partial);
         check_launch();
         return kCompressBlocks;
     }
-    return dot_partial ? (int)g.x : 0;
+    return dot_partial ? dot_blocks(g, nb) : 0;
 }
 int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate, double* dot_partial,
          const double* dot_with) {
@@ -2969,11 +2989,11 @@ void residual_restrict8(hipStream_t st, int nb, const SellView& A, const double*
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
         if (A.bv && A.f32)
-            sell_spmm_kernel<NB, 2, 2, false, 0, false, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
+            sell_spmm_kernel<NB, 2, 2, false, 0, false, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
         else if (A.bv)
-            sell_spmm_kernel<NB, true, 2, false, 0, false, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
+            sell_spmm_kernel<NB, true, 2, false, 0, false, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
         else
-            sell_spmm_kernel<NB, false, 2, false, 0, false, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
+            sell_spmm_kernel<NB, false, 2, false, 0, false, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, coarse, nb);
     });
     check_launch();
 }
@@ -2984,11 +3004,11 @@ void residual(hipStream_t st, int nb, const SellView& A, const double* r, const 
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
         if (A.bv && A.f32)
-            sell_spmm_kernel<NB, 2, 2, false, 0><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, 2, 2, false, 0><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
         else if (A.bv)
-            sell_spmm_kernel<NB, true, 2, false, 0><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, true, 2, false, 0><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
         else
-            sell_spmm_kernel<NB, false, 2, false, 0><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
+            sell_spmm_kernel<NB, false, 2, false, 0><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, x, out, r, nullptr, nullptr, nb);
     });
     check_launch();
 }
@@ -3003,23 +3023,23 @@ static int cheb_step_t(hipStream_t st, int nb, const SellView& A, const double* 
     PMC_DISPATCH_NB(nb, {
         if (A.bv && A.f32) {
             if (dot_partial)
-                sell_cheb_kernel<NB, 2, true, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
+                sell_cheb_kernel<NB, 2, true, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
             else
-                sell_cheb_kernel<NB, 2, false, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
+                sell_cheb_kernel<NB, 2, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
         } else if (A.bv) {
             if (dot_partial)
-                sell_cheb_kernel<NB, 1, true, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
+                sell_cheb_kernel<NB, 1, true, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
             else
-                sell_cheb_kernel<NB, 1, false, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
+                sell_cheb_kernel<NB, 1, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
         } else {
             if (dot_partial)
-                sell_cheb_kernel<NB, 0, true, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
+                sell_cheb_kernel<NB, 0, true, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, dot_partial, nb);
             else
-                sell_cheb_kernel<NB, 0, false, OT><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
+                sell_cheb_kernel<NB, 0, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.sched, A.cols, A.vals, dinv, r, xin, d, xout, a, b, nullptr, nb);
         }
     });
     check_launch();
-    return dot_partial ? (int)g.x : 0;
+    return dot_partial ? dot_blocks(g, nb) : 0;
 }
 
 int cheb_step(hipStream_t st, int nb, const SellView& A, const double* dinv, bool dinv_bv, const double* r,
@@ -3045,28 +3065,28 @@ static int poly2_t(hipStream_t st, int nb, const SellView& As, const double* din
     PMC_DISPATCH_NB(nb, {
         if (As.bv && As.f32) {
             if (dot_partial)
-                sell_poly2_kernel<NB, 2, true, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
+                sell_poly2_kernel<NB, 2, true, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, 2, false, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
+                sell_poly2_kernel<NB, 2, false, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         } else if (As.bv) {
             if (dot_partial)
-                sell_poly2_kernel<NB, 1, true, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
+                sell_poly2_kernel<NB, 1, true, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, 1, false, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
+                sell_poly2_kernel<NB, 1, false, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         } else if (nt_poly(As, NB)) {
             if (dot_partial)
-                sell_poly2_kernel<NB, 0, true, true, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
+                sell_poly2_kernel<NB, 0, true, true, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, 0, false, true, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
+                sell_poly2_kernel<NB, 0, false, true, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         } else {
             if (dot_partial)
-                sell_poly2_kernel<NB, 0, true, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
+                sell_poly2_kernel<NB, 0, true, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, dot_partial, xadd, dot_with, padd_idx, padd_x, nb);
             else
-                sell_poly2_kernel<NB, 0, false, false, OT><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
+                sell_poly2_kernel<NB, 0, false, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.sched, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, xadd, dot_with, padd_idx, padd_x, nb);
         }
     });
     check_launch();
-    return dot_partial ? (int)g.x : 0;
+    return dot_partial ? dot_blocks(g, nb) : 0;
 }
 
 int poly2(hipStream_t st, int nb, const SellView& As, const double* dinv, bool dinv_bv, const double* r, double* xout,
@@ -3100,15 +3120,15 @@ void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* di
     if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_presmooth32: shared values expected");
     const dim3 g = grid_slices(As.nslices);
     if (deep_level(As, nb)) {
-        vc_poly2_kernel<kGroup, double, float, float, false, false, 0, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+        vc_poly2_kernel<kGroup, double, float, float, false, false, 0, 2><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
         check_launch();
         return;
     }
     PMC_DISPATCH_NB(nb, {
         if (nt_poly(As, NB))
-            vc_poly2_kernel<NB, double, float, float, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+            vc_poly2_kernel<NB, double, float, float, false, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
         else
-            vc_poly2_kernel<NB, double, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+            vc_poly2_kernel<NB, double, float, float, false><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
     });
     check_launch();
 }
@@ -3123,9 +3143,9 @@ void vc_presmooth32_r32(hipStream_t st, int nb, const SellView& As, const double
     const dim3 g = grid_slices(As.nslices);
     PMC_DISPATCH_NB(nb, {
         if (nt_poly(As, NB))
-            vc_poly2_kernel<NB, float, float, float, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r32, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+            vc_poly2_kernel<NB, float, float, float, false, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r32, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
         else
-            vc_poly2_kernel<NB, float, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r32, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+            vc_poly2_kernel<NB, float, float, float, false><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r32, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
     });
     check_launch();
 }
@@ -3137,7 +3157,7 @@ void vc_residual_restrict8_32(hipStream_t st, int nb, const SellView& A, const d
     if (A.bv || A.nrows % 8 != 0) throw Error(PMC_ERR_INTERNAL, "vc_residual_restrict8_32: shared values and groups of 8 rows expected");
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
-        vc_residual_kernel<NB, float, double, float, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, coarse, nb);
+        vc_residual_kernel<NB, float, double, float, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, coarse, nb);
     });
     check_launch();
 }
@@ -3148,12 +3168,12 @@ void vc_residual32(hipStream_t st, int nb, const SellView& A, const double* r, c
     if (A.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual32: shared values expected");
     const dim3 g = grid_slices(A.nslices);
     if (deep_level(A, nb)) {
-        vc_residual_kernel<kGroup, float, double, float, false, 0, true, 4><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
+        vc_residual_kernel<kGroup, float, double, float, false, 0, true, 4><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
         check_launch();
         return;
     }
     PMC_DISPATCH_NB(nb, {
-        vc_residual_kernel<NB, float, double, float, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
+        vc_residual_kernel<NB, float, double, float, false><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
     });
     check_launch();
 }
@@ -3165,7 +3185,7 @@ void vc_residual_restrict_agg32(hipStream_t st, int nb, const SellView& A, const
     if (A.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual_restrict_agg32: shared values expected");
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
-        vc_residual_kernel<NB, float, double, float, false, 0, true, 1, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, coarse, nb, seg_ptr, seg_cid, seg_pos);
+        vc_residual_kernel<NB, float, double, float, false, 0, true, 1, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, coarse, nb, seg_ptr, seg_cid, seg_pos);
     });
     check_launch();
 }
@@ -3177,7 +3197,7 @@ void vc_residual_restrict_agg32_r32(hipStream_t st, int nb, const SellView& A, c
     if (A.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual_restrict_agg32_r32: shared values expected");
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
-        vc_residual_kernel<NB, float, float, float, false, 0, true, 1, true><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r32, out, coarse, nb, seg_ptr, seg_cid, seg_pos);
+        vc_residual_kernel<NB, float, float, float, false, 0, true, 1, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r32, out, coarse, nb, seg_ptr, seg_cid, seg_pos);
     });
     check_launch();
 }
@@ -3188,7 +3208,7 @@ void vc_residual32_r32(hipStream_t st, int nb, const SellView& A, const float* r
     if (A.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual32_r32: shared values expected");
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
-        vc_residual_kernel<NB, float, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r32, out, nullptr, nb);
+        vc_residual_kernel<NB, float, float, float, false><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r32, out, nullptr, nb);
     });
     check_launch();
 }
@@ -3199,12 +3219,12 @@ void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res
     if (SP.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual_coarse32: shared values expected");
     const dim3 g = grid_slices(SP.nslices);
     if (deep_level(SP, nb)) {
-        vc_residual_kernel<kGroup, double, float, float, false, 0, true, 2><<<groups(g, nb), kBlock, 0, st>>>(SP.nrows, SP.nslices, SP.slice_off, SP.cols, SP.vals, xc, res, res, nullptr, nb);
+        vc_residual_kernel<kGroup, double, float, float, false, 0, true, 2><<<groups_xcd(g, nb), kBlock, 0, st>>>(SP.nrows, SP.nslices, SP.slice_off, SP.cols, SP.vals, xc, res, res, nullptr, nb);
         check_launch();
         return;
     }
     PMC_DISPATCH_NB(nb, {
-        vc_residual_kernel<NB, double, float, float, false><<<groups(g, nb), kBlock, 0, st>>>(SP.nrows, SP.nslices, SP.slice_off, SP.cols, SP.vals, xc, res, res, nullptr, nb);
+        vc_residual_kernel<NB, double, float, float, false><<<groups_xcd(g, nb), kBlock, 0, st>>>(SP.nrows, SP.nslices, SP.slice_off, SP.cols, SP.vals, xc, res, res, nullptr, nb);
     });
     check_launch();
 }
@@ -3219,25 +3239,25 @@ static int vc_postsmooth32_t(hipStream_t st, int nb, const SellView& As, const d
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     if (deep_level(As, nb)) {
         if (dot_partial)
-            vc_poly2_kernel<kGroup, float, OT, float, true, false, 0, 4><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
+            vc_poly2_kernel<kGroup, float, OT, float, true, false, 0, 4><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
         else
-            vc_poly2_kernel<kGroup, float, OT, float, false, false, 0, 4><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
+            vc_poly2_kernel<kGroup, float, OT, float, false, false, 0, 4><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
         check_launch();
-        return dot_partial ? (int)g.x : 0;
+        return dot_partial ? dot_blocks(g, nb) : 0;
     }
     PMC_DISPATCH_NB(nb, {
         if (nt_poly(As, NB)) {
             if (dot_partial)
-                vc_poly2_kernel<NB, float, OT, float, true, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
+                vc_poly2_kernel<NB, float, OT, float, true, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
             else
-                vc_poly2_kernel<NB, float, OT, float, false, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
+                vc_poly2_kernel<NB, float, OT, float, false, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
         } else if (dot_partial)
-            vc_poly2_kernel<NB, float, OT, float, true><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
+            vc_poly2_kernel<NB, float, OT, float, true><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
         else
-            vc_poly2_kernel<NB, float, OT, float, false><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
+            vc_poly2_kernel<NB, float, OT, float, false><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
     });
     check_launch();
-    return dot_partial ? (int)g.x : 0;
+    return dot_partial ? dot_blocks(g, nb) : 0;
 }
 
 int vc_postsmooth32(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
@@ -3258,7 +3278,7 @@ void vc_presmooth32_bv(hipStream_t st, int nb, const SellView& As, const double*
     if (!(As.bv && As.f32)) throw Error(PMC_ERR_INTERNAL, "vc_presmooth32_bv: per-realization fp32 values expected");
     const dim3 g = grid_slices(As.nslices);
     PMC_DISPATCH_NB(nb, {
-        vc_poly2_kernel<NB, double, float, float, false, false, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
+        vc_poly2_kernel<NB, double, float, float, false, false, 2><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
     });
     check_launch();
 }
@@ -3269,7 +3289,7 @@ void vc_restrict8_32_bv(hipStream_t st, int nb, const SellView& A, const double*
     if (!(A.bv && A.f32) || A.nrows % 8 != 0) throw Error(PMC_ERR_INTERNAL, "vc_restrict8_32_bv: operand mismatch");
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
-        vc_residual_kernel<NB, float, double, float, true, 2, false><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, nullptr, coarse, nb);
+        vc_residual_kernel<NB, float, double, float, true, 2, false><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, nullptr, coarse, nb);
     });
     check_launch();
 }
@@ -3286,7 +3306,7 @@ void vc_residual32_bv(hipStream_t st, int nb, const SellView& A, const double* r
     if (!(A.bv && A.f32)) throw Error(PMC_ERR_INTERNAL, "vc_residual32_bv: per-realization fp32 values expected");
     const dim3 g = grid_slices(A.nslices);
     PMC_DISPATCH_NB(nb, {
-        vc_residual_kernel<NB, float, double, float, false, 2><<<groups(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
+        vc_residual_kernel<NB, float, double, float, false, 2><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
     });
     check_launch();
 }
@@ -3300,12 +3320,12 @@ static int vc_postsmooth32_bv_t(hipStream_t st, int nb, const SellView& As, cons
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (dot_partial)
-            vc_poly2_kernel<NB, float, OT, float, true, false, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, nullptr, nullptr, nb);
+            vc_poly2_kernel<NB, float, OT, float, true, false, 2><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, nullptr, nullptr, nb);
         else
-            vc_poly2_kernel<NB, float, OT, float, false, false, 2><<<groups(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, nullptr, nullptr, nb);
+            vc_poly2_kernel<NB, float, OT, float, false, false, 2><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, nullptr, nullptr, nb);
     });
     check_launch();
-    return dot_partial ? (int)g.x : 0;
+    return dot_partial ? dot_blocks(g, nb) : 0;
 }
 
 int vc_postsmooth32_bv(hipStream_t st, int nb, const SellView& As, const double* dinv, const float* res, const float* x,
@@ -3331,16 +3351,16 @@ static int eg_pair_spmm_t(hipStream_t st, int nb, const EgView& M, const double*
     PMC_DISPATCH_NB(nb, {
         if (nt_flat((size_t)M.nrows * NB * 2)) {   // from 4 MiB per vector on
             if (dot_partial)
-                eg_pair_spmm_kernel<NB, true, true, XT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
+                eg_pair_spmm_kernel<NB, true, true, XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
             else
-                eg_pair_spmm_kernel<NB, false, true, XT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
+                eg_pair_spmm_kernel<NB, false, true, XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
         } else if (dot_partial)
-            eg_pair_spmm_kernel<NB, true, false, XT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
+            eg_pair_spmm_kernel<NB, true, false, XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
         else
-            eg_pair_spmm_kernel<NB, false, false, XT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
+            eg_pair_spmm_kernel<NB, false, false, XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
     });
     check_launch();
-    return dot_partial ? (int)g.x : 0;
+    return dot_partial ? dot_blocks(g, nb) : 0;
 }
 
 int eg_pair_spmm(hipStream_t st, int nb, const EgView& M, const double* coef, const double* x1, const SellView& A2,
@@ -3364,16 +3384,16 @@ static int eg_poly2_t(hipStream_t st, int nb, const EgView& M, const double* coe
     PMC_DISPATCH_NB(nb, {
         if (nt_flat((size_t)M.nrows * NB * 2)) {
             if (dot_partial)
-                eg_poly2_kernel<NB, true, true, OT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
+                eg_poly2_kernel<NB, true, true, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
             else
-                eg_poly2_kernel<NB, false, true, OT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
+                eg_poly2_kernel<NB, false, true, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
         } else if (dot_partial)
-            eg_poly2_kernel<NB, true, false, OT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
+            eg_poly2_kernel<NB, true, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, dot_partial, nb);
         else
-            eg_poly2_kernel<NB, false, false, OT><<<groups(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
+            eg_poly2_kernel<NB, false, false, OT><<<groups_xcd(g, nb), kBlock, 0, st>>>(M.nrows, M.nslices, M.gw, M.cols, M.w, M.e12, coef, dinv, r, xout, c0, c1, nullptr, nb);
     });
     check_launch();
-    return dot_partial ? (int)g.x : 0;
+    return dot_partial ? dot_blocks(g, nb) : 0;
 }
 
 int eg_poly2(hipStream_t st, int nb, const EgView& M, const double* coef, const double* dinv, const double* r, double* xout,
@@ -3396,12 +3416,12 @@ static int pair_spmm_t(hipStream_t st, int nb, const SellView& A1, const XT* x1,
     const dim3 g = grid_bounded(grid_slices(A1.nslices), dot_partial != nullptr);
     PMC_DISPATCH_NB(nb, {
         if (dot_partial)
-            sell_pair_spmm_kernel<NB, true, XT><<<groups(g, nb), kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
+            sell_pair_spmm_kernel<NB, true, XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, dot_with, dot_partial, nb);
         else
-            sell_pair_spmm_kernel<NB, false, XT><<<groups(g, nb), kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
+            sell_pair_spmm_kernel<NB, false, XT><<<groups_xcd(g, nb), kBlock, 0, st>>>(A1.nrows, A1.nslices, A1.slice_off, A1.cols, A1.vals, A2.slice_off, A2.cols, A2.vals, x1, x2, y, nullptr, nullptr, nb);
     });
     check_launch();
-    return dot_partial ? (int)g.x : 0;
+    return dot_partial ? dot_blocks(g, nb) : 0;
 }
 
 int pair_spmm(hipStream_t st, int nb, const SellView& A1, const double* x1, const SellView& A2, const double* x2, double* y,
