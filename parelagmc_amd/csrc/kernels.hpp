@@ -81,7 +81,12 @@ namespace k {
 // The w / x updates of up to kWxDefer consecutive MINRES iterations are applied in ONE pass over the vectors
 // (minres_wx_deferred): nothing reads w or x before the solve ends, and every update needs only its own iteration's
 // coefficients and preconditioned vector.  One pass costs (kWxDefer + 5) vector streams instead of 6 kWxDefer.
-static constexpr int kWxDefer = 4;
+// (round 5: 8 instead of 4 - per iteration (8 x 4 + 6 x 8) / 8 = 10 bytes per entry instead of 16 with fp32-stored u; the ring
+// of preconditioned vectors grows from 5 to 9)
+#ifndef PMC_WX_DEFER_N
+#define PMC_WX_DEFER_N 8
+#endif
+static constexpr int kWxDefer = PMC_WX_DEFER_N;
 struct WxDeferred {
     const void* u[kWxDefer];    // preconditioned vectors of the pending iterations (rows of the maintained block), oldest first
     int slot[kWxDefer];          // coefficient set (MinresState::cW ring) of each

@@ -672,11 +672,14 @@ MinresResult minres_solve(Ctx& ctx, int nb, const LinOp& A, const PrecFn& prec, 
     } else if (defer) {
         // ring of kWxDefer + 1 preconditioned vectors: the pending iterations' z stay alive until their updates are flushed
         constexpr int R = k::kWxDefer + 1;
-        w.u2.ensure(len, z32);
-        w.u3.ensure(len, z32);
-        w.u4.ensure(len, z32);
-        zvec ub[R] = {u1, u0, w.u2.v(z32), w.u3.v(z32), w.u4.v(z32)};
-        static_assert(R == 5, "ring buffers of the deferred w / x update");
+        if ((int)w.ring.size() < R - 2) w.ring.resize(R - 2);
+        zvec ub[R];
+        ub[0] = u1;
+        ub[1] = u0;
+        for (int j = 2; j < R; ++j) {
+            w.ring[(size_t)j - 2].ensure(len, z32);
+            ub[j] = w.ring[(size_t)j - 2].v(z32);
+        }
         int c = 0;                                   // ub[c] holds the preconditioned vector of the current Lanczos vector
         k::WxDeferred pending{};
         pending.f32 = z32;

@@ -2,6 +2,7 @@
 #pragma once
 #include <functional>
 #include <map>
+#include <vector>
 
 #include "kernels.hpp"
 
@@ -251,7 +252,7 @@ struct MinresWork {
     ZBuf u0, u1;                             // preconditioned vectors (storage: pmc_solver_opts.precond_storage)
     DevBuf<double> stage;                    // first-stage sums of the scalar kernel (k::minres_scal21)
     ZBuf u2;                                 // third preconditioned vector: only when the w / x update runs one iteration late
-    ZBuf u3, u4;                             // ring of the deferred w / x update (with u0, u1, u2: kWxDefer + 1 vectors)
+    std::vector<ZBuf> ring;                  // ring of the deferred w / x update (with u0, u1: kWxDefer + 1 vectors)
     DevBuf<double> partial_op;               // partials of the operator's fused <u, Au> (the preconditioner's live in `partial`)
     // want_r32 (set by the owner of the solve): every vector handed to the preconditioner is also kept in fp32 (r32); the
     // solver raises r32_valid right before each preconditioner call, the preconditioner's closure consumes the flag - a
