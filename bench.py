@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+WX_DEFER = 8.0       # csrc/kernels.hpp::kWxDefer: MINRES iterations whose w / x updates one pass applies
 
 
 LINE_CAP = 4096     # the driver keeps ~8 000 characters of stdout: the ONE JSON line stays well below that (BENCH_r04: a 21.7 kB
@@ -410,8 +411,8 @@ def solver_bytes_per_iteration(problem, nb, zb=4):
     total = mat(L[0].nnz, n) + (Z + V) * n                    # K5: q = A u (u is a z; the dot takes u from the gathers)
     total += V * 4 * n                                         # v_new = c0 q + c1 v1 + c2 v0
     total += mat(L[0].M.nnz, n_u) + 8.0 * n_u + (V + Z) * n_u  # M-block: one-pass degree-2 polynomial, r in, z out
-    total += (4 * Z + 5 * V) / 4.0 * n_s                       # w / x updates on the s-block, four iterations per pass (kWxDefer):
-    #                                                            reads 4 u + w0 + w1 + x, writes w0 + w1 + x per 4 iterations
+    total += (WX_DEFER * Z + 5 * V) / WX_DEFER * n_s           # w / x updates on the s-block, WX_DEFER iterations per pass (kWxDefer):
+    #                                                            reads 8 u + w0 + w1 + x, writes w0 + w1 + x per 8 iterations
     # V-cycle on the Schur block, level by level until the first level handled by the LDS tail (<= ~6k rows) / last level
     for lv in range(len(L)):
         ns_l = L[lv].n_s
@@ -444,7 +445,7 @@ def hybrid_bytes_per_iteration(hp, smp, nb, zb=4):
     R = F if zb == 4 else V
     total = 12.0 * nnz + 4.0 * n + (Z + V) * n                 # K5 on H: q = H u
     total += V * 4 * n + (F * n if zb == 4 else 0.0)           # v_new = c0 q + c1 v1 + c2 v0 (+ its fp32 copy)
-    total += (4 * Z + 6 * V) / 4.0 * n                         # w / x updates on ALL rows, four iterations per pass
+    total += (WX_DEFER * Z + 6 * V) / WX_DEFER * n             # w / x updates on ALL rows, WX_DEFER iterations per pass
     total += 12.0 * nnz + 12.0 * n + (R + F) * n               # pre-smoothing: r in, x out
     total += 12.0 * nnz + 4.0 * n + (R + 2 * F) * n            # residual: r, x in; res out
     fused = bool(smp.vcycle_levels(0)[0]["fused_restriction"])

@@ -63,7 +63,7 @@ def main():
         if "lincomb3_kernel" in name:
             return ("Lanczos update v = c0 q + c1 v1 + c2 v0 (+ the fp32 copy the V-cycle reads)", (4 * V + (F if zb == 4 else 0)) * n[0], None)
         if "minres_wx_deferred_kernel" in name:
-            return ("w / x update, four iterations per launch", (4 * zb * nb + 6 * V) * n[0], None)
+            return ("w / x update, eight iterations per launch", (8 * zb * nb + 6 * V) * n[0], None)
         if l is None:
             return None
         nxt = n[l + 1] if l + 1 < len(n) else 0
