@@ -303,3 +303,27 @@ def test_both_device_solvers_reproduce_the_tetrahedral_golden_vectors(gpu_ctx, s
             assert all(t[1] == 1 for t in st)
             assert rel(s, g[key]) < tol, (solver, key, rel(s, g[key]))
         smp.close()
+
+
+def test_vcycle_info_reports_the_hierarchy_the_sampler_runs(gpu_ctx, hex_hierarchy_small):
+    """pmc_sampler_vcycle_info (what scripts/roofline_table.py prices the per-kernel table with): levels shrink, the finest level
+    of a hybridized handle is H itself and has its restriction fused (fp32 storage) or not (fp64 storage: generic V-cycle), the
+    saddle-point handle reports its Schur-complement hierarchy; out-of-range queries are errors, not garbage."""
+    import ctypes as C
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_hybrid_sampler_problem, build_sampler_problem
+    hp = build_hybrid_sampler_problem(hex_hierarchy_small, corlen=0.1, builder=capi.library_hybrid_builder)
+    for storage, fused in ((capi.PMC_STORAGE_FP32, 1), (capi.PMC_STORAGE_FP64, 0)):
+        smp = capi.PDESampler(gpu_ctx, hp, capi.solver_opts(precond_storage=storage))
+        lv = smp.vcycle_levels(0)
+        assert lv[0]["rows"] == hp.levels[0].n_lambda and lv[0]["nnz"] == hp.levels[0].H.nnz
+        assert all(a["rows"] > b["rows"] for a, b in zip(lv, lv[1:])) and lv[0]["slots"] >= lv[0]["nnz"]
+        assert lv[0]["fused_restriction"] == fused and lv[0]["sp_nnz"] > 0
+        nv, info = C.c_int(0), (C.c_int64 * 7)()
+        assert gpu_ctx.lib.pmc_sampler_vcycle_info(smp.h, 0, len(lv), C.byref(nv), info) != 0      # vlevel out of range
+        assert gpu_ctx.lib.pmc_sampler_vcycle_info(smp.h, 9, 0, C.byref(nv), info) != 0            # level out of range
+        smp.close()
+    sa = capi.PDESampler(gpu_ctx, build_sampler_problem(hex_hierarchy_small, corlen=0.1))
+    lv = sa.vcycle_levels(0)
+    assert lv[0]["rows"] == hex_hierarchy_small.spaces[0].n_s and len(lv) == 2
+    sa.close()
