@@ -139,17 +139,6 @@ struct Sell {
     // algorithmic bytes of one SpMV with this matrix: 12 nnz + 12 nrows + 8 ncols
     double spmv_bytes() const { return 12.0 * nnz + 12.0 * nrows + 8.0 * ncols; }
 };
-// LDS-blocked companion of a SELL matrix (round 5, laboratory): per block of 4 slices (256 rows) the sorted list of the
-// DISTINCT columns its rows gather (ucols[blk_ptr[b] .. blk_ptr[b + 1])) and, in the SELL slot layout, the position of every
-// entry's column in that list (lcols, 16 bit).  A kernel built on it loads every distinct row of x ONCE into LDS and gathers
-// from there: at 400 k multipliers a block gathers 1 768 rows of which 482 are distinct.
-struct SellLB {
-    bool ok = false;
-    int nblocks = 0, max_unique = 0;
-    DevBuf<int> blk_ptr, ucols;
-    DevBuf<unsigned short> lcols;
-};
-void sell_lb_build(SellLB& B, const Sell& S, hipStream_t st);
 // diag_last: request the diagonal-last order (granted when A is square and stores its whole diagonal)
 void sell_build(Sell& S, const HostCsr& A, bool upload_vals, bool keep_src, hipStream_t st, bool diag_last = false);
 // values of A*diag(colscale) laid out on the SELL pattern S was built with (S must keep its host mirrors)

@@ -32,7 +32,6 @@ struct SamplerLevel {
     // internal numbering of the multipliers (aggregates of the V-cycle's finest level contiguous, agg_pack_rows): internal
     // row i is the caller's row lam_new2old[i]; empty = the caller's numbering
     DevBuf<int> lam_new2old, lam_old2new;
-    SellLB A_lb;            // LDS-blocked companion of A (laboratory switch PMC_K5_LB)
 };
 
 struct Sampler {

@@ -583,102 +583,6 @@ __device__ __forceinline__ void sell_row_product(const int* __restrict__ slice_o
     sell_row_range<NB, BV, false, true, false, XT>(cols, vals, x, nullptr, off, width, lane, LD, acc);
 }
 
-// LDS-blocked SpMM (laboratory, SellLB): y = A x for a shared-value SELL matrix and an fp32-stored x, 32 columns per group.  A
-// workgroup takes 4 consecutive slices; it first loads every DISTINCT row of x its 256 rows gather into LDS - each byte once
-// through the L1 -> register path, which is what bounds the gather kernels (LAB_NOTES 10.4) - and then sweeps its slices with
-// the gathers served from LDS.  DOT: fused <x, A x> of a diagonal-last matrix (the last slice column gathers x[row]).
-// Blocks are dealt to the XCDs like slice_walk does: XCD x owns one contiguous eighth of the slice blocks.
-template <bool DOT>
-__global__ __launch_bounds__(kBlock, 2) void sell_spmm_lb_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
-                                                                 const unsigned short* __restrict__ lcols,
-                                                                 const double* __restrict__ vals, const int* __restrict__ blk_ptr,
-                                                                 const int* __restrict__ ucols, const float* __restrict__ x,
-                                                                 double* __restrict__ y, double* __restrict__ partial, int ld) {
-    constexpr int NB = kGroup;
-    constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
-    extern __shared__ __align__(16) float lb_tile[];
-    const int LD = ld;
-    {
-        const int c0 = (int)blockIdx.y * NB;
-        x += c0; y += c0;
-        if constexpr (DOT) partial += c0;
-    }
-    const int ngrp = (nslices + 3) / 4, per = (ngrp + 7) / 8;
-    const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-    const int b = xcd * per + idx;
-    const bool live = idx < per && b < ngrp;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const int g = lane / T, t = lane % T;
-    double p[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) p[c] = 0.0;
-    if (live) {
-        const int u0 = blk_ptr[b], nu = blk_ptr[b + 1] - u0;
-        // phase 1: 32 rows per pass (8 lanes x 16 bytes each), four passes in flight
-        const int ri = threadIdx.x / T;
-        constexpr int RP = kBlock / T;
-        for (int u = ri; u < nu; u += 4 * RP) {
-            pmc_f4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int uu = u + q * RP < nu ? u + q * RP : u;
-                v[q] = *reinterpret_cast<const pmc_f4*>(x + (size_t)ucols[u0 + uu] * LD + t * C);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (u + q * RP < nu) *reinterpret_cast<pmc_f4*>(lb_tile + (size_t)(u + q * RP) * NB + t * C) = v[q];
-        }
-    }
-    __syncthreads();
-    const int slice = 4 * b + wave;
-    if (live && slice < nslices) {
-        const int off = slice_off[slice];
-        const int width = (slice_off[slice + 1] - off) >> 6;
-        double acc[T][C];
-#pragma unroll
-        for (int rs = 0; rs < T; ++rs)
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[rs][c] = 0.0;
-        int slot = off + lane;
-        int cj = width > 0 ? (int)lcols[slot] : 0;
-        double vj = width > 0 ? vals[slot] : 0.0;
-        for (int j = 0; j < width; ++j, slot += kWave) {
-            int cn = cj;
-            double vn = vj;
-            if (j + 1 < width) {
-                cn = (int)lcols[slot + kWave];
-                vn = vals[slot + kWave];
-            }
-            pmc_f4 xr[T];
-#pragma unroll
-            for (int rs = 0; rs < T; ++rs)
-                xr[rs] = *reinterpret_cast<const pmc_f4*>(lb_tile + __shfl(cj, rs * G + g, kWave) * NB + t * C);
-#pragma unroll
-            for (int rs = 0; rs < T; ++rs) {
-                const double a = __shfl(vj, rs * G + g, kWave);
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[rs][c] = fma(a, (double)xr[rs][c], acc[rs][c]);
-            }
-            if constexpr (DOT) {
-                if (j + 1 == width) {
-#pragma unroll
-                    for (int rs = 0; rs < T; ++rs)
-#pragma unroll
-                        for (int c = 0; c < C; ++c) p[c] = fma((double)xr[rs][c], acc[rs][c], p[c]);
-                }
-            }
-            cj = cn;
-            vj = vn;
-        }
-#pragma unroll
-        for (int rs = 0; rs < T; ++rs) {
-            const int row = slice * kWave + rs * G + g;
-            if (row < nrows) store_c<C>(y + (size_t)row * LD + t * C, acc[rs]);
-        }
-    }
-    if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
-}
-
 // XCD-aware slice assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (block b runs on XCD b % 8),
 // and each XCD has its own 4 MiB L2.  XCD x owns one CONTIGUOUS eighth of the slices (in processing order), so the x
 // entries its gathers touch (mesh neighbours = nearby indices) stay in that XCD's L2 instead of being fetched by all
@@ -3068,33 +2972,6 @@ static int spmm_t(hipStream_t st, int nb, const SellView& A, const XT* x, double
     }
     return dot_partial ? dot_blocks(g, nb) : 0;
 }
-int spmm_lb(hipStream_t st, int nb, const SellView& A, const unsigned short* lcols, const int* blk_ptr, const int* ucols,
-            int max_unique, const float* x, double* y, double* dot_partial) {
-    if (A.nrows == 0) return 0;
-    if (A.bv || nb < kGroup || nb % kGroup != 0) throw Error(PMC_ERR_INTERNAL, "spmm_lb: shared values, column groups of 32");
-    if (dot_partial && !A.diag_last) throw Error(PMC_ERR_INTERNAL, "spmm_lb: the fused dot needs a diagonal-last matrix");
-    check_offsets32(A, nb);
-    const int ngrp = (A.nslices + 3) / 4, per = (ngrp + 7) / 8;
-    const dim3 g((unsigned)(per * 8), (unsigned)(nb / kGroup));
-    const size_t bytes = (size_t)max_unique * kGroup * sizeof(float);
-    if (bytes > 150 * 1024) throw Error(PMC_ERR_INTERNAL, "spmm_lb: a block's distinct rows exceed the LDS");
-    static std::atomic<size_t> attr_bytes[2] = {{0}, {0}};
-    const int which = dot_partial ? 1 : 0;
-    if (attr_bytes[which].load() < bytes) {
-        if (dot_partial)
-            PMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sell_spmm_lb_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        else
-            PMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sell_spmm_lb_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_bytes[which].store(bytes);
-    }
-    if (dot_partial)
-        sell_spmm_lb_kernel<true><<<g, kBlock, bytes, st>>>(A.nrows, A.nslices, A.slice_off, lcols, A.vals, blk_ptr, ucols, x, y, dot_partial, nb);
-    else
-        sell_spmm_lb_kernel<false><<<g, kBlock, bytes, st>>>(A.nrows, A.nslices, A.slice_off, lcols, A.vals, blk_ptr, ucols, x, y, nullptr, nb);
-    check_launch();
-    return dot_partial ? (int)g.x : 0;
-}
-
 int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate, double* dot_partial,
          const double* dot_with) {
     return spmm_t<double>(st, nb, A, x, y, accumulate, dot_partial, dot_with);

@@ -109,10 +109,6 @@ struct MinresState {
 
 // y = A x (accumulate=false) or y += A x.  If dot_partial != nullptr (accumulate must be false) also
 // writes per-block partial sums of <dot_with, A x>; returns the number of partial blocks written.
-// LDS-blocked product (laboratory; SellLB of csrc/common.hpp): y = A x, x fp32-stored, nb a multiple of 32; dot_partial != nullptr
-// also writes per-block partials of <x, A x> (diagonal-last A) and returns their count
-int spmm_lb(hipStream_t st, int nb, const SellView& A, const unsigned short* lcols, const int* blk_ptr, const int* ucols,
-            int max_unique, const float* x, double* y, double* dot_partial);
 int spmm(hipStream_t st, int nb, const SellView& A, const double* x, double* y, bool accumulate,
           double* dot_partial, const double* dot_with);
 // the same product from a vector in zvec storage (shared values, no accumulation): the operator products of the solver loop

@@ -335,10 +335,7 @@ Sampler::Sampler(Ctx& c, int nlevels_, const pmc_hybrid_level* in, double alpha_
             }
             segs[(size_t)pl] = std::move(sg);
         }
-        const char* e_lb = lab_env("PMC_K5_LB");
-        const bool want_lb = e_lb && atoi(e_lb) != 0;
-        sell_build(d.A, H, true, want_lb, st, diag_last_on());     // (the host mirrors are kept for the LDS-blocked companion)
-        if (want_lb) sell_lb_build(d.A_lb, d.A, st);
+        sell_build(d.A, H, true, false, st, diag_last_on());
         sell_build(d.Gl, csr_transpose(G), true, false, st);
         for (int i = 0; i < G.nrows; ++i)
             for (int p = G.rowptr[i]; p < G.rowptr[i + 1]; ++p) G.vals[p] /= L.z_diag[G.colind[p]];
@@ -584,13 +581,6 @@ void Sampler::solve_system(int level, int nb, bool zero_guess, int x_row0, int x
     A.apply_z = [Av](const Lanes& L, int nb_, zvec x, double* y, double* partial, double*) {
         return k::DotParts{partial, k::spmm_z(L.main, nb_, Av, x, y, partial, x)};
     };
-    if (hybrid && d.A_lb.ok && nb >= kGroup && Av.diag_last && opts.precond_storage != PMC_STORAGE_FP64) {
-        const SellLB* lb = &d.A_lb;
-        A.apply_z = [Av, lb](const Lanes& L, int nb_, zvec x, double* y, double* partial, double*) {
-            return k::DotParts{partial, k::spmm_lb(L.main, nb_, Av, lb->lcols.p, lb->blk_ptr.p, lb->ucols.p, lb->max_unique,
-                                                   x.as<float>(), y, partial)};
-        };
-    }
     PrecFn prec = preconditioner(level, nb, degM, mgp, mg_l0);
     // hybridized solver: the Lanczos update also writes the fp32 copy the cycle's first two kernels read (LAB_NOTES 10.9)
     work.want_r32 = hybrid && opts.precond_storage != PMC_STORAGE_FP64 && mgp->top_reads_r32(mg_l0, nb);

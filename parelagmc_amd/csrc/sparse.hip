@@ -419,35 +419,6 @@ std::vector<int> agg_pack_rows(const HostCsr& P, std::vector<int>& seg_ptr, std:
     return new2old;
 }
 
-void sell_lb_build(SellLB& B, const Sell& S, hipStream_t st) {
-    B = SellLB();
-    if (S.h_slice_off.empty() || S.h_cols.empty()) return;        // host mirrors already dropped
-    const int nblocks = (S.nslices + 3) / 4;
-    std::vector<int> blk_ptr(1, 0), ucols, tmp;
-    std::vector<unsigned short> lcols(S.h_cols.size());
-    int max_unique = 0;
-    for (int b = 0; b < nblocks; ++b) {
-        const int s0 = 4 * b, s1 = std::min(S.nslices, s0 + 4);
-        const int lo = S.h_slice_off[(size_t)s0], hi = S.h_slice_off[(size_t)s1];
-        tmp.assign(S.h_cols.begin() + lo, S.h_cols.begin() + hi);
-        std::sort(tmp.begin(), tmp.end());
-        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-        if (tmp.size() > 65535) return;
-        for (int p = lo; p < hi; ++p)
-            lcols[(size_t)p] = (unsigned short)(std::lower_bound(tmp.begin(), tmp.end(), S.h_cols[(size_t)p]) - tmp.begin());
-        ucols.insert(ucols.end(), tmp.begin(), tmp.end());
-        blk_ptr.push_back((int)ucols.size());
-        max_unique = std::max(max_unique, (int)tmp.size());
-    }
-    B.nblocks = nblocks;
-    B.max_unique = max_unique;
-    B.blk_ptr.upload(blk_ptr, st);
-    B.ucols.upload(ucols, st);
-    B.lcols.upload(lcols, st);
-    PMC_HIP(hipStreamSynchronize(st));
-    B.ok = true;
-}
-
 // rows (and, sym, columns) of A renumbered: row i of the result is row new2old[i] of A
 HostCsr csr_permute(const HostCsr& A, const std::vector<int>& new2old, bool rows, bool cols) {
     HostCsr B;
