@@ -2574,6 +2574,23 @@ PMC_TAIL_INLINE void tail_vcycle_lds(const TailParams& P, int nb, int k, double*
         double* r = lds + L.lds_off;
         double* x = r + L.n;
         double* d = x + L.n;
+        if (l == nlev - 1 && L.ainv) {   // exact coarse solve with the precomputed dense inverse (symmetric: read column-wise)
+            const int n = L.n;
+            for (int i = threadIdx.x; i < n; i += kTailThreads) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int j = 0;
+                for (; j + 3 < n; j += 4) {
+                    s0 = fma(L.ainv[(size_t)j * n + i], r[j], s0);
+                    s1 = fma(L.ainv[(size_t)(j + 1) * n + i], r[j + 1], s1);
+                    s2 = fma(L.ainv[(size_t)(j + 2) * n + i], r[j + 2], s2);
+                    s3 = fma(L.ainv[(size_t)(j + 3) * n + i], r[j + 3], s3);
+                }
+                for (; j < n; ++j) s0 = fma(L.ainv[(size_t)j * n + i], r[j], s0);
+                x[i] = (s0 + s1) + (s2 + s3);
+            }
+            __syncthreads();
+            break;
+        }
         if (l == nlev - 1) {     // host guarantees last_degree > 0 on the final tail level
             // rows in registers: 3 rows x 5 entries (tets: 4 neighbours + diagonal) or 2 rows x 7 (hexahedra) per thread
             if (!(L.last_degree > 2 && (tail_cheb_cached<3, 5>(L, P.bv, nb, k, L.last_degree, L.last_ratio, r, x, d) ||

@@ -275,6 +275,10 @@ struct TailLevelDev {
     int last_degree;            // > 0: this level ends the recursion with a Chebyshev solve of that degree
     double last_ratio;
     int lds_off;                // offset (in doubles) of this level's [r | x | d] block
+    // last tail level only, may be null: the dense inverse of its (shared-value, symmetric) operator, n x n - the recursion
+    // then ends with x = A^-1 r in one pass instead of a many-step Chebyshev solve whose every step re-reads the matrix behind
+    // two barriers (a 64-row level with 30 entries per row: ~40 of the tail's 146 us per cycle, all of it latency)
+    const double* ainv;
 };
 static constexpr size_t kTailLdsDoubles = (160 * 1024 - 1024) / 8;
 struct TailParams {

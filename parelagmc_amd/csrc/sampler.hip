@@ -110,6 +110,57 @@ static std::unique_ptr<Multigrid> build_chain(const std::vector<AmgLevelHost>& l
             }
         }
     }
+    // The coarsest level of such a hierarchy is tiny and comparatively dense (64 rows with ~30 entries each at 400 k multipliers):
+    // its many-step Chebyshev solve was ~40 us of pure latency per cycle inside the LDS tail.  Up to 192 rows it is solved
+    // exactly with a dense inverse computed here once (host, Cholesky on the SPD level operator).
+    if (f32_any_injection && !mg->L.empty()) {
+        MgLevel& m = mg->L.back();
+        const HostCsr& S = lv[mg->L.size() - 1].S;
+        const int n = S.nrows;
+        const char* e = lab_env("PMC_TAIL_AINV");
+        if (n >= 2 && n <= 192 && !(e && atoi(e) == 0)) {
+            std::vector<double> a((size_t)n * n, 0.0), inv((size_t)n * n, 0.0);
+            for (int i = 0; i < n; ++i)
+                for (int p = S.rowptr[i]; p < S.rowptr[i + 1]; ++p) a[(size_t)i * n + S.colind[p]] = S.vals[p];
+            // Cholesky a = L L^T (lower, in place), then inv = L^-T L^-1
+            bool ok = true;
+            for (int j = 0; j < n && ok; ++j) {
+                double dj = a[(size_t)j * n + j];
+                for (int k = 0; k < j; ++k) dj -= a[(size_t)j * n + k] * a[(size_t)j * n + k];
+                ok = dj > 0.0 && std::isfinite(dj);
+                if (!ok) break;
+                const double l = std::sqrt(dj);
+                a[(size_t)j * n + j] = l;
+                for (int i = j + 1; i < n; ++i) {
+                    double v = a[(size_t)i * n + j];
+                    for (int k = 0; k < j; ++k) v -= a[(size_t)i * n + k] * a[(size_t)j * n + k];
+                    a[(size_t)i * n + j] = v / l;
+                }
+            }
+            if (ok) {
+                std::vector<double> y(n);
+                for (int c = 0; c < n; ++c) {          // column c of the inverse: L y = e_c, L^T x = y
+                    for (int i = 0; i < n; ++i) {
+                        double v = i == c ? 1.0 : 0.0;
+                        for (int k = 0; k < i; ++k) v -= a[(size_t)i * n + k] * y[k];
+                        y[i] = v / a[(size_t)i * n + i];
+                    }
+                    for (int i = n - 1; i >= 0; --i) {
+                        double v = y[i];
+                        for (int k = i + 1; k < n; ++k) v -= a[(size_t)k * n + i] * inv[(size_t)k * n + c];
+                        inv[(size_t)i * n + c] = v / a[(size_t)i * n + i];
+                    }
+                }
+                for (int i = 0; i < n; ++i)             // exactly symmetric (the kernel reads it column-wise)
+                    for (int j = 0; j < i; ++j) {
+                        const double v = 0.5 * (inv[(size_t)i * n + j] + inv[(size_t)j * n + i]);
+                        inv[(size_t)i * n + j] = inv[(size_t)j * n + i] = v;
+                    }
+                m.ainv.upload(inv, st);
+                PMC_HIP(hipStreamSynchronize(st));
+            }
+        }
+    }
     mg->build_tails(st);
     return mg;
 }

@@ -172,6 +172,7 @@ void Multigrid::build_tails(hipStream_t st) {
             d.lds_off = (int)off;
             off += 3 * (size_t)m.n;
             const bool last = m.is_last || l == nl - 1;
+            d.ainv = last ? m.ainv.p : nullptr;
             d.last_degree = last ? (m.is_last ? m.last_degree : coarse_degree) : 0;
             d.last_ratio = last ? (m.is_last ? m.last_ratio : coarse_ratio) : 1.0;
             if (last) break;

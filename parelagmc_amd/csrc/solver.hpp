@@ -93,6 +93,7 @@ struct MgLevel {
     bool p_agg = false;
     DevBuf<int> seg_ptr, seg_cid, seg_pos;
     DevBuf<double> r, xa, xb, d, res;
+    DevBuf<double> ainv;         // last level of a small shared-value hierarchy: dense inverse (see TailLevelDev::ainv)
     void ensure(int nb);
     SellView sview() const { return bv ? (f32 ? view_bv32(S, vals32.p) : view_bv(S, vals_bv.p)) : view(S); }
     // column-scaled values in the storage sview() uses
