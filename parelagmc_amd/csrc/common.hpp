@@ -96,6 +96,7 @@ HostCsr prolongator_from_agg(const std::vector<int>& agg, int nc);
 // (new2old; empty = not possible) + per slice the segments [seg_ptr[s], seg_ptr[s + 1]): coarse id, (first row in slice << 8) | rows
 std::vector<int> agg_pack_rows(const HostCsr& P, std::vector<int>& seg_ptr, std::vector<int>& seg_cid, std::vector<int>& seg_pos);
 HostCsr csr_permute(const HostCsr& A, const std::vector<int>& new2old, bool rows, bool cols);
+HostCsr csr_split_rows(const HostCsr& A, int sl);
 
 HostCsr csr_spgemm(const HostCsr& A, const HostCsr& B);
 // P(i, i / 8) == 1 is the only entry of row i, for every row, and P has 8 rows per column

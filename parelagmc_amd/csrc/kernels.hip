@@ -1032,14 +1032,30 @@ template <int NB, typename XT, int BV, int DEEP>
 constexpr int vc_min_waves() {
     return (NB >= 32 && BV == 0 && DEEP == 1) ? (sizeof(XT) == 4 ? PMC_VC_MIN_WAVES : PMC_VC_MIN_WAVES_D) : 1;
 }
-template <int NB, typename XT, typename OT, typename AT, bool DOT, bool NT = false, int BV = 0, int DEEP = 1>
+// SPL (launches of at most 8 realizations on the small levels of an aggregation hierarchy, whose rows hold 20-40 entries): the
+// matrix stores every row as 2^sl consecutive pieces (csr_split_rows), nrows counts the ROWS; the pieces of a row sit in
+// neighbouring lane groups and are added with a shuffle tree, the first piece's lanes finish the row.  A 5 k-row level then
+// runs 2^sl times the wavefronts over slices 2^sl times shorter - these launches are one chain of dependent gathers per slice.
+template <int NB, int C, int T>
+__device__ __forceinline__ void split_row_sums(double (&acc)[T][C], int sl) {
+#pragma unroll
+    for (int rs = 0; rs < T; ++rs)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            double v = acc[rs][c];
+            for (int o = 0; o < sl; ++o) v += __shfl_xor(v, T << o, kWave);
+            acc[rs][c] = v;
+        }
+}
+template <int NB, typename XT, typename OT, typename AT, bool DOT, bool NT = false, int BV = 0, int DEEP = 1, bool SPL = false>
 __global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                           const int* __restrict__ cols, const double* __restrict__ vals_scaled,
                                                           const double* __restrict__ dinv, const XT* __restrict__ r, OT* xout,
                                                           double c0, double c1, double* __restrict__ partial, const AT* xadd,
                                                           const double* __restrict__ dot_with,
                                                           const int* __restrict__ padd_idx, const double* __restrict__ padd_x,
-                                                          int ld) {
+                                                          int ld, int sl = 0) {
+    static_assert(!SPL || (NB <= 8 && BV == 0 && DEEP == 1), "row-split instantiations: narrow launches, shared values");
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
     const int LD = row_ld<NB>(ld);
     {
@@ -1061,6 +1077,7 @@ __global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc
         double acc[T][C];
         const int off = slice_off[slice];
         sell_row_range_t<NB, XT, NT, BV, DEEP>(cols, vals_scaled, r, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+        if constexpr (SPL) split_row_sums<NB, C, T>(acc, sl);
         // row steps in pairs: the own-row reads of both (and the parent indices of the coarse correction) are issued before
         // either is consumed - rows past the end re-read the last row and store nothing
         // (pairs only where the gathers above leave the registers for it - the fp32-gather instantiations; the fp64-gather
@@ -1074,9 +1091,10 @@ __global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc
             bool ok[H];
 #pragma unroll
             for (int u = 0; u < H; ++u) {
-                const int row = slice * kWave + (h0 + u) * G + g;
-                ok[u] = row < nrows;
-                const int rowc = ok[u] ? row : nrows - 1;
+                const int piece = slice * kWave + (h0 + u) * G + g;
+                const int row = SPL ? piece >> sl : piece;
+                ok[u] = row < nrows && (!SPL || (piece & ((1 << sl) - 1)) == 0);
+                const int rowc = row < nrows ? row : nrows - 1;
                 at[u] = (size_t)rowc * LD + t * C;
                 load_v<C>(r + at[u], rv[u]);
                 if constexpr (BV != 0) {
@@ -1128,14 +1146,17 @@ __global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc
 // wavefront keeps its 64 x NB residual tile - the fp32 values it has just stored - in LDS and sums its own aggregates from it
 // in increasing row order: coarse[cid] = sum of the rows of segment (cid, first row, rows).  No other wavefront touches those
 // coarse rows: deterministic, no atomics, and the separate product with P^T (one more pass over the residual) is gone.
-template <int NB, typename XT, typename RT, typename YT, bool R8, int BV = 0, bool STORE = true, int DEEP = 1, bool RAGG = false>
+// SPL: rows stored in 2^sl pieces, see vc_poly2_kernel
+template <int NB, typename XT, typename RT, typename YT, bool R8, int BV = 0, bool STORE = true, int DEEP = 1, bool RAGG = false,
+          bool SPL = false>
 __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                              const int* __restrict__ cols, const double* __restrict__ vals,
                                                              const XT* __restrict__ x, const RT* r, YT* y,
                                                              double* __restrict__ coarse, int ld,
                                                              const int* __restrict__ seg_ptr = nullptr,
                                                              const int* __restrict__ seg_cid = nullptr,
-                                                             const int* __restrict__ seg_pos = nullptr) {
+                                                             const int* __restrict__ seg_pos = nullptr, int sl = 0) {
+    static_assert(!SPL || (NB <= 8 && BV == 0 && DEEP == 1 && !R8 && !RAGG && STORE), "row-split instantiations: narrow launches, plain residual");
     static_assert(STORE || R8, "a residual that is neither stored nor restricted");
     static_assert(!RAGG || (!R8 && STORE && BV == 0 && sizeof(YT) == 4), "fused aggregate restriction: shared values, fp32 residual");
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
@@ -1156,21 +1177,23 @@ __global__ __launch_bounds__(kBlock) void vc_residual_kernel(int nrows, int nsli
         double acc[T][C];
         const int off = slice_off[slice];
         sell_row_range_t<NB, XT, false, BV, DEEP>(cols, vals, x, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+        if constexpr (SPL) split_row_sums<NB, C, T>(acc, sl);
         // the own-row reads of H row steps are issued together (rows past the end re-read the last row): one latency per
         // batch instead of one per row step - these launches are single occupancy rounds of dependent loads
         constexpr int H = T >= 4 ? 4 : T;
         double rvb[H][C];
 #pragma unroll
         for (int rs = 0; rs < T; ++rs) {
-            const int row = slice * kWave + rs * G + g;
+            const int piece = slice * kWave + rs * G + g;
+            const int row = SPL ? piece >> sl : piece;
             if (rs % H == 0) {
 #pragma unroll
                 for (int u = 0; u < H; ++u) {
-                    const int ru = row + u * G;
+                    const int ru = SPL ? (piece + u * G) >> sl : row + u * G;
                     load_v<C>(r + (size_t)(ru < nrows ? ru : nrows - 1) * LD + t * C, rvb[u]);
                 }
             }
-            if (row < nrows) {
+            if (row < nrows && (!SPL || (piece & ((1 << sl) - 1)) == 0)) {
                 const size_t at = (size_t)row * LD + t * C;
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[rs][c] = rvb[rs % H][c] - acc[rs][c];
@@ -2816,6 +2839,16 @@ __global__ __launch_bounds__(kTailThreads) void mini_sampler_kernel(MiniSamplerP
         default: throw Error(PMC_ERR_INTERNAL, "unsupported batch width"); \
     }
 
+// the row-split instantiations (SellView::split_log2) exist for launches of at most 8 realizations
+#define PMC_DISPATCH_NARROW(nb, ...)                                      \
+    switch (nb) {                                                         \
+        case 1: { constexpr int NB = 1; __VA_ARGS__; } break;             \
+        case 2: { constexpr int NB = 2; __VA_ARGS__; } break;             \
+        case 4: { constexpr int NB = 4; __VA_ARGS__; } break;             \
+        case 8: { constexpr int NB = 8; __VA_ARGS__; } break;             \
+        default: throw Error(PMC_ERR_INTERNAL, "row-split level kernels serve launches of 1, 2, 4 or 8 realizations"); \
+    }
+
 // grid of a group-capable kernel: y = number of column groups of a batch of nb realizations (1 up to kGroup)
 static inline dim3 groups(dim3 g, int nb) { return dim3(g.x, nb > kGroup ? (unsigned)(nb / kGroup) : 1u); }
 // the slice kernels' grid (see vblock()): column groups of the same slices adjacent on the same XCD
@@ -3136,6 +3169,13 @@ void vc_presmooth32(hipStream_t st, int nb, const SellView& As, const double* di
     if (As.nrows == 0) return;
     if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_presmooth32: shared values expected");
     const dim3 g = grid_slices(As.nslices);
+    if (As.split_log2) {
+        PMC_DISPATCH_NARROW(nb, {
+            vc_poly2_kernel<NB, double, float, float, false, false, 0, 1, true><<<g, kBlock, 0, st>>>(As.nrows >> As.split_log2, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb, As.split_log2);
+        });
+        check_launch();
+        return;
+    }
     if (deep_level(As, nb)) {
         vc_poly2_kernel<kGroup, double, float, float, false, false, 0, 2><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, r, xout, c0, c1, nullptr, nullptr, nullptr, nullptr, nullptr, nb);
         check_launch();
@@ -3184,6 +3224,13 @@ void vc_residual32(hipStream_t st, int nb, const SellView& A, const double* r, c
     if (A.nrows == 0) return;
     if (A.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual32: shared values expected");
     const dim3 g = grid_slices(A.nslices);
+    if (A.split_log2) {
+        PMC_DISPATCH_NARROW(nb, {
+            vc_residual_kernel<NB, float, double, float, false, 0, true, 1, false, true><<<g, kBlock, 0, st>>>(A.nrows >> A.split_log2, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb, nullptr, nullptr, nullptr, A.split_log2);
+        });
+        check_launch();
+        return;
+    }
     if (deep_level(A, nb)) {
         vc_residual_kernel<kGroup, float, double, float, false, 0, true, 4><<<groups_xcd(g, nb), kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_off, A.cols, A.vals, x, r, out, nullptr, nb);
         check_launch();
@@ -3235,6 +3282,13 @@ void vc_residual_coarse32(hipStream_t st, int nb, const SellView& SP, float* res
     if (SP.nrows == 0) return;
     if (SP.bv) throw Error(PMC_ERR_INTERNAL, "vc_residual_coarse32: shared values expected");
     const dim3 g = grid_slices(SP.nslices);
+    if (SP.split_log2) {
+        PMC_DISPATCH_NARROW(nb, {
+            vc_residual_kernel<NB, double, float, float, false, 0, true, 1, false, true><<<g, kBlock, 0, st>>>(SP.nrows >> SP.split_log2, SP.nslices, SP.slice_off, SP.cols, SP.vals, xc, res, res, nullptr, nb, nullptr, nullptr, nullptr, SP.split_log2);
+        });
+        check_launch();
+        return;
+    }
     if (deep_level(SP, nb)) {
         vc_residual_kernel<kGroup, double, float, float, false, 0, true, 2><<<groups_xcd(g, nb), kBlock, 0, st>>>(SP.nrows, SP.nslices, SP.slice_off, SP.cols, SP.vals, xc, res, res, nullptr, nb);
         check_launch();
@@ -3254,6 +3308,14 @@ static int vc_postsmooth32_t(hipStream_t st, int nb, const SellView& As, const d
     if (As.nrows == 0) return 0;
     if (As.bv) throw Error(PMC_ERR_INTERNAL, "vc_postsmooth32: shared values expected");
     const dim3 g = grid_bounded(grid_slices(As.nslices), dot_partial != nullptr);
+    if (As.split_log2) {
+        if (dot_partial) throw Error(PMC_ERR_INTERNAL, "vc_postsmooth32: the row-split form serves inner levels (no fused dot)");
+        PMC_DISPATCH_NARROW(nb, {
+            vc_poly2_kernel<NB, float, OT, float, false, false, 0, 1, true><<<g, kBlock, 0, st>>>(As.nrows >> As.split_log2, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb, As.split_log2);
+        });
+        check_launch();
+        return 0;
+    }
     if (deep_level(As, nb)) {
         if (dot_partial)
             vc_poly2_kernel<kGroup, float, OT, float, true, false, 0, 4><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
@@ -3742,6 +3804,43 @@ void transpose_bv(hipStream_t st, int nb, size_t count, const double* in, double
     if (count == 0) return;
     const size_t total = count * nb;
     transpose_bv_kernel<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, st>>>(count, nb, in, out);
+    check_launch();
+}
+
+// x[i][k] = sum_j ainv[i][j] r[j][k] for a launch of at most 8 realizations: one wavefront per row, lanes over the columns of the
+// (symmetric, row-major) dense inverse, so the matrix is read once, coalesced, by n wavefronts spread over the chip - the exact
+// solve of a level of a few hundred rows that a narrow launch would otherwise cycle through in ONE workgroup's LDS tail
+__global__ __launch_bounds__(kBlock) void dense_apply_kernel(int n, int nb, const double* __restrict__ ainv,
+                                                              const double* __restrict__ r, double* __restrict__ x) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int i = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    double acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+    const double* row = ainv + (size_t)i * n;
+    for (int j = lane; j < n; j += kWave) {
+        const double a = row[j];
+        const double* rj = r + (size_t)j * nb;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < nb) acc[k] = fma(a, rj[k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k >= nb) break;
+        double v = acc[k];
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+        if (lane == 0) x[(size_t)i * nb + k] = v;
+    }
+}
+
+void dense_apply(hipStream_t st, int nb, int n, const double* ainv, const double* r, double* x) {
+    if (nb < 1 || nb > 8) throw Error(PMC_ERR_INTERNAL, "dense_apply: serves launches of at most 8 realizations");
+    if (n <= 0) return;
+    const int rows_per_block = kBlock / kWave;
+    dense_apply_kernel<<<(n + rows_per_block - 1) / rows_per_block, kBlock, 0, st>>>(n, nb, ainv, r, x);
     check_launch();
 }
 

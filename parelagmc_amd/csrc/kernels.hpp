@@ -44,9 +44,17 @@ struct SellView {
     int ncols_hint = 0;           // number of columns (rows of x): kernels with 32-bit gather offsets check it
     bool diag_last = false;       // see Sell::diag_last
     bool f32 = false;             // bv only: vals points at fp32 values (per-realization values of a PRECONDITIONER matrix)
+    // > 0: the matrix was built from csr_split_rows(A, split_log2) - nrows counts the pieces; the k::vc_* launchers then
+    // start their row-split instantiations (launches of at most 8 realizations), which add the pieces of a row
+    int split_log2 = 0;
 };
 inline SellView view(const Sell& S) {
     return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, S.vals.p, false, S.sched.p, 0, S.ncols, S.diag_last};
+}
+inline SellView view_split(const Sell& S, int sl) {
+    SellView v = view(S);
+    v.split_log2 = sl;
+    return v;
 }
 inline SellView view_bv(const Sell& S, const double* vals) {
     return {S.nrows, S.nslices, S.slice_off.p, S.cols.p, vals, true, S.sched.p, 0, S.ncols};
@@ -313,6 +321,8 @@ inline int mg_tail_z(hipStream_t st, int nb, const TailParams* dev_params, size_
                      double* dot_partial) {
     return mg_tail(st, nb, dev_params, lds_doubles, r, xout.as<double>(), dot_partial, xout.f32);
 }
+// x = ainv r, ainv dense n x n row-major (symmetric), r / x interleaved [row][nb], nb <= 8 (see dense_apply_kernel)
+void dense_apply(hipStream_t st, int nb, int n, const double* ainv, const double* r, double* x);
 // out[k][i] = in[i][k]: per-realization values of a small level re-laid column-major for the tail kernel, whose
 // workgroup k then streams only its own realization's values
 void transpose_bv(hipStream_t st, int nb, size_t count, const double* in, double* out);

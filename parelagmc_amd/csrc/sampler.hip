@@ -51,6 +51,47 @@ HostCsr schur_host(const HostCsr& B, const HostCsr& Bt, const std::vector<double
 struct AggSegments {   // agg_pack_rows' tables of the finest level (empty: the restriction stays a product with P^T)
     std::vector<int> ptr, cid, pos;
 };
+// inv = S^-1 (dense, row-major, exactly symmetric) of a small SPD operator by Cholesky; false when S is not numerically SPD
+static bool spd_dense_inverse(const HostCsr& S, std::vector<double>& inv) {
+    const int n = S.nrows;
+    std::vector<double> a((size_t)n * n, 0.0);
+    inv.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int p = S.rowptr[i]; p < S.rowptr[i + 1]; ++p) a[(size_t)i * n + S.colind[p]] = S.vals[p];
+    for (int j = 0; j < n; ++j) {   // a = L L^T (lower, in place)
+        double dj = a[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) dj -= a[(size_t)j * n + k] * a[(size_t)j * n + k];
+        if (!(dj > 0.0) || !std::isfinite(dj)) return false;
+        const double l = std::sqrt(dj);
+        a[(size_t)j * n + j] = l;
+        for (int i = j + 1; i < n; ++i) {
+            double v = a[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) v -= a[(size_t)i * n + k] * a[(size_t)j * n + k];
+            a[(size_t)i * n + j] = v / l;
+        }
+    }
+    std::vector<double> y(n);
+    for (int c = 0; c < n; ++c) {          // column c of the inverse: L y = e_c, L^T x = y
+        for (int i = 0; i < c; ++i) y[i] = 0.0;
+        for (int i = c; i < n; ++i) {
+            double v = i == c ? 1.0 : 0.0;
+            for (int k = c; k < i; ++k) v -= a[(size_t)i * n + k] * y[k];
+            y[i] = v / a[(size_t)i * n + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double v = y[i];
+            for (int k = i + 1; k < n; ++k) v -= a[(size_t)k * n + i] * inv[(size_t)k * n + c];
+            inv[(size_t)i * n + c] = v / a[(size_t)i * n + i];
+        }
+    }
+    for (int i = 0; i < n; ++i)             // exactly symmetric (the kernels read it either way round)
+        for (int j = 0; j < i; ++j) {
+            const double v = 0.5 * (inv[(size_t)i * n + j] + inv[(size_t)j * n + i]);
+            inv[(size_t)i * n + j] = inv[(size_t)j * n + i] = v;
+        }
+    return true;
+}
+
 static std::unique_ptr<Multigrid> build_chain(const std::vector<AmgLevelHost>& lv, const pmc_solver_opts& o, hipStream_t st,
                                               double ratio_scale = 1.0, bool f32_any_injection = false,
                                               const std::vector<AggSegments>* segs = nullptr) {
@@ -114,51 +155,56 @@ static std::unique_ptr<Multigrid> build_chain(const std::vector<AmgLevelHost>& l
     // its many-step Chebyshev solve was ~40 us of pure latency per cycle inside the LDS tail.  Up to 192 rows it is solved
     // exactly with a dense inverse computed here once (host, Cholesky on the SPD level operator).
     if (f32_any_injection && !mg->L.empty()) {
-        MgLevel& m = mg->L.back();
-        const HostCsr& S = lv[mg->L.size() - 1].S;
-        const int n = S.nrows;
         const char* e = lab_env("PMC_TAIL_AINV");
-        if (n >= 2 && n <= 192 && !(e && atoi(e) == 0)) {
-            std::vector<double> a((size_t)n * n, 0.0), inv((size_t)n * n, 0.0);
-            for (int i = 0; i < n; ++i)
-                for (int p = S.rowptr[i]; p < S.rowptr[i + 1]; ++p) a[(size_t)i * n + S.colind[p]] = S.vals[p];
-            // Cholesky a = L L^T (lower, in place), then inv = L^-T L^-1
-            bool ok = true;
-            for (int j = 0; j < n && ok; ++j) {
-                double dj = a[(size_t)j * n + j];
-                for (int k = 0; k < j; ++k) dj -= a[(size_t)j * n + k] * a[(size_t)j * n + k];
-                ok = dj > 0.0 && std::isfinite(dj);
-                if (!ok) break;
-                const double l = std::sqrt(dj);
-                a[(size_t)j * n + j] = l;
-                for (int i = j + 1; i < n; ++i) {
-                    double v = a[(size_t)i * n + j];
-                    for (int k = 0; k < j; ++k) v -= a[(size_t)i * n + k] * a[(size_t)j * n + k];
-                    a[(size_t)i * n + j] = v / l;
+        const int n = lv[mg->L.size() - 1].S.nrows;
+        std::vector<double> inv;
+        if (n >= 2 && n <= 192 && !(e && atoi(e) == 0) && spd_dense_inverse(lv[mg->L.size() - 1].S, inv)) {
+            mg->L.back().ainv.upload(inv, st);
+            PMC_HIP(hipStreamSynchronize(st));
+        }
+        // Launches of at most 8 realizations (one per call under the reference's serial manager) leave the cycle even earlier:
+        // the first inner level of at most 768 rows is solved exactly by a multi-workgroup dense product (Multigrid::cycle)
+        mg->dense_nb = 8;
+        if (const char* d = lab_env("PMC_DENSE_NB")) mg->dense_nb = atoi(d);
+        const char* spl = lab_env("PMC_ROW_SPLIT");
+        for (size_t l = 1; mg->dense_nb > 0 && l < mg->L.size(); ++l) {
+            const int m = lv[l].S.nrows;
+            if (m > 768) {
+                // ... and the inner levels above it run row-split: their rows carry 17-40 entries, one wavefront walks a slice of
+                // 64 of them as ONE chain of dependent gathers (a 5 k-row level: 80 wavefronts, 9-12 us per kernel whatever the
+                // width).  Pieces of about 5 entries; levels of up to 65 536 rows (the split copy is extra memory and setup).
+                MgLevel& ml = mg->L[l];
+                if (m > 65536 || !ml.has_sp || ml.p_agg || ml.p_oct || (spl && atoi(spl) == 0)) continue;
+                auto pieces = [](const HostCsr& A) {
+                    const double avg = (double)A.rowptr[A.nrows] / std::max(1, A.nrows);
+                    int sl = 0;
+                    while (sl < 4 && avg / (1 << sl) > 6.0) ++sl;
+                    return sl;
+                };
+                std::vector<double> dS = csr_diag(lv[l].S);
+                for (double& v : dS) v = 1.0 / v;
+                ml.split_log2 = pieces(lv[l].S);
+                if (ml.split_log2 > 0) {
+                    const HostCsr Ssp = csr_split_rows(lv[l].S, ml.split_log2);
+                    sell_build(ml.S_split, Ssp, true, true, st);
+                    ml.scaled_split.upload(sell_scaled_values(ml.S_split, Ssp, dS), st);
+                    PMC_HIP(hipStreamSynchronize(st));
+                    ml.S_split.h_src.clear(); ml.S_split.h_src.shrink_to_fit();
+                    ml.S_split.h_cols.clear(); ml.S_split.h_cols.shrink_to_fit();
+                    const HostCsr SPh = csr_spgemm(lv[l].S, lv[l].P);
+                    ml.sp_split_log2 = pieces(SPh);
+                    if (ml.sp_split_log2 > 0) {
+                        sell_build(ml.SP_split, csr_split_rows(SPh, ml.sp_split_log2), true, false, st);
+                        PMC_HIP(hipStreamSynchronize(st));
+                    }
                 }
+                continue;
             }
-            if (ok) {
-                std::vector<double> y(n);
-                for (int c = 0; c < n; ++c) {          // column c of the inverse: L y = e_c, L^T x = y
-                    for (int i = 0; i < n; ++i) {
-                        double v = i == c ? 1.0 : 0.0;
-                        for (int k = 0; k < i; ++k) v -= a[(size_t)i * n + k] * y[k];
-                        y[i] = v / a[(size_t)i * n + i];
-                    }
-                    for (int i = n - 1; i >= 0; --i) {
-                        double v = y[i];
-                        for (int k = i + 1; k < n; ++k) v -= a[(size_t)k * n + i] * inv[(size_t)k * n + c];
-                        inv[(size_t)i * n + c] = v / a[(size_t)i * n + i];
-                    }
-                }
-                for (int i = 0; i < n; ++i)             // exactly symmetric (the kernel reads it column-wise)
-                    for (int j = 0; j < i; ++j) {
-                        const double v = 0.5 * (inv[(size_t)i * n + j] + inv[(size_t)j * n + i]);
-                        inv[(size_t)i * n + j] = inv[(size_t)j * n + i] = v;
-                    }
-                m.ainv.upload(inv, st);
+            if (m > 192 && spd_dense_inverse(lv[l].S, inv)) {
+                mg->L[l].dense_inv.upload(inv, st);
                 PMC_HIP(hipStreamSynchronize(st));
             }
+            break;
         }
     }
     mg->build_tails(st);

@@ -201,6 +201,13 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
     // realizations, and a tail that starts at a level of several thousand rows with 17-27 entries each is bound by ONE
     // unit's L2 port (LAB_NOTES 9.16: 142 us per cycle - half of a one-realization Eval of the hybridized sampler).  Such
     // a level runs as kernels then and the tail starts one level further down.
+    // ... and it ends on the first level that carries a dense inverse: x = A^-1 r by n wavefronts (k::dense_apply) instead of
+    // one workgroup cycling through the remaining levels (573 rows at 400 k multipliers: 25 -> 4 us per cycle)
+    if (l > l0 && nb <= dense_nb && lv.dense_inv.p && !target && !ztarget && !dot_partial) {
+        if (side && *side) (*side)();
+        k::dense_apply(st, nb, lv.n, lv.dense_inv.p, r, lv.xa.p);
+        return lv.xa.p;
+    }
     const bool tail_later = nb <= tail_later_nb && lv.n > 4096 && !last && l + 1 < (int)tail.size() && tail[l + 1].p;
     const bool tail_here = use_tail && l < (int)tail.size() && tail[l].p && !tail_later;
     const bool f32_shared = !last && !lv.bv && lv.has_sp && (lv.p_oct || f32_any_injection) && smooth_degree == 2 &&
@@ -236,6 +243,24 @@ double* Multigrid::cycle(hipStream_t st, int nb, int l, int l0, const double* r,
         // top level of a cycle inside the MINRES loop of an aggregation hierarchy: the fp32 copy of r, if the caller has one
         const float* r32 = (l == l0 && !lv.p_oct) ? r32_top : nullptr;
         if (l == l0) r32_top = nullptr;
+        // inner level of a launch of at most 8 realizations: the row-split forms of the four kernels (MgLevel::S_split)
+        if (l > l0 && nb <= dense_nb && lv.split_log2 > 0 && !lv.p_oct && !lv.p_agg && !dot_partial) {
+            const SellView Asp = view_split(lv.S_split, lv.split_log2);
+            SellView Assp = Asp;
+            Assp.vals = lv.scaled_split.p;
+            const SellView SPv = lv.sp_split_log2 > 0 ? view_split(lv.SP_split, lv.sp_split_log2) : view(lv.SP);
+            k::vc_presmooth32(st, nb, Assp, lv.dinv.p, r, xf, c0, c1);
+            MgLevel& lcs = L[l + 1];
+            lcs.ensure(nb);
+            k::vc_residual32(st, nb, Asp, r, xf, resf);
+            k::spmm_z(st, nb, view(lv.Pt), zvec(resf, true), lcs.r.p, nullptr, zvec());
+            double* xcs = cycle(st, nb, l + 1, l0, lcs.r.p, nullptr, zvec(), nullptr, nullptr, side);
+            k::vc_residual_coarse32(st, nb, SPv, resf, xcs);
+            if (ztarget) k::vc_postsmooth32_z(st, nb, Assp, lv.dinv.p, resf, xf, ztarget, c0, c1, r, lv.parent.p, xcs, nullptr);
+            else k::vc_postsmooth32(st, nb, Assp, lv.dinv.p, resf, xf, out, c0, c1, r, lv.parent.p, xcs, nullptr);
+            if (dot_blocks) *dot_blocks = 0;
+            return ztarget ? nullptr : out;
+        }
         if (r32) k::vc_presmooth32_r32(st, nb, As, lv.dinv.p, r32, xf, c0, c1);
         else k::vc_presmooth32(st, nb, As, lv.dinv.p, r, xf, c0, c1);
         MgLevel& lc = L[l + 1];

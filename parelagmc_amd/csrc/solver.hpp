@@ -94,6 +94,14 @@ struct MgLevel {
     DevBuf<int> seg_ptr, seg_cid, seg_pos;
     DevBuf<double> r, xa, xb, d, res;
     DevBuf<double> ainv;         // last level of a small shared-value hierarchy: dense inverse (see TailLevelDev::ainv)
+    // an inner level of a few hundred rows: dense inverse for launches of at most Multigrid::dense_nb realizations, which
+    // end their cycle there with one multi-workgroup matrix-vector product instead of the one-workgroup LDS tail
+    DevBuf<double> dense_inv;
+    // the same launches on the inner levels above it: the operator (values: the level's own and S D^-1) and S P with every row
+    // cut into 2^split_log2 / 2^sp_split_log2 pieces (csr_split_rows; 0 = not built) for the row-split V-cycle kernels
+    int split_log2 = 0, sp_split_log2 = 0;
+    Sell S_split, SP_split;
+    DevBuf<double> scaled_split;
     void ensure(int nb);
     SellView sview() const { return bv ? (f32 ? view_bv32(S, vals32.p) : view_bv(S, vals_bv.p)) : view(S); }
     // column-scaled values in the storage sview() uses
@@ -123,6 +131,7 @@ struct Multigrid {
     // the hybridized sampler (LAB_NOTES 9.16); the structured and per-realization (Darcy) hierarchies keep 0, so a
     // realization of a ragged remainder chunk takes the same kernels as one of a full launch there.
     int tail_later_nb = 0;
+    int dense_nb = 0;            // see MgLevel::dense_inv (0: never)
     // fp32 copy of the right-hand side of the NEXT cycle's top level (set by the caller right before vcycle_z, consumed and
     // cleared by it): the pre-smoothing and residual kernels of that level gather / read it instead of the fp64 vector.  The
     // MINRES loop provides it for free-standing cost of one more fp32 stream in the Lanczos update (MinresWork::r32).

@@ -447,6 +447,27 @@ HostCsr csr_permute(const HostCsr& A, const std::vector<int>& new2old, bool rows
     return B;
 }
 
+// Every row of A cut into 2^sl consecutive pieces of (nearly) equal length: row i of A is the sum of the rows
+// (i << sl) .. (i << sl) + 2^sl - 1 of the result.  A narrow launch walks 2^sl times as many wavefronts through slices that
+// are 2^sl times shorter (the row-split kernels of the V-cycle add the pieces with a shuffle tree, see SellView::split_log2).
+HostCsr csr_split_rows(const HostCsr& A, int sl) {
+    const int S = 1 << sl;
+    PMC_REQUIRE(sl >= 0 && sl <= 4 && (int64_t)A.nrows * S < (int64_t)INT32_MAX, "csr_split_rows: split factor");
+    HostCsr B;
+    B.nrows = A.nrows * S;
+    B.ncols = A.ncols;
+    B.colind = A.colind;
+    B.vals = A.vals;
+    B.rowptr.assign((size_t)B.nrows + 1, 0);
+    for (int i = 0; i < A.nrows; ++i) {
+        const int p0 = A.rowptr[i], len = A.rowptr[i + 1] - p0;
+        for (int q = 0; q <= S; ++q)   // piece q holds the entries [len q / S, len (q + 1) / S)
+            if (q > 0 || i == 0) B.rowptr[(size_t)i * S + q] = p0 + (int)((int64_t)len * q / S);
+    }
+    B.rowptr[B.nrows] = A.rowptr[A.nrows];
+    return B;
+}
+
 // Plain (unsmoothed) aggregation hierarchy of an SPD operator whose off-diagonal entries have either sign (the hybridized
 // sampler's multiplier system: positive couplings across right / obtuse dihedral angles): the matching is steered by the
 // MAGNITUDE of the couplings, the prolongator is the aggregates' indicator (an injection - the V-cycle folds the coarse
