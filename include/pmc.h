@@ -319,8 +319,10 @@ int pmc_sampler_smoother_time(pmc_sampler* s, double* total_ms, int64_t* launche
 int pmc_sampler_smoother_bytes(const pmc_sampler* s, int level, int nbatch, double* bytes);
 /* Sizes of the V-cycle hierarchy the sampler runs on `level` (diagnostics: what scripts/collect_profiles.py prices the
  * per-kernel roofline table with): info[0] = rows, [1] = entries of the level operator, [2] = its stored SELL slots,
- * [3] = entries of S P (0 when the coarse correction is not folded), [4] = slots of S P, [5] = 1 when the level runs inside
- * the LDS tail kernel (launches of more than 8 realizations), [6] = 1 when its restriction is fused into the residual kernel.
+ * [3] = entries of S P (0 when the coarse correction is not folded), [4] = slots of S P, [5] = flags: bit 0 = the level runs
+ * inside the LDS tail kernel (launches of more than 8 realizations), bit 1 = launches of at most 8 realizations end their
+ * cycle on this level with an exact dense solve, bits 4.. = log2 of the pieces its rows are cut into for such launches (0: not
+ * split), [6] = 1 when its restriction is fused into the residual kernel.
  * Returns the number of V-cycle levels through *nvlevels; vlevel out of range is an error. */
 int pmc_sampler_vcycle_info(const pmc_sampler* s, int level, int vlevel, int* nvlevels, int64_t info[7]);
 

@@ -445,12 +445,16 @@ class PDESampler:
         return self.ctx.lib.pmc_sampler_batch_width(self.h, level)
 
     def vcycle_levels(self, level):
-        """[{rows, nnz, slots, sp_nnz, sp_slots, in_tail, fused_restriction}] of the V-cycle hierarchy of `level`"""
+        """[{rows, nnz, slots, sp_nnz, sp_slots, in_tail, fused_restriction, narrow_dense, narrow_pieces}] of the V-cycle
+        hierarchy of `level` (narrow_*: what launches of at most 8 realizations do on the level, see include/pmc.h)"""
         out, nv, info = [], C.c_int(0), (C.c_int64 * 7)()
         v = 0
         while True:
             _check(self.ctx.lib.pmc_sampler_vcycle_info(self.h, level, v, C.byref(nv), info))
-            out.append(dict(zip(("rows", "nnz", "slots", "sp_nnz", "sp_slots", "in_tail", "fused_restriction"), [int(x) for x in info])))
+            d = dict(zip(("rows", "nnz", "slots", "sp_nnz", "sp_slots", "in_tail", "fused_restriction"), [int(x) for x in info]))
+            flags = d["in_tail"]
+            d.update(in_tail=flags & 1, narrow_dense=(flags >> 1) & 1, narrow_pieces=1 << (flags >> 4))
+            out.append(d)
             v += 1
             if v >= nv.value:
                 return out

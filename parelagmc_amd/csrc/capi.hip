@@ -459,7 +459,7 @@ int pmc_sampler_vcycle_info(const pmc_sampler* s, int level, int vlevel, int* nv
         info[2] = m.S.nslots;
         info[3] = m.has_sp ? m.SP.nnz : 0;
         info[4] = m.has_sp ? m.SP.nslots : 0;
-        info[5] = in_tail ? 1 : 0;
+        info[5] = (in_tail ? 1 : 0) | (m.dense_inv.p ? 2 : 0) | ((int64_t)m.split_log2 << 4);
         info[6] = (m.p_agg || m.p_oct) ? 1 : 0;
     });
 }

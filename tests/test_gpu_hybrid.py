@@ -268,6 +268,8 @@ def test_hybrid_ragged_remainder_takes_the_late_tail_and_gives_the_same_field(gp
         smp = capi.PDESampler(gpu_ctx, hp, opts)
         lv = smp.vcycle_levels(0)
         assert lv[1]["rows"] > 4096 and lv[1]["in_tail"] == 1 and lv[0]["fused_restriction"] == 1, lv
+        # ... and narrow launches run that level with its rows cut into pieces and end on the exact solve of the next one
+        assert lv[1]["narrow_pieces"] >= 2 and lv[2]["narrow_dense"] == 1 and lv[2]["rows"] <= 768, lv
         w = smp.BatchWidth(0)
         n = w + 3                                           # chunks of w, 2 and 1
         xi = smp.Sample(0, first_id=77, nbatch=n)
@@ -280,6 +282,8 @@ def test_hybrid_ragged_remainder_takes_the_late_tail_and_gives_the_same_field(gp
             assert rel(s[k], smp.Eval(0, xi[k:k + 1])[0]) < tol
         # a member of the full launch against the same realization in a narrow chunk of 2 (late tail)
         assert rel(full[3], smp.Eval(0, xi[2:4])[1]) < tol
+        for m in (4, 8):                                    # the 4- and 8-wide forms of the row-split kernels
+            assert rel(smp.Eval(0, xi[:m]), full[:m]) < tol
         smp.close()
 
 
