@@ -104,6 +104,9 @@ cases = [("product: V(1,1), degree 2 everywhere", {}),
          ("two smoothing passes on the coarse levels", dict(nsm_c=2)),
          ("W from level 1 + degree 4 coarse", dict(gamma=2, wfrom=1, deg_c=4)),
          ("degree 3 on the finest level too", dict(deg0=3, deg_c=3)),
+         ("degree 1 (damped Jacobi) on the finest level only", dict(deg0=1)),
+         ("degree 1 on the finest level, ratio 4", dict(deg0=1, ratio0=4.0)),
+         ("degree 1 on the finest level, degree 4 coarse", dict(deg0=1, deg_c=4)),
          ("exact coarse solve from level 1 (bound)", None)]
 for name, kw in cases:
     if kw is None:
