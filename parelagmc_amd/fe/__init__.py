@@ -9,6 +9,7 @@ from .problems import (DarcyLevel, DarcyProblem, Hierarchy, SamplerLevel, Sample
                        build_darcy_problem, build_hierarchy, build_sampler_problem,
                        elements_near_points, l2_projection_ops, matern_coefficient)
 from .hybrid import HybridLevel, HybridSamplerProblem, build_hybrid_sampler_problem  # noqa: F401
+from .darcy_hybrid import DarcyHybridLevel, darcy_hybrid_level  # noqa: F401
 from .rt0 import build_spaces, mass_contributions, mass_matrix, prolongation_p0  # noqa: F401
 from .transfer import (box_intersection_gt, clipped_intersection_gt, intersection_gt,  # noqa: F401
                        l2_projection_hierarchy)
