@@ -15,7 +15,7 @@ hp = bench.build_hybrid_problem(5)
 n = hp.levels[0].n_s
 ctx = capi.Context(0, seed=3)
 smp = capi.PDESampler(ctx, hp)
-w = smp.BatchWidth(0)
+w = int(os.environ.get("SOAK_WIDTH", "0")) or smp.BatchWidth(0)      # SOAK_WIDTH=1: the narrow-launch route (row-split levels, dense solve)
 xi = ctx.array(np.random.default_rng(1).standard_normal(w * n))
 out = ctx.empty(w * n)
 stop = False
@@ -24,10 +24,11 @@ stop = False
 def noise():
     c2 = capi.Context(0, seed=9)
     s2 = capi.PDESampler(c2, hp)
-    x2, o2 = c2.empty(w * n), c2.empty(w * n)
+    w2 = s2.BatchWidth(0)
+    x2, o2 = c2.empty(w2 * n), c2.empty(w2 * n)
     i = 0
     while not stop:
-        s2.Sample(0, first_id=i * w, nbatch=w, out=x2)
+        s2.Sample(0, first_id=i * w2, nbatch=w2, out=x2)
         s2.Eval(0, x2, xi_level=0, s_out=o2)
         i += 1
     s2.close()
