@@ -98,6 +98,17 @@ std::vector<int> agg_pack_rows(const HostCsr& P, std::vector<int>& seg_ptr, std:
 HostCsr csr_permute(const HostCsr& A, const std::vector<int>& new2old, bool rows, bool cols);
 HostCsr csr_split_rows(const HostCsr& A, int sl);
 
+// Element-local inverses behind both hybridized systems (hybrid_build.hip): per element (row of B, which lists its faces with
+// the sign of the outward normal against the face's global one) [[X, y], [y^T, z]] = [[M_e, b_e^T], [b_e, corner_e]]^-1 with
+// M_e recovered from the contribution lists of the u-mass matrix (pmc_darcy_level's format); X and y carry the signs
+// C_e = sign(B[e, f]): X = C X C^T (m x m per element, m = most faces of an element), Y = C y.  corner == nullptr: zeros.
+struct ElementInverses {
+    int m = 0;
+    std::vector<double> X, Y, z;
+};
+ElementInverses element_inverses(const HostCsr& Mp, const HostCsr& B, const int32_t* c_ptr, const int32_t* c_elem,
+                                 const double* c_val, const double* corner, const char* who);
+
 HostCsr csr_spgemm(const HostCsr& A, const HostCsr& B);
 // P(i, i / 8) == 1 is the only entry of row i, for every row, and P has 8 rows per column
 bool csr_is_oct_injection(const HostCsr& P);

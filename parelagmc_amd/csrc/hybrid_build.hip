@@ -88,6 +88,86 @@ static void parallel_ranges(int n, F&& f) {
         if (e) std::rethrow_exception(e);
 }
 
+ElementInverses element_inverses(const HostCsr& Mp, const HostCsr& B, const int32_t* c_ptr, const int32_t* c_elem,
+                                 const double* c_val, const double* corner, const char* who) {
+    const std::string w(who);
+    const int nu = Mp.nrows, ns = B.nrows;
+    PMC_REQUIRE(Mp.ncols == nu && B.ncols == nu, w + ": operator shapes");
+    PMC_REQUIRE(c_ptr && c_elem && c_val, w + ": NULL contribution array");
+    // element -> faces: the row of B (no boundary elimination: every face of the element is listed)
+    int nfe_max = 0;
+    for (int e = 0; e < ns; ++e) {
+        const int len = B.rowptr[e + 1] - B.rowptr[e];
+        PMC_REQUIRE(len >= 2 && len <= kMaxFe, w + ": an element (row of B) must list 2 ... 12 faces");
+        nfe_max = std::max(nfe_max, len);
+    }
+    for (int64_t t = 0; t < B.nnz(); ++t)
+        PMC_REQUIRE(B.vals[t] != 0.0, w + ": B stores an explicit zero (eliminated columns? hand over B as assembled)");
+    // element mass matrices, global face orientation: Me[e][a][b] = sum of the contributions of element e to entry
+    // (face a, face b) of the u-mass matrix
+    const int m = nfe_max;
+    std::vector<double> Me((size_t)ns * m * m, 0.0);
+    const int64_t nnzM = Mp.nnz();
+    PMC_REQUIRE(c_ptr[0] == 0, w + ": c_ptr[0] != 0");
+    // rows of M are independent of each other only per ELEMENT pair, and two rows may write the same element block (at
+    // different (a, b)): writes never collide, so rows can be split over threads
+    parallel_ranges(nu, [&](int r0, int r1) {
+        for (int i = r0; i < r1; ++i)
+            for (int p = Mp.rowptr[i]; p < Mp.rowptr[i + 1]; ++p) {
+                const int j = Mp.colind[p];
+                for (int t = c_ptr[p]; t < c_ptr[p + 1]; ++t) {
+                    const int e = c_elem[t];
+                    PMC_REQUIRE(e >= 0 && e < ns, w + ": c_elem out of range");
+                    const int b0 = B.rowptr[e], len = B.rowptr[e + 1] - b0;
+                    int la = -1, lb = -1;
+                    for (int q = 0; q < len; ++q) {
+                        if (B.colind[b0 + q] == i) la = q;
+                        if (B.colind[b0 + q] == j) lb = q;
+                    }
+                    PMC_REQUIRE(la >= 0 && lb >= 0, w + ": a mass contribution names an element that does not own the face");
+                    Me[((size_t)e * m + la) * m + lb] += c_val[t];
+                }
+            }
+    });
+    PMC_REQUIRE(c_ptr[nnzM] >= nnzM, w + ": fewer contributions than stored entries");
+    // local inverses
+    ElementInverses out;
+    out.m = m;
+    out.X.resize((size_t)ns * m * m);
+    out.Y.resize((size_t)ns * m);
+    out.z.resize(ns);
+    std::vector<double>&X = out.X, &Y = out.Y;
+    std::vector<int> bad(1, -1);
+    parallel_ranges(ns, [&](int e0, int e1) {
+        double a[(kMaxFe + 1) * (kMaxFe + 1)];
+        for (int e = e0; e < e1; ++e) {
+            const int b0 = B.rowptr[e], len = B.rowptr[e + 1] - b0, n = len + 1;
+            for (int p = 0; p < len; ++p) {
+                for (int q = 0; q < len; ++q) a[p * n + q] = Me[((size_t)e * m + p) * m + q];
+                a[p * n + len] = a[len * n + p] = B.vals[b0 + p];
+            }
+            a[len * n + len] = corner ? corner[e] : 0.0;
+            if (!invert_small(a, n)) {
+                bad[0] = e;
+                continue;
+            }
+            for (int p = 0; p < len; ++p) {
+                // C_e = sign of the element's B entry
+                const double cp = B.vals[b0 + p] > 0.0 ? 1.0 : -1.0;
+                for (int q = 0; q < len; ++q) {
+                    const double cq = B.vals[b0 + q] > 0.0 ? 1.0 : -1.0;
+                    // symmetrised: the inverse of a symmetric matrix, rounded asymmetrically by the elimination order
+                    X[((size_t)e * m + p) * m + q] = cp * cq * 0.5 * (a[p * n + q] + a[q * n + p]);
+                }
+                Y[(size_t)e * m + p] = cp * 0.5 * (a[p * n + len] + a[len * n + p]);
+            }
+            out.z[e] = a[len * n + len];
+        }
+    });
+    PMC_REQUIRE(bad[0] < 0, w + ": a local saddle-point matrix is singular (element " + std::to_string(bad[0]) + ")");
+    return out;
+}
+
 static std::unique_ptr<HybridSystem> hybrid_build(const pmc_hybrid_elements& in, double alpha) {
     PMC_REQUIRE(in.n_u > 0 && in.n_s > 0 && alpha > 0.0 && std::isfinite(alpha), "pmc_hybrid_build: sizes / alpha");
     PMC_REQUIRE(in.c_ptr && in.c_elem && in.c_val && in.w_diag, "pmc_hybrid_build: NULL array");
@@ -104,78 +184,19 @@ static std::unique_ptr<HybridSystem> hybrid_build(const pmc_hybrid_elements& in,
         PMC_REQUIRE(sys->P.nrows == ns, "pmc_hybrid_build: P must have n_s rows");
         sys->has_P = true;
     }
-    // element -> faces: the row of B (no boundary elimination: every face of the element is listed)
-    int nfe_max = 0;
+    std::vector<double> corner(ns);
     for (int e = 0; e < ns; ++e) {
-        const int len = B.rowptr[e + 1] - B.rowptr[e];
-        PMC_REQUIRE(len >= 2 && len <= kMaxFe, "pmc_hybrid_build: an element (row of B) must list 2 ... 12 faces");
         PMC_REQUIRE(in.w_diag[e] > 0.0, "pmc_hybrid_build: w_diag must be positive");
-        nfe_max = std::max(nfe_max, len);
+        corner[e] = -alpha * in.w_diag[e];
     }
     std::vector<int> face_count(nu, 0);
-    for (int64_t t = 0; t < B.nnz(); ++t) {
-        PMC_REQUIRE(B.vals[t] != 0.0, "pmc_hybrid_build: B stores an explicit zero (eliminated columns? hand over B as assembled)");
+    for (int64_t t = 0; t < B.nnz(); ++t)
         PMC_REQUIRE(++face_count[B.colind[t]] <= 2, "pmc_hybrid_build: a face belongs to more than two elements");
-    }
     for (int f = 0; f < nu; ++f) PMC_REQUIRE(face_count[f] >= 1, "pmc_hybrid_build: a face belongs to no element");
-    // element mass matrices, global face orientation: Me[e][a][b] = sum of the contributions of element e to entry
-    // (face a, face b) of the u-mass matrix
-    const int m = nfe_max;
-    std::vector<double> Me((size_t)ns * m * m, 0.0);
-    const int64_t nnzM = Mp.nnz();
-    PMC_REQUIRE(in.c_ptr[0] == 0, "pmc_hybrid_build: c_ptr[0] != 0");
-    // rows of M are independent of each other only per ELEMENT pair, and two rows may write the same element block (at
-    // different (a, b)): writes never collide, so rows can be split over threads
-    parallel_ranges(nu, [&](int r0, int r1) {
-        for (int i = r0; i < r1; ++i)
-            for (int p = Mp.rowptr[i]; p < Mp.rowptr[i + 1]; ++p) {
-                const int j = Mp.colind[p];
-                for (int t = in.c_ptr[p]; t < in.c_ptr[p + 1]; ++t) {
-                    const int e = in.c_elem[t];
-                    PMC_REQUIRE(e >= 0 && e < ns, "pmc_hybrid_build: c_elem out of range");
-                    const int b0 = B.rowptr[e], len = B.rowptr[e + 1] - b0;
-                    int la = -1, lb = -1;
-                    for (int q = 0; q < len; ++q) {
-                        if (B.colind[b0 + q] == i) la = q;
-                        if (B.colind[b0 + q] == j) lb = q;
-                    }
-                    PMC_REQUIRE(la >= 0 && lb >= 0, "pmc_hybrid_build: a mass contribution names an element that does not own the face");
-                    Me[((size_t)e * m + la) * m + lb] += in.c_val[t];
-                }
-            }
-    });
-    PMC_REQUIRE(in.c_ptr[nnzM] >= nnzM, "pmc_hybrid_build: fewer contributions than stored entries");
-    // local inverses
-    std::vector<double> X((size_t)ns * m * m), Y((size_t)ns * m);
-    sys->z.resize(ns);
-    std::vector<int> bad(1, -1);
-    parallel_ranges(ns, [&](int e0, int e1) {
-        double a[(kMaxFe + 1) * (kMaxFe + 1)];
-        for (int e = e0; e < e1; ++e) {
-            const int b0 = B.rowptr[e], len = B.rowptr[e + 1] - b0, n = len + 1;
-            for (int p = 0; p < len; ++p) {
-                for (int q = 0; q < len; ++q) a[p * n + q] = Me[((size_t)e * m + p) * m + q];
-                a[p * n + len] = a[len * n + p] = B.vals[b0 + p];
-            }
-            a[len * n + len] = -alpha * in.w_diag[e];
-            if (!invert_small(a, n)) {
-                bad[0] = e;
-                continue;
-            }
-            for (int p = 0; p < len; ++p) {
-                // C_e = sign of the element's B entry
-                const double cp = B.vals[b0 + p] > 0.0 ? 1.0 : -1.0;
-                for (int q = 0; q < len; ++q) {
-                    const double cq = B.vals[b0 + q] > 0.0 ? 1.0 : -1.0;
-                    // symmetrised: the inverse of a symmetric matrix, rounded asymmetrically by the elimination order
-                    X[((size_t)e * m + p) * m + q] = cp * cq * 0.5 * (a[p * n + q] + a[q * n + p]);
-                }
-                Y[(size_t)e * m + p] = cp * 0.5 * (a[p * n + len] + a[len * n + p]);
-            }
-            sys->z[e] = a[len * n + len];
-        }
-    });
-    PMC_REQUIRE(bad[0] < 0, "pmc_hybrid_build: a local saddle-point matrix is singular (element " + std::to_string(bad[0]) + ")");
+    ElementInverses inv = element_inverses(Mp, B, in.c_ptr, in.c_elem, in.c_val, corner.data(), "pmc_hybrid_build");
+    const int m = inv.m;
+    const std::vector<double>&X = inv.X, &Y = inv.Y;
+    sys->z = inv.z;
     // face -> (element, local index), at most two per face, in element order
     std::vector<int> fe((size_t)nu * 2, -1), fl((size_t)nu * 2, -1);
     for (int e = 0; e < ns; ++e)
