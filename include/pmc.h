@@ -329,6 +329,16 @@ int pmc_sampler_vcycle_info(const pmc_sampler* s, int level, int vlevel, int* nv
 /* ---- DarcySolver ------------------------------------------------------------------------ */
 int pmc_darcy_create(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_darcy_level* levels,
                      int k_divides, const pmc_solver_opts* opts, pmc_darcy** out);
+/* The same handle with SolveFwd through the HYBRIDIZED form of the mixed system - the reference's "Hybridization" branch of
+ * DarcySolver (src/DarcySolver.cpp:586,619: the solver factory eliminates flux and pressure element by element).  Same level
+ * structs: the element-local inverses are formed inside the library from the contribution lists of M (as pmc_hybrid_build does
+ * for the sampler), one Lagrange multiplier per interior / essential face, H(k) lambda = rhs(k) with H linear in the
+ * realization's coefficients solved by MINRES + one V-cycle of a per-realization aggregation hierarchy, then the element-local
+ * back-substitution; Q, the returned solution and the pressure block are those of the saddle-point solve to the solver
+ * tolerance.  Needs every face to belong to at most two elements and essential dofs on boundary faces only.  ComputeG keeps
+ * the saddle-point path. */
+int pmc_darcy_create_hybrid(pmc_ctx* ctx, int nlevels, int n_mc_levels, const pmc_darcy_level* levels,
+                            int k_divides, const pmc_solver_opts* opts, pmc_darcy** out);
 void pmc_darcy_destroy(pmc_darcy* d);
 int pmc_darcy_num_dofs(const pmc_darcy* d, int level); /* GetGlobalNumberOfDofs() */
 int pmc_darcy_num_pressure_dofs(const pmc_darcy* d, int level); /* GetSizeOfStochasticData(): entries of k */

@@ -135,6 +135,8 @@ SYMBOLS = {
     "pmc_sampler_operator_event_overhead": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "pmc_darcy_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_darcy_level), C.c_int,
                                    C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
+    "pmc_darcy_create_hybrid": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(pmc_darcy_level), C.c_int,
+                                          C.POINTER(pmc_solver_opts), C.POINTER(_VP)]),
     "pmc_darcy_destroy": (None, [_VP]),
     "pmc_darcy_num_dofs": (C.c_int, [_VP, C.c_int]),
     "pmc_darcy_num_pressure_dofs": (C.c_int, [_VP, C.c_int]),
@@ -613,7 +615,8 @@ class PDESampler:
 class DarcySolver:
     """Device mixed Darcy solver; mirrors parelagmc::DarcySolver (SolveFwd, GetNNZ, ...)."""
 
-    def __init__(self, ctx: Context, problem, opts: Optional[pmc_solver_opts] = None):
+    def __init__(self, ctx: Context, problem, opts: Optional[pmc_solver_opts] = None, hybrid: bool = False):
+        """hybrid: SolveFwd through the hybridized form (pmc_darcy_create_hybrid, the reference's "Hybridization" option)"""
         self.ctx, self.problem = ctx, problem
         keep = _Keep()
         nl = len(problem.levels)
@@ -624,8 +627,8 @@ class DarcySolver:
                                      keep.f64(L.ess_data), keep.f64(L.obs), keep.csr(L.P))
         h = _VP()
         o = opts if opts is not None else solver_opts()
-        _check(ctx.lib.pmc_darcy_create(ctx.h, nl, problem.n_mc_levels, arr, 1 if problem.k_divides else 0,
-                                        C.byref(o), C.byref(h)))
+        create = ctx.lib.pmc_darcy_create_hybrid if hybrid else ctx.lib.pmc_darcy_create
+        _check(create(ctx.h, nl, problem.n_mc_levels, arr, 1 if problem.k_divides else 0, C.byref(o), C.byref(h)))
         self.h = h
         ctx._adopt(self)
         self.nlevels = problem.n_mc_levels

@@ -473,8 +473,8 @@ int pmc_sampler_operator_event_overhead(pmc_sampler* s, double* total_ms) {
 }
 
 // ---- Darcy ------------------------------------------------------------------------------------
-int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_level* levels, int k_divides,
-                     const pmc_solver_opts* opts, pmc_darcy** out) {
+static int darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_level* levels, int k_divides,
+                        const pmc_solver_opts* opts, pmc_darcy** out, bool hybrid) {
     return guarded([&] {
         PMC_REQUIRE(c != nullptr && out != nullptr, "pmc_darcy_create: NULL argument");
         *out = nullptr;
@@ -488,8 +488,16 @@ int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_l
                         (o.cheb_ratio_M <= 0.0 || o.cheb_ratio_M > 1.0) && o.mg_smooth_ratio > 1.0 && o.mg_coarse_ratio > 1.0 &&
                         (o.precond_storage == PMC_STORAGE_FP32 || o.precond_storage == PMC_STORAGE_FP64),
                     "solver options out of range");
-        *out = new pmc_darcy(*c, nlevels, n_mc_levels, levels, k_divides != 0, o);
+        *out = new pmc_darcy(*c, nlevels, n_mc_levels, levels, k_divides != 0, o, hybrid);
     });
+}
+int pmc_darcy_create(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_level* levels, int k_divides,
+                     const pmc_solver_opts* opts, pmc_darcy** out) {
+    return darcy_create(c, nlevels, n_mc_levels, levels, k_divides, opts, out, false);
+}
+int pmc_darcy_create_hybrid(pmc_ctx* c, int nlevels, int n_mc_levels, const pmc_darcy_level* levels, int k_divides,
+                            const pmc_solver_opts* opts, pmc_darcy** out) {
+    return darcy_create(c, nlevels, n_mc_levels, levels, k_divides, opts, out, true);
 }
 void pmc_darcy_destroy(pmc_darcy* d) {
     if (!d) return;

@@ -112,15 +112,20 @@ std::vector<int> diag_slots(const Sell& S, const HostCsr& pat) {
 }
 
 // chain of one MC level: own Schur lists `own` (over diag(M)), prolongators from the k == 1 operator K1
-std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, const pmc_solver_opts& o, hipStream_t st) {
-    std::vector<AmgLevelHost> lvh = sa_hierarchy(K1, std::vector<double>(), /*passes=*/2, /*theta=*/0.25,
-                                                 /*min_size=*/256, /*max_levels=*/14);
+// plain: plain aggregation by coupling magnitude (indicator prolongators) instead of smoothed aggregation; galerkin_scale: the
+// coarse operators are that factor times P^T S P (over-correction of a piecewise-constant prolongator, LAB_NOTES 10.15)
+std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, const pmc_solver_opts& o, hipStream_t st,
+                                        bool plain = false, double galerkin_scale = 1.0, double ratio_scale = 1.0) {
+    std::vector<AmgLevelHost> lvh = plain ? agg_hierarchy(K1, /*passes0=*/3, /*passes=*/3, /*theta=*/0.25, /*min_size=*/256,
+                                                          /*max_levels=*/14)
+                                          : sa_hierarchy(K1, std::vector<double>(), /*passes=*/2, /*theta=*/0.25,
+                                                         /*min_size=*/256, /*max_levels=*/14);
     SetupClock clk;
     clk.lap("  sa_hierarchy", (int)lvh.size());
     std::unique_ptr<DarcyChain> ch(new DarcyChain());
     Multigrid& mg = ch->mg;
     mg.smooth_degree = o.mg_smooth_degree;
-    mg.smooth_ratio = o.mg_smooth_ratio;
+    mg.smooth_ratio = ratio_scale * o.mg_smooth_ratio;
     mg.coarse_degree = o.mg_coarse_degree;
     mg.coarse_ratio = o.mg_coarse_ratio;
     mg.f32_intermediates = o.precond_storage != PMC_STORAGE_FP64;
@@ -161,7 +166,7 @@ std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, 
                 const int e2 = pat.colind[p];
                 for (int a = P.rowptr[e]; a < P.rowptr[e + 1]; ++a)
                     for (int b = P.rowptr[e2]; b < P.rowptr[e2 + 1]; ++b)
-                        tr.push_back({P.colind[a], P.colind[b], n2s[p], P.vals[a] * P.vals[b]});
+                        tr.push_back({P.colind[a], P.colind[b], n2s[p], galerkin_scale * P.vals[a] * P.vals[b]});
             }
         const size_t ntr = tr.size();
         Symbolic next = build_symbolic(P.ncols, tr);
@@ -184,8 +189,8 @@ std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, 
 }  // namespace
 
 
-Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kdiv, const pmc_solver_opts& o)
-    : ctx(c), nlevels(nlevels_), n_mc(n_mc_), k_divides(kdiv), opts(o) {
+Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kdiv, const pmc_solver_opts& o, bool hybrid_)
+    : ctx(c), nlevels(nlevels_), n_mc(n_mc_), k_divides(kdiv), hybrid(hybrid_), opts(o) {
     SetupClock clk;
     PMC_REQUIRE(nlevels >= 1 && n_mc >= 1 && n_mc <= nlevels, "darcy: need 1 <= n_mc_levels <= nlevels");
     PMC_REQUIRE(in != nullptr, "darcy: levels is NULL");
@@ -374,6 +379,13 @@ Darcy::Darcy(Ctx& c, int nlevels_, int n_mc_, const pmc_darcy_level* in, bool kd
         PMC_HIP(hipStreamSynchronize(st));
     }
 
+    if (hybrid) {
+        hyb.resize(n_mc);
+        for (int l = 0; l < n_mc; ++l) {
+            build_hybrid(l, in[l]);
+            clk.lap("hybridized system", l);
+        }
+    }
     clk.lap("levels done", -1);
     // Level patterns: S_l pattern = own pattern U Galerkin image of level l-1's pattern.
     std::vector<HostCsr> pattern(nlevels);
@@ -757,6 +769,245 @@ void Darcy::solve_chunk(int level, int nb, const double* k_d, double* Q_host, do
     for (int kcol = 0; kcol < nb; ++kcol) Q_host[kcol] = ctx.h_scal[kcol];
 }
 
+// Setup of the hybridized form of one level (see DarcyHybrid; numpy twin: parelagmc_amd/fe/darcy_hybrid.py).
+void Darcy::build_hybrid(int level, const pmc_darcy_level& L) {
+    hipStream_t st = ctx.stream;
+    const int nu = L.n_u, np = L.n_p;
+    HostCsr Mp = csr_from_c(L.M_pattern, false, "darcy M_pattern");
+    HostCsr B = csr_from_c(L.B, true, "darcy B");
+    csr_sort_rows(B);
+    ElementInverses inv = element_inverses(Mp, B, L.c_ptr, L.c_elem, L.c_val, nullptr, "pmc_darcy_create_hybrid");
+    const int m = inv.m;
+    // face -> its (one or two) elements in element order; multipliers: interior faces and essential boundary faces
+    std::vector<int> fe((size_t)nu * 2, -1), fl((size_t)nu * 2, -1), cnt(nu, 0);
+    for (int e = 0; e < np; ++e)
+        for (int p = B.rowptr[e]; p < B.rowptr[e + 1]; ++p) {
+            const int f = B.colind[p];
+            PMC_REQUIRE(cnt[f] < 2, "pmc_darcy_create_hybrid: a face belongs to more than two elements");
+            fe[2 * (size_t)f + cnt[f]] = e;
+            fl[2 * (size_t)f + cnt[f]] = p - B.rowptr[e];
+            ++cnt[f];
+        }
+    std::vector<int> lam_of(nu, -1);
+    int nl = 0;
+    for (int f = 0; f < nu; ++f) {
+        PMC_REQUIRE(cnt[f] >= 1, "pmc_darcy_create_hybrid: a face belongs to no element");
+        PMC_REQUIRE(!(cnt[f] == 2 && L.ess_mask[f]), "pmc_darcy_create_hybrid: an essential dof on an interior face");
+        if (cnt[f] == 2 || L.ess_mask[f]) lam_of[f] = nl++;
+    }
+    PMC_REQUIRE(nl > 0, "pmc_darcy_create_hybrid: no multipliers (every face carries a pressure condition)");
+    auto hy = std::make_unique<DarcyHybrid>();
+    hy->n_lambda = nl;
+    // signed element data: sgn = C_e, fs = C_e f_e with rhs_u of a face given to its first element
+    auto sgn = [&](int e, int q) { return B.vals[B.rowptr[e] + q] > 0.0 ? 1.0 : -1.0; };
+    auto fs = [&](int e, int q) {
+        const int f = B.colind[B.rowptr[e] + q];
+        return fe[2 * (size_t)f] == e ? sgn(e, q) * L.rhs[f] : 0.0;
+    };
+    // H(kappa) as lists over the elements, R, b0, back-substitution operators
+    std::vector<Triple> tr;
+    tr.reserve((size_t)np * m * m);
+    HostCsr R, UL, PL;
+    R.nrows = nl; R.ncols = np;
+    UL.nrows = nu; UL.ncols = nl;
+    PL.nrows = np; PL.ncols = nl;
+    std::vector<std::vector<std::pair<int, double>>> Rrows(nl);
+    std::vector<double> b0(nl, 0.0), U0(nu, 0.0), ug(nu, 0.0), P0(np, 0.0), zg(np, 0.0);
+    std::vector<int> owner(nu, 0);
+    UL.rowptr.assign(nu + 1, 0);
+    PL.rowptr.assign(np + 1, 0);
+    std::vector<std::vector<std::pair<int, double>>> ULrows(nu);
+    for (int e = 0; e < np; ++e) {
+        const int b0e = B.rowptr[e], len = B.rowptr[e + 1] - b0e;
+        const double g = L.rhs[nu + e];
+        const double* Xe = &inv.X[(size_t)e * m * m];
+        const double* Ye = &inv.Y[(size_t)e * m];
+        zg[e] = -inv.z[e] * g;
+        for (int p = 0; p < len; ++p) {
+            const int f = B.colind[b0e + p];
+            double xf = 0.0;                          // sum_q Xs[p][q] fs[q] = c_p (X_e f_e)[p]
+            for (int q = 0; q < len; ++q) xf += Xe[p * m + q] * fs(e, q);
+            P0[e] += Ye[p] * fs(e, p);
+            const int lp = lam_of[f];
+            if (lp >= 0) {
+                for (int q = 0; q < len; ++q) {
+                    const int lq = lam_of[B.colind[b0e + q]];
+                    if (lq >= 0) tr.push_back({lp, lq, e, Xe[p * m + q]});
+                }
+                if (xf != 0.0) Rrows[lp].push_back({e, xf});
+                b0[lp] += Ye[p] * g;
+                PL.colind.push_back(lp);
+                PL.vals.push_back(Ye[p]);
+            }
+            if (fe[2 * (size_t)f] == e) {             // this element reports the face's flux
+                owner[f] = e;
+                U0[f] = sgn(e, p) * xf;
+                ug[f] = sgn(e, p) * Ye[p] * g;
+                for (int q = 0; q < len; ++q) {
+                    const int lq = lam_of[B.colind[b0e + q]];
+                    if (lq >= 0) ULrows[f].push_back({lq, sgn(e, p) * Xe[p * m + q]});
+                }
+                if (lp >= 0 && cnt[f] == 1) b0[lp] -= sgn(e, p) * L.ess_data[f];   // essential face: c u = c d
+            }
+        }
+        PL.rowptr[e + 1] = (int)PL.colind.size();
+    }
+    auto rows_to_csr = [](HostCsr& A, std::vector<std::vector<std::pair<int, double>>>& rows) {
+        A.rowptr.assign(rows.size() + 1, 0);
+        for (size_t i = 0; i < rows.size(); ++i) {
+            std::sort(rows[i].begin(), rows[i].end());
+            for (auto& cv : rows[i]) { A.colind.push_back(cv.first); A.vals.push_back(cv.second); }
+            A.rowptr[i + 1] = (int)A.colind.size();
+        }
+    };
+    rows_to_csr(R, Rrows);
+    rows_to_csr(UL, ULrows);
+    csr_sort_rows(PL);
+    Symbolic own = build_symbolic(nl, tr);
+    HostCsr K1 = own.pat;
+    for (int64_t p = 0; p < K1.nnz(); ++p) {
+        double v = 0.0;
+        for (int t = own.ptr[p]; t < own.ptr[p + 1]; ++t) v += own.w[t];
+        K1.vals[p] = v;
+    }
+    {   // element-grouped layout of H(kappa): per row two groups of m slots (its one or two elements), shared entries
+        const int gw = m;
+        PMC_REQUIRE(gw <= 16, "pmc_darcy_create_hybrid: more than 16 faces per element");
+        HostCsr Heg;
+        Heg.nrows = Heg.ncols = nl;
+        Heg.rowptr.resize(nl + 1);
+        Heg.colind.assign((size_t)nl * 2 * gw, 0);
+        Heg.vals.assign((size_t)nl * 2 * gw, 0.0);
+        std::vector<int> e12((size_t)nl * 2, np);        // np: the constant-one coefficient row (padding groups, weight 0)
+        for (int i = 0; i <= nl; ++i) Heg.rowptr[i] = i * 2 * gw;
+        for (int f = 0; f < nu; ++f) {
+            const int lp = lam_of[f];
+            if (lp < 0) continue;
+            for (int q = 0; q < 2 * gw; ++q) Heg.colind[(size_t)lp * 2 * gw + q] = lp;
+            for (int sidx = 0; sidx < cnt[f]; ++sidx) {
+                const int e = fe[2 * (size_t)f + sidx], p = fl[2 * (size_t)f + sidx];
+                const int b0e = B.rowptr[e], len = B.rowptr[e + 1] - b0e;
+                e12[2 * (size_t)lp + sidx] = e;
+                for (int q = 0; q < len; ++q) {
+                    const int lq = lam_of[B.colind[b0e + q]];
+                    if (lq < 0) continue;
+                    Heg.colind[(size_t)lp * 2 * gw + sidx * gw + q] = lq;
+                    Heg.vals[(size_t)lp * 2 * gw + sidx * gw + q] = inv.X[((size_t)e * m + p) * m + q];
+                }
+            }
+        }
+        sell_build(hy->Heg, Heg, true, false, st);
+        hy->eg_e12.upload(e12, st);
+        hy->eg_gw = gw;
+        hy->no_rows.upload(std::vector<int>((size_t)hy->Heg.nslices + 1, 0), st);
+    }
+    double scale = 0.5;
+    if (const char* e = lab_env("PMC_DARCY_HYB_SCALE")) scale = atof(e);
+    hy->chain = build_chain(own, K1, opts, st, /*plain=*/true, scale, /*ratio_scale=*/2.0);
+    sell_build(hy->R, R, true, false, st);
+    sell_build(hy->UL, UL, true, false, st);
+    sell_build(hy->PL, PL, true, false, st);
+    hy->b0.upload(b0, st);
+    hy->U0.upload(U0, st);
+    hy->ug.upload(ug, st);
+    hy->P0.upload(P0, st);
+    hy->zg.upload(zg, st);
+    hy->owner.upload(owner, st);
+    PMC_HIP(hipStreamSynchronize(st));
+    hyb[level] = std::move(hy);
+}
+
+// SolveFwd through the hybridized form: H(kappa) lambda = R kappa + b_0 by MINRES with one V-cycle of the per-realization
+// aggregation hierarchy, then the element-local back-substitution into the full solution vector (what Q, the returned
+// solution and the pressure block are taken from, exactly as after the saddle-point solve).
+void Darcy::solve_chunk_hybrid(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats, int row0,
+                               int nrows) {
+    hipStream_t st = ctx.stream;
+    DarcyLevel& d = lv[level];
+    DarcyHybrid& hy = *hyb[level];
+    const int n_u = d.n_u, n_p = d.n_p, n = n_u + n_p, nl = hy.n_lambda;
+    DarcyChain& ch = *hy.chain;
+    // sizes at this launch width
+    ch.mg.ensure_bv_tail_width(st, nb);
+    for (MgLevel& m : ch.mg.L) {
+        m.vals_bv.ensure((size_t)m.S.nslots * nb);
+        if (m.f32) {
+            m.vals32.ensure((size_t)m.S.nslots * nb);
+            m.scaled32.ensure((size_t)m.S.nslots * nb);
+        } else {
+            m.vals_scaled.ensure((size_t)m.S.nslots * nb);
+        }
+        m.dinv.ensure((size_t)m.n * nb);
+    }
+    hy.coef.ensure((size_t)(n_p + 1) * nb);     // + the constant-one row of the element-grouped layout
+    hy.rhs.ensure((size_t)nl * nb);
+    hy.lam.ensure((size_t)nl * nb);
+    hy.tu.ensure((size_t)n_u * nb);
+    hy.tp.ensure((size_t)n_p * nb);
+    sol.ensure((size_t)n * nb);
+    qpartial.ensure((size_t)dot_capacity(n, nb) * nb);
+    qout.ensure(kMaxBatch);
+    gwork.ensure(kMaxBatch);
+    if (stats) ctx.phase_mark(0);
+    // kappa = 1 / c(k); operators of the hierarchy; right-hand side
+    k::darcy_coef(st, nb, n_p, k_d, !k_divides, hy.coef.p);
+    k::fill(st, (size_t)nb, hy.coef.p + (size_t)n_p * nb, 1.0);
+    for (size_t j = 0; j < ch.cl.size(); ++j) {
+        MgLevel& m = ch.mg.L[j];
+        DarcyChainLevel& c = ch.cl[j];
+        const double* src = (j == 0) ? hy.coef.p : ch.mg.L[j - 1].vals_bv.p;
+        k::refresh(st, nb, m.S.nslots, c.ptr.p, c.idx.p, c.w.p, src, false, m.vals_bv.p);
+        k::diag_inv(st, nb, m.n, c.diag_slot.p, m.vals_bv.p, m.dinv.p);
+        k::gersh_scale_bv(st, nb, view_bv(m.S, m.vals_bv.p), m.dinv.p, gwork.p);
+        if (m.f32) k::scale_cols_bv32(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.scaled32.p, m.vals32.p);
+        else k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
+    }
+    ch.mg.refresh_bv_tail(st, nb);
+    k::broadcast(st, nb, nl, hy.b0.p, hy.rhs.p);
+    k::spmm(st, nb, view(hy.R), hy.coef.p, hy.rhs.p, true, nullptr, nullptr);
+    if (stats) ctx.phase_mark(1);
+    const EgView Hg{nl, hy.Heg.nslices, hy.eg_gw, hy.Heg.cols.p, hy.Heg.vals.p, hy.eg_e12.p};
+    SellView none;                    // the element-grouped operator kernel adds a second, shared-value operator: none here
+    none.nrows = nl;
+    none.nslices = hy.Heg.nslices;
+    none.slice_off = hy.no_rows.p;
+    none.ncols_hint = nl;
+    const double* coefp = hy.coef.p;
+    LinOp A;
+    A.n = nl;
+    A.n0 = 0;
+    A.apply_z = [Hg, none, coefp](const Lanes& L, int nb_, zvec x, double* y, double* partial, double*) {
+        return k::DotParts{partial, k::eg_pair_spmm_z(L.main, nb_, Hg, coefp, x, none, x, y, partial, x)};
+    };
+    Multigrid* mgp = &ch.mg;
+    PrecFn prec = [mgp](const Lanes& L, int nb_, const double* r, zvec z, double* dot_partial, double*) {
+        const int nblk = mgp->vcycle_z(L.main, nb_, 0, r, z, dot_partial);
+        return k::DotParts{dot_partial, nblk, nullptr, 0};
+    };
+    work.want_r32 = false;
+    GraphHint hint;
+    hint.key = hash_mix(hash_mix(hash_mix(0xdb, (uint64_t)level + 1), (uint64_t)nb), 7);
+    hint.sig = hash_ptr(hash_ptr(mgp->signature(0), hy.rhs.p), hy.lam.p);
+    MinresResult res = minres_solve(ctx, nb, A, prec, hy.rhs.p, hy.lam.p, true, opts, work, 0, nl, nullptr, hint);
+    if (stats) {
+        ctx.phase_mark(2);
+        for (int kcol = 0; kcol < nb; ++kcol) stats[kcol] = res.col[kcol];
+        ctx.phase_report(stats, nb);
+    }
+    // element-local back-substitution
+    k::spmm(st, nb, view(hy.UL), hy.lam.p, hy.tu.p, false, nullptr, nullptr);
+    k::darcy_backsub_u(st, nb, n_u, hy.owner.p, hy.coef.p, hy.U0.p, hy.ug.p, hy.tu.p, sol.p);
+    k::spmm(st, nb, view(hy.PL), hy.lam.p, hy.tp.p, false, nullptr, nullptr);
+    k::darcy_backsub_p(st, nb, n_p, hy.coef.p, hy.P0.p, hy.zg.p, hy.tp.p, sol.p + (size_t)n_u * nb);
+    // Q = <obs, sol>
+    const int qblocks = k::wdot(st, nb, n, d.obs.p, sol.p, qpartial.p);
+    k::reduce_final(st, nb, qblocks, qpartial.p, qout.p);
+    PMC_HIP(hipMemcpyAsync(ctx.h_scal, qout.p, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+    if (sol_d) k::deinterleave(st, nb, nrows, sol.p + (size_t)row0 * nb, nullptr, nullptr, false, sol_d);
+    PMC_HIP(hipStreamSynchronize(st));
+    for (int kcol = 0; kcol < nb; ++kcol) Q_host[kcol] = ctx.h_scal[kcol];
+}
+
 void Darcy::solve_fwd(int level, int nbatch, const double* kf, double* Q, double* C, double* sol_out, int memspace,
                       pmc_stats* stats, int sol_kind) {
     PMC_REQUIRE(level >= 0 && level < n_mc, "SolveFwd: level out of range");
@@ -773,17 +1024,20 @@ void Darcy::solve_fwd(int level, int nbatch, const double* kf, double* Q, double
         const int row0 = (sol_kind == 2) ? d.n_u : 0;
         const size_t nout = (sol_kind == 2) ? (size_t)d.n_p : n;
         double* sol_d = sol_out ? sol_out + (size_t)done * nout : nullptr;
+        auto chunk = [&](const double* kd, double* q, double* so, pmc_stats* stt) {
+            if (hybrid) solve_chunk_hybrid(level, nb, kd, q, so, stt, row0, (int)nout);
+            else solve_chunk(level, nb, kd, q, so, stt, row0, (int)nout, nullptr);
+        };
         if (memspace == PMC_MEM_HOST) {
             ensure(level, nb);
             PMC_HIP(hipMemcpyAsync(stage_k.p, k_d, sizeof(double) * d.n_p * nb, hipMemcpyHostToDevice, st));
-            solve_chunk(level, nb, stage_k.p, Q + done, sol_d ? stage_sol.p : nullptr, stats ? stats + done : nullptr, row0,
-                        (int)nout, nullptr);
+            chunk(stage_k.p, Q + done, sol_d ? stage_sol.p : nullptr, stats ? stats + done : nullptr);
             if (sol_d) {
                 PMC_HIP(hipMemcpyAsync(sol_d, stage_sol.p, sizeof(double) * nout * nb, hipMemcpyDeviceToHost, st));
                 PMC_HIP(hipStreamSynchronize(st));
             }
         } else {
-            solve_chunk(level, nb, k_d, Q + done, sol_d, stats ? stats + done : nullptr, row0, (int)nout, nullptr);
+            chunk(k_d, Q + done, sol_d, stats ? stats + done : nullptr);
         }
         if (C)
             for (int b = 0; b < nb; ++b) C[done + b] = (double)n;   // global true dofs (DarcySolver.cpp:429)

@@ -126,10 +126,33 @@ struct DarcyChain {
     std::vector<DarcyChainLevel> cl;
 };
 
+// Hybridized form of one Monte Carlo level (pmc_darcy_create_hybrid: the reference's "Hybridization" branch of DarcySolver,
+// src/DarcySolver.cpp:586,619; algebra: parelagmc_amd/fe/darcy_hybrid.py).  One multiplier per interior / essential face,
+//     H(kappa) lambda = R kappa + b_0,     H(kappa) = sum_e kappa_e C_e X_e C_e^T     (kappa = 1 / c(k), SPD, linear in kappa)
+//     u = kappa_owner (U_0 - U_L lambda) + u_g,     p = P_0 - P_L lambda - z_g / kappa.
+// chain: level 0 holds H(kappa) on its fixed pattern through contribution lists over the coefficient table, the coarser
+// levels the OVER-CORRECTED Galerkin products s P^T H P of a plain-aggregation hierarchy frozen at kappa == 1 (LAB_NOTES
+// 10.15: s = 0.45 makes the iteration count nearly level-independent), all refreshed per realization.
+struct DarcyHybrid {
+    int n_lambda = 0;
+    std::unique_ptr<DarcyChain> chain;
+    Sell R, UL, PL;
+    // element-grouped form of H(kappa) (EgView, as DarcyLevel::Meg for M(k)): the operator of the MINRES loop never reads the
+    // explicit per-realization values of level 0 (1.1 GB per pass at 0.8 M multipliers x 16)
+    Sell Heg;
+    DevBuf<int> eg_e12, no_rows;       // no_rows: slice offsets of an operator without entries (the kernel's second operand)
+    int eg_gw = 0;
+    DevBuf<double> b0, U0, ug, P0, zg;
+    DevBuf<int> owner;
+    DevBuf<double> coef, rhs, lam, tu, tp;     // per launch: kappa [n_p][nb], right-hand side, multipliers, U_L lambda, P_L lambda
+};
+
 struct Darcy {
     Ctx& ctx;
     int nlevels, n_mc;
     bool k_divides;
+    bool hybrid = false;             // SolveFwd through the hybridized form (ComputeG keeps the saddle-point path)
+    std::vector<std::unique_ptr<DarcyHybrid>> hyb;   // per MC level
     pmc_solver_opts opts;
     std::vector<DarcyLevel> lv;
     Multigrid mg;                    // batched values
@@ -150,7 +173,8 @@ struct Darcy {
     void set_observations(int level, const pmc_csr* Gobs);
     void compute_G(int level, int nbatch, const double* k, double* G, double* C, double* Q, int memspace, pmc_stats* stats);
 
-    Darcy(Ctx& c, int nlevels, int n_mc, const pmc_darcy_level* in, bool k_divides, const pmc_solver_opts& o);
+    Darcy(Ctx& c, int nlevels, int n_mc, const pmc_darcy_level* in, bool k_divides, const pmc_solver_opts& o,
+          bool hybrid = false);
     // sol_kind: 0 none, 1 full solution (n_u+n_p per realization), 2 pressure block only (n_p per realization)
     void solve_fwd(int level, int nbatch, const double* k, double* Q, double* C, double* sol_out, int memspace,
                    pmc_stats* stats, int sol_kind = 1);
@@ -159,6 +183,9 @@ struct Darcy {
     void ensure(int level, int nb);
     void solve_chunk(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats, int row0,
                      int nrows, double* G_host);
+    void build_hybrid(int level, const pmc_darcy_level& L);
+    void solve_chunk_hybrid(int level, int nb, const double* k_d, double* Q_host, double* sol_d, pmc_stats* stats, int row0,
+                            int nrows);
 };
 
 }  // namespace pmc

@@ -3807,6 +3807,43 @@ void transpose_bv(hipStream_t st, int nb, size_t count, const double* in, double
     check_launch();
 }
 
+// Back-substitution of the hybridized Darcy system (DarcyHybrid): interleaved [row][nb] vectors, one thread per entry.
+//   flux:     out[f][k] = kappa[owner[f]][k] * (U0[f] - t[f][k]) + ug[f]          t = U_L lambda
+//   pressure: out[e][k] = P0[e] - t[e][k] - zg[e] / kappa[e][k]                  t = P_L lambda
+__global__ __launch_bounds__(kBlock) void darcy_backsub_u_kernel(size_t total, int nb, const int* __restrict__ owner,
+                                                                  const double* __restrict__ kappa, const double* __restrict__ U0,
+                                                                  const double* __restrict__ ug, const double* __restrict__ t,
+                                                                  double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const size_t f = i / (size_t)nb;
+    const int k = (int)(i % (size_t)nb);
+    out[i] = kappa[(size_t)owner[f] * nb + k] * (U0[f] - t[i]) + ug[f];
+}
+__global__ __launch_bounds__(kBlock) void darcy_backsub_p_kernel(size_t total, int nb, const double* __restrict__ kappa,
+                                                                  const double* __restrict__ P0, const double* __restrict__ zg,
+                                                                  const double* __restrict__ t, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const size_t e = i / (size_t)nb;
+    out[i] = P0[e] - t[i] - zg[e] / kappa[i];
+}
+
+void darcy_backsub_u(hipStream_t st, int nb, int n_u, const int* owner, const double* kappa, const double* U0, const double* ug,
+                     const double* t, double* out) {
+    const size_t total = (size_t)n_u * nb;
+    if (total == 0) return;
+    darcy_backsub_u_kernel<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, st>>>(total, nb, owner, kappa, U0, ug, t, out);
+    check_launch();
+}
+void darcy_backsub_p(hipStream_t st, int nb, int n_p, const double* kappa, const double* P0, const double* zg, const double* t,
+                     double* out) {
+    const size_t total = (size_t)n_p * nb;
+    if (total == 0) return;
+    darcy_backsub_p_kernel<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, st>>>(total, nb, kappa, P0, zg, t, out);
+    check_launch();
+}
+
 // x[i][k] = sum_j ainv[i][j] r[j][k] for a launch of at most 8 realizations: one wavefront per row, lanes over the columns of the
 // (symmetric, row-major) dense inverse, so the matrix is read once, coalesced, by n wavefronts spread over the chip - the exact
 // solve of a level of a few hundred rows that a narrow launch would otherwise cycle through in ONE workgroup's LDS tail

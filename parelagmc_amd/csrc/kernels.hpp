@@ -261,6 +261,11 @@ int eg_poly2_z(hipStream_t st, int nb, const EgView& M, const double* coef, cons
 void gersh_scale_bv(hipStream_t st, int nb, const SellView& S, double* dinv, double* gwork);
 void refresh(hipStream_t st, int nb, int64_t nslots, const int* ptr, const int* idx, const double* w, const double* src,
              bool recip, double* out);
+// back-substitution of the hybridized Darcy system (DarcyHybrid; interleaved [row][nb] vectors)
+void darcy_backsub_u(hipStream_t st, int nb, int n_u, const int* owner, const double* kappa, const double* U0, const double* ug,
+                     const double* t, double* out);
+void darcy_backsub_p(hipStream_t st, int nb, int n_p, const double* kappa, const double* P0, const double* zg, const double* t,
+                     double* out);
 void diag_inv(hipStream_t st, int nb, int n, const int* diag_slot, const double* vals, double* dinv);
 
 }  // namespace k

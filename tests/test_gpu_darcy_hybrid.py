@@ -1,0 +1,86 @@
+"""The hybridized Darcy solver on the device (pmc_darcy_create_hybrid: the reference's "Hybridization" branch of DarcySolver,
+src/DarcySolver.cpp:586,619) against the oracle's saddle-point direct solve and against the default device solver.  Run with
+-m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = dict(rel_tol=1e-12, abs_tol=1e-30, max_iter=400)
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("k_divides", [True, False])
+def test_hybrid_darcy_matches_direct_solve_all_levels(gpu_ctx, hex_hierarchy, seeded_rng, k_divides):
+    """flux, pressure and QoI of every level against the direct solve: 1e-8 at rel 1e-12, QoI 1e-4 at the default 1e-6; ragged
+    batch (3 = 2 + 1); all converged"""
+    from oracle.darcy_oracle import DarcyOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem
+    dp = build_darcy_problem(hex_hierarchy, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], k_divides=k_divides)
+    do = DarcyOracle(dp)
+    for opts, qtol, stol in ((capi.solver_opts(**TIGHT), 1e-9, 1e-8), (capi.solver_opts(), 1e-4, 1e-3)):
+        ds = capi.DarcySolver(gpu_ctx, dp, opts, hybrid=True)
+        for lvl in range(3):
+            k = np.exp(seeded_rng.standard_normal((3, dp.levels[lvl].n_p)))
+            Q, C, sol, st = ds.SolveFwd(lvl, k, want_solution=True, return_stats=True)
+            for b in range(3):
+                Qr, Cr, sr = do.solve_fwd(lvl, k[b], return_solution=True)
+                assert abs(Q[b] - Qr) < qtol * abs(Qr) and C[b] == Cr
+                assert rel(sol[b], sr) < stol
+            assert all(t[1] == 1 for t in st)
+        ds.close()
+
+
+def test_hybrid_darcy_general_boundary_data_and_volume_qoi(gpu_ctx, hex_hierarchy_small, seeded_rng):
+    """nonzero essential fluxes, a volume source, the pressure-integral QoI: the right-hand side and back-substitution pieces
+    that the drivers' default data leave zero"""
+    from oracle.darcy_oracle import DarcyOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], qoi="p_int")
+    for L in dp.levels:
+        L.ess_data = 0.05 * seeded_rng.standard_normal(L.n_u) * L.ess_mask
+        L.rhs[L.n_u:] = 0.1 * seeded_rng.standard_normal(L.n_p)
+    do = DarcyOracle(dp)
+    ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT), hybrid=True)
+    for lvl in range(2):
+        k = np.exp(seeded_rng.standard_normal((2, dp.levels[lvl].n_p)))
+        Q, _, sol = ds.SolveFwd(lvl, k, want_solution=True)
+        for b in range(2):
+            Qr, _, sr = do.solve_fwd(lvl, k[b], return_solution=True)
+            assert abs(Q[b] - Qr) < 1e-8 * max(1.0, abs(Qr)) and rel(sol[b], sr) < 1e-8
+    ds.close()
+
+
+def test_hybrid_darcy_on_tetrahedra_and_against_the_default_solver(gpu_ctx, seeded_rng):
+    """cube_tet refined twice with the boundary relabelled by position (inflow x = min, outflow x = max, no-flux elsewhere): the
+    hybridized and the saddle-point device solvers against the oracle and each other"""
+    from oracle.darcy_oracle import DarcyOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem, build_hierarchy, mesh_from_json
+    m = mesh_from_json(golden_path("meshes", "cube_tet.json"))
+    cen = m.verts[m.bdr].mean(axis=1)
+    lo, hi = m.verts[:, 0].min(), m.verts[:, 0].max()
+    m.bdr_attr = np.where(np.isclose(cen[:, 0], lo), 1, np.where(np.isclose(cen[:, 0], hi), 6, 2)).astype(m.bdr_attr.dtype)
+    h = build_hierarchy(m, 2)
+    dp = build_darcy_problem(h, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], n_mc_levels=2)
+    do = DarcyOracle(dp)
+    hy = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT), hybrid=True)
+    sa = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT))
+    for lvl in range(2):
+        k = np.exp(seeded_rng.standard_normal((5, dp.levels[lvl].n_p)))
+        Qh, _, sh, st = hy.SolveFwd(lvl, k, want_solution=True, return_stats=True)
+        Qs, _, ss = sa.SolveFwd(lvl, k, want_solution=True)
+        assert all(t[1] == 1 for t in st)
+        for b in range(5):
+            Qr, _, sr = do.solve_fwd(lvl, k[b], return_solution=True)
+            assert abs(Qh[b] - Qr) < 1e-8 * abs(Qr) and rel(sh[b], sr) < 1e-8
+            assert rel(sh[b], ss[b]) < 1e-7
+    hy.close()
+    sa.close()
