@@ -116,7 +116,10 @@ std::vector<int> diag_slots(const Sell& S, const HostCsr& pat) {
 // coarse operators are that factor times P^T S P (over-correction of a piecewise-constant prolongator, LAB_NOTES 10.15)
 std::unique_ptr<DarcyChain> build_chain(const Symbolic& own, const HostCsr& K1, const pmc_solver_opts& o, hipStream_t st,
                                         bool plain = false, double galerkin_scale = 1.0, double ratio_scale = 1.0) {
-    std::vector<AmgLevelHost> lvh = plain ? agg_hierarchy(K1, /*passes0=*/3, /*passes=*/3, /*theta=*/0.25, /*min_size=*/256,
+    int passes0 = 3, passes1 = 3;
+    if (const char* e = lab_env("PMC_DARCY_HYB_PASSES0")) passes0 = atoi(e);
+    if (const char* e = lab_env("PMC_DARCY_HYB_PASSES1")) passes1 = atoi(e);
+    std::vector<AmgLevelHost> lvh = plain ? agg_hierarchy(K1, passes0, passes1, /*theta=*/0.25, /*min_size=*/256,
                                                           /*max_levels=*/14)
                                           : sa_hierarchy(K1, std::vector<double>(), /*passes=*/2, /*theta=*/0.25,
                                                          /*min_size=*/256, /*max_levels=*/14);
@@ -900,6 +903,14 @@ void Darcy::build_hybrid(int level, const pmc_darcy_level& L) {
         hy->eg_e12.upload(e12, st);
         hy->eg_gw = gw;
         hy->no_rows.upload(std::vector<int>((size_t)hy->Heg.nslices + 1, 0), st);
+        HostCsr I;
+        I.nrows = I.ncols = nl;
+        I.rowptr.resize(nl + 1);
+        I.colind.resize(nl);
+        I.vals.assign(nl, 1.0);
+        for (int i = 0; i <= nl; ++i) I.rowptr[i] = i;
+        for (int i = 0; i < nl; ++i) I.colind[i] = i;
+        sell_build(hy->ident, I, true, false, st);
     }
     double scale = 0.5;
     if (const char* e = lab_env("PMC_DARCY_HYB_SCALE")) scale = atof(e);
@@ -948,10 +959,21 @@ void Darcy::solve_chunk_hybrid(int level, int nb, const double* k_d, double* Q_h
     qpartial.ensure((size_t)dot_capacity(n, nb) * nb);
     qout.ensure(kMaxBatch);
     gwork.ensure(kMaxBatch);
+    static const bool eg_off = lab_env("PMC_DARCY_HYB_NO_EG") != nullptr;   // laboratory A/B: generic V-cycle on explicit values
+    const bool eg_cycle = ch.mg.L.size() >= 2 && ch.mg.smooth_degree == 2 && !eg_off;
+    if (eg_cycle) {
+        hy.negcoef.ensure((size_t)(n_p + 1) * nb);
+        hy.vx.ensure((size_t)nl * nb);
+        hy.vres.ensure((size_t)nl * nb);
+        hy.vd.ensure((size_t)nl * nb);
+        hy.vxc.ensure((size_t)ch.mg.L[1].n * nb);
+        ch.mg.L[1].ensure(nb);
+    }
     if (stats) ctx.phase_mark(0);
     // kappa = 1 / c(k); operators of the hierarchy; right-hand side
     k::darcy_coef(st, nb, n_p, k_d, !k_divides, hy.coef.p);
     k::fill(st, (size_t)nb, hy.coef.p + (size_t)n_p * nb, 1.0);
+    if (eg_cycle) k::scale(st, (size_t)(n_p + 1) * nb, hy.coef.p, -1.0, hy.negcoef.p);
     for (size_t j = 0; j < ch.cl.size(); ++j) {
         MgLevel& m = ch.mg.L[j];
         DarcyChainLevel& c = ch.cl[j];
@@ -959,6 +981,7 @@ void Darcy::solve_chunk_hybrid(int level, int nb, const double* k_d, double* Q_h
         k::refresh(st, nb, m.S.nslots, c.ptr.p, c.idx.p, c.w.p, src, false, m.vals_bv.p);
         k::diag_inv(st, nb, m.n, c.diag_slot.p, m.vals_bv.p, m.dinv.p);
         k::gersh_scale_bv(st, nb, view_bv(m.S, m.vals_bv.p), m.dinv.p, gwork.p);
+        if (j == 0 && eg_cycle) continue;      // the finest level is smoothed in element-grouped form: no scaled copies of it
         if (m.f32) k::scale_cols_bv32(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.scaled32.p, m.vals32.p);
         else k::scale_cols_bv(st, nb, m.S.nslots, m.S.cols.p, m.vals_bv.p, m.dinv.p, m.vals_scaled.p);
     }
@@ -980,10 +1003,36 @@ void Darcy::solve_chunk_hybrid(int level, int nb, const double* k_d, double* Q_h
         return k::DotParts{partial, k::eg_pair_spmm_z(L.main, nb_, Hg, coefp, x, none, x, y, partial, x)};
     };
     Multigrid* mgp = &ch.mg;
-    PrecFn prec = [mgp](const Lanes& L, int nb_, const double* r, zvec z, double* dot_partial, double*) {
-        const int nblk = mgp->vcycle_z(L.main, nb_, 0, r, z, dot_partial);
-        return k::DotParts{dot_partial, nblk, nullptr, 0};
-    };
+    PrecFn prec;
+    if (!eg_cycle) {
+        prec = [mgp](const Lanes& L, int nb_, const double* r, zvec z, double* dot_partial, double*) {
+            const int nblk = mgp->vcycle_z(L.main, nb_, 0, r, z, dot_partial);
+            return k::DotParts{dot_partial, nblk, nullptr, 0};
+        };
+    } else {
+        // V(1,1) with the finest level in element-grouped form: x = p2(H) r; res = r - H x; x += P B_1 P^T res;
+        // x += p2(H)(r - H x) - every pass over H(kappa) is the operator kernel (shared element entries + two coefficient rows
+        // per multiplier) or its one-pass polynomial form, never the explicit per-realization values
+        double c0, c1;
+        cheb2_coefficients(1.0, ch.mg.smooth_ratio, &c0, &c1);
+        const SellView Iv = view(hy.ident), Ptv = view(ch.mg.L[0].Pt), Pv = view(ch.mg.L[0].P);
+        const double* negc = hy.negcoef.p;
+        const double* dinv0 = ch.mg.L[0].dinv.p;
+        double *vx = hy.vx.p, *vres = hy.vres.p, *vd = hy.vd.p, *vxc = hy.vxc.p, *rc = ch.mg.L[1].r.p;
+        prec = [=](const Lanes& L, int nb_, const double* r, zvec z, double* dot_partial, double*) {
+            hipStream_t s = L.main;
+            k::eg_poly2(s, nb_, Hg, coefp, dinv0, r, vx, c0, c1, nullptr);
+            k::eg_pair_spmm(s, nb_, Hg, negc, vx, Iv, r, vres, nullptr, nullptr);
+            k::spmm(s, nb_, Ptv, vres, rc, false, nullptr, nullptr);
+            mgp->vcycle(s, nb_, 1, rc, vxc);
+            k::spmm(s, nb_, Pv, vxc, vx, true, nullptr, nullptr);
+            k::eg_pair_spmm(s, nb_, Hg, negc, vx, Iv, r, vres, nullptr, nullptr);
+            k::eg_poly2(s, nb_, Hg, coefp, dinv0, vres, vd, c0, c1, nullptr);
+            k::spmm(s, nb_, Iv, vd, vx, true, nullptr, nullptr);
+            const int nblk = k::convert_z(s, nb_, nl, vx, z, r, dot_partial);
+            return k::DotParts{dot_partial, dot_partial ? nblk : 0, nullptr, 0};
+        };
+    }
     work.want_r32 = false;
     GraphHint hint;
     hint.key = hash_mix(hash_mix(hash_mix(0xdb, (uint64_t)level + 1), (uint64_t)nb), 7);

@@ -145,6 +145,10 @@ struct DarcyHybrid {
     DevBuf<double> b0, U0, ug, P0, zg;
     DevBuf<int> owner;
     DevBuf<double> coef, rhs, lam, tu, tp;     // per launch: kappa [n_p][nb], right-hand side, multipliers, U_L lambda, P_L lambda
+    // finest level of the V-cycle in element-grouped form (solve_chunk_hybrid): -kappa (the residual r - H x is ONE launch of
+    // the operator kernel with the negated coefficients and the identity as its second operand), iterate, residual, update
+    Sell ident;
+    DevBuf<double> negcoef, vx, vres, vd, vxc;
 };
 
 struct Darcy {

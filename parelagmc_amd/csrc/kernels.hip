@@ -3663,6 +3663,16 @@ void fill(hipStream_t st, size_t n, double* x, double v) {
     check_launch();
 }
 
+__global__ __launch_bounds__(kBlock) void scale_kernel(size_t n, const double* __restrict__ in, double a, double* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) out[i] = a * in[i];
+}
+void scale(hipStream_t st, size_t n, const double* in, double a, double* out) {
+    if (n == 0) return;
+    const unsigned g = (unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, 2048);
+    scale_kernel<<<g, kBlock, 0, st>>>(n, in, a, out);
+    check_launch();
+}
+
 void copy(hipStream_t st, size_t n, const double* src, double* dst) {
     if (n && src != dst) PMC_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, st));
 }

@@ -206,6 +206,7 @@ void minres_wx(hipStream_t st, int nb, int n, const double* c0, zvec u, const do
                const double* c2, const double* w1, const double* c3, double* x);
 void fill(hipStream_t st, size_t n, double* x, double v);
 void copy(hipStream_t st, size_t n, const double* src, double* dst);
+void scale(hipStream_t st, size_t n, const double* in, double a, double* out);   // out = a in
 
 // per-block partial sums of one dot product, in up to two segments (n blocks of nb doubles each): kernels that run side
 // by side on two streams write a segment each

@@ -1,7 +1,7 @@
 """Hybridized form of the mixed DARCY system (setup side, numpy) - the algebra of the reference's "Hybridization" branch of
 `DarcySolver` (/root/reference/src/DarcySolver.cpp:586,619: the solver factory is handed the block operator, ParELAG's
-HybridHdivL2 eliminates (u, p) element by element).  Round 5 states and TESTS the reduction; the device path on top of it is the
-next round's (LAB_NOTES 10.15).
+HybridHdivL2 eliminates (u, p) element by element).  The numpy statement of the reduction the library performs in
+`pmc_darcy_create_hybrid` (csrc/darcy.hip::build_hybrid; LAB_NOTES 10.15 and 10.18), pinned against the oracle.
 
 With the flux continuity across interior faces (and the essential value on no-flux boundary faces) imposed by one Lagrange
 multiplier per such face, every element keeps its own copy u_e of the fluxes through its faces (GLOBAL face orientation):

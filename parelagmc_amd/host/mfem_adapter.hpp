@@ -205,8 +205,10 @@ struct DarcyLevelOps {
 
 class DeviceDarcySolver {
   public:
+    // hybridization: the reference's "Hybridization" solver option (src/DarcySolver.cpp:586,619) - SolveFwd through the
+    // element-local elimination and the multiplier system (pmc_darcy_create_hybrid); same operators, same results
     DeviceDarcySolver(pmc_ctx* ctx, const std::vector<DarcyLevelOps>& levels, int n_mc_levels, bool k_divides,
-                      const pmc_solver_opts* opts = nullptr) {
+                      const pmc_solver_opts* opts = nullptr, bool hybridization = false) {
         std::vector<pmc_darcy_level> lv(levels.size());
         std::vector<std::vector<uint8_t>> mask(levels.size());
         for (size_t i = 0; i < levels.size(); ++i) {
@@ -230,7 +232,11 @@ class DeviceDarcySolver {
             lv[i].obs = L.obs->GetData();
             if (L.P) lv[i].P = as_csr(*L.P);
         }
-        check(pmc_darcy_create(ctx, (int)lv.size(), n_mc_levels, lv.data(), k_divides ? 1 : 0, opts, &h_), "pmc_darcy_create");
+        if (hybridization)
+            check(pmc_darcy_create_hybrid(ctx, (int)lv.size(), n_mc_levels, lv.data(), k_divides ? 1 : 0, opts, &h_),
+                  "pmc_darcy_create_hybrid");
+        else
+            check(pmc_darcy_create(ctx, (int)lv.size(), n_mc_levels, lv.data(), k_divides ? 1 : 0, opts, &h_), "pmc_darcy_create");
     }
     DeviceDarcySolver(const DeviceDarcySolver&) = delete;
     DeviceDarcySolver& operator=(const DeviceDarcySolver&) = delete;

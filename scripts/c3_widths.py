@@ -22,7 +22,7 @@ for arg in sys.argv[1:] or ["4:32"]:
     lanes, batch = (int(x) for x in arg.split(":"))
     ctxs = [capi.Context(0, seed=20261003) for _ in range(lanes)]
     sm = [capi.PDESampler(c, sp, opts) for c in ctxs]
-    dr = [capi.DarcySolver(c, dp, opts) for c in ctxs]
+    dr = [capi.DarcySolver(c, dp, opts, hybrid=os.environ.get("C3_DARCY_HYBRID", "0") == "1") for c in ctxs]   # C3_DARCY_HYBRID=1: pmc_darcy_create_hybrid
     mgr = host_api.MLMCManager(3, sampler=sm[0], solver=dr[0], wall_time=True, batch=batch)
     for i in range(1, lanes):
         mgr.add_lane(sm[i], dr[i])

@@ -107,6 +107,23 @@ int main(int argc, char** argv) {
                 }
             }
         std::printf("adapter darcy: %d levels ok\n", p.d_nlevels);
+        {   // the same levels through the hybridized solver (the reference's "Hybridization" option of DarcySolver)
+            mfem_adapter::DeviceDarcySolver hyb(sampler.context(), dops, p.d_nlevels, p.k_divides != 0, &opts, true);
+            for (int l = 0; l < p.d_nlevels; ++l)
+                for (int b = 0; b < p.nbatch; ++b) {
+                    mfem::Vector k(p.k[l] + (size_t)b * p.dl[l].n_p, p.dl[l].n_p), pr;
+                    double Q = 0, C = 0, Q2 = 0, C2 = 0;
+                    hyb.SolveFwd(l, k, Q, C);
+                    hyb.SolveFwd_RtnPressure(l, k, pr, C2, Q2, true);
+                    if (!(std::fabs(Q - p.q_expect[l][b]) < 1e-8 * std::fabs(p.q_expect[l][b])) ||
+                        !(std::fabs(Q2 - Q) <= 1e-9 * std::fabs(Q)) || pr.Size() != hyb.GetSizeOfStochasticData(l)) {
+                        std::fprintf(stderr, "adapter hybridized darcy level %d sample %d: Q %.12g, expected %.12g\n", l, b, Q,
+                                     p.q_expect[l][b]);
+                        return 1;
+                    }
+                }
+            std::printf("adapter hybridized darcy: %d levels ok\n", p.d_nlevels);
+        }
         {   // the hybridized solver through the adapter: the same MFEM objects a ParELAGMC class holds before it eliminates
             // boundary rows (the Darcy levels carry the element decomposition and the un-eliminated B of the same mesh)
             std::vector<mfem_adapter::HybridLevelOps> hops(p.s_nlevels);
