@@ -124,6 +124,11 @@ def compact_line(full):
     put("c3_eg_poly_frac", _r(_get(c3, "roofline", "m_block_polynomial", "frac")))
     put("c3_eg_poly_traffic", _r(_get(c3, "roofline", "m_block_polynomial", "traffic"), 6))
     put("c3_dropin_round", _r(_get(ex, "dropin_nb1_config3", "round_64_256_1024_realizations_per_s")))
+    dh = ex.get("darcy_hybridization", {})
+    put("c3_darcy_saddle_ms", _r(_get(dh, "saddle_point", "ms_per_realization")))
+    put("c3_darcy_saddle_iterations", _r(_get(dh, "saddle_point", "iterations_mean")))
+    put("c3_darcy_hybrid_ms", _r(_get(dh, "hybridized", "ms_per_realization")))
+    put("c3_darcy_hybrid_iterations", _r(_get(dh, "hybridized", "iterations_mean")))
     hx = ex.get("hex64", {})
     put("hex64_value", _r(hx.get("value")))
     put("hex64_k5_frac", _r(_get(hx, "roofline", "frac")))
@@ -1086,6 +1091,40 @@ def dropin_sampler(problem, dev, seed, n=16, use_graph=0):
             "mean_minres_iterations": float(np.mean(its)), "use_graph": use_graph}
 
 
+def darcy_hybrid_point(probs, dev, seed, launches=2):
+    """The Darcy solve of config 3's finest level (cube_hex 64^3, 1 060 864 DoF) by both device solvers on the same lognormal
+    draws: the default saddle-point MINRES with the block-diagonal preconditioner, and the hybridized solver
+    (pmc_darcy_create_hybrid: the reference's "Hybridization" branch, /root/reference/src/DarcySolver.cpp:586,619).  One lane,
+    `launches` full launches each after a warm-up launch; iterations and device-inclusive wall milliseconds per realization."""
+    from parelagmc_amd import capi
+    sp, dp = probs
+    c = capi.Context(dev, seed=seed)
+    smp = capi.PDESampler(c, sp)
+    out = {"workload": f"Darcy SolveFwd, level 0 of config 3 ({dp.levels[0].n_u + dp.levels[0].n_p} DoF), one lane"}
+    try:
+        k = None
+        for name, hyb in (("saddle_point", False), ("hybridized", True)):
+            ds = capi.DarcySolver(c, dp, None, hybrid=hyb)
+            try:
+                w = ds.BatchWidth(0)
+                if k is None:
+                    k = smp.Eval(0, smp.Sample(0, first_id=11, nbatch=launches * w))
+                ds.SolveFwd(0, k[:w])
+                t0 = time.perf_counter()
+                Q, _, st = ds.SolveFwd(0, k, return_stats=True)
+                dt = time.perf_counter() - t0
+                out[name] = {"ms_per_realization": dt * 1e3 / len(k), "iterations_mean": float(np.mean([t[0] for t in st])),
+                             "all_converged": bool(all(t[1] == 1 for t in st)), "realizations": int(len(k)),
+                             "per_launch": int(w), "Q0": float(Q[0])}
+            finally:
+                ds.close()
+        out["Q_relative_difference"] = abs(out["hybridized"]["Q0"] - out["saddle_point"]["Q0"]) / abs(out["saddle_point"]["Q0"])
+    finally:
+        smp.close()
+        c.close()
+    return out
+
+
 def dropin_mlmc(probs, dev, seed, ns=(2, 8, 32), use_graph=0):
     """Config 3 driven the way the reference's serial MLMC_Manager::InitRun drives its plugins
     (/root/reference/src/MLMC_Manager.cpp:113-173): per realization of a level pair Sample(l), Eval(l+1), SolveFwd(l+1),
@@ -1356,6 +1395,7 @@ def main():
                 return m
             attempt("mlmc_config3", c3)
             attempt("dropin_nb1_config3", lambda: dropin_mlmc(probs3, dev, args.seed))
+            attempt("darcy_hybridization", lambda: darcy_hybrid_point(probs3, dev, args.seed))
             # the north star's "~1 M DoF 3D SPDE sampler": level 0 of config 3's hierarchy on its own, 1 060 864 DoF
             attempt("hex64", lambda: sampler_point(
                 probs3[0], dev, args.seed, args.batch, ns, 6, "hex64",
