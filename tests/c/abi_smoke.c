@@ -242,6 +242,26 @@ int main(int argc, char** argv) {
         free(Q); free(C); free(st);
     }
     pmc_darcy_destroy(dar);
+    /* the same level structs through the hybridized solver (the reference's "Hybridization" option of DarcySolver,
+     * src/DarcySolver.cpp:586,619): Q and the pressure block against the oracle / the default solver */
+    pmc_darcy* hyb = NULL;
+    CHECK(pmc_darcy_create_hybrid(ctx, p.d_nlevels, p.d_nlevels, dl, p.k_divides, &opts, &hyb));
+    for (int l = 0; l < p.d_nlevels; ++l) {
+        double* Q = (double*)malloc(8 * (size_t)p.nbatch);
+        double* C = (double*)malloc(8 * (size_t)p.nbatch);
+        double* Q2 = (double*)malloc(8 * (size_t)p.nbatch);
+        double* pr = (double*)malloc(8 * (size_t)p.nbatch * (size_t)p.dl[l].n_p);
+        pmc_stats* st = (pmc_stats*)calloc((size_t)p.nbatch, sizeof(pmc_stats));
+        CHECK(pmc_darcy_solve_fwd(hyb, l, p.nbatch, p.k[l], Q, C, NULL, PMC_MEM_HOST, st));
+        CHECK(pmc_darcy_solve_fwd_pressure(hyb, l, p.nbatch, p.k[l], pr, C, Q2, 1, PMC_MEM_HOST, NULL));
+        const double e = rel_err(Q, p.q_expect[l], (size_t)p.nbatch);
+        printf("hybridized darcy level %d: Q[0] = %.12g, rel. error vs oracle %.2e, iterations %d\n", l, Q[0], e, st[0].iterations);
+        if (!(e < 1e-8) || !(rel_err(Q2, Q, (size_t)p.nbatch) < 1e-9) || st[0].converged != 1 ||
+            C[0] != (double)(p.dl[l].n_u + p.dl[l].n_p))
+            return 1;
+        free(Q); free(C); free(Q2); free(pr); free(st);
+    }
+    pmc_darcy_destroy(hyb);
     pmc_sampler_destroy(smp);
     pmc_ctx_destroy(ctx);
     printf("abi_smoke OK\n");
