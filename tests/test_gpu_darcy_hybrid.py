@@ -84,3 +84,22 @@ def test_hybrid_darcy_on_tetrahedra_and_against_the_default_solver(gpu_ctx, seed
             assert rel(sh[b], ss[b]) < 1e-7
     hy.close()
     sa.close()
+
+
+def test_hybrid_darcy_on_stretched_cells(gpu_ctx, seeded_rng):
+    """SPE10-shaped cells (1200 x 2200 x 170 box, 7 x 27 x 10 coarse cells refined once: aspect ratio ~10): the aggregation
+    hierarchy is built from the coupling magnitudes of H(1), so the anisotropy is followed; converged, QoI against the oracle"""
+    from oracle.darcy_oracle import DarcyOracle
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import box_mesh, build_darcy_problem, build_hierarchy
+    h = build_hierarchy(box_mesh([7, 27, 10], [1200.0, 2200.0, 170.0], "hex"), 1)
+    dp = build_darcy_problem(h, [1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0], n_mc_levels=1)
+    do = DarcyOracle(dp)
+    k = np.exp(1.2 * seeded_rng.standard_normal((4, dp.levels[0].n_p)))
+    for opts, qtol in ((capi.solver_opts(**TIGHT), 1e-8), (capi.solver_opts(), 1e-4)):
+        ds = capi.DarcySolver(gpu_ctx, dp, opts, hybrid=True)
+        Q, _, st = ds.SolveFwd(0, k, return_stats=True)
+        assert all(t[1] == 1 for t in st), st
+        for b in range(4):
+            assert abs(Q[b] - do.solve_fwd(0, k[b])[0]) < qtol * abs(Q[b])
+        ds.close()
