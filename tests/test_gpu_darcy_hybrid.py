@@ -103,3 +103,23 @@ def test_hybrid_darcy_on_stretched_cells(gpu_ctx, seeded_rng):
         for b in range(4):
             assert abs(Q[b] - do.solve_fwd(0, k[b])[0]) < qtol * abs(Q[b])
         ds.close()
+
+
+def test_mlmc_manager_runs_unchanged_on_a_hybridized_darcy_solver(gpu_ctx, hex_hierarchy_small):
+    """the managers see a pmc_darcy: the same InitRun (same generator, same realizations, level pairs with warm starts) through
+    the hybridized handle gives the accumulators of the default handle to the solver tolerance; ragged plugin batches included"""
+    from parelagmc_amd import capi, host_api
+    from parelagmc_amd.fe import build_darcy_problem, build_sampler_problem
+    sp = build_sampler_problem(hex_hierarchy_small, corlen=0.1, lognormal=True)
+    dp = build_darcy_problem(hex_hierarchy_small, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1])
+    smp = capi.PDESampler(gpu_ctx, sp, capi.solver_opts(**TIGHT))
+    out = []
+    for hybrid in (False, True):
+        ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(**TIGHT), hybrid=hybrid)
+        mgr = host_api.MLMCManager(2, sampler=smp, solver=ds, wall_time=False, batch=4)
+        out.append(mgr.InitRun([5, 9]))
+        mgr.close()
+        ds.close()
+    smp.close()
+    assert np.allclose(out[0]["sums"], out[1]["sums"], rtol=1e-7, atol=1e-9)
+    assert out[0]["estimate"] == pytest.approx(out[1]["estimate"], rel=1e-7)
