@@ -1047,7 +1047,11 @@ __device__ __forceinline__ void split_row_sums(double (&acc)[T][C], int sl) {
             acc[rs][c] = v;
         }
 }
-template <int NB, typename XT, typename OT, typename AT, bool DOT, bool NT = false, int BV = 0, int DEEP = 1, bool SPL = false>
+// GIB (launches of 64 realizations = two column groups): ONE workgroup sweeps a slice for both groups back to back - the slice's
+// (index, value) pairs come from L1 / L2 the second time instead of being fetched again by another workgroup at another time
+// (what `traffic` showed as 1.34 x the algorithmic bytes) - gridDim.y is 1 and the partial sums keep their layout.
+template <int NB, typename XT, typename OT, typename AT, bool DOT, bool NT = false, int BV = 0, int DEEP = 1, bool SPL = false,
+          bool GIB = false>
 __global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc_poly2_kernel(int nrows, int nslices, const int* __restrict__ slice_off,
                                                           const int* __restrict__ cols, const double* __restrict__ vals_scaled,
                                                           const double* __restrict__ dinv, const XT* __restrict__ r, OT* xout,
@@ -1056,9 +1060,11 @@ __global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc
                                                           const int* __restrict__ padd_idx, const double* __restrict__ padd_x,
                                                           int ld, int sl = 0) {
     static_assert(!SPL || (NB <= 8 && BV == 0 && DEEP == 1), "row-split instantiations: narrow launches, shared values");
+    static_assert(!GIB || (NB == kGroup && BV == 0 && DEEP == 1 && !SPL), "both column groups in one workgroup: 64 wide, shared values");
     constexpr int C = Lay<NB>::C, T = Lay<NB>::T, G = Lay<NB>::G;
+    constexpr int NG = GIB ? 2 : 1;
     const int LD = row_ld<NB>(ld);
-    {
+    if constexpr (!GIB) {
         const int g0 = col0<NB>();
         r += g0; xout += g0;
         if constexpr (BV != 0) { vals_scaled = shift_bv<BV>(vals_scaled, g0); dinv += g0; }
@@ -1069,14 +1075,24 @@ __global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc
     }
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / T, t = lane % T;
-    double p[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) p[c] = 0.0;
     const SliceWalk sw = slice_walk(nslices);
-    for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
+    // (the group loop is the OUTER one and not unrolled: inside the slice loop the two groups' gathers interleave and 84-188
+    // registers spill; a workgroup walks one or two slices per wavefront, so the second sweep still finds them in L1 / L2)
+#pragma unroll 1
+    for (int grp = 0; grp < NG; ++grp) {
+      const int go = grp * NB;                         // 0 unless GIB
+      const XT* rg = r + go;
+      OT* xg = xout + go;
+      const AT* xa = xadd ? xadd + go : nullptr;
+      const double* dw = dot_with ? dot_with + go : nullptr;
+      const double* px = padd_x ? padd_x + go : nullptr;
+      double p[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) p[c] = 0.0;
+      for (int slice = sw.begin; slice < sw.end; slice += sw.stride) {
         double acc[T][C];
         const int off = slice_off[slice];
-        sell_row_range_t<NB, XT, NT, BV, DEEP>(cols, vals_scaled, r, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
+        sell_row_range_t<NB, XT, NT, BV, DEEP>(cols, vals_scaled, rg, off, (slice_off[slice + 1] - off) >> 6, lane, LD, acc);
         if constexpr (SPL) split_row_sums<NB, C, T>(acc, sl);
         // row steps in pairs: the own-row reads of both (and the parent indices of the coarse correction) are issued before
         // either is consumed - rows past the end re-read the last row and store nothing
@@ -1096,7 +1112,7 @@ __global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc
                 ok[u] = row < nrows && (!SPL || (piece & ((1 << sl) - 1)) == 0);
                 const int rowc = row < nrows ? row : nrows - 1;
                 at[u] = (size_t)rowc * LD + t * C;
-                load_v<C>(r + at[u], rv[u]);
+                load_v<C>(rg + at[u], rv[u]);
                 if constexpr (BV != 0) {
                     load_c<C>(dinv + at[u], di[u]);
                 } else {
@@ -1104,20 +1120,20 @@ __global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc
 #pragma unroll
                     for (int c = 0; c < C; ++c) di[u][c] = sdi;
                 }
-                if (xadd) load_v<C>(xadd + at[u], x0[u]);
+                if (xa) load_v<C>(xa + at[u], x0[u]);
                 if (padd_idx) par[u] = padd_idx[rowc];
-                if constexpr (DOT) load_c<C>(dot_with + at[u], wv[u]);
+                if constexpr (DOT) load_c<C>(dw + at[u], wv[u]);
             }
             if (padd_idx) {
 #pragma unroll
-                for (int u = 0; u < H; ++u) load_c<C>(padd_x + (size_t)par[u] * LD + t * C, pc[u]);
+                for (int u = 0; u < H; ++u) load_c<C>(px + (size_t)par[u] * LD + t * C, pc[u]);
             }
 #pragma unroll
             for (int u = 0; u < H; ++u) {
                 double xv[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c) xv[c] = di[u][c] * (c0 * rv[u][c] - c1 * acc[h0 + u][c]);
-                if (xadd) {
+                if (xa) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) xv[c] += x0[u][c];
                 }
@@ -1131,12 +1147,16 @@ __global__ __launch_bounds__(kBlock, (vc_min_waves<NB, XT, BV, DEEP>())) void vc
 #pragma unroll
                         for (int c = 0; c < C; ++c) p[c] = fma(wv[u][c], xv[c], p[c]);
                     }
-                    store_v_stream<NT, C>(xout + at[u], xv);
+                    store_v_stream<NT, C>(xg + at[u], xv);
                 }
             }
         }
+      }
+      if constexpr (DOT) {
+          reduce_cols_store<NB>(p, partial + go, LD);
+          if (grp + 1 < NG) __syncthreads();            // the reduction's LDS scratch is reused by the next group
+      }
     }
-    if constexpr (DOT) reduce_cols_store<NB>(p, partial, LD);
 }
 
 // y = r - A x with x of type XT (gathered), r of type RT, y of type YT; R8: rows also summed in groups of 8 into `coarse`
@@ -3323,6 +3343,17 @@ static int vc_postsmooth32_t(hipStream_t st, int nb, const SellView& As, const d
             vc_poly2_kernel<kGroup, float, OT, float, false, false, 0, 4><<<groups_xcd(g, nb), kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
         check_launch();
         return dot_partial ? dot_blocks(g, nb) : 0;
+    }
+    // 64 per launch on a large level: both column groups of a slice in one workgroup (vc_poly2_kernel, GIB).  Off in the
+    // product: one lane 2 870 -> 2 815 samples/s, four lanes 3 745 -> 3 757 (LAB_NOTES 10.19); laboratory switch PMC_GIB=1
+    static const bool gib = [] { const char* e = lab_env("PMC_GIB"); return e && atoi(e) != 0; }();
+    if (gib && nb == 2 * kGroup && nt_poly(As, kGroup) && !xcd_layout(g, nb)) {
+        if (dot_partial)
+            vc_poly2_kernel<kGroup, float, OT, float, true, true, 0, 1, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, dot_partial, x, r, parent, xc, nb);
+        else
+            vc_poly2_kernel<kGroup, float, OT, float, false, true, 0, 1, false, true><<<g, kBlock, 0, st>>>(As.nrows, As.nslices, As.slice_off, As.cols, As.vals, dinv, res, xout, c0, c1, nullptr, x, nullptr, parent, xc, nb);
+        check_launch();
+        return dot_partial ? (int)g.x : 0;
     }
     PMC_DISPATCH_NB(nb, {
         if (nt_poly(As, NB)) {
