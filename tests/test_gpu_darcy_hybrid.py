@@ -123,3 +123,21 @@ def test_mlmc_manager_runs_unchanged_on_a_hybridized_darcy_solver(gpu_ctx, hex_h
     smp.close()
     assert np.allclose(out[0]["sums"], out[1]["sums"], rtol=1e-7, atol=1e-9)
     assert out[0]["estimate"] == pytest.approx(out[1]["estimate"], rel=1e-7)
+
+
+def test_hybrid_darcy_hipgraph_replay_gives_the_eager_result(gpu_ctx, hex_hierarchy, seeded_rng):
+    """pairs of MINRES iterations replayed as one hipGraph (pmc_solver_opts.use_graph): the element-grouped cycle of the
+    hybridized solver is captured like any other preconditioner - same QoI, same iteration counts"""
+    from parelagmc_amd import capi
+    from parelagmc_amd.fe import build_darcy_problem
+    dp = build_darcy_problem(hex_hierarchy, [0, 1, 1, 1, 1, 0], [1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], n_mc_levels=1)
+    k = np.exp(seeded_rng.standard_normal((6, dp.levels[0].n_p)))
+    out = []
+    for g in (0, 1):
+        ds = capi.DarcySolver(gpu_ctx, dp, capi.solver_opts(use_graph=g), hybrid=True)
+        Q, _, st = ds.SolveFwd(0, k, return_stats=True)
+        Q2, _ = ds.SolveFwd(0, k)                     # second call: the captured graph is replayed from the first pair on
+        out.append((Q, [t[0] for t in st], Q2))
+        ds.close()
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert np.array_equal(out[1][0], out[1][2])
