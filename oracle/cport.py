@@ -24,9 +24,34 @@ class _level(C.Structure):
                 ("aw", C.POINTER(C.c_double)), ("P", _csr), ("Pt", _csr)]
 
 
+def _cpu_flags():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
+_FLAGS = os.path.join(_HERE, "_build", "built_on_cpu_flags.txt")
+
+
 def build(force=False):
+    """The library is compiled -march=native where build() ran and travels to the GPU box as a built file: it is rebuilt
+    there (gcc is in the image) when that host's CPU lacks a flag of the build host's, instead of dying on an illegal
+    instruction."""
+    here = _cpu_flags()
+    if not force and os.path.exists(LIB) and os.path.exists(_FLAGS):
+        with open(_FLAGS) as f:
+            force = not set(f.read().split()) <= here
+    elif not force and os.path.exists(LIB) and not os.path.exists(_FLAGS):
+        force = True
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(_HERE, "c", "pmc_ref.c")):
-        subprocess.run(["make", "-C", _HERE, "_build/libpmc_ref.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-B", "-C", _HERE, "_build/libpmc_ref.so"], check=True, capture_output=True)
+        with open(_FLAGS, "w") as f:
+            f.write(" ".join(sorted(here)))
     return LIB
 
 
