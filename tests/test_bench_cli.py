@@ -101,3 +101,26 @@ def test_compact_line_survives_failed_secondary_figures():
     full["cpu_baseline"] = {"error": "z" * 9000}
     d = json.loads(bench.compact_line(full))
     assert "mlmc_config3" in d["extra"]["errors"] and d["value"] > 0
+
+
+def test_compact_line_of_the_round5_record_carries_the_event_overhead_fields():
+    """the full record of this round's gate run (profiles/r05_gate_bench_full.json, written before bench.py computed the net
+    figure itself): raw frac is kept as it is, the net-of-event-overhead figure is passed through when the record has it"""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05_gate_bench_full.json")) as f:
+        full = json.load(f)
+    rf = full["roofline"]
+    net = rf["bytes_per_launch"] / ((rf["avg_kernel_ms"] - rf["event_overhead_ms"]) * 1e-3) / 1e9 / bench.PEAK_GBS
+    rf["frac_net_of_event_overhead"] = net
+    line = bench.compact_line(full)
+    assert len(line) < bench.LINE_CAP
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+    r = d["roofline"]
+    assert abs(r["frac"] - rf["frac"]) < 1e-3 and abs(r["frac_net_of_event_overhead"] - net) < 1e-3
+    assert r["frac"] < r["frac_net_of_event_overhead"] < r["frac"] * 1.06      # a 4-5 us bracket on a ~147 us launch
+    assert 0.003 < r["event_overhead_ms"] < 0.008
+    assert d["cpu_baseline"]["solver"].startswith("PCG") and d["config"]["solver"] == "hybridization"
